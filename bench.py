@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- scan-pairs/s of the MI355X scan-matching core on BASELINE.json's workload.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one batch of B complete scan-pair registrations: from the two raw ring clouds already resident
+in HBM to the solved pose -- target index build (velo_set_target), query list (velo_set_source) and
+velo_frame_to_frame (6 association rounds + 6 Levenberg-Marquardt solves to Ceres-default tolerances).
+Workload (configs[1] of BASELINE.json): synthetic HDL-64E pair, 64 x 1875 = 120,000 points each, icp_skip = 1.
+
+Multi-GPU (--mode):
+  replicas (default)  every rank registers its own pairs, no data-path collective           -> "scaling": "weak"
+  sharded             ONE pair per step, queries split 1/N per rank, RCCL all-reduce of the
+                      28-double normal-equation block every LM evaluation (north_star)      -> "scaling": "strong"
+Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas")
+    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
+                    help="c2: 120k pair; c3: + 2000 stereo blocks; c4: 120k scan vs 2M-point map")
+    ap.add_argument("--batch", type=int, default=8, help="independent pairs in flight per GPU (one context + stream each)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-skip", type=int, default=16)
+    return ap.parse_args()
+
+
+def make_workload(name):
+    from velo_amd import synth
+    if name == "c4":
+        d = synth.scan_to_map(2_000_000)
+        label = "synthetic HDL-64E 120k-pt scan vs 2M-pt accumulated map (configs[3]), icp_skip=1"
+    else:
+        d = synth.scan_pair()
+        label = "synthetic HDL-64E 64x1875=120k-pt scan pair (configs[1]), icp_skip=1, point-to-plane ICP"
+    vis = None
+    if name == "c3":
+        vis = synth.stereo_matches(1000)
+        label = "configs[2]: 120k-pt pair + 2000 stereo reprojection blocks, icp_skip=1"
+    return d, vis, label
+
+
+def cpu_baseline(d, vis, sample_skip):
+    """The CPU restatement (oracle = 'port') timed on this host: (i) all cores on the full pair,
+    (ii) one thread -- the reference's configuration (velo.h:900) -- on a 1/sample_skip query sample."""
+    import oracle_lib
+    cores = oracle_lib.max_threads()
+    out = {}
+    o = oracle_lib.Oracle(threads=cores, icp_skip=1)
+    t0 = time.perf_counter()
+    o.set_target(d["tgt_xyz"], d["tgt_off"])
+    o.set_source(d["src_xyz"], d["src_off"])
+    if vis is not None:
+        o.set_visual(vis)
+    x, _, s = o.frame_to_frame(d["x0"])
+    t_all = time.perf_counter() - t0
+    o1 = oracle_lib.Oracle(threads=1, icp_skip=sample_skip)
+    t0 = time.perf_counter()
+    o1.set_target(d["tgt_xyz"], d["tgt_off"])
+    o1.set_source(d["src_xyz"], d["src_off"])
+    if vis is not None:
+        o1.set_visual(vis)
+    o1.frame_to_frame(d["x0"])
+    t_one = (time.perf_counter() - t0) * sample_skip
+    out = {
+        "value": 1.0 / t_all, "unit": "scan-pairs/s", "cores": cores, "kind": "port",
+        "sample": f"1 full pair (icp_skip=1) on {cores} OpenMP threads = {t_all:.2f} s; single-thread "
+                  f"(reference configuration) extrapolated from a 1/{sample_skip} query sample = {t_one:.1f} s/pair",
+        "single_thread_pairs_per_s": 1.0 / t_one,
+        "x": [float(v) for v in x],
+    }
+    return out
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import velo_amd  # noqa: F401
+    from velo_amd import api
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    d, vis, label = make_workload(a.workload)
+    B = 1 if a.mode == "sharded" else max(1, a.batch)
+    # inputs resident in HBM before the timed region (torch is only the allocator here)
+    tgt = torch.from_numpy(d["tgt_xyz"]).to(dev)
+    src = torch.from_numpy(d["src_xyz"]).to(dev)
+    torch.cuda.synchronize()
+    ctxs = [api.Context(local_rank, icp_skip=1) for _ in range(B)]
+    for c in ctxs:
+        c.set_timing(True)
+        if vis is not None:
+            c.set_visual(vis)
+    if a.mode == "sharded" and world > 1:
+        uid = [api.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctxs[0].comm_init(uid[0], rank, world)
+
+    results = [None] * B
+
+    def one_pair(i):
+        c = ctxs[i]
+        c.set_target(tgt, d["tgt_off"])
+        c.set_source(src, d["src_off"])
+        results[i] = c.frame_to_frame(d["x0"])
+
+    pool = ThreadPoolExecutor(max_workers=B) if B > 1 else None
+
+    def step():
+        if pool is None:
+            one_pair(0)
+        else:
+            list(pool.map(one_pair, range(B)))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        for c in ctxs:
+            c.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    assoc_ms, assoc_n, alg_bytes, assoc_bytes, evals = 0.0, 0, 0, 0, 0
+    for _ in range(a.steps):
+        step()
+        for r in results:
+            s = r[2]
+            assoc_ms += s.assoc_kernel_ms
+            assoc_n += s.assoc_kernel_launches
+            alg_bytes += s.algorithmic_bytes
+            assoc_bytes += s.assoc_bytes
+            evals += sum(s.solves[k].evaluations for k in range(s.n_solves))
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    pairs_per_rank = a.steps * B
+    total_pairs = pairs_per_rank * (world if a.mode == "replicas" else 1)
+    value = total_pairs / dt
+    x_gpu = results[0][0]
+    s0 = results[0][2]
+
+    if rank == 0:
+        n_pairs_timed = a.steps * B
+        per_pair_bytes = alg_bytes / max(n_pairs_timed, 1)
+        # dominant kernel: the association search.  Algorithmic bytes per launch = 12 Nq + 12 Nt + 28 Nq
+        b_launch = assoc_bytes / max(a.steps * B * max(s0.n_assoc_rounds, 1), 1)
+        avg_ms = assoc_ms / max(assoc_n, 1)
+        achieved = (b_launch / 1e9) / (avg_ms / 1e3) if avg_ms > 0 else 0.0
+        line = {
+            "metric": "scan-pairs/sec + achieved HBM GB/s, 120k-pt HDL-64E frame-to-frame ICP",
+            "value": value, "unit": "scan-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True,
+            "scaling": "weak" if a.mode == "replicas" else "strong", "vs_baseline": None,
+            "dtype": "f32 association / f64 residuals+solve", "data": "synthetic",
+            "config": {"workload": label, "pairs_in_flight_per_gpu": B, "mode": a.mode,
+                       "Nq": int(s0.n_queries), "Nt": int(s0.n_target),
+                       "lm_evaluations_per_pair": evals / max(n_pairs_timed, 1),
+                       "valid_correspondences_last_round": int(s0.solves[s0.n_solves - 1].n_icp_valid),
+                       "algorithmic_bytes_per_pair": per_pair_bytes},
+            "achieved_hbm_GBs_whole_path": per_pair_bytes * value / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "assoc_search_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": b_launch,
+                         "note": "launch duration from HIP events on the context stream, measured in the timed region"},
+            "solution_x": [float(v) for v in x_gpu],
+        }
+        if not a.no_cpu_baseline:
+            cb = cpu_baseline(d, vis, a.cpu_sample_skip)
+            xo = np.array(cb.pop("x"))
+            cb["pose_diff_vs_gpu"] = {"dt_m": float(np.linalg.norm(xo[3:] - x_gpu[3:])),
+                                      "dw_rad": float(np.linalg.norm(xo[:3] - x_gpu[:3]))}
+            line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        for c in ctxs:
+            c.close()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,224 @@
+/*
+ * velo_hip.h -- C-ABI of the MI355X (gfx950) scan-matching core.
+ *
+ * This is the drop-in boundary for ONE path of lichunshang/vision-enhanced-lidar-odometry (VELO):
+ * the frame-to-frame registration loop  frameToFrame()  (reference velo.h:598-919).  The reference has
+ * no FFI/plugin interface; the three de-facto seams the path sits behind are
+ *     (1) frameToFrame(...)                     velo.h:598-614, sole caller main.cpp:388-405
+ *     (2) the residual functors                 costfunctions.h:17-220
+ *     (3) ceres::CostFunction::Evaluate [3P]    used at velo.h:683-689,710-718,744-752,777-785,875-891
+ * Each entry point below names the reference lines it replaces.  include/velo_frame_to_frame.hpp is the
+ * header-only C++ adaptor that offers seam (1)'s parameter list on top of these calls; INTEGRATION.md
+ * shows the binding a maintainer of the reference would add.
+ *
+ * Conventions: plain pointers and sizes only; every call returns an int status (VELO_OK == 0, < 0 error)
+ * and never throws; the caller owns host buffers, the context owns device buffers; one context per host
+ * thread (a context is not internally thread-safe), several contexts may share one GPU.
+ * x = (omega[3], t[3]) is the reference's `double transform[6]` (velo.h:610): p_prev = R(omega) p_cur + t.
+ */
+#ifndef VELO_HIP_H_
+#define VELO_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VELO_OK 0
+#define VELO_ERR_INVALID (-1)   /* bad argument (NULL, negative size, empty ring, ...) */
+#define VELO_ERR_HIP (-2)       /* a HIP runtime call failed; velo_last_error() has the text */
+#define VELO_ERR_STATE (-3)     /* call order violated (e.g. associate before set_target) */
+#define VELO_ERR_COMM (-4)      /* RCCL failure */
+#define VELO_ERR_NODEVICE (-5)  /* no gfx950 device visible: the product path has NO CPU fallback */
+
+/* residual_type values, same order as the reference enum ResidualType (velo.h:3-8) */
+#define VELO_RESIDUAL_3D3D 0
+#define VELO_RESIDUAL_3D2D 1
+#define VELO_RESIDUAL_2D3D 2
+#define VELO_RESIDUAL_2D2D 3
+
+/* ceres::TerminationType [3P] for one LM solve (velo.h:902) */
+#define VELO_CONVERGENCE 0
+#define VELO_NO_CONVERGENCE 1
+#define VELO_FAILURE 2
+
+#define VELO_MAX_SOLVES 64
+
+/* Every tunable of the path.  Defaults = the reference's compile-time constants (kitti.h:8-10,20-32,
+ * main.cpp:43-45) and the Ceres defaults the reference leaves untouched at velo.h:897-902. */
+typedef struct velo_params {
+    int32_t icp_skip;              /* kitti.h:8   200 (BASELINE configs 2-5 use 1) */
+    int32_t f2f_iterations;        /* kitti.h:9   2 */
+    int32_t icp_iterations;        /* kitti.h:10  3 */
+    int32_t enable_icp;            /* velo.h:613,806; caller passes true (main.cpp:404) */
+    int32_t enable_2d2d;           /* main.cpp:44 ENABLE_2D2D (defined) */
+    int32_t enable_3d2d;           /* main.cpp:45 ENABLE_3D2D (defined) */
+    int32_t max_num_iterations;    /* ceres default 50 */
+    int32_t max_consecutive_invalid_steps; /* ceres default 5 */
+    double weight_3D2D;            /* kitti.h:20  10 */
+    double weight_2D2D;            /* kitti.h:21  500 */
+    double weight_3DPD;            /* kitti.h:22  1 */
+    double loss_thresh_3D2D;       /* kitti.h:23  0.01 */
+    double loss_thresh_2D2D;       /* kitti.h:24  2e-5 */
+    double loss_thresh_3DPD;       /* kitti.h:25  0.1 */
+    double loss_thresh_3D3D;       /* kitti.h:26  0.04 */
+    double outlier_reject;         /* kitti.h:30  5 */
+    double correspondence_thresh_icp; /* kitti.h:31  0.5 (a SQUARED distance, velo.h:829) */
+    double icp_norm_condition;     /* kitti.h:32  1e-5 */
+    double function_tolerance;     /* ceres default 1e-6 */
+    double gradient_tolerance;     /* ceres default 1e-10 */
+    double parameter_tolerance;    /* ceres default 1e-8 */
+    double initial_trust_region_radius; /* 1e4 */
+    double max_trust_region_radius;     /* 1e16 */
+    double min_trust_region_radius;     /* 1e-32 */
+    double min_relative_decrease;       /* 1e-3 */
+    double min_lm_diagonal;             /* 1e-6 */
+    double max_lm_diagonal;             /* 1e32 */
+} velo_params;
+
+/* What velo.h:627-654 gathers for one feature match before it chooses residual types. */
+typedef struct velo_match {
+    float p3_1[3];   /* 3-D keypoint, frame1 (current), camera-0 frame     velo.h:650 */
+    float p3_2[3];   /* 3-D keypoint or landmark, frame2 (previous)        velo.h:634-648 */
+    float p2_1[2];   /* canonical 2-D observation in frame1                velo.h:653 */
+    float p2_2[2];   /* canonical 2-D observation in frame2                velo.h:654 */
+    float t_cam[3];  /* cam_trans[cam]                                     kitti.h:76-78 */
+    int32_t cam;
+    int32_t point1;  /* passed through into good_matches                   velo.h:628 */
+    int32_t point2;  /*                                                    velo.h:629 */
+    uint8_t d1;      /* has_depth in frame1                                velo.h:631 */
+    uint8_t d2;      /* has_depth in frame2 or landmark                    velo.h:632,644 */
+    uint8_t pad[2];
+} velo_match;
+
+/* One entry of good_matches[cam] / residual_type[cam] (velo.h:691-692,719-720,754-755,787-788). */
+typedef struct velo_good_match {
+    int32_t cam;
+    int32_t point1;
+    int32_t point2;
+    int32_t residual_type;
+} velo_good_match;
+
+/* One point-to-plane correspondence as the association loop builds it (velo.h:822-874). */
+typedef struct velo_corr {
+    int32_t valid;       /* 0 = skipped by one of the `continue`s at velo.h:849-851,873 */
+    int32_t ring_i;      /* np_s_i */
+    int32_t idx_i;       /* np_i   */
+    int32_t ring_j;      /* np_s_j */
+    int32_t idx_j;       /* np_j   */
+    int32_t idx_k;       /* np_k   */
+    int32_t src_ring;    /* sm  */
+    int32_t src_idx;     /* smi */
+    float dist_i;        /* np_dist_i (squared, float) */
+    float dist_j;        /* np_dist_j */
+    float p[3];          /* pointM_untransformed  velo.h:809 */
+    float n[3];          /* N                     velo.h:872-874 */
+    float v0[3];         /* v0                    velo.h:869 */
+} velo_corr;
+
+typedef struct velo_solve_summary {
+    int32_t termination;       /* VELO_CONVERGENCE / NO_CONVERGENCE / FAILURE */
+    int32_t lm_iterations;     /* trust-region iterations, successful or not */
+    int32_t evaluations;       /* residual(+Jacobian) sweeps over all blocks */
+    int32_t n_icp_valid;       /* point-to-plane blocks in this solve */
+    int32_t n_visual_blocks;   /* visual residual blocks in this solve */
+    int32_t n_visual_residuals;
+    double initial_cost;
+    double final_cost;
+} velo_solve_summary;
+
+typedef struct velo_summary {
+    int32_t n_solves;
+    int32_t n_assoc_rounds;
+    int32_t n_queries;                 /* Nq per round */
+    int32_t n_target;                  /* Nt */
+    uint64_t algorithmic_bytes;        /* sum B_assoc + sum B_eval */
+    uint64_t assoc_bytes;              /* the B_assoc part */
+    double assoc_kernel_ms;            /* sum of association-search launch durations (HIP events) when timing is on */
+    int32_t assoc_kernel_launches;
+    int32_t eval_kernel_launches;
+    double eval_kernel_ms;
+    velo_solve_summary solves[VELO_MAX_SOLVES];
+} velo_summary;
+
+typedef struct velo_ctx velo_ctx;
+
+/* --- lifetime ------------------------------------------------------------------------------------ */
+/* Binds a context (device buffers + one HIP stream) to `device`.  Replaces cv::cuda::setDevice (main.cpp:64)
+ * as the device selection of the path.  Fails with VELO_ERR_NODEVICE when no GPU is visible. */
+int velo_create(velo_ctx** out, int device);
+int velo_destroy(velo_ctx* ctx);
+const char* velo_last_error(void);
+const char* velo_version(void);
+
+/* --- configuration: kitti.h:8-10,20-32 + ceres::Solver::Options defaults (velo.h:897-901) ----------- */
+int velo_default_params(velo_params* p);
+int velo_set_params(velo_ctx* ctx, const velo_params* p);
+int velo_get_params(const velo_ctx* ctx, velo_params* p);
+/* Per-launch HIP-event timing of the association search and evaluation kernels (off by default). */
+int velo_set_timing(velo_ctx* ctx, int enable);
+
+/* --- inputs --------------------------------------------------------------------------------------- */
+/* Target = frame2 rings.  Replaces `scans_S` + `kd_trees` (velo.h:606-607) and the per-ring
+ * KdTreeFLANN::setInputCloud of ScanData (lru.h:17-20): the spatial index is built on the device here.
+ * xyz: first float of point 0; stride_bytes between points (12 packed, 16 for pcl::PointXYZ);
+ * ring_offsets[n_rings+1]: ring r = points [ring_offsets[r], ring_offsets[r+1]), each ring an ordered cyclic
+ * polyline (kitti.h:158-183).  on_device != 0: xyz is already a device pointer (stays caller-owned, copied). */
+int velo_set_target(velo_ctx* ctx, const float* xyz, int64_t stride_bytes, const int32_t* ring_offsets,
+                    int32_t n_rings, int on_device);
+/* Source = frame1 rings (`scans_M`, velo.h:605).  Queries are every icp_skip-th point of each ring (velo.h:807). */
+int velo_set_source(velo_ctx* ctx, const float* xyz, int64_t stride_bytes, const int32_t* ring_offsets,
+                    int32_t n_rings, int on_device);
+/* Visual matches of both cameras, in the reference's iteration order cam-major (velo.h:622-627). n may be 0. */
+int velo_set_visual(velo_ctx* ctx, const velo_match* matches, int32_t n);
+
+/* --- the pieces (each also usable on its own; tests call them one by one) ---------------------------- */
+/* One association round at pose x with the gate of outer iteration `iter` (1-based): velo.h:806-874.
+ * Leaves the correspondence table on the device for velo_evaluate / velo_solve. */
+int velo_associate(velo_ctx* ctx, const double x[6], int32_t iter, int32_t* n_valid);
+/* Copies the table back (one record per query, in query order sm-major / smi ascending). */
+int velo_get_correspondences(velo_ctx* ctx, velo_corr* out, int32_t capacity, int32_t* n_queries);
+/* Visual block selection + outlier gate G1 at pose x: velo.h:622-792. */
+int velo_build_visual(velo_ctx* ctx, const double x[6], int32_t iter, int32_t* n_blocks);
+int velo_get_good_matches(velo_ctx* ctx, velo_good_match* out, int32_t capacity, int32_t* n);
+/* Robustified cost + normal equations of all current blocks at x: what one Ceres evaluation produces
+ * (functors costfunctions.h:39-54,76-87,111-126,151-168,192-216; losses velo.h:688,714-717,748-751,
+ * 781-784,887-890).  JtJ is the full symmetric 6x6 row-major, Jtr = J^T r, cost = sum 1/2 rho(s). */
+int velo_evaluate(velo_ctx* ctx, const double x[6], double* cost, double JtJ[36], double Jtr[6]);
+/* Optional row-level output for a ceres::CostFunction adaptor (seam 3): residuals[n_res] and row-major
+ * jacobian[n_res*6], robustifier already applied.  Order: visual blocks, then ICP blocks (velo.h order). */
+int velo_evaluate_rows(velo_ctx* ctx, const double x[6], double* residuals, double* jacobian,
+                       int32_t capacity_rows, int32_t* n_rows);
+/* One ceres::Solve (velo.h:897-902) on the current blocks, x in/out. */
+int velo_solve(velo_ctx* ctx, double x[6], velo_solve_summary* summary);
+
+/* --- the path -------------------------------------------------------------------------------------- */
+/* frameToFrame (velo.h:598-919): f2f_iterations x [visual blocks; icp_iterations x (associate; solve)].
+ * x: in = initial guess, out = solution.  T: 4x4 row-major of the solution (util::pose_mat2vec, utility.h:67-82). */
+int velo_frame_to_frame(velo_ctx* ctx, double x[6], double T[16], velo_summary* summary);
+/* Several independent scan pairs in flight (one context each), one host thread per context. */
+int velo_frame_to_frame_batch(velo_ctx** ctxs, int32_t n, double* x /* n*6 */, double* T /* n*16 */,
+                              velo_summary* summaries /* n or NULL */);
+
+/* --- pose helpers (utility.h:67-96; note the reference's swapped names) ---------------- */
+int velo_pose_vec_to_mat(const double x[6], double T[16]);  /* util::pose_mat2vec */
+int velo_pose_mat_to_vec(const double T[16], double x[6]);  /* util::pose_vec2mat */
+
+/* --- multi-GPU: one process per GPU, RCCL over xGMI ---------------------------------- */
+/* Query-sharded mode: every rank holds the whole target and a contiguous 1/world share of the query list;
+ * each evaluation all-reduces the 28-double block (21 JtJ + 6 Jtr + cost) so all ranks take the same LM
+ * decisions.  The 128-byte id comes from rank 0 and is distributed by the host program. */
+int velo_comm_unique_id(char id[128]);
+int velo_comm_init(velo_ctx* ctx, const char id[128], int32_t rank, int32_t world);
+int velo_comm_destroy(velo_ctx* ctx);
+/* Restrict this context's queries to share `rank` of `world` WITHOUT a communicator (tests / replicas). */
+int velo_set_query_shard(velo_ctx* ctx, int32_t rank, int32_t world);
+
+/* Blocks until everything queued on the context's stream is done. */
+int velo_synchronize(velo_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VELO_HIP_H_ */

@@ -1,0 +1,811 @@
+// velo_oracle.cpp -- CPU restatement of VELO's frame-to-frame registration loop.
+//
+// *** TEST INFRASTRUCTURE ONLY. ***  This file is the parity oracle and the timed CPU baseline.  Only
+// tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; nothing under
+// vision-enhanced-lidar-odometry_amd/ links, imports or executes it, and the product path has no CPU fallback.
+//
+// *** PARITY UNPINNED. ***  The reference (/root/reference) ships no tests, golden vectors or fixtures
+//  and cannot be built here: frameToFrame needs PCL/FLANN, Ceres, Eigen, OpenCV, none of
+// which exist in this image, and even costfunctions.h alone needs ceres/rotation.h.  No stand-ins are
+// written for those libraries, so there is no oracle/_ref build.  What is restated here therefore follows
+//   (a) the reference's own source lines, cited at each function, and
+//   (b) the published behaviour of its un-vendored, un-pinned dependencies, marked [3P]:
+//       Ceres Solver (README.md:11, version unpinned; trust_region_minimizer.cc, levenberg_marquardt_strategy.cc,
+//       loss_function.cc, corrector.cc, rotation.h), PCL 1.7.2/1.8 KdTreeFLANN + FLANN KDTreeSingleIndex
+//       (README.md:10, CMakeLists.txt:5; exact 1-NN, L2_Simple float accumulation x->y->z).
+// Independent cross-checks (scipy cKDTree / Rotation / least_squares, finite differences) live in tests/.
+//
+// Build: oracle/Makefile  ->  oracle/_build/libvelo_oracle.so   (g++ -O3 -ffp-contract=off [-fopenmp])
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <vector>
+
+#include "../include/velo_hip.h"  // POD layouts only (velo_params, velo_match, velo_corr, summaries)
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+const double kInf = 1e18;  // utility.h:1
+
+// ------------------------------------------------------------------------------------------------
+// Forward-mode dual number with N partials: the arithmetic ceres::Jet<double,N> performs [3P].
+// ------------------------------------------------------------------------------------------------
+template <int N>
+struct Jet {
+    double a;
+    double v[N];
+    Jet() : a(0.0) { for (int i = 0; i < N; i++) v[i] = 0.0; }
+    Jet(double s) : a(s) { for (int i = 0; i < N; i++) v[i] = 0.0; }  // NOLINT (implicit on purpose)
+    Jet(double s, int k) : a(s) { for (int i = 0; i < N; i++) v[i] = 0.0; v[k] = 1.0; }
+};
+template <int N> inline Jet<N> operator+(const Jet<N>& f, const Jet<N>& g) {
+    Jet<N> h; h.a = f.a + g.a; for (int i = 0; i < N; i++) h.v[i] = f.v[i] + g.v[i]; return h; }
+template <int N> inline Jet<N> operator-(const Jet<N>& f, const Jet<N>& g) {
+    Jet<N> h; h.a = f.a - g.a; for (int i = 0; i < N; i++) h.v[i] = f.v[i] - g.v[i]; return h; }
+template <int N> inline Jet<N> operator-(const Jet<N>& f) {
+    Jet<N> h; h.a = -f.a; for (int i = 0; i < N; i++) h.v[i] = -f.v[i]; return h; }
+template <int N> inline Jet<N> operator*(const Jet<N>& f, const Jet<N>& g) {
+    Jet<N> h; h.a = f.a * g.a; for (int i = 0; i < N; i++) h.v[i] = f.a * g.v[i] + f.v[i] * g.a; return h; }
+template <int N> inline Jet<N> operator/(const Jet<N>& f, const Jet<N>& g) {
+    Jet<N> h; const double gi = 1.0 / g.a; const double q = f.a * gi; h.a = q;
+    for (int i = 0; i < N; i++) h.v[i] = (f.v[i] - q * g.v[i]) * gi; return h; }
+template <int N> inline Jet<N>& operator+=(Jet<N>& f, const Jet<N>& g) { f = f + g; return f; }
+template <int N> inline Jet<N>& operator/=(Jet<N>& f, const Jet<N>& g) { f = f / g; return f; }
+template <int N> inline Jet<N> operator*(double s, const Jet<N>& g) { return Jet<N>(s) * g; }
+template <int N> inline Jet<N> operator*(const Jet<N>& g, double s) { return g * Jet<N>(s); }
+template <int N> inline Jet<N> operator+(const Jet<N>& g, double s) { return g + Jet<N>(s); }
+template <int N> inline Jet<N> operator-(const Jet<N>& g, double s) { return g - Jet<N>(s); }
+template <int N> inline Jet<N> operator-(double s, const Jet<N>& g) { return Jet<N>(s) - g; }
+template <int N> inline bool operator>(const Jet<N>& f, const Jet<N>& g) { return f.a > g.a; }
+template <int N> inline Jet<N> sqrt(const Jet<N>& f) {
+    Jet<N> h; h.a = std::sqrt(f.a); const double d = 1.0 / (2.0 * h.a);
+    for (int i = 0; i < N; i++) h.v[i] = f.v[i] * d; return h; }
+template <int N> inline Jet<N> sin(const Jet<N>& f) {
+    Jet<N> h; h.a = std::sin(f.a); const double c = std::cos(f.a);
+    for (int i = 0; i < N; i++) h.v[i] = c * f.v[i]; return h; }
+template <int N> inline Jet<N> cos(const Jet<N>& f) {
+    Jet<N> h; h.a = std::cos(f.a); const double s = -std::sin(f.a);
+    for (int i = 0; i < N; i++) h.v[i] = s * f.v[i]; return h; }
+using std::sqrt; using std::sin; using std::cos;
+
+// ------------------------------------------------------------------------------------------------
+// ceres::AngleAxisRotatePoint [3P rotation.h]: Rodrigues when theta^2 > DBL_EPSILON,
+// first-order p + w x p otherwise.  Used by utility.h:99 and every functor of costfunctions.h.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+inline void angle_axis_rotate_point(const T w[3], const T p[3], T out[3]) {
+    const T theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    if (theta2 > T(std::numeric_limits<double>::epsilon())) {
+        const T theta = sqrt(theta2);
+        const T c = cos(theta);
+        const T s = sin(theta);
+        const T ti = T(1.0) / theta;
+        const T u[3] = {w[0] * ti, w[1] * ti, w[2] * ti};
+        const T uxp[3] = {u[1] * p[2] - u[2] * p[1], u[2] * p[0] - u[0] * p[2], u[0] * p[1] - u[1] * p[0]};
+        const T tmp = (u[0] * p[0] + u[1] * p[1] + u[2] * p[2]) * (T(1.0) - c);
+        out[0] = p[0] * c + uxp[0] * s + u[0] * tmp;
+        out[1] = p[1] * c + uxp[1] * s + u[1] * tmp;
+        out[2] = p[2] * c + uxp[2] * s + u[2] * tmp;
+    } else {
+        const T wxp[3] = {w[1] * p[2] - w[2] * p[1], w[2] * p[0] - w[0] * p[2], w[0] * p[1] - w[1] * p[0]};
+        out[0] = p[0] + wxp[0];
+        out[1] = p[1] + wxp[1];
+        out[2] = p[2] + wxp[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Residual functors (rows R1-R5).  c[] holds the constructor arguments in the reference's order.
+// ------------------------------------------------------------------------------------------------
+// R1 cost3DPD  costfunctions.h:39-54   c = point(3), normal(3), offset(3)
+template <typename T> inline void res_3dpd(const double* c, const T* x, T* r) {
+    T m0[3] = {T(c[0]), T(c[1]), T(c[2])}, m[3];
+    angle_axis_rotate_point(x, m0, m);
+    m[0] += x[3] - T(c[6]);
+    m[1] += x[4] - T(c[7]);
+    m[2] += x[5] - T(c[8]);
+    r[0] = m[0] * T(c[3]) + m[1] * T(c[4]) + m[2] * T(c[5]);
+}
+// R4 cost3D3D  costfunctions.h:76-87   c = m(3), s(3)
+template <typename T> inline void res_3d3d(const double* c, const T* x, T* r) {
+    T m0[3] = {T(c[0]), T(c[1]), T(c[2])}, m[3];
+    angle_axis_rotate_point(x, m0, m);
+    r[0] = m[0] + x[3] - T(c[3]);
+    r[1] = m[1] + x[4] - T(c[4]);
+    r[2] = m[2] + x[5] - T(c[5]);
+}
+// R2 cost3D2D  costfunctions.h:111-126  c = m(3), s(2), t(3)
+template <typename T> inline void res_3d2d(const double* c, const T* x, T* r) {
+    T m0[3] = {T(c[0]), T(c[1]), T(c[2])}, m[3];
+    angle_axis_rotate_point(x, m0, m);
+    m[0] += x[3] + T(c[5]);
+    m[1] += x[4] + T(c[6]);
+    m[2] += x[5] + T(c[7]);
+    r[0] = m[0] - T(c[3]) * m[2];
+    r[1] = m[1] - T(c[4]) * m[2];
+}
+// R3 cost2D3D  costfunctions.h:151-168  c = m(3), s(2), t(3)
+template <typename T> inline void res_2d3d(const double* c, const T* x, T* r) {
+    T rot[3] = {-x[0], -x[1], -x[2]};
+    T m0[3] = {T(c[0]) - x[3], T(c[1]) - x[4], T(c[2]) - x[5]}, m[3];
+    angle_axis_rotate_point(rot, m0, m);
+    m[0] += T(c[5]);
+    m[1] += T(c[6]);
+    m[2] += T(c[7]);
+    r[0] = m[0] - T(c[3]) * m[2];
+    r[1] = m[1] - T(c[4]) * m[2];
+}
+// R5 cost2D2D  costfunctions.h:192-216  c = m(2), s(2), t(3)
+template <typename T> inline void res_2d2d(const double* c, const T* x, T* r) {
+    T m0[3] = {T(c[0]), T(c[1]), T(1.0)}, m[3];
+    angle_axis_rotate_point(x, m0, m);
+    T rt0[3] = {T(c[4]), T(c[5]), T(c[6])}, rt[3];
+    angle_axis_rotate_point(x, rt0, rt);
+    T tx = -rt[0] + x[3] + T(c[4]);
+    T ty = -rt[1] + x[4] + T(c[5]);
+    T tz = -rt[2] + x[5] + T(c[6]);
+    const T tn = sqrt(tx * tx + ty * ty + tz * tz);
+    tx /= tn;
+    ty /= tn;
+    tz /= tn;
+    const double sx = c[2], sy = c[3];
+    r[0] = m[0] * (-sy * tz + ty) + m[1] * (sx * tz - tx) + m[2] * (-sx * ty + sy * tx);
+}
+
+enum BlockKind { K_3D3D = VELO_RESIDUAL_3D3D, K_3D2D = VELO_RESIDUAL_3D2D, K_2D3D = VELO_RESIDUAL_2D3D,
+                 K_2D2D = VELO_RESIDUAL_2D2D, K_3DPD = 4 };
+inline int kind_dim(int k) { return k == K_3D3D ? 3 : (k == K_3D2D || k == K_2D3D) ? 2 : 1; }
+
+template <typename T> inline void res_any(int kind, const double* c, const T* x, T* r) {
+    switch (kind) {
+        case K_3D3D: res_3d3d(c, x, r); break;
+        case K_3D2D: res_3d2d(c, x, r); break;
+        case K_2D3D: res_2d3d(c, x, r); break;
+        case K_2D2D: res_2d2d(c, x, r); break;
+        default: res_3dpd(c, x, r); break;
+    }
+}
+
+// residuals + (optionally) the autodiff Jacobian, row-major dim x 6: ceres::AutoDiffCostFunction<F,dim,6> [3P]
+inline void block_eval(int kind, const double* c, const double* x, double* r, double* J) {
+    if (!J) { res_any<double>(kind, c, x, r); return; }
+    typedef Jet<6> J6;
+    J6 xj[6], rj[3];
+    for (int i = 0; i < 6; i++) xj[i] = J6(x[i], i);
+    res_any<J6>(kind, c, xj, rj);
+    const int d = kind_dim(kind);
+    for (int k = 0; k < d; k++) { r[k] = rj[k].a; for (int i = 0; i < 6; i++) J[k * 6 + i] = rj[k].v[i]; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Loss functions (row L1) [3P loss_function.cc].  type: 0 trivial, 1 Cauchy(a), 2 Arctan(a); scaled by w.
+// ------------------------------------------------------------------------------------------------
+struct Loss { int type; double a; double w; };
+inline void loss_eval(const Loss& L, double s, double rho[3]) {
+    if (L.type == 1) {
+        const double b = L.a * L.a, c = 1.0 / b;
+        const double sum = 1.0 + s * c, inv = 1.0 / sum;
+        rho[0] = b * std::log(sum);
+        rho[1] = std::max(std::numeric_limits<double>::min(), inv);
+        rho[2] = -c * (inv * inv);
+    } else if (L.type == 2) {
+        const double b = 1.0 / (L.a * L.a);
+        const double sum = 1.0 + s * s * b, inv = 1.0 / sum;
+        rho[0] = L.a * std::atan2(s, L.a);
+        rho[1] = std::max(std::numeric_limits<double>::min(), inv);
+        rho[2] = -2.0 * s * b * (inv * inv);
+    } else {
+        rho[0] = s; rho[1] = 1.0; rho[2] = 0.0;
+    }
+    rho[0] *= L.w; rho[1] *= L.w; rho[2] *= L.w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact 1-NN per ring.  Stands for pcl::KdTreeFLANN<PointXYZ>::nearestKSearch(p,1,...) [3P] (lru.h:17-20,
+// velo.h:828): single KD-tree, leaf size 15, exhaustive (checks=-1, eps=0), float L2_Simple distances.
+// FLANN's choice among EXACT distance ties is traversal-order dependent and unpinned; here ties go to the
+// lowest point index (documented in DESIGN.md; the HIP path uses the same rule).
+// ------------------------------------------------------------------------------------------------
+inline float dist2f(const float* a, const float* b) {
+    const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    float r = dx * dx;
+    r = r + dy * dy;
+    r = r + dz * dz;
+    return r;
+}
+
+struct KdTree {
+    struct Node { int left, right; int lo, hi; int dim; float split; };
+    std::vector<Node> nodes;
+    std::vector<int> perm;
+    const float* pts = nullptr;  // n x 3 packed
+    int n = 0;
+    static const int kLeaf = 15;
+
+    void build(const float* p, int count) {
+        pts = p; n = count; perm.resize(n); nodes.clear();
+        for (int i = 0; i < n; i++) perm[i] = i;
+        if (n > 0) { nodes.reserve(2 * (n / kLeaf + 1)); build_rec(0, n); }
+    }
+    int build_rec(int lo, int hi) {
+        const int id = (int)nodes.size();
+        nodes.push_back(Node{-1, -1, lo, hi, 0, 0.f});
+        if (hi - lo <= kLeaf) return id;
+        float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int i = lo; i < hi; i++) for (int d = 0; d < 3; d++) {
+            const float v = pts[3 * perm[i] + d]; mn[d] = std::min(mn[d], v); mx[d] = std::max(mx[d], v); }
+        int dim = 0;
+        for (int d = 1; d < 3; d++) if (mx[d] - mn[d] > mx[dim] - mn[dim]) dim = d;
+        const int mid = (lo + hi) / 2;
+        std::nth_element(perm.begin() + lo, perm.begin() + mid, perm.begin() + hi,
+                         [&](int a, int b) { return pts[3 * a + dim] < pts[3 * b + dim]; });
+        const float split = pts[3 * perm[mid] + dim];
+        nodes[id].dim = dim; nodes[id].split = split;
+        const int l = build_rec(lo, mid);
+        const int r = build_rec(mid, hi);
+        nodes[id].left = l; nodes[id].right = r;
+        return id;
+    }
+    void search_rec(int id, const float* q, float& best, int& bi) const {
+        const Node& nd = nodes[id];
+        if (nd.left < 0) {
+            for (int i = nd.lo; i < nd.hi; i++) {
+                const int k = perm[i];
+                const float d = dist2f(q, pts + 3 * k);
+                if (d < best || (d == best && k < bi)) { best = d; bi = k; }
+            }
+            return;
+        }
+        const float diff = q[nd.dim] - nd.split;
+        const int near_c = diff < 0.f ? nd.left : nd.right;
+        const int far_c = diff < 0.f ? nd.right : nd.left;
+        search_rec(near_c, q, best, bi);
+        // every point beyond the plane has float distance >= fl(diff*diff) (monotone rounding), so
+        // pruning on a strict ">" keeps exactness AND equal-distance candidates (lowest-index tie rule).
+        if (!(diff * diff > best)) search_rec(far_c, q, best, bi);
+    }
+    // returns number found (0 for an empty ring; PCL would throw -- the reference never guards)
+    int nearest(const float* q, int* idx, float* d2) const {
+        if (n == 0) return 0;
+        float best = FLT_MAX; int bi = 0x7fffffff;
+        search_rec(0, q, best, bi);
+        *idx = bi; *d2 = best;
+        return 1;
+    }
+};
+
+struct Block { int kind; double c[9]; Loss loss; };
+
+struct Oracle {
+    velo_params P;
+    // target (frame2): scans_S + kd_trees
+    std::vector<float> tgt; std::vector<int> tgt_off; std::vector<KdTree> trees;
+    // source (frame1): scans_M
+    std::vector<float> src; std::vector<int> src_off;
+    std::vector<velo_match> matches;
+    // current blocks
+    std::vector<velo_corr> corr;       // one per query
+    std::vector<Block> icp_blocks;     // valid ones, query order
+    std::vector<Block> vis_blocks;
+    std::vector<velo_good_match> good;
+    int threads = 1;
+    int shard_rank = 0, shard_world = 1;
+};
+
+void default_params(velo_params* p) {
+    std::memset(p, 0, sizeof(*p));
+    p->icp_skip = 200; p->f2f_iterations = 2; p->icp_iterations = 3;          // kitti.h:8-10
+    p->enable_icp = 1; p->enable_2d2d = 1; p->enable_3d2d = 1;                  // main.cpp:43-45,404
+    p->max_num_iterations = 50; p->max_consecutive_invalid_steps = 5;          // ceres defaults
+    p->weight_3D2D = 10; p->weight_2D2D = 500; p->weight_3DPD = 1;              // kitti.h:20-22
+    p->loss_thresh_3D2D = 0.01; p->loss_thresh_2D2D = 0.00002;                  // kitti.h:23-24
+    p->loss_thresh_3DPD = 0.1; p->loss_thresh_3D3D = 0.04;                      // kitti.h:25-26
+    p->outlier_reject = 5.0; p->correspondence_thresh_icp = 0.5;                // kitti.h:30-31
+    p->icp_norm_condition = 1e-5;                                               // kitti.h:32
+    p->function_tolerance = 1e-6; p->gradient_tolerance = 1e-10; p->parameter_tolerance = 1e-8;
+    p->initial_trust_region_radius = 1e4; p->max_trust_region_radius = 1e16;
+    p->min_trust_region_radius = 1e-32; p->min_relative_decrease = 1e-3;
+    p->min_lm_diagonal = 1e-6; p->max_lm_diagonal = 1e32;
+}
+
+void copy_cloud(const float* xyz, int64_t stride, const int32_t* off, int nr, std::vector<float>& dst,
+                std::vector<int>& doff) {
+    const int n = off[nr];
+    dst.resize((size_t)3 * n);
+    for (int i = 0; i < n; i++) {
+        const float* p = (const float*)((const char*)xyz + (size_t)i * stride);
+        dst[3 * i] = p[0]; dst[3 * i + 1] = p[1]; dst[3 * i + 2] = p[2];
+    }
+    doff.assign(off, off + nr + 1);
+}
+
+// util::transform_point  utility.h:97-103: rotate in double, add t, store to float.
+inline void transform_point(const float* p, const double x[6], float* out) {
+    const double pd[3] = {p[0], p[1], p[2]};
+    double y[3] = {0, 0, 0};
+    angle_axis_rotate_point<double>(x, pd, y);
+    out[0] = (float)(y[0] + x[3]);
+    out[1] = (float)(y[1] + x[4]);
+    out[2] = (float)(y[2] + x[5]);
+}
+
+// util::norm2 after util::subtract_assign  utility.h:35-39,51-53: float ops, widened to double on return.
+inline double sub_norm2(const float* a, const float* b) {
+    const float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+    return (double)(dx * dx + dy * dy + dz * dz);
+}
+
+// One query of the association loop, velo.h:808-874 (rows A1-A5).
+void associate_one(const Oracle& o, int sm, int smi, const double x[6], int iter, velo_corr* out) {
+    std::memset(out, 0, sizeof(*out));
+    out->src_ring = sm; out->src_idx = smi;
+    const float* pM0 = &o.src[3 * (size_t)(o.src_off[sm] + smi)];
+    float pM[3];
+    transform_point(pM0, x, pM);                                                  // velo.h:810
+    out->p[0] = pM0[0]; out->p[1] = pM0[1]; out->p[2] = pM0[2];                   // velo.h:809
+    int np_i = 0, np_j = 0, np_k = 0, np_s_i = -1, np_s_j = -1;
+    double np_dist_i = kInf, np_dist_j = kInf;
+    const double it = (double)iter;
+    const double gate = o.P.correspondence_thresh_icp / it / it / it / it;        // velo.h:829
+    const int Rs = (int)o.trees.size();
+    for (int ss = 0; ss < Rs; ss++) {                                             // velo.h:825
+        int id; float d2;
+        if (o.trees[ss].nearest(pM, &id, &d2) <= 0 || (double)d2 > gate) continue;
+        const float* np = &o.tgt[3 * (size_t)(o.tgt_off[ss] + id)];
+        const double d = sub_norm2(np, pM);                                       // velo.h:834-835
+        if (d < np_dist_i) {
+            np_dist_j = np_dist_i; np_j = np_i; np_s_j = np_s_i;
+            np_dist_i = d; np_i = id; np_s_i = ss;
+        } else if (d < np_dist_j) {
+            np_dist_j = d; np_j = id; np_s_j = ss;
+        }
+    }
+    out->ring_i = np_s_i; out->idx_i = np_i; out->ring_j = np_s_j; out->idx_j = np_j;
+    out->dist_i = (float)np_dist_i; out->dist_j = (float)np_dist_j;
+    if (np_s_i == -1 || np_s_j == -1) return;                                     // velo.h:849-851
+    const float* ring_i = &o.tgt[3 * (size_t)o.tgt_off[np_s_i]];
+    const int n = o.tgt_off[np_s_i + 1] - o.tgt_off[np_s_i];
+    const int k1 = (np_i + 1) % n, k2 = (np_i - 1 + n) % n;                       // velo.h:852-854
+    np_k = (sub_norm2(ring_i + 3 * k1, pM) < sub_norm2(ring_i + 3 * k2, pM)) ? k1 : k2;  // velo.h:859
+    out->idx_k = np_k;
+    const float* v0 = ring_i + 3 * np_i;
+    const float* v1 = &o.tgt[3 * (size_t)(o.tgt_off[np_s_j] + np_j)];
+    const float* v2 = ring_i + 3 * np_k;
+    // Eigen::Vector3f arithmetic, velo.h:868-874: (v1-v0).cross(v2-v0), norm(), N /= norm()
+    const float a[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
+    const float b[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
+    float N[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+    const float nn = std::sqrt(N[0] * N[0] + N[1] * N[1] + N[2] * N[2]);
+    if ((double)nn < o.P.icp_norm_condition) return;                              // velo.h:873
+    N[0] /= nn; N[1] /= nn; N[2] /= nn;
+    out->n[0] = N[0]; out->n[1] = N[1]; out->n[2] = N[2];
+    out->v0[0] = v0[0]; out->v0[1] = v0[1]; out->v0[2] = v0[2];
+    out->valid = 1;
+}
+
+// the query list of one round: for sm, for smi += icp_skip  (velo.h:806-807), optionally one shard of it
+void query_list(const Oracle& o, std::vector<std::pair<int, int>>& q) {
+    q.clear();
+    if (!o.P.enable_icp) return;
+    const int Rm = (int)o.src_off.size() - 1;
+    for (int sm = 0; sm < Rm; sm++) {
+        const int n = o.src_off[sm + 1] - o.src_off[sm];
+        for (int smi = 0; smi < n; smi += o.P.icp_skip) q.emplace_back(sm, smi);
+    }
+    if (o.shard_world > 1) {
+        const int64_t nq = (int64_t)q.size();
+        const int64_t lo = nq * o.shard_rank / o.shard_world, hi = nq * (o.shard_rank + 1) / o.shard_world;
+        std::vector<std::pair<int, int>> s(q.begin() + lo, q.begin() + hi);
+        q.swap(s);
+    }
+}
+
+int associate(Oracle& o, const double x[6], int iter) {
+    std::vector<std::pair<int, int>> q;
+    query_list(o, q);
+    o.corr.resize(q.size());
+    const int nq = (int)q.size();
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64) num_threads(o.threads)
+#endif
+    for (int i = 0; i < nq; i++) associate_one(o, q[i].first, q[i].second, x, iter, &o.corr[i]);
+    o.icp_blocks.clear();
+    for (int i = 0; i < nq; i++) {
+        const velo_corr& c = o.corr[i];
+        if (!c.valid) continue;
+        Block b; b.kind = K_3DPD;                                                 // velo.h:875-892
+        for (int k = 0; k < 3; k++) { b.c[k] = c.p[k]; b.c[3 + k] = c.n[k]; b.c[6 + k] = c.v0[k]; }
+        b.loss = Loss{1, o.P.loss_thresh_3DPD, o.P.weight_3DPD};
+        o.icp_blocks.push_back(b);
+    }
+    return (int)o.icp_blocks.size();
+}
+
+// Visual block selection + outlier gate, velo.h:622-792 (row G1).
+int build_visual(Oracle& o, const double x[6], int iter) {
+    o.vis_blocks.clear(); o.good.clear();
+    const velo_params& P = o.P;
+    for (const velo_match& m : o.matches) {
+        const bool d1 = m.d1 != 0, d2 = m.d2 != 0;
+        double r[3];
+        auto push = [&](const Block& b, int type) {
+            o.vis_blocks.push_back(b);
+            o.good.push_back(velo_good_match{m.cam, m.point1, m.point2, type});
+        };
+        if (d1 && d2) {                                                           // velo.h:662-693
+            Block b; b.kind = K_3D3D;
+            for (int k = 0; k < 3; k++) { b.c[k] = m.p3_1[k]; b.c[3 + k] = m.p3_2[k]; }
+            b.loss = Loss{2, P.loss_thresh_3D3D, 1.0};
+            block_eval(b.kind, b.c, x, r, nullptr);
+            const double th = P.loss_thresh_3D3D * P.outlier_reject / iter;
+            if (iter > 1 && r[0] * r[0] + r[1] * r[1] + r[2] * r[2] > th * th) continue;
+            push(b, VELO_RESIDUAL_3D3D);
+        }
+        if (!d1 && !d2) {                                                         // velo.h:694-722
+            if (P.enable_2d2d) {
+                Block b; b.kind = K_2D2D;
+                b.c[0] = m.p2_1[0]; b.c[1] = m.p2_1[1]; b.c[2] = m.p2_2[0]; b.c[3] = m.p2_2[1];
+                b.c[4] = m.t_cam[0]; b.c[5] = m.t_cam[1]; b.c[6] = m.t_cam[2];
+                b.loss = Loss{2, P.loss_thresh_2D2D, P.weight_2D2D};
+                block_eval(b.kind, b.c, x, r, nullptr);
+                // velo.h:709 writes abs(); restated with fabs (SURVEY.md row G1 gotcha)
+                if (iter > 1 && std::fabs(r[0]) > P.loss_thresh_2D2D * P.outlier_reject / iter) continue;
+                push(b, VELO_RESIDUAL_2D2D);
+            }
+        }
+        if (P.enable_3d2d) {
+            const double th = P.loss_thresh_3D2D * P.outlier_reject / iter;
+            if (d1) {                                                             // velo.h:724-756
+                Block b; b.kind = K_3D2D;
+                for (int k = 0; k < 3; k++) { b.c[k] = m.p3_1[k]; b.c[5 + k] = m.t_cam[k]; }
+                b.c[3] = m.p2_2[0]; b.c[4] = m.p2_2[1];
+                b.loss = Loss{2, P.loss_thresh_3D2D, P.weight_3D2D};
+                block_eval(b.kind, b.c, x, r, nullptr);
+                if (iter > 1 && r[0] * r[0] + r[1] * r[1] > th * th) continue;
+                push(b, VELO_RESIDUAL_3D2D);
+            }
+            if (d2) {                                                             // velo.h:757-789
+                Block b; b.kind = K_2D3D;
+                for (int k = 0; k < 3; k++) { b.c[k] = m.p3_2[k]; b.c[5 + k] = m.t_cam[k]; }
+                b.c[3] = m.p2_1[0]; b.c[4] = m.p2_1[1];
+                b.loss = Loss{2, P.loss_thresh_3D2D, P.weight_3D2D};
+                block_eval(b.kind, b.c, x, r, nullptr);
+                if (iter > 1 && r[0] * r[0] + r[1] * r[1] > th * th) continue;
+                push(b, VELO_RESIDUAL_2D3D);
+            }
+        }
+    }
+    return (int)o.vis_blocks.size();
+}
+
+// One Ceres evaluation [3P residual_block.cc + corrector.cc]: per block r, J (autodiff), s=|r|^2, rho(s);
+// cost += rho/2; rho'' <= 0 for Cauchy/Arctan so the corrector is r *= sqrt(rho'), J *= sqrt(rho').
+// Accumulates H = J^T J (full 6x6), g = J^T r.  Optional row output (visual blocks first, then ICP).
+struct EvalOut { double cost; double H[36]; double g[6]; };
+void evaluate(const Oracle& o, const double x[6], bool want_jac, EvalOut* out, double* rows_r, double* rows_J) {
+    out->cost = 0.0;
+    std::memset(out->H, 0, sizeof(out->H));
+    std::memset(out->g, 0, sizeof(out->g));
+    int row = 0;
+    auto run = [&](const std::vector<Block>& blocks) {
+        for (const Block& b : blocks) {
+            double r[3], J[18];
+            block_eval(b.kind, b.c, x, r, want_jac ? J : nullptr);
+            const int d = kind_dim(b.kind);
+            double s = 0.0;
+            for (int k = 0; k < d; k++) s += r[k] * r[k];
+            double rho[3];
+            loss_eval(b.loss, s, rho);
+            out->cost += 0.5 * rho[0];
+            const double sr = std::sqrt(rho[1]);
+            for (int k = 0; k < d; k++) {
+                const double rk = r[k] * sr;
+                if (rows_r) rows_r[row] = rk;
+                if (want_jac) {
+                    double Jk[6];
+                    for (int i = 0; i < 6; i++) Jk[i] = J[k * 6 + i] * sr;
+                    if (rows_J) for (int i = 0; i < 6; i++) rows_J[(size_t)row * 6 + i] = Jk[i];
+                    for (int i = 0; i < 6; i++) {
+                        out->g[i] += Jk[i] * rk;
+                        for (int j = 0; j < 6; j++) out->H[i * 6 + j] += Jk[i] * Jk[j];
+                    }
+                }
+                row++;
+            }
+        }
+    };
+    run(o.vis_blocks);   // visual blocks are added first (velo.h:622-792), ICP blocks after (velo.h:875-892)
+    run(o.icp_blocks);
+}
+
+// 6x6 SPD solve by Cholesky (what DENSE_SCHUR degenerates to for a single 6-dof block [3P])
+bool chol_solve6(const double A[36], const double b[6], double y[6]) {
+    double L[36];
+    std::memset(L, 0, sizeof(L));
+    for (int j = 0; j < 6; j++) {
+        double d = A[j * 6 + j];
+        for (int k = 0; k < j; k++) d -= L[j * 6 + k] * L[j * 6 + k];
+        if (!(d > 0.0) || !std::isfinite(d)) return false;
+        L[j * 6 + j] = std::sqrt(d);
+        for (int i = j + 1; i < 6; i++) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
+            L[i * 6 + j] = s / L[j * 6 + j];
+        }
+    }
+    double z[6];
+    for (int i = 0; i < 6; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * z[k]; z[i] = s / L[i * 6 + i]; }
+    for (int i = 5; i >= 0; i--) { double s = z[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * y[k]; y[i] = s / L[i * 6 + i]; }
+    for (int i = 0; i < 6; i++) if (!std::isfinite(y[i])) return false;
+    return true;
+}
+
+// ceres::Solve with trust-region Levenberg-Marquardt, all defaults (row S1) [3P].
+void solve(Oracle& o, double x[6], velo_solve_summary* S) {
+    const velo_params& P = o.P;
+    std::memset(S, 0, sizeof(*S));
+    S->n_icp_valid = (int)o.icp_blocks.size();
+    S->n_visual_blocks = (int)o.vis_blocks.size();
+    for (const Block& b : o.vis_blocks) S->n_visual_residuals += kind_dim(b.kind);
+    EvalOut E;
+    evaluate(o, x, true, &E, nullptr, nullptr);
+    S->evaluations = 1;
+    double cost = E.cost;
+    S->initial_cost = cost; S->final_cost = cost;
+    double x_norm = 0; for (int i = 0; i < 6; i++) x_norm += x[i] * x[i]; x_norm = std::sqrt(x_norm);
+    auto gmax = [&](const EvalOut& e) { double m = 0; for (int i = 0; i < 6; i++) m = std::max(m, std::fabs(e.g[i])); return m; };
+    if (gmax(E) <= P.gradient_tolerance) { S->termination = VELO_CONVERGENCE; return; }
+    double scale[6];   // Jacobi scaling, once per solve: 1/(1+||J[:,j]||)
+    for (int j = 0; j < 6; j++) scale[j] = 1.0 / (1.0 + std::sqrt(E.H[j * 6 + j]));
+    double radius = P.initial_trust_region_radius, decrease = 2.0;
+    bool reuse_diag = false;
+    double diag[6];
+    int invalid = 0;
+    S->termination = VELO_NO_CONVERGENCE;
+    for (int it = 1;; it++) {
+        if (it > P.max_num_iterations) { S->termination = VELO_NO_CONVERGENCE; break; }
+        if (radius < P.min_trust_region_radius) { S->termination = VELO_CONVERGENCE; break; }
+        S->lm_iterations = it;
+        double Hs[36], gs[6];
+        for (int i = 0; i < 6; i++) { gs[i] = E.g[i] * scale[i]; for (int j = 0; j < 6; j++) Hs[i * 6 + j] = E.H[i * 6 + j] * scale[i] * scale[j]; }
+        if (!reuse_diag) for (int j = 0; j < 6; j++) diag[j] = std::min(std::max(Hs[j * 6 + j], P.min_lm_diagonal), P.max_lm_diagonal);
+        double A[36];
+        std::memcpy(A, Hs, sizeof(A));
+        for (int j = 0; j < 6; j++) { const double l = std::sqrt(diag[j] / radius); A[j * 6 + j] += l * l; }
+        double y[6], step[6];
+        bool ok = chol_solve6(A, gs, y);
+        reuse_diag = true;
+        double model_change = 0.0;
+        if (ok) {
+            for (int i = 0; i < 6; i++) step[i] = -y[i];
+            double gd = 0, dHd = 0;
+            for (int i = 0; i < 6; i++) { gd += gs[i] * step[i]; for (int j = 0; j < 6; j++) dHd += step[i] * Hs[i * 6 + j] * step[j]; }
+            model_change = -(gd + 0.5 * dHd);
+            if (!(model_change > 0.0)) ok = false;
+        }
+        if (!ok) {  // invalid step
+            if (++invalid >= P.max_consecutive_invalid_steps) { S->termination = VELO_FAILURE; break; }
+            radius = radius / decrease; decrease *= 2.0; reuse_diag = true;
+            continue;
+        }
+        invalid = 0;
+        double xc[6], dn = 0;
+        for (int i = 0; i < 6; i++) { const double d = step[i] * scale[i]; xc[i] = x[i] + d; dn += d * d; }
+        dn = std::sqrt(dn);
+        EvalOut Ec;
+        evaluate(o, xc, true, &Ec, nullptr, nullptr);   // Ceres evaluates the cost only here and J after acceptance; same numbers
+        S->evaluations++;
+        if (dn <= P.parameter_tolerance * (x_norm + P.parameter_tolerance)) { S->termination = VELO_CONVERGENCE; break; }
+        const double cost_change = cost - Ec.cost;
+        if (std::fabs(cost_change) <= P.function_tolerance * cost) { S->termination = VELO_CONVERGENCE; break; }
+        const double q = cost_change / model_change;
+        if (q > P.min_relative_decrease) {
+            for (int i = 0; i < 6; i++) x[i] = xc[i];
+            cost = Ec.cost; E = Ec;
+            x_norm = 0; for (int i = 0; i < 6; i++) x_norm += x[i] * x[i]; x_norm = std::sqrt(x_norm);
+            if (gmax(E) <= P.gradient_tolerance) { S->termination = VELO_CONVERGENCE; break; }
+            const double t = 2.0 * q - 1.0;
+            radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
+            radius = std::min(P.max_trust_region_radius, radius);
+            decrease = 2.0; reuse_diag = false;
+        } else {
+            radius = radius / decrease; decrease *= 2.0; reuse_diag = true;
+        }
+    }
+    S->final_cost = cost;
+}
+
+// util::pose_mat2vec  utility.h:67-82 (returns the MATRIX of a 6-vector), row-major out.
+void pose_vec_to_mat(const double x[6], double T[16]) {
+    for (int i = 0; i < 16; i++) T[i] = 0.0;
+    T[15] = 1.0;
+    for (int j = 0; j < 3; j++) {  // column j of R = R(omega) e_j  == ceres::AngleAxisToRotationMatrix [3P]
+        double e[3] = {0, 0, 0}, c[3];
+        e[j] = 1.0;
+        angle_axis_rotate_point<double>(x, e, c);
+        for (int i = 0; i < 3; i++) T[i * 4 + j] = c[i];
+    }
+    T[3] = x[3]; T[7] = x[4]; T[11] = x[5];
+}
+// util::pose_vec2mat  utility.h:83-96 via ceres::RotationMatrixToAngleAxis [3P] (quaternion route)
+void pose_mat_to_vec(const double T[16], double x[6]) {
+    const double R00 = T[0], R01 = T[1], R02 = T[2], R10 = T[4], R11 = T[5], R12 = T[6], R20 = T[8], R21 = T[9], R22 = T[10];
+    double q[4];
+    const double tr = R00 + R11 + R22;
+    if (tr >= 0.0) {
+        double t = std::sqrt(tr + 1.0);
+        q[0] = 0.5 * t; t = 0.5 / t;
+        q[1] = (R21 - R12) * t; q[2] = (R02 - R20) * t; q[3] = (R10 - R01) * t;
+    } else {
+        const double R[3][3] = {{R00, R01, R02}, {R10, R11, R12}, {R20, R21, R22}};
+        int i = 0;
+        if (R11 > R00) i = 1;
+        if (R22 > R[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        double t = std::sqrt(R[i][i] - R[j][j] - R[k][k] + 1.0);
+        q[i + 1] = 0.5 * t; t = 0.5 / t;
+        q[0] = (R[k][j] - R[j][k]) * t; q[j + 1] = (R[j][i] + R[i][j]) * t; q[k + 1] = (R[k][i] + R[i][k]) * t;
+    }
+    const double s2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    if (s2 > 0.0) {
+        const double s = std::sqrt(s2);
+        const double two_theta = 2.0 * ((q[0] < 0.0) ? std::atan2(-s, -q[0]) : std::atan2(s, q[0]));
+        const double k = two_theta / s;
+        x[0] = q[1] * k; x[1] = q[2] * k; x[2] = q[3] * k;
+    } else {
+        x[0] = q[1] * 2.0; x[1] = q[2] * 2.0; x[2] = q[3] * 2.0;
+    }
+    x[3] = T[3]; x[4] = T[7]; x[5] = T[11];
+}
+
+// frameToFrame  velo.h:616-919 (row D1)
+void frame_to_frame(Oracle& o, double x[6], double T[16], velo_summary* sum) {
+    velo_summary local;
+    velo_summary* S = sum ? sum : &local;
+    std::memset(S, 0, sizeof(*S));
+    S->n_target = (int)(o.tgt.size() / 3);
+    for (int iter = 1; iter <= o.P.f2f_iterations; iter++) {
+        build_visual(o, x, iter);
+        o.icp_blocks.clear();
+        for (int icp_iter = 0; icp_iter < o.P.icp_iterations; icp_iter++) {
+            associate(o, x, iter);
+            S->n_assoc_rounds++;
+            S->n_queries = (int)o.corr.size();
+            const uint64_t b_assoc = (uint64_t)12 * o.corr.size() + (uint64_t)12 * S->n_target + (uint64_t)28 * o.corr.size();
+            S->assoc_bytes += b_assoc; S->algorithmic_bytes += b_assoc;
+            velo_solve_summary ss;
+            solve(o, x, &ss);
+            S->algorithmic_bytes += (uint64_t)ss.evaluations * ((uint64_t)36 * ss.n_icp_valid + (uint64_t)32 * ss.n_visual_blocks + 224);
+            if (S->n_solves < VELO_MAX_SOLVES) S->solves[S->n_solves] = ss;
+            S->n_solves++;
+        }
+    }
+    if (T) pose_vec_to_mat(x, T);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C entry points (ctypes); same shapes as include/velo_hip.h so the parity tests read alike.
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+void* vo_create(void) { Oracle* o = new Oracle(); default_params(&o->P); return o; }
+void vo_destroy(void* h) { delete (Oracle*)h; }
+int vo_default_params(velo_params* p) { default_params(p); return 0; }
+int vo_set_params(void* h, const velo_params* p) { ((Oracle*)h)->P = *p; return 0; }
+int vo_set_threads(void* h, int n) { ((Oracle*)h)->threads = n < 1 ? 1 : n; return 0; }
+int vo_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+int vo_set_query_shard(void* h, int rank, int world) {
+    Oracle* o = (Oracle*)h;
+    if (world < 1 || rank < 0 || rank >= world) return -1;
+    o->shard_rank = rank; o->shard_world = world; return 0;
+}
+int vo_set_target(void* h, const float* xyz, int64_t stride, const int32_t* off, int32_t nr) {
+    Oracle* o = (Oracle*)h;
+    copy_cloud(xyz, stride, off, nr, o->tgt, o->tgt_off);
+    o->trees.assign(nr, KdTree());
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) num_threads(o->threads)
+#endif
+    for (int r = 0; r < nr; r++) o->trees[r].build(&o->tgt[3 * (size_t)off[r]], off[r + 1] - off[r]);  // lru.h:17-20
+    return 0;
+}
+int vo_set_source(void* h, const float* xyz, int64_t stride, const int32_t* off, int32_t nr) {
+    Oracle* o = (Oracle*)h;
+    copy_cloud(xyz, stride, off, nr, o->src, o->src_off);
+    return 0;
+}
+int vo_set_visual(void* h, const velo_match* m, int32_t n) {
+    Oracle* o = (Oracle*)h;
+    o->matches.assign(m, m + n);
+    return 0;
+}
+int vo_associate(void* h, const double* x, int32_t iter, int32_t* n_valid) {
+    const int n = associate(*(Oracle*)h, x, iter);
+    if (n_valid) *n_valid = n;
+    return 0;
+}
+int vo_get_correspondences(void* h, velo_corr* out, int32_t cap, int32_t* nq) {
+    Oracle* o = (Oracle*)h;
+    const int n = (int)o->corr.size();
+    if (nq) *nq = n;
+    if (out) std::memcpy(out, o->corr.data(), sizeof(velo_corr) * (size_t)std::min(n, cap));
+    return 0;
+}
+int vo_build_visual(void* h, const double* x, int32_t iter, int32_t* nb) {
+    const int n = build_visual(*(Oracle*)h, x, iter);
+    if (nb) *nb = n;
+    return 0;
+}
+int vo_get_good_matches(void* h, velo_good_match* out, int32_t cap, int32_t* n) {
+    Oracle* o = (Oracle*)h;
+    const int m = (int)o->good.size();
+    if (n) *n = m;
+    if (out) std::memcpy(out, o->good.data(), sizeof(velo_good_match) * (size_t)std::min(m, cap));
+    return 0;
+}
+int vo_evaluate(void* h, const double* x, double* cost, double* JtJ, double* Jtr) {
+    EvalOut E;
+    evaluate(*(Oracle*)h, x, true, &E, nullptr, nullptr);
+    if (cost) *cost = E.cost;
+    if (JtJ) std::memcpy(JtJ, E.H, sizeof(E.H));
+    if (Jtr) std::memcpy(Jtr, E.g, sizeof(E.g));
+    return 0;
+}
+int vo_evaluate_rows(void* h, const double* x, double* res, double* jac, int32_t cap, int32_t* n_rows) {
+    Oracle* o = (Oracle*)h;
+    int rows = (int)o->icp_blocks.size();
+    for (const Block& b : o->vis_blocks) rows += kind_dim(b.kind);
+    if (n_rows) *n_rows = rows;
+    if (cap < rows) return -1;
+    EvalOut E;
+    evaluate(*o, x, true, &E, res, jac);
+    return 0;
+}
+int vo_solve(void* h, double* x, velo_solve_summary* s) {
+    velo_solve_summary tmp;
+    solve(*(Oracle*)h, x, s ? s : &tmp);
+    return 0;
+}
+int vo_frame_to_frame(void* h, double* x, double* T, velo_summary* s) {
+    frame_to_frame(*(Oracle*)h, x, T, s);
+    return 0;
+}
+int vo_pose_vec_to_mat(const double* x, double* T) { pose_vec_to_mat(x, T); return 0; }
+int vo_pose_mat_to_vec(const double* T, double* x) { pose_mat_to_vec(T, x); return 0; }
+
+// --- test hooks -----------------------------------------------------------------------------------
+// one functor, raw: kind 0..3 = ResidualType order, 4 = cost3DPD; c = constructor args widened to double
+int vo_functor(int kind, const double* c, const double* x, double* r, double* J) { block_eval(kind, c, x, r, J); return kind_dim(kind); }
+int vo_loss(int type, double a, double w, double s, double* rho) { loss_eval(Loss{type, a, w}, s, rho); return 0; }
+int vo_transform_point(const float* p, const double* x, float* out) { transform_point(p, x, out); return 0; }
+int vo_rotate_point(const double* w, const double* p, double* out) { angle_axis_rotate_point<double>(w, p, out); return 0; }
+// exact 1-NN of q in ring r by the tree and by brute force (lowest index on ties); returns found count
+int vo_ring_nn(void* h, int ring, const float* q, int* idx_tree, float* d_tree, int* idx_brute, float* d_brute) {
+    Oracle* o = (Oracle*)h;
+    const int n = o->tgt_off[ring + 1] - o->tgt_off[ring];
+    const float* base = &o->tgt[3 * (size_t)o->tgt_off[ring]];
+    const int f = o->trees[ring].nearest(q, idx_tree, d_tree);
+    float best = FLT_MAX; int bi = -1;
+    for (int i = 0; i < n; i++) { const float d = dist2f(q, base + 3 * i); if (d < best) { best = d; bi = i; } }
+    *idx_brute = bi; *d_brute = best;
+    return f;
+}
+
+}  // extern "C"

@@ -1,0 +1,37 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_present() -> bool:
+    return os.path.exists("/dev/kfd")
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The product library; GPU tests fail loudly (no skip, no fallback) when it is missing."""
+    import velo_amd  # noqa: F401
+    from velo_amd import api
+    return api.load_library()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    oracle_lib.lib()
+    return oracle_lib
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` on a box without a GPU is a usage error we want to see, so nothing is skipped silently here.
+    return

@@ -1,0 +1,215 @@
+"""ctypes wrapper of oracle/_build/libvelo_oracle.so -- the CHECKER.  Lives under tests/ because only tests,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg may touch the oracle."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import velo_amd  # noqa: F401  (import shim)
+from velo_amd.api import (CORR_DTYPE, GOOD_DTYPE, MATCH_DTYPE, VeloParams, VeloSolveSummary, VeloSummary,
+                          matches_from_dict)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "libvelo_oracle.so")
+
+_dp = C.POINTER(C.c_double)
+_lib = None
+
+
+def build_oracle(force: bool = False) -> str:
+    src = os.path.join(ORACLE_DIR, "velo_oracle.cpp")
+    hdr = os.path.join(ROOT, "include", "velo_hip.h")
+    if (force or not os.path.exists(ORACLE_SO)
+            or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        subprocess.run(["make", "-C", ORACLE_DIR, "-B"], check=True, stdout=subprocess.DEVNULL)
+    return ORACLE_SO
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build_oracle())
+        _lib.vo_create.restype = C.c_void_p
+        for name in ("vo_destroy", "vo_set_params", "vo_set_threads", "vo_set_target", "vo_set_source",
+                     "vo_set_visual", "vo_associate", "vo_get_correspondences", "vo_build_visual",
+                     "vo_get_good_matches", "vo_evaluate", "vo_evaluate_rows", "vo_solve", "vo_frame_to_frame",
+                     "vo_ring_nn", "vo_set_query_shard", "vo_max_threads"):
+            getattr(_lib, name).restype = C.c_int
+    return _lib
+
+
+def _d(a, n):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+    assert a.size == n
+    return a
+
+
+def default_params() -> VeloParams:
+    p = VeloParams()
+    lib().vo_default_params(C.byref(p))
+    return p
+
+
+def max_threads() -> int:
+    return lib().vo_max_threads()
+
+
+class Oracle:
+    def __init__(self, threads: int = 1, **params):
+        self._l = lib()
+        self._h = C.c_void_p(self._l.vo_create())
+        self._l.vo_set_threads(self._h, int(threads))
+        self.params = default_params()
+        if params:
+            self.set_params(**params)
+
+    def __del__(self):
+        try:
+            self._l.vo_destroy(self._h)
+        except Exception:
+            pass
+
+    def set_params(self, **kw):
+        for k, v in kw.items():
+            assert hasattr(self.params, k), k
+            setattr(self.params, k, v)
+        self._l.vo_set_params(self._h, C.byref(self.params))
+
+    def set_threads(self, n):
+        self._l.vo_set_threads(self._h, int(n))
+
+    def set_query_shard(self, rank, world):
+        assert self._l.vo_set_query_shard(self._h, int(rank), int(world)) == 0
+
+    def set_target(self, xyz, off):
+        a = np.ascontiguousarray(xyz, dtype=np.float32)
+        o = np.ascontiguousarray(off, dtype=np.int32)
+        self._l.vo_set_target(self._h, C.c_void_p(a.ctypes.data), C.c_int64(a.strides[0]),
+                              C.c_void_p(o.ctypes.data), C.c_int32(len(o) - 1))
+
+    def set_source(self, xyz, off):
+        a = np.ascontiguousarray(xyz, dtype=np.float32)
+        o = np.ascontiguousarray(off, dtype=np.int32)
+        self._l.vo_set_source(self._h, C.c_void_p(a.ctypes.data), C.c_int64(a.strides[0]),
+                              C.c_void_p(o.ctypes.data), C.c_int32(len(o) - 1))
+
+    def set_visual(self, matches):
+        if isinstance(matches, dict):
+            matches = matches_from_dict(matches)
+        m = np.ascontiguousarray(matches, dtype=MATCH_DTYPE)
+        self._l.vo_set_visual(self._h, C.c_void_p(m.ctypes.data), C.c_int32(len(m)))
+
+    def associate(self, x, it):
+        n = C.c_int32(0)
+        xv = _d(x, 6)
+        self._l.vo_associate(self._h, xv.ctypes.data_as(_dp), C.c_int32(it), C.byref(n))
+        return n.value
+
+    def correspondences(self):
+        n = C.c_int32(0)
+        self._l.vo_get_correspondences(self._h, None, C.c_int32(0), C.byref(n))
+        out = np.zeros(n.value, dtype=CORR_DTYPE)
+        self._l.vo_get_correspondences(self._h, C.c_void_p(out.ctypes.data), n, C.byref(n))
+        return out
+
+    def build_visual(self, x, it):
+        n = C.c_int32(0)
+        xv = _d(x, 6)
+        self._l.vo_build_visual(self._h, xv.ctypes.data_as(_dp), C.c_int32(it), C.byref(n))
+        return n.value
+
+    def good_matches(self):
+        n = C.c_int32(0)
+        self._l.vo_get_good_matches(self._h, None, C.c_int32(0), C.byref(n))
+        out = np.zeros(n.value, dtype=GOOD_DTYPE)
+        self._l.vo_get_good_matches(self._h, C.c_void_p(out.ctypes.data), n, C.byref(n))
+        return out
+
+    def evaluate(self, x):
+        xv = _d(x, 6)
+        cost = C.c_double(0)
+        H = np.zeros(36)
+        g = np.zeros(6)
+        self._l.vo_evaluate(self._h, xv.ctypes.data_as(_dp), C.byref(cost), H.ctypes.data_as(_dp),
+                            g.ctypes.data_as(_dp))
+        return cost.value, H.reshape(6, 6), g
+
+    def evaluate_rows(self, x):
+        xv = _d(x, 6)
+        n = C.c_int32(0)
+        self._l.vo_evaluate_rows(self._h, xv.ctypes.data_as(_dp), None, None, C.c_int32(0), C.byref(n))
+        r = np.zeros(n.value)
+        J = np.zeros((n.value, 6))
+        self._l.vo_evaluate_rows(self._h, xv.ctypes.data_as(_dp), r.ctypes.data_as(_dp), J.ctypes.data_as(_dp),
+                                 n, C.byref(n))
+        return r, J
+
+    def solve(self, x):
+        xv = _d(x, 6).copy()
+        s = VeloSolveSummary()
+        self._l.vo_solve(self._h, xv.ctypes.data_as(_dp), C.byref(s))
+        return xv, s
+
+    def frame_to_frame(self, x0):
+        xv = _d(x0, 6).copy()
+        T = np.zeros(16)
+        s = VeloSummary()
+        self._l.vo_frame_to_frame(self._h, xv.ctypes.data_as(_dp), T.ctypes.data_as(_dp), C.byref(s))
+        return xv, T.reshape(4, 4), s
+
+    def ring_nn(self, ring, q):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        it, ib = C.c_int(0), C.c_int(0)
+        dt, db = C.c_float(0), C.c_float(0)
+        f = self._l.vo_ring_nn(self._h, C.c_int(ring), C.c_void_p(q.ctypes.data), C.byref(it), C.byref(dt),
+                               C.byref(ib), C.byref(db))
+        return f, it.value, dt.value, ib.value, db.value
+
+
+def functor(kind: int, c, x):
+    """(residuals, jacobian dim x 6) of one residual functor at x; kind 0..3 = ResidualType order, 4 = cost3DPD."""
+    cv = np.zeros(9)
+    cv[:len(c)] = c
+    xv = _d(x, 6)
+    r = np.zeros(3)
+    J = np.zeros(18)
+    d = lib().vo_functor(C.c_int(kind), cv.ctypes.data_as(_dp), xv.ctypes.data_as(_dp), r.ctypes.data_as(_dp),
+                         J.ctypes.data_as(_dp))
+    return r[:d].copy(), J[:6 * d].reshape(d, 6).copy()
+
+
+def loss(type_: int, a: float, w: float, s: float):
+    rho = np.zeros(3)
+    lib().vo_loss(C.c_int(type_), C.c_double(a), C.c_double(w), C.c_double(s), rho.ctypes.data_as(_dp))
+    return rho
+
+
+def transform_point(p, x):
+    p = np.ascontiguousarray(p, dtype=np.float32)
+    out = np.zeros(3, dtype=np.float32)
+    xv = _d(x, 6)
+    lib().vo_transform_point(C.c_void_p(p.ctypes.data), xv.ctypes.data_as(_dp), C.c_void_p(out.ctypes.data))
+    return out
+
+
+def rotate_point(w, p):
+    wv, pv = _d(w, 3), _d(p, 3)
+    out = np.zeros(3)
+    lib().vo_rotate_point(wv.ctypes.data_as(_dp), pv.ctypes.data_as(_dp), out.ctypes.data_as(_dp))
+    return out
+
+
+def pose_vec_to_mat(x):
+    T = np.zeros(16)
+    lib().vo_pose_vec_to_mat(_d(x, 6).ctypes.data_as(_dp), T.ctypes.data_as(_dp))
+    return T.reshape(4, 4)
+
+
+def pose_mat_to_vec(T):
+    x = np.zeros(6)
+    lib().vo_pose_mat_to_vec(_d(T, 16).ctypes.data_as(_dp), x.ctypes.data_as(_dp))
+    return x

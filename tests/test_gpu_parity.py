@@ -1,0 +1,241 @@
+"""-m gpu: the HIP path (through the C-ABI, via ctypes) against the CPU oracle on identical seeded inputs.
+
+Bars: correspondence tables index-exact and bit-exact, JtJ/Jtr/cost <= 1e-12 relative,
+solved pose within 1e-4 m / 1e-5 rad (north_star)."""
+import numpy as np
+import pytest
+
+import helpers as H
+from velo_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def ctx(hip_lib):
+    c = api.Context(0)
+    yield c
+    c.close()
+
+
+def test_default_params_match_header_python_and_oracle(hip_lib, oracle):
+    import ctypes as C
+    p = api.VeloParams()
+    assert hip_lib.velo_default_params(C.byref(p)) == 0
+    q = api.default_params()
+    o = oracle.default_params()
+    for name, _ in api.VeloParams._fields_:
+        assert getattr(p, name) == getattr(q, name) == getattr(o, name), name
+
+
+@pytest.mark.parametrize("iter_", [1, 2])
+@pytest.mark.parametrize("skip", [1, 7])
+def test_association_index_exact(ctx, oracle, iter_, skip):
+    d = H.small_pair(16, 128)
+    orc = oracle.Oracle(threads=4)
+    H.load_both(ctx, orc, d, icp_skip=skip)
+    for x in (d["x0"], d["x_true"], np.zeros(6), [0.3, -0.2, 0.1, 0.5, -0.25, 2.0]):
+        n_gpu = ctx.associate(x, iter_)
+        n_cpu = orc.associate(x, iter_)
+        a, b = ctx.correspondences(), orc.correspondences()
+        H.assert_corr_equal(a, b)
+        assert n_gpu == n_cpu == int(a["valid"].sum())
+
+
+def test_association_medium_cloud(ctx, oracle):
+    d = H.small_pair(32, 512)
+    orc = oracle.Oracle(threads=8)
+    H.load_both(ctx, orc, d, icp_skip=1)
+    for it in (1, 2, 3):
+        assert ctx.associate(d["x0"], it) == orc.associate(d["x0"], it)
+        H.assert_corr_equal(ctx.correspondences(), orc.correspondences())
+
+
+def test_evaluate_normal_equations(ctx, oracle):
+    d = H.small_pair(16, 128)
+    orc = oracle.Oracle(threads=4)
+    H.load_both(ctx, orc, d, icp_skip=1)
+    ctx.associate(d["x0"], 1)
+    orc.associate(d["x0"], 1)
+    for x in (d["x0"], d["x_true"], np.zeros(6), [1e-9, 0, 0, 0, 0, 1.0], [0.3, -0.2, 0.1, 0.5, -0.25, 2.0]):
+        c1, H1, g1 = ctx.evaluate(x)
+        c2, H2, g2 = orc.evaluate(x)
+        assert abs(c1 - c2) <= 1e-12 * max(abs(c2), 1e-300)
+        assert H.rel_err(H1, H2) <= 1e-12
+        assert H.rel_err(g1, g2) <= 1e-12
+
+
+def test_evaluate_rows_match(ctx, oracle):
+    d = H.small_pair(16, 64)
+    vis = synth.stereo_matches(n_per_cam=40, mix="all")
+    orc = oracle.Oracle()
+    H.load_both(ctx, orc, d, visual=vis, icp_skip=3)
+    x = d["x0"] + 0.01
+    assert ctx.build_visual(x, 1) == orc.build_visual(x, 1)
+    assert ctx.associate(x, 1) == orc.associate(x, 1)
+    r1, J1 = ctx.evaluate_rows(x)
+    r2, J2 = orc.evaluate_rows(x)
+    assert r1.shape == r2.shape and J1.shape == J2.shape and len(r1) > 0
+    np.testing.assert_allclose(r1, r2, rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(J1, J2, rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("mix", ["reproj", "all"])
+@pytest.mark.parametrize("iter_", [1, 2])
+def test_visual_gate_and_evaluate(ctx, oracle, mix, iter_):
+    d = H.small_pair(8, 64)
+    vis = synth.stereo_matches(n_per_cam=150, mix=mix)
+    orc = oracle.Oracle()
+    H.load_both(ctx, orc, d, visual=vis, icp_skip=4)
+    for x in (d["x_true"], d["x0"]):
+        assert ctx.build_visual(x, iter_) == orc.build_visual(x, iter_)
+        g1, g2 = ctx.good_matches(), orc.good_matches()
+        assert np.array_equal(g1, g2)
+        c1, H1, gg1 = ctx.evaluate(x)     # no association yet on a fresh table -> visual blocks only
+        c2, H2, gg2 = orc.evaluate(x)
+        assert abs(c1 - c2) <= 1e-12 * abs(c2)
+        assert H.rel_err(H1, H2) <= 1e-12 and H.rel_err(gg1, gg2) <= 1e-12
+
+
+def test_single_solve_matches(ctx, oracle):
+    d = H.small_pair(16, 128)
+    orc = oracle.Oracle(threads=4)
+    H.load_both(ctx, orc, d, icp_skip=1)
+    ctx.associate(d["x0"], 1)
+    orc.associate(d["x0"], 1)
+    x1, s1 = ctx.solve(d["x0"])
+    x2, s2 = orc.solve(d["x0"])
+    assert s1.termination == s2.termination
+    assert s1.lm_iterations == s2.lm_iterations and s1.evaluations == s2.evaluations
+    assert s1.n_icp_valid == s2.n_icp_valid
+    assert abs(s1.final_cost - s2.final_cost) <= 1e-10 * s2.final_cost
+    assert H.pose_close(x1, x2, 1e-9, 1e-10)
+
+
+@pytest.mark.parametrize("shape", [(16, 128), (32, 400)])
+def test_frame_to_frame_pose_parity(ctx, oracle, shape):
+    d = H.small_pair(*shape)
+    orc = oracle.Oracle(threads=8)
+    H.load_both(ctx, orc, d, icp_skip=1)
+    x1, T1, s1 = ctx.frame_to_frame(d["x0"])
+    x2, T2, s2 = orc.frame_to_frame(d["x0"])
+    assert H.pose_close(x1, x2), (x1, x2)                       # 1e-4 m / 1e-5 rad
+    assert s1.n_solves == s2.n_solves == 6
+    for k in range(6):
+        a, b = s1.solves[k], s2.solves[k]
+        assert (a.termination, a.lm_iterations, a.evaluations, a.n_icp_valid) == \
+               (b.termination, b.lm_iterations, b.evaluations, b.n_icp_valid)
+    assert s1.algorithmic_bytes == s2.algorithmic_bytes
+    np.testing.assert_allclose(T1, T2, atol=1e-6)
+    # and both recover the simulated motion to noise level
+    assert np.linalg.norm(x1[3:] - d["x_true"][3:]) < 5e-3 and np.linalg.norm(x1[:3] - d["x_true"][:3]) < 2e-3
+
+
+def test_frame_to_frame_with_visual(ctx, oracle):
+    d = H.small_pair(16, 128)
+    vis = synth.stereo_matches(n_per_cam=200, mix="all")
+    orc = oracle.Oracle(threads=4)
+    H.load_both(ctx, orc, d, visual=vis, icp_skip=2)
+    x1, _, s1 = ctx.frame_to_frame(d["x0"])
+    x2, _, s2 = orc.frame_to_frame(d["x0"])
+    assert H.pose_close(x1, x2), (x1, x2)
+    assert np.array_equal(ctx.good_matches(), orc.good_matches())
+    for k in range(6):
+        assert s1.solves[k].n_visual_blocks == s2.solves[k].n_visual_blocks
+        assert s1.solves[k].n_visual_residuals == s2.solves[k].n_visual_residuals
+
+
+def test_reference_constants_config1(ctx, oracle):
+    """BASELINE config 1 shape: reference constants (icp_skip=200) on a full 64x1875 KITTI-layout pair."""
+    d = synth.scan_pair()
+    orc = oracle.Oracle(threads=8)
+    H.load_both(ctx, orc, d)           # defaults = reference constants
+    x1, _, s1 = ctx.frame_to_frame(d["x0"])
+    x2, _, s2 = orc.frame_to_frame(d["x0"])
+    assert s1.n_queries == s2.n_queries == 64 * 10
+    assert H.pose_close(x1, x2), (x1, x2)
+
+
+def test_query_shards_sum_to_whole(ctx, oracle):
+    """Multi-GPU contract on one GPU: the per-shard normal equations add up to the unsharded ones."""
+    d = H.small_pair(16, 128)
+    ctx.set_params(icp_skip=1)
+    ctx.set_target(d["tgt_xyz"], d["tgt_off"])
+    ctx.set_source(d["src_xyz"], d["src_off"])
+    x = d["x0"]
+    ctx.associate(x, 1)
+    c0, H0, g0 = ctx.evaluate(x)
+    whole = ctx.correspondences()
+    acc_c, acc_H, acc_g, parts = 0.0, np.zeros((6, 6)), np.zeros(6), []
+    for r in range(3):
+        ctx.set_query_shard(r, 3)
+        ctx.associate(x, 1)
+        parts.append(ctx.correspondences())
+        c, Hm, g = ctx.evaluate(x)
+        acc_c += c
+        acc_H += Hm
+        acc_g += g
+    ctx.set_query_shard(0, 1)
+    assert np.array_equal(np.concatenate(parts), whole)
+    assert abs(acc_c - c0) <= 1e-12 * c0 and H.rel_err(acc_H, H0) <= 1e-12 and H.rel_err(acc_g, g0) <= 1e-12
+
+
+def test_edge_cases(ctx, oracle):
+    d = H.small_pair(4, 32)
+    orc = oracle.Oracle()
+    # far-away guess: no ring within the gate -> zero blocks, solve converges immediately, x unchanged
+    H.load_both(ctx, orc, d, icp_skip=1)
+    far = np.array([0, 0, 0, 500.0, 0, 0])
+    assert ctx.associate(far, 1) == orc.associate(far, 1) == 0
+    x1, s1 = ctx.solve(far)
+    x2, s2 = orc.solve(far)
+    assert np.array_equal(x1, far) and np.array_equal(x2, far)
+    assert s1.termination == s2.termination == 0 and s1.lm_iterations == s2.lm_iterations == 0
+    # single-ring target: never two distinct rings -> nothing valid
+    one = dict(d)
+    one["tgt_xyz"], one["tgt_off"] = d["tgt_xyz"][:32], np.array([0, 32], dtype=np.int32)
+    H.load_both(ctx, orc, one, icp_skip=1)
+    assert ctx.associate(d["x_true"], 1) == orc.associate(d["x_true"], 1) == 0
+    H.assert_corr_equal(ctx.correspondences(), orc.correspondences())
+    # ragged rings (different lengths, one of length 1) and 16-byte stride input
+    offs = np.array([0, 1, 20, 52, 128], dtype=np.int32)
+    rag = dict(d)
+    rag["tgt_off"] = offs
+    xyz4 = np.zeros((128, 4), dtype=np.float32)
+    xyz4[:, :3] = d["tgt_xyz"]
+    ctx.set_target(xyz4, offs)
+    orc.set_target(d["tgt_xyz"], offs)
+    ctx.set_source(d["src_xyz"], d["src_off"])
+    orc.set_source(d["src_xyz"], d["src_off"])
+    assert ctx.associate(d["x_true"], 1) == orc.associate(d["x_true"], 1)
+    H.assert_corr_equal(ctx.correspondences(), orc.correspondences())
+
+
+def test_tie_breaks_and_wraparound(ctx, oracle):
+    """Equal distances across rings -> lower ring wins (velo.h:836,843); np_i = 0 / n-1 wrap (velo.h:852-854);
+    equal neighbour distances -> the -1 neighbour (velo.h:859); degenerate triangle -> skipped (velo.h:873).
+    Coordinates are multiples of 1/8 so that the ties are exact in float."""
+    u = np.float32(0.125)
+
+    def ring(y):
+        return np.stack([np.arange(5, dtype=np.float32) * u, np.full(5, y, np.float32), np.zeros(5, np.float32)], 1)
+
+    dup = np.tile(np.float32([[2 * u, 3 * u, 0]]), (5, 1))          # ring 3: five copies of one point
+    tgt = np.concatenate([ring(u), ring(-u), ring(-u), dup])        # rings 1 and 2 tie with ring 0 for y = 0 queries
+    off = np.array([0, 5, 10, 15, 20], dtype=np.int32)
+    src = np.array([[0, 0, 0], [4 * u, 0, 0], [2 * u, 0, 0], [2 * u, 3 * u, 0]], dtype=np.float32)
+    soff = np.array([0, 4], dtype=np.int32)
+    orc = oracle.Oracle()
+    for o in (ctx, orc):
+        o.set_params(icp_skip=1)
+        o.set_target(tgt, off)
+        o.set_source(src, soff)
+    x = np.zeros(6)
+    assert ctx.associate(x, 1) == orc.associate(x, 1) == 3
+    a, b = ctx.correspondences(), orc.correspondences()
+    H.assert_corr_equal(a, b)
+    assert list(a["ring_i"][:3]) == [0, 0, 0] and list(a["ring_j"][:3]) == [1, 1, 1]     # ties -> lowest rings
+    assert (a["idx_i"][0], a["idx_k"][0]) == (0, 1)        # neighbours 1 and 4 (wrap): 1 is closer
+    assert (a["idx_i"][1], a["idx_k"][1]) == (4, 3)        # neighbours 0 (wrap) and 3: 3 is closer
+    assert (a["idx_i"][2], a["idx_k"][2]) == (2, 1)        # equidistant neighbours -> the -1 one
+    assert a["valid"][3] == 0 and a["ring_i"][3] == 3 and a["idx_i"][3] == 0 and a["ring_j"][3] == 0   # |N| = 0

@@ -1,0 +1,365 @@
+"""ctypes mirror of include/velo_hip.h -- plumbing only, no arithmetic happens in Python.
+
+The shared library (csrc/libvelo_hip.so, built by build.py / __graft_entry__.build()) is the product.
+If it is missing or no MI355X is visible every entry point raises: there is NO CPU fallback and this
+module never imports anything from oracle/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvelo_hip.so")
+
+VELO_MAX_SOLVES = 64
+RESIDUAL_NAMES = {0: "3D3D", 1: "3D2D", 2: "2D3D", 3: "2D2D"}
+TERMINATION_NAMES = {0: "CONVERGENCE", 1: "NO_CONVERGENCE", 2: "FAILURE"}
+
+
+class VeloError(RuntimeError):
+    pass
+
+
+class VeloParams(C.Structure):
+    _fields_ = [
+        ("icp_skip", C.c_int32), ("f2f_iterations", C.c_int32), ("icp_iterations", C.c_int32),
+        ("enable_icp", C.c_int32), ("enable_2d2d", C.c_int32), ("enable_3d2d", C.c_int32),
+        ("max_num_iterations", C.c_int32), ("max_consecutive_invalid_steps", C.c_int32),
+        ("weight_3D2D", C.c_double), ("weight_2D2D", C.c_double), ("weight_3DPD", C.c_double),
+        ("loss_thresh_3D2D", C.c_double), ("loss_thresh_2D2D", C.c_double),
+        ("loss_thresh_3DPD", C.c_double), ("loss_thresh_3D3D", C.c_double),
+        ("outlier_reject", C.c_double), ("correspondence_thresh_icp", C.c_double),
+        ("icp_norm_condition", C.c_double),
+        ("function_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+        ("parameter_tolerance", C.c_double), ("initial_trust_region_radius", C.c_double),
+        ("max_trust_region_radius", C.c_double), ("min_trust_region_radius", C.c_double),
+        ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double),
+        ("max_lm_diagonal", C.c_double),
+    ]
+
+
+class VeloSolveSummary(C.Structure):
+    _fields_ = [
+        ("termination", C.c_int32), ("lm_iterations", C.c_int32), ("evaluations", C.c_int32),
+        ("n_icp_valid", C.c_int32), ("n_visual_blocks", C.c_int32), ("n_visual_residuals", C.c_int32),
+        ("initial_cost", C.c_double), ("final_cost", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class VeloSummary(C.Structure):
+    _fields_ = [
+        ("n_solves", C.c_int32), ("n_assoc_rounds", C.c_int32), ("n_queries", C.c_int32),
+        ("n_target", C.c_int32),
+        ("algorithmic_bytes", C.c_uint64), ("assoc_bytes", C.c_uint64),
+        ("assoc_kernel_ms", C.c_double), ("assoc_kernel_launches", C.c_int32),
+        ("eval_kernel_launches", C.c_int32), ("eval_kernel_ms", C.c_double),
+        ("solves", VeloSolveSummary * VELO_MAX_SOLVES),
+    ]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "solves"}
+        d["solves"] = [self.solves[i].as_dict() for i in range(min(self.n_solves, VELO_MAX_SOLVES))]
+        return d
+
+
+MATCH_DTYPE = np.dtype([
+    ("p3_1", np.float32, 3), ("p3_2", np.float32, 3), ("p2_1", np.float32, 2), ("p2_2", np.float32, 2),
+    ("t_cam", np.float32, 3), ("cam", np.int32), ("point1", np.int32), ("point2", np.int32),
+    ("d1", np.uint8), ("d2", np.uint8), ("pad", np.uint8, 2)], align=True)
+GOOD_DTYPE = np.dtype([("cam", np.int32), ("point1", np.int32), ("point2", np.int32),
+                       ("residual_type", np.int32)], align=True)
+CORR_DTYPE = np.dtype([
+    ("valid", np.int32), ("ring_i", np.int32), ("idx_i", np.int32), ("ring_j", np.int32),
+    ("idx_j", np.int32), ("idx_k", np.int32), ("src_ring", np.int32), ("src_idx", np.int32),
+    ("dist_i", np.float32), ("dist_j", np.float32),
+    ("p", np.float32, 3), ("n", np.float32, 3), ("v0", np.float32, 3)], align=True)
+assert MATCH_DTYPE.itemsize == 68 and GOOD_DTYPE.itemsize == 16 and CORR_DTYPE.itemsize == 76
+
+
+def matches_from_dict(rec: dict) -> np.ndarray:
+    """synth.stereo_matches() dict -> packed velo_match array."""
+    n = len(rec["cam"])
+    m = np.zeros(n, dtype=MATCH_DTYPE)
+    for k in ("p3_1", "p3_2", "p2_1", "p2_2", "t_cam", "cam", "point1", "point2", "d1", "d2"):
+        m[k] = rec[k]
+    return m
+
+
+def default_params() -> VeloParams:
+    """The reference's constants (kitti.h:8-10,20-32; main.cpp:43-45) + Ceres defaults, filled in Python so
+    that it also works on a box without the library; tests check it against velo_default_params()."""
+    p = VeloParams()
+    p.icp_skip, p.f2f_iterations, p.icp_iterations = 200, 2, 3
+    p.enable_icp = p.enable_2d2d = p.enable_3d2d = 1
+    p.max_num_iterations, p.max_consecutive_invalid_steps = 50, 5
+    p.weight_3D2D, p.weight_2D2D, p.weight_3DPD = 10.0, 500.0, 1.0
+    p.loss_thresh_3D2D, p.loss_thresh_2D2D, p.loss_thresh_3DPD, p.loss_thresh_3D3D = 0.01, 0.00002, 0.1, 0.04
+    p.outlier_reject, p.correspondence_thresh_icp, p.icp_norm_condition = 5.0, 0.5, 1e-5
+    p.function_tolerance, p.gradient_tolerance, p.parameter_tolerance = 1e-6, 1e-10, 1e-8
+    p.initial_trust_region_radius, p.max_trust_region_radius, p.min_trust_region_radius = 1e4, 1e16, 1e-32
+    p.min_relative_decrease, p.min_lm_diagonal, p.max_lm_diagonal = 1e-3, 1e-6, 1e32
+    return p
+
+
+# ---- every symbol include/velo_hip.h declares (tests check the .so exports all of them) -----------
+_P = C.POINTER
+_ctx = C.c_void_p
+_dp = _P(C.c_double)
+SIGNATURES = {
+    "velo_create": (C.c_int, [_P(_ctx), C.c_int]),
+    "velo_destroy": (C.c_int, [_ctx]),
+    "velo_last_error": (C.c_char_p, []),
+    "velo_version": (C.c_char_p, []),
+    "velo_default_params": (C.c_int, [_P(VeloParams)]),
+    "velo_set_params": (C.c_int, [_ctx, _P(VeloParams)]),
+    "velo_get_params": (C.c_int, [_ctx, _P(VeloParams)]),
+    "velo_set_timing": (C.c_int, [_ctx, C.c_int]),
+    "velo_set_target": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int]),
+    "velo_set_source": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int]),
+    "velo_set_visual": (C.c_int, [_ctx, C.c_void_p, C.c_int32]),
+    "velo_associate": (C.c_int, [_ctx, _dp, C.c_int32, _P(C.c_int32)]),
+    "velo_get_correspondences": (C.c_int, [_ctx, C.c_void_p, C.c_int32, _P(C.c_int32)]),
+    "velo_build_visual": (C.c_int, [_ctx, _dp, C.c_int32, _P(C.c_int32)]),
+    "velo_get_good_matches": (C.c_int, [_ctx, C.c_void_p, C.c_int32, _P(C.c_int32)]),
+    "velo_evaluate": (C.c_int, [_ctx, _dp, _dp, _dp, _dp]),
+    "velo_evaluate_rows": (C.c_int, [_ctx, _dp, _dp, _dp, C.c_int32, _P(C.c_int32)]),
+    "velo_solve": (C.c_int, [_ctx, _dp, _P(VeloSolveSummary)]),
+    "velo_frame_to_frame": (C.c_int, [_ctx, _dp, _dp, _P(VeloSummary)]),
+    "velo_frame_to_frame_batch": (C.c_int, [_P(_ctx), C.c_int32, _dp, _dp, _P(VeloSummary)]),
+    "velo_pose_vec_to_mat": (C.c_int, [_dp, _dp]),
+    "velo_pose_mat_to_vec": (C.c_int, [_dp, _dp]),
+    "velo_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "velo_comm_init": (C.c_int, [_ctx, C.c_char_p, C.c_int32, C.c_int32]),
+    "velo_comm_destroy": (C.c_int, [_ctx]),
+    "velo_set_query_shard": (C.c_int, [_ctx, C.c_int32, C.c_int32]),
+    "velo_synchronize": (C.c_int, [_ctx]),
+}
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen the HIP library and type every entry point.  Raises VeloError when it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise VeloError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(p, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library drift; tests guard it
+        fn.restype, fn.argtypes = res, args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _dvec(a, n):
+    arr = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+    if arr.size != n:
+        raise ValueError(f"expected {n} doubles, got {arr.size}")
+    return arr
+
+
+def _ptr(arr: np.ndarray):
+    return arr.ctypes.data_as(_dp)
+
+
+class Context:
+    """One scan-matching context = one `velo_ctx*` (device buffers + a HIP stream on `device`)."""
+
+    def __init__(self, device: int = 0, **params):
+        self._lib = load_library()
+        self._h = _ctx()
+        self._check(self._lib.velo_create(C.byref(self._h), int(device)))
+        if params:
+            self.set_params(**params)
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def _check(self, status: int):
+        if status != 0:
+            msg = self._lib.velo_last_error()
+            raise VeloError(f"velo status {status}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.velo_destroy(self._h)
+            self._h = _ctx()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    # -- configuration -------------------------------------------------------------------------------
+    def get_params(self) -> VeloParams:
+        p = VeloParams()
+        self._check(self._lib.velo_get_params(self._h, C.byref(p)))
+        return p
+
+    def set_params(self, **kw):
+        p = self.get_params()
+        for k, v in kw.items():
+            if not hasattr(p, k):
+                raise AttributeError(f"velo_params has no field {k}")
+            setattr(p, k, v)
+        self._check(self._lib.velo_set_params(self._h, C.byref(p)))
+
+    def set_timing(self, enable: bool):
+        self._check(self._lib.velo_set_timing(self._h, int(bool(enable))))
+
+    # -- inputs ----------------------------------------------------------------------------------------
+    @staticmethod
+    def _cloud_args(xyz, ring_offsets):
+        off = np.ascontiguousarray(np.asarray(ring_offsets, dtype=np.int32))
+        if hasattr(xyz, "data_ptr"):   # a torch tensor on the GPU: (n,3) or (n,4) float32, row stride in bytes
+            stride = xyz.stride(0) * xyz.element_size()
+            return C.c_void_p(xyz.data_ptr()), stride, off, 1, xyz
+        a = np.asarray(xyz, dtype=np.float32)
+        if a.ndim != 2 or a.shape[1] not in (3, 4):
+            raise ValueError("xyz must be (n,3) or (n,4) float32")
+        a = np.ascontiguousarray(a)
+        return C.c_void_p(a.ctypes.data), a.strides[0], off, 0, a
+
+    def set_target(self, xyz, ring_offsets):
+        ptr, stride, off, dev, keep = self._cloud_args(xyz, ring_offsets)
+        self._check(self._lib.velo_set_target(self._h, ptr, stride, C.c_void_p(off.ctypes.data), len(off) - 1, dev))
+
+    def set_source(self, xyz, ring_offsets):
+        ptr, stride, off, dev, keep = self._cloud_args(xyz, ring_offsets)
+        self._check(self._lib.velo_set_source(self._h, ptr, stride, C.c_void_p(off.ctypes.data), len(off) - 1, dev))
+
+    def set_visual(self, matches):
+        if isinstance(matches, dict):
+            matches = matches_from_dict(matches)
+        m = np.ascontiguousarray(matches, dtype=MATCH_DTYPE) if matches is not None else np.zeros(0, MATCH_DTYPE)
+        self._check(self._lib.velo_set_visual(self._h, C.c_void_p(m.ctypes.data) if len(m) else None, len(m)))
+
+    # -- pieces ------------------------------------------------------------------------------------------
+    def associate(self, x, iter: int) -> int:
+        xv = _dvec(x, 6)
+        n = C.c_int32(0)
+        self._check(self._lib.velo_associate(self._h, _ptr(xv), int(iter), C.byref(n)))
+        return n.value
+
+    def correspondences(self) -> np.ndarray:
+        n = C.c_int32(0)
+        self._check(self._lib.velo_get_correspondences(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=CORR_DTYPE)
+        if n.value:
+            self._check(self._lib.velo_get_correspondences(self._h, C.c_void_p(out.ctypes.data), n.value, C.byref(n)))
+        return out
+
+    def build_visual(self, x, iter: int) -> int:
+        xv = _dvec(x, 6)
+        n = C.c_int32(0)
+        self._check(self._lib.velo_build_visual(self._h, _ptr(xv), int(iter), C.byref(n)))
+        return n.value
+
+    def good_matches(self) -> np.ndarray:
+        n = C.c_int32(0)
+        self._check(self._lib.velo_get_good_matches(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=GOOD_DTYPE)
+        if n.value:
+            self._check(self._lib.velo_get_good_matches(self._h, C.c_void_p(out.ctypes.data), n.value, C.byref(n)))
+        return out
+
+    def evaluate(self, x):
+        xv = _dvec(x, 6)
+        cost = C.c_double(0)
+        H = np.zeros(36)
+        g = np.zeros(6)
+        self._check(self._lib.velo_evaluate(self._h, _ptr(xv), C.byref(cost), _ptr(H), _ptr(g)))
+        return cost.value, H.reshape(6, 6), g
+
+    def evaluate_rows(self, x):
+        xv = _dvec(x, 6)
+        n = C.c_int32(0)
+        self._lib.velo_evaluate_rows(self._h, _ptr(xv), None, None, 0, C.byref(n))
+        r = np.zeros(n.value)
+        J = np.zeros((n.value, 6))
+        if n.value:
+            self._check(self._lib.velo_evaluate_rows(self._h, _ptr(xv), _ptr(r), _ptr(J), n.value, C.byref(n)))
+        return r, J
+
+    def solve(self, x):
+        xv = _dvec(x, 6).copy()
+        s = VeloSolveSummary()
+        self._check(self._lib.velo_solve(self._h, _ptr(xv), C.byref(s)))
+        return xv, s
+
+    # -- the path ------------------------------------------------------------------------------------------
+    def frame_to_frame(self, x0):
+        xv = _dvec(x0, 6).copy()
+        T = np.zeros(16)
+        s = VeloSummary()
+        self._check(self._lib.velo_frame_to_frame(self._h, _ptr(xv), _ptr(T), C.byref(s)))
+        return xv, T.reshape(4, 4), s
+
+    def synchronize(self):
+        self._check(self._lib.velo_synchronize(self._h))
+
+    # -- multi-GPU -------------------------------------------------------------------------------------------
+    def set_query_shard(self, rank: int, world: int):
+        self._check(self._lib.velo_set_query_shard(self._h, int(rank), int(world)))
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(self._lib.velo_comm_init(self._h, buf, int(rank), int(world)))
+
+    def comm_destroy(self):
+        self._check(self._lib.velo_comm_destroy(self._h))
+
+
+def comm_unique_id() -> bytes:
+    lib = load_library()
+    buf = C.create_string_buffer(128)
+    st = lib.velo_comm_unique_id(buf)
+    if st != 0:
+        raise VeloError(f"velo_comm_unique_id failed: {st}")
+    return buf.raw
+
+
+def frame_to_frame_batch(ctxs, x0s):
+    """B independent scan pairs in flight, one context (and host thread inside the library) each."""
+    lib = load_library()
+    n = len(ctxs)
+    arr = (_ctx * n)(*[c.handle for c in ctxs])
+    x = np.ascontiguousarray(np.asarray(x0s, dtype=np.float64).reshape(n, 6)).copy()
+    T = np.zeros((n, 16))
+    S = (VeloSummary * n)()
+    st = lib.velo_frame_to_frame_batch(arr, n, _ptr(x), _ptr(T), S)
+    if st != 0:
+        msg = lib.velo_last_error()
+        raise VeloError(f"velo status {st}: {msg.decode() if msg else ''}")
+    return x, T.reshape(n, 4, 4), list(S)
+
+
+def pose_vec_to_mat(x) -> np.ndarray:
+    lib = load_library()
+    xv = _dvec(x, 6)
+    T = np.zeros(16)
+    lib.velo_pose_vec_to_mat(_ptr(xv), _ptr(T))
+    return T.reshape(4, 4)
+
+
+def pose_mat_to_vec(T) -> np.ndarray:
+    lib = load_library()
+    Tv = _dvec(T, 16)
+    x = np.zeros(6)
+    lib.velo_pose_mat_to_vec(_ptr(Tv), _ptr(x))
+    return x

@@ -1,0 +1,71 @@
+"""Build recipes: the HIP shared library (the product) and, separately, the CPU oracle (the checker).
+
+    python -m velo_amd.build            # via the root shim:  python -c "import velo_amd.build as b; b.build_all()"
+
+hipcc cross-compiles gfx950 code objects without a GPU, so this runs in the authoring container; the built
+.so travels to the GPU box with the gpurun snapshot (it is git-ignored, not gpurun-ignored).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+LIB = os.path.join(CSRC, "libvelo_hip.so")
+SOURCES = ["velo_hip.hip"]
+HEADERS = ["velo_kernels.h", "velo_device_math.h", os.path.join(ROOT, "include", "velo_hip.h")]
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # the association compares float distances bit-for-bit with the CPU restatement: no FMA contraction anywhere
+    "-ffp-contract=off", "-fno-fast-math",
+    "-Wall", "-Wno-unused-function", "-Wno-unused-result",
+]
+
+
+def _rocm() -> str:
+    return os.environ.get("ROCM_PATH", "/opt/rocm")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_hip(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+    hipcc = shutil.which("hipcc") or os.path.join(_rocm(), "bin", "hipcc")
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    if not force and not _stale(LIB, deps):
+        return LIB
+    cmd = [hipcc, *HIPCC_FLAGS, *extra_flags, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(_rocm(), "include"),
+           *srcs, "-o", LIB, "-L", os.path.join(_rocm(), "lib"), "-lrccl", "-lpthread",
+           f"-Wl,-rpath,{os.path.join(_rocm(), 'lib')}"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+def build_oracle(force: bool = False) -> str:
+    """Compiles oracle/velo_oracle.cpp (test infrastructure).  Building the checker is not using it."""
+    odir = os.path.join(ROOT, "oracle")
+    out = os.path.join(odir, "_build", "libvelo_oracle.so")
+    deps = [os.path.join(odir, "velo_oracle.cpp"), os.path.join(ROOT, "include", "velo_hip.h"), os.path.join(odir, "Makefile")]
+    if force or _stale(out, deps):
+        subprocess.run(["make", "-C", odir, "-B"], check=True, stdout=subprocess.DEVNULL)
+    return out
+
+
+def build_all(force: bool = False, verbose: bool = False):
+    return build_hip(force, verbose), build_oracle(force)
+
+
+if __name__ == "__main__":
+    print(build_all(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,1000 @@
+// velo_hip.hip -- host side of the C-ABI declared in include/velo_hip.h (gfx950 only; no CPU fallback).
+//
+// One context = one HIP stream + device-resident target index, source cloud, correspondence table and LM
+// state.  frame_to_frame (reference velo.h:598-919) runs as
+//     for iter:  visual gate kernel;  for icp_iter:  association kernel;  LM solve = chunks of
+//     [eval sweep -> (RCCL all-reduce) -> lm_step] launches that early-exit on the device-side `done` flag,
+// with one small D2H status copy per chunk (the only host synchronisation inside a solve).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/velo_hip.h"
+#include "velo_kernels.h"
+
+using namespace velo;
+
+namespace {
+
+thread_local std::string g_err;
+std::string g_err_shared;   // last error of any thread (read by velo_last_error when the caller's own is empty)
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    g_err_shared = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess) return fail(VELO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+#define NCCL_TRY(expr)                                                                                  \
+    do {                                                                                                \
+        ncclResult_t r__ = (expr);                                                                      \
+        if (r__ != ncclSuccess) return fail(VELO_ERR_COMM, "%s failed: %s (%s:%d)", #expr, ncclGetErrorString(r__), __FILE__, __LINE__); \
+    } while (0)
+#define VELO_TRY(expr)           \
+    do {                         \
+        int s__ = (expr);        \
+        if (s__ != VELO_OK) return s__; \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n) {
+        if (n <= cap) return VELO_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e != hipSuccess) return fail(VELO_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e));
+        cap = want;
+        return VELO_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Grid {
+    GridDesc d{};
+    double gate = 0.0;          // squared-distance gate this grid was sized for
+    DevBuf<int> cell_start;     // ncells + 1
+    DevBuf<float4> sorted;
+    bool built = false;
+};
+
+struct HostStatus {   // pinned; one D2H copy per LM chunk
+    LMState s;
+};
+
+void default_params(velo_params* p) {
+    std::memset(p, 0, sizeof(*p));
+    p->icp_skip = 200; p->f2f_iterations = 2; p->icp_iterations = 3;          // kitti.h:8-10
+    p->enable_icp = 1; p->enable_2d2d = 1; p->enable_3d2d = 1;                  // main.cpp:43-45,404
+    p->max_num_iterations = 50; p->max_consecutive_invalid_steps = 5;
+    p->weight_3D2D = 10; p->weight_2D2D = 500; p->weight_3DPD = 1;              // kitti.h:20-22
+    p->loss_thresh_3D2D = 0.01; p->loss_thresh_2D2D = 0.00002;                  // kitti.h:23-24
+    p->loss_thresh_3DPD = 0.1; p->loss_thresh_3D3D = 0.04;                      // kitti.h:25-26
+    p->outlier_reject = 5.0; p->correspondence_thresh_icp = 0.5;                // kitti.h:30-31
+    p->icp_norm_condition = 1e-5;                                               // kitti.h:32
+    p->function_tolerance = 1e-6; p->gradient_tolerance = 1e-10; p->parameter_tolerance = 1e-8;
+    p->initial_trust_region_radius = 1e4; p->max_trust_region_radius = 1e16;
+    p->min_trust_region_radius = 1e-32; p->min_relative_decrease = 1e-3;
+    p->min_lm_diagonal = 1e-6; p->max_lm_diagonal = 1e32;
+}
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace
+
+struct velo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    velo_params P;
+    bool timing = false;
+
+    // target (frame2)
+    int n_tgt = 0, n_tgt_rings = 0;
+    DevBuf<float4> tgt;
+    DevBuf<int> tgt_off, tgt_ring_of, tgt_cell_of;
+    std::vector<int> h_tgt_off;
+    std::vector<Grid> grids;             // one per distinct gate among iter = 1..f2f_iterations
+    std::vector<int> grid_of_iter;       // iter (1-based) -> grid index
+    DevBuf<int> scan_tiles, cursor, scan_total;
+    DevBuf<unsigned> bbox_keys;
+    float bbox[6] = {0, 0, 0, 0, 0, 0};
+    bool bbox_valid = false;
+    bool have_target = false;
+
+    // source (frame1)
+    int n_src = 0, n_src_rings = 0, n_q = 0;
+    DevBuf<float4> src;
+    DevBuf<int> src_off, q_off, q_src;
+    std::vector<int> h_src_off, h_q_off;
+    int src_skip = 0;                    // icp_skip the query list was built with
+    bool have_source = false;
+
+    DevBuf<char> staging;                // raw host clouds land here before packing
+
+    // correspondence table
+    DevBuf<float4> cp, cn, cv0, aux1;
+    DevBuf<int4> aux0;
+    DevBuf<int> n_valid;
+    bool have_corr = false;
+    int last_n_valid = 0;
+
+    // visual
+    int n_matches = 0;
+    DevBuf<VisualMatch> vm;
+    DevBuf<unsigned char> vflags;
+    std::vector<velo_match> h_matches;
+    std::vector<unsigned char> h_vflags;
+    bool vflags_valid = false;
+
+    // LM
+    DevBuf<LMState> state;
+    DevBuf<double> partials, reduced, xdev;
+    HostStatus* h_status = nullptr;      // pinned
+    double* h_x = nullptr;               // pinned, 8 doubles
+    int* h_int = nullptr;                // pinned scratch
+    DevBuf<int> row_off_vis, row_off_icp;
+    DevBuf<double> rows_r, rows_J;
+
+    // sharding / comm
+    int shard_rank = 0, shard_world = 1;
+    ncclComm_t comm = nullptr;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> assoc_events;   // reused pool
+    int assoc_events_used = 0;
+};
+
+namespace {
+
+int q_range(const velo_ctx* c, int* b, int* e) {
+    const int64_t nq = c->n_q;
+    *b = (int)(nq * c->shard_rank / c->shard_world);
+    *e = (int)(nq * (c->shard_rank + 1) / c->shard_world);
+    return VELO_OK;
+}
+
+int upload_cloud(velo_ctx* c, const float* xyz, int64_t stride, int n, int on_device, DevBuf<float4>& dst) {
+    VELO_TRY(dst.reserve((size_t)std::max(n, 1)));
+    if (n == 0) return VELO_OK;
+    const char* dsrc = (const char*)xyz;
+    if (!on_device) {
+        const size_t bytes = (size_t)(n - 1) * (size_t)stride + 12;
+        VELO_TRY(c->staging.reserve(bytes));
+        HIP_TRY(hipMemcpyAsync(c->staging.p, xyz, bytes, hipMemcpyHostToDevice, c->stream));
+        dsrc = c->staging.p;
+    }
+    hipLaunchKernelGGL(pack_points_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, dsrc, stride, n, dst.p);
+    HIP_TRY(hipGetLastError());
+    return VELO_OK;
+}
+
+double gate_of_iter(const velo_params& P, int iter) {
+    const double it = (double)iter;
+    return P.correspondence_thresh_icp / it / it / it / it;     // velo.h:829
+}
+
+// largest float f with (double)f <= gate : the reference rejects when (double)dist2 > gate
+unsigned gate_bits_of(double gate) {
+    if (!(gate >= 0.0)) return 0u;   // negative / NaN gate: only d2 == 0 could pass a ">" test... keep 0
+    float f = (float)gate;
+    if ((double)f > gate) f = std::nextafterf(f, 0.0f);
+    if (std::isinf(f)) f = FLT_MAX;
+    unsigned u;
+    std::memcpy(&u, &f, 4);
+    return u;
+}
+
+int build_grid(velo_ctx* c, Grid& G, double gate) {
+    G.gate = gate;
+    const double radius = std::sqrt(std::max(gate, 0.0));
+    double h = std::max(radius * 1.01, 1e-6);
+    const double ext[3] = {(double)c->bbox[3] - c->bbox[0], (double)c->bbox[4] - c->bbox[1], (double)c->bbox[5] - c->bbox[2]};
+    int dims[3];
+    for (;;) {   // per-axis <= 8192 cells and <= 2^25 cells in all, else coarsen (still exhaustive: cell >= radius)
+        bool ok = true;
+        double total = 1.0;
+        for (int k = 0; k < 3; k++) {
+            const double dk = std::floor(std::max(ext[k], 0.0) / h) + 1.0;
+            if (dk > 8192.0) ok = false;
+            dims[k] = (int)std::min(dk, 8192.0);
+            total *= dk;
+        }
+        if (ok && total <= 33554432.0) break;
+        h *= 1.26;
+    }
+    G.d.ox = c->bbox[0]; G.d.oy = c->bbox[1]; G.d.oz = c->bbox[2];
+    G.d.inv_h = (float)(1.0 / h);
+    G.d.nx = dims[0]; G.d.ny = dims[1]; G.d.nz = dims[2];
+    G.d.ncells = dims[0] * dims[1] * dims[2];
+    const int nc = G.d.ncells, n = c->n_tgt;
+    VELO_TRY(G.cell_start.reserve((size_t)nc + 1));
+    VELO_TRY(G.sorted.reserve((size_t)std::max(n, 1)));
+    VELO_TRY(c->cursor.reserve((size_t)nc + 1));
+    const int n_tiles = cdiv(nc, kScanTile);
+    VELO_TRY(c->scan_tiles.reserve((size_t)n_tiles + 1));
+    VELO_TRY(c->scan_total.reserve(1));
+    HIP_TRY(hipMemsetAsync(G.cell_start.p, 0, sizeof(int) * ((size_t)nc + 1), c->stream));
+    if (n > 0) hipLaunchKernelGGL(grid_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, G.d, c->tgt.p, n, c->tgt_cell_of.p, G.cell_start.p);
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(n_tiles), dim3(kScanThreads), 0, c->stream, G.cell_start.p, nc, c->scan_tiles.p);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kScanThreads), 0, c->stream, c->scan_tiles.p, n_tiles, c->scan_total.p);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(cdiv(nc + 1, 256)), dim3(256), 0, c->stream, G.cell_start.p, nc, c->scan_tiles.p, c->scan_total.p, c->cursor.p);
+    if (n > 0) hipLaunchKernelGGL(grid_scatter_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->tgt.p, c->tgt_cell_of.p, n, c->cursor.p, G.sorted.p);
+    HIP_TRY(hipGetLastError());
+    G.built = true;
+    return VELO_OK;
+}
+
+// (re)build the grids for the gates of iter = 1..f2f_iterations
+int build_grids(velo_ctx* c) {
+    c->grid_of_iter.assign((size_t)c->P.f2f_iterations + 1, 0);
+    std::vector<double> gates;
+    for (int it = 1; it <= c->P.f2f_iterations; it++) {
+        const double g = gate_of_iter(c->P, it);
+        int found = -1;
+        for (size_t k = 0; k < gates.size(); k++) if (gates[k] == g) found = (int)k;
+        if (found < 0) { gates.push_back(g); found = (int)gates.size() - 1; }
+        c->grid_of_iter[it] = found;
+    }
+    if (c->grids.size() < gates.size()) c->grids.resize(gates.size());
+    for (size_t k = 0; k < gates.size(); k++) VELO_TRY(build_grid(c, c->grids[k], gates[k]));
+    for (size_t k = gates.size(); k < c->grids.size(); k++) c->grids[k].built = false;
+    return VELO_OK;
+}
+
+Grid* grid_for_iter(velo_ctx* c, int iter) {
+    // any iter is allowed through velo_associate: build on demand if its gate has no grid yet
+    const double g = gate_of_iter(c->P, iter);
+    for (Grid& G : c->grids) if (G.built && G.gate == g) return &G;
+    c->grids.emplace_back();
+    if (build_grid(c, c->grids.back(), g) != VELO_OK) { c->grids.pop_back(); return nullptr; }
+    return &c->grids.back();
+}
+
+int build_query_list(velo_ctx* c) {
+    const int skip = std::max(c->P.icp_skip, 1);
+    c->h_q_off.assign((size_t)c->n_src_rings + 1, 0);
+    for (int r = 0; r < c->n_src_rings; r++) {
+        const int n = c->h_src_off[r + 1] - c->h_src_off[r];
+        c->h_q_off[r + 1] = c->h_q_off[r] + (n + skip - 1) / skip;        // smi = 0, skip, 2 skip, ... < n  (velo.h:807)
+    }
+    c->n_q = c->P.enable_icp ? c->h_q_off[c->n_src_rings] : 0;            // velo.h:806 `* enable_icp`
+    c->src_skip = skip;
+    VELO_TRY(c->q_off.reserve((size_t)c->n_src_rings + 1));
+    VELO_TRY(c->q_src.reserve((size_t)std::max(c->n_q, 1)));
+    HIP_TRY(hipMemcpyAsync(c->q_off.p, c->h_q_off.data(), sizeof(int) * ((size_t)c->n_src_rings + 1), hipMemcpyHostToDevice, c->stream));
+    if (c->n_q > 0) {
+        hipLaunchKernelGGL(query_list_kernel, dim3(cdiv(c->n_q, 256)), dim3(256), 0, c->stream, c->src_off.p, c->q_off.p, c->n_src_rings, skip, c->n_q, c->q_src.p);
+        HIP_TRY(hipGetLastError());
+    }
+    const size_t nq = (size_t)std::max(c->n_q, 1);
+    VELO_TRY(c->cp.reserve(nq)); VELO_TRY(c->cn.reserve(nq)); VELO_TRY(c->cv0.reserve(nq));
+    VELO_TRY(c->aux0.reserve(nq)); VELO_TRY(c->aux1.reserve(nq));
+    c->have_corr = false;
+    // the pageable h_q_off copy must finish before the vector can change again
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VELO_OK;
+}
+
+void pose_scalars(const double x[6], PoseScalars* S) {
+    // the point-independent part of ceres::AngleAxisRotatePoint [3P], in double with the host libm
+    std::memset(S, 0, sizeof(*S));
+    for (int k = 0; k < 3; k++) { S->w[k] = x[k]; S->t[k] = x[3 + k]; }
+    const double theta2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+    if (theta2 > std::numeric_limits<double>::epsilon()) {
+        const double theta = std::sqrt(theta2);
+        S->c = std::cos(theta); S->s = std::sin(theta);
+        const double ti = 1.0 / theta;
+        S->u[0] = x[0] * ti; S->u[1] = x[1] * ti; S->u[2] = x[2] * ti;
+        S->omc = 1.0 - S->c;
+        S->small = 0;
+    } else {
+        S->small = 1;
+    }
+}
+
+VisualParams visual_params(const velo_params& P) {
+    VisualParams V;
+    V.w_3d2d = P.weight_3D2D; V.w_2d2d = P.weight_2D2D;
+    V.th_3d2d = P.loss_thresh_3D2D; V.th_2d2d = P.loss_thresh_2D2D; V.th_3d3d = P.loss_thresh_3D3D;
+    V.outlier_reject = P.outlier_reject; V.enable_2d2d = P.enable_2d2d; V.enable_3d2d = P.enable_3d2d;
+    return V;
+}
+LMParams lm_params(const velo_params& P) {
+    LMParams Q;
+    Q.max_num_iterations = P.max_num_iterations; Q.max_invalid = P.max_consecutive_invalid_steps;
+    Q.function_tolerance = P.function_tolerance; Q.gradient_tolerance = P.gradient_tolerance; Q.parameter_tolerance = P.parameter_tolerance;
+    Q.initial_radius = P.initial_trust_region_radius; Q.max_radius = P.max_trust_region_radius; Q.min_radius = P.min_trust_region_radius;
+    Q.min_relative_decrease = P.min_relative_decrease; Q.min_diag = P.min_lm_diagonal; Q.max_diag = P.max_lm_diagonal;
+    return Q;
+}
+
+constexpr int kMaxVisBlocks = 64;
+struct EvalPlan { int nb_icp, nb_vis; int total() const { return nb_icp + nb_vis; } };
+
+EvalArgs eval_args(velo_ctx* c, const double* x_override) {
+    EvalArgs A;
+    std::memset(&A, 0, sizeof(A));
+    A.state = c->state.p;
+    A.x_override = x_override;
+    A.cp = c->cp.p; A.cn = c->cn.p; A.cv0 = c->cv0.p;
+    if (c->have_corr) q_range(c, &A.q_begin, &A.q_end);
+    A.vm = c->vm.p; A.vflags = c->vflags.p;
+    A.n_matches = (c->vflags_valid && c->shard_rank == 0) ? c->n_matches : 0;   // visual blocks live on rank 0 only
+    A.loss_a_3dpd = c->P.loss_thresh_3DPD; A.w_3dpd = c->P.weight_3DPD;
+    A.V = visual_params(c->P);
+    A.partials = c->partials.p;
+    return A;
+}
+
+EvalPlan eval_plan(const EvalArgs& A) {
+    EvalPlan E;
+    const int nq = A.q_end - A.q_begin;
+    E.nb_icp = nq > 0 ? std::min(std::max(cdiv(nq, kEvalThreads), 1), kMaxEvalBlocks) : 0;
+    E.nb_vis = A.n_matches > 0 ? std::min(std::max(cdiv(3 * A.n_matches, kEvalThreads), 1), kMaxVisBlocks) : 0;
+    return E;
+}
+
+// the evaluation sweep: lean point-to-plane kernel + (only when visual blocks exist) the visual kernel
+void launch_eval(velo_ctx* c, EvalArgs A, const EvalPlan& E) {
+    if (E.nb_icp > 0) hipLaunchKernelGGL(eval_icp_kernel, dim3(E.nb_icp), dim3(kEvalThreads), 0, c->stream, A);
+    if (E.nb_vis > 0) {
+        A.vis_row0 = E.nb_icp;
+        hipLaunchKernelGGL(eval_visual_kernel, dim3(E.nb_vis), dim3(kEvalThreads), 0, c->stream, A);
+    }
+}
+
+int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool wait, int* n_valid) {
+    if (!c->have_target || !c->have_source) return fail(VELO_ERR_STATE, "associate needs set_target and set_source first");
+    if (iter < 1) return fail(VELO_ERR_INVALID, "iter must be >= 1");
+    if (c->src_skip != std::max(c->P.icp_skip, 1) || (c->n_q > 0) != (c->P.enable_icp != 0 && c->h_q_off[c->n_src_rings] > 0)) VELO_TRY(build_query_list(c));
+    Grid* G = grid_for_iter(c, iter);
+    if (!G) return VELO_ERR_HIP;
+    int qb, qe;
+    q_range(c, &qb, &qe);
+    VELO_TRY(c->n_valid.reserve(1));
+    HIP_TRY(hipMemsetAsync(c->n_valid.p, 0, sizeof(int), c->stream));
+    if (qe > qb) {
+        PoseScalars S;
+        pose_scalars(x, &S);
+        GridView V;
+        V.d = G->d; V.cell_start = G->cell_start.p; V.sorted = G->sorted.p;
+        AssocOut out;
+        out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p;
+        const unsigned gb = gate_bits_of(G->gate);
+        std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+        if (c->timing) {
+            if (c->assoc_events_used >= (int)c->assoc_events.size()) {
+                hipEvent_t a, b;
+                HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+                c->assoc_events.emplace_back(a, b);
+            }
+            ev = &c->assoc_events[c->assoc_events_used++];
+            HIP_TRY(hipEventRecord(ev->first, c->stream));
+        }
+        hipLaunchKernelGGL(assoc_search_kernel, dim3(cdiv(qe - qb, kAssocThreads)), dim3(kAssocThreads), 0, c->stream,
+                           S, V, c->src.p, c->q_src.p, qb, qe, c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gb, c->P.icp_norm_condition, out, want_aux ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+        if (ev) HIP_TRY(hipEventRecord(ev->second, c->stream));
+    }
+    c->have_corr = true;
+    if (wait) {
+        HIP_TRY(hipMemcpyAsync(c->h_int, c->n_valid.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->last_n_valid = c->h_int[0];
+        if (n_valid) *n_valid = c->last_n_valid;
+    }
+    return VELO_OK;
+}
+
+int do_build_visual(velo_ctx* c, const double* x_host, bool x_on_state, int iter, int* n_blocks) {
+    // x: either a host vector (copied to xdev) or the device LM state's x
+    const int n = c->n_matches;
+    c->vflags_valid = true;
+    if (n == 0) { if (n_blocks) *n_blocks = 0; c->h_vflags.clear(); return VELO_OK; }
+    const double* xd = nullptr;
+    if (x_on_state) xd = c->state.p->x;
+    else {
+        std::memcpy(c->h_x, x_host, sizeof(double) * 6);
+        HIP_TRY(hipMemcpyAsync(c->xdev.p, c->h_x, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
+        xd = c->xdev.p;
+    }
+    hipLaunchKernelGGL(visual_gate_kernel, dim3(cdiv(n, 128)), dim3(128), 0, c->stream, xd, visual_params(c->P), c->vm.p, n, iter, c->vflags.p);
+    HIP_TRY(hipGetLastError());
+    c->h_vflags.resize((size_t)3 * n);
+    HIP_TRY(hipMemcpyAsync(c->h_vflags.data(), c->vflags.p, (size_t)3 * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int nb = 0;
+    for (unsigned char f : c->h_vflags) nb += f ? 1 : 0;
+    if (n_blocks) *n_blocks = nb;
+    return VELO_OK;
+}
+
+void visual_counts(const velo_ctx* c, int* blocks, int* residuals) {
+    int nb = 0, nr = 0;
+    for (unsigned char f : c->h_vflags) {
+        if (!f) continue;
+        nb++;
+        const int t = f - 1;
+        nr += (t == VELO_RESIDUAL_3D3D) ? 3 : (t == VELO_RESIDUAL_2D2D) ? 1 : 2;
+    }
+    *blocks = nb; *residuals = nr;
+}
+
+// enqueue: eval sweep at the state's current point, (all-reduce), LM transition
+int enqueue_lm_iteration(velo_ctx* c, const EvalArgs& A, const EvalPlan& E, const LMParams& Q) {
+    launch_eval(c, A, E);
+    const int nblocks = E.total();
+    if (c->comm) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, c->stream, (const LMState*)c->state.p, (const double*)c->partials.p, nblocks, c->reduced.p);
+        // every rank reaches this call the same number of times: `done` is identical on all ranks, and when it is
+        // set the kernels above exit early and the buffer keeps its previous (identical) content
+        NCCL_TRY(ncclAllReduce(c->reduced.p, c->reduced.p + kNumAcc, kNumAcc, ncclDouble, ncclSum, c->comm, c->stream));
+        hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, (const double*)(c->reduced.p + kNumAcc), 1);
+    } else {
+        hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, (const double*)c->partials.p, nblocks);
+    }
+    HIP_TRY(hipGetLastError());
+    return VELO_OK;
+}
+
+// One ceres::Solve on the device.  x_in: host x to start from, or nullptr to continue from the state's x.
+int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summary* S, int* eval_launches) {
+    const LMParams Q = lm_params(c->P);
+    const EvalArgs A = eval_args(c, nullptr);
+    const EvalPlan E = eval_plan(A);
+    const double* xd = nullptr;
+    if (x_in) {
+        std::memcpy(c->h_x, x_in, sizeof(double) * 6);
+        HIP_TRY(hipMemcpyAsync(c->xdev.p, c->h_x, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
+        xd = c->xdev.p;
+    }
+    hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->state.p, xd);
+    int launched = 0;
+    int chunk = 4;                          // LM iterations per host round trip; later chunks are shorter
+    const int max_iters = c->P.max_num_iterations + 1;
+    for (;;) {
+        for (int k = 0; k < chunk; k++) { VELO_TRY(enqueue_lm_iteration(c, A, E, Q)); launched++; }
+        HIP_TRY(hipMemcpyAsync(&c->h_status->s, c->state.p, sizeof(LMState), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->h_status->s.done) break;
+        if (launched > max_iters + 8) return fail(VELO_ERR_STATE, "LM did not terminate after %d sweeps", launched);
+        chunk = 3;
+    }
+    const LMState& s = c->h_status->s;
+    for (int k = 0; k < 6; k++) x_out[k] = s.x[k];
+    if (S) {
+        std::memset(S, 0, sizeof(*S));
+        S->termination = s.termination; S->lm_iterations = s.iter; S->evaluations = s.evals;
+        S->n_icp_valid = c->have_corr ? c->last_n_valid : 0;
+        visual_counts(c, &S->n_visual_blocks, &S->n_visual_residuals);
+        if (c->shard_rank != 0) { S->n_visual_blocks = 0; S->n_visual_residuals = 0; }
+        S->initial_cost = s.initial_cost; S->final_cost = s.cost;
+    }
+    if (eval_launches) *eval_launches = s.evals;
+    return VELO_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================================
+extern "C" {
+
+const char* velo_last_error(void) { return g_err.empty() ? g_err_shared.c_str() : g_err.c_str(); }
+const char* velo_version(void) { return "velo_hip 0.1 (gfx950)"; }
+
+int velo_default_params(velo_params* p) {
+    if (!p) return fail(VELO_ERR_INVALID, "null params");
+    default_params(p);
+    return VELO_OK;
+}
+
+int velo_create(velo_ctx** out, int device) {
+    if (!out) return fail(VELO_ERR_INVALID, "null out");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+        return fail(VELO_ERR_NODEVICE, "no HIP device visible: this library has no CPU fallback");
+    if (device < 0 || device >= count) return fail(VELO_ERR_INVALID, "device %d out of range (0..%d)", device, count - 1);
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(VELO_ERR_NODEVICE, "device %d is %s; this library carries gfx950 code objects only", device, prop.gcnArchName);
+    velo_ctx* c = new velo_ctx();
+    c->device = device;
+    default_params(&c->P);
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipHostMalloc((void**)&c->h_status, sizeof(HostStatus), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&c->h_x, sizeof(double) * 64, hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc((void**)&c->h_int, sizeof(int) * 16, hipHostMallocDefault));
+    VELO_TRY(c->state.reserve(1));
+    VELO_TRY(c->partials.reserve((size_t)(kMaxEvalBlocks + kMaxVisBlocks) * kNumAcc));
+    VELO_TRY(c->reduced.reserve(2 * kNumAcc));
+    VELO_TRY(c->xdev.reserve(8));
+    VELO_TRY(c->bbox_keys.reserve(6));
+    VELO_TRY(c->n_valid.reserve(1));
+    HIP_TRY(hipMemsetAsync(c->state.p, 0, sizeof(LMState), c->stream));
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out = c;
+    return VELO_OK;
+}
+
+int velo_destroy(velo_ctx* c) {
+    if (!c) return VELO_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+    c->tgt.release(); c->tgt_off.release(); c->tgt_ring_of.release(); c->tgt_cell_of.release();
+    for (Grid& G : c->grids) { G.cell_start.release(); G.sorted.release(); }
+    c->scan_tiles.release(); c->cursor.release(); c->scan_total.release(); c->bbox_keys.release();
+    c->src.release(); c->src_off.release(); c->q_off.release(); c->q_src.release(); c->staging.release();
+    c->cp.release(); c->cn.release(); c->cv0.release(); c->aux0.release(); c->aux1.release(); c->n_valid.release();
+    c->vm.release(); c->vflags.release();
+    c->state.release(); c->partials.release(); c->reduced.release(); c->xdev.release();
+    c->row_off_vis.release(); c->row_off_icp.release(); c->rows_r.release(); c->rows_J.release();
+    if (c->h_status) (void)hipHostFree(c->h_status);
+    if (c->h_x) (void)hipHostFree(c->h_x);
+    if (c->h_int) (void)hipHostFree(c->h_int);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (auto& e : c->assoc_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return VELO_OK;
+}
+
+int velo_set_params(velo_ctx* c, const velo_params* p) {
+    if (!c || !p) return fail(VELO_ERR_INVALID, "null argument");
+    if (p->icp_skip < 1 || p->f2f_iterations < 0 || p->icp_iterations < 0 || p->max_num_iterations < 0)
+        return fail(VELO_ERR_INVALID, "icp_skip must be >= 1 and iteration counts >= 0");
+    if (p->f2f_iterations * std::max(p->icp_iterations, 1) > VELO_MAX_SOLVES)
+        return fail(VELO_ERR_INVALID, "more than %d solves per call", VELO_MAX_SOLVES);
+    HIP_TRY(hipSetDevice(c->device));
+    const bool gates_changed = p->correspondence_thresh_icp != c->P.correspondence_thresh_icp || p->f2f_iterations != c->P.f2f_iterations;
+    const bool queries_changed = p->icp_skip != c->P.icp_skip || p->enable_icp != c->P.enable_icp;
+    c->P = *p;
+    if (gates_changed && c->have_target) VELO_TRY(build_grids(c));
+    if (queries_changed && c->have_source) VELO_TRY(build_query_list(c));
+    return VELO_OK;
+}
+
+int velo_get_params(const velo_ctx* c, velo_params* p) {
+    if (!c || !p) return fail(VELO_ERR_INVALID, "null argument");
+    *p = c->P;
+    return VELO_OK;
+}
+
+int velo_set_timing(velo_ctx* c, int enable) {
+    if (!c) return fail(VELO_ERR_INVALID, "null ctx");
+    c->timing = enable != 0;
+    return VELO_OK;
+}
+
+int velo_set_target(velo_ctx* c, const float* xyz, int64_t stride, const int32_t* off, int32_t n_rings, int on_device) {
+    if (!c || !off || n_rings < 0) return fail(VELO_ERR_INVALID, "null/negative argument");
+    if (stride < 12) return fail(VELO_ERR_INVALID, "stride_bytes must be >= 12");
+    if (off[0] != 0) return fail(VELO_ERR_INVALID, "ring_offsets[0] must be 0");
+    for (int r = 0; r < n_rings; r++) {
+        // an empty ring makes pcl::KdTreeFLANN::setInputCloud fail in the reference; reject it loudly
+        if (off[r + 1] <= off[r]) return fail(VELO_ERR_INVALID, "target ring %d is empty or offsets are not increasing", r);
+    }
+    const int n = n_rings > 0 ? off[n_rings] : 0;
+    if (n > 0 && !xyz) return fail(VELO_ERR_INVALID, "null xyz");
+    HIP_TRY(hipSetDevice(c->device));
+    c->have_target = false; c->have_corr = false;
+    c->n_tgt = n; c->n_tgt_rings = n_rings;
+    c->h_tgt_off.assign(off, off + n_rings + 1);
+    VELO_TRY(upload_cloud(c, xyz, stride, n, on_device, c->tgt));
+    VELO_TRY(c->tgt_off.reserve((size_t)n_rings + 1));
+    VELO_TRY(c->tgt_ring_of.reserve((size_t)std::max(n, 1)));
+    VELO_TRY(c->tgt_cell_of.reserve((size_t)std::max(n, 1)));
+    HIP_TRY(hipMemcpyAsync(c->tgt_off.p, c->h_tgt_off.data(), sizeof(int) * ((size_t)n_rings + 1), hipMemcpyHostToDevice, c->stream));
+    // bbox of the finite points -> host (the only sync of set_target; the grid dimensions are sized from it)
+    unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    std::memcpy(c->h_int, init, sizeof(init));
+    HIP_TRY(hipMemcpyAsync(c->bbox_keys.p, c->h_int, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(ring_of_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->tgt_off.p, n_rings, n, c->tgt_ring_of.p);
+        hipLaunchKernelGGL(bbox_kernel, dim3(std::min(cdiv(n, 256), 1024)), dim3(256), 0, c->stream, c->tgt.p, n, c->bbox_keys.p);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_int + 8, c->bbox_keys.p, sizeof(init), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned keys[6];
+    std::memcpy(keys, c->h_int + 8, sizeof(keys));
+    if (keys[0] == 0xffffffffu) {   // no finite point at all
+        for (int k = 0; k < 6; k++) c->bbox[k] = 0.f;
+    } else {
+        for (int k = 0; k < 6; k++) c->bbox[k] = key2f(keys[k]);
+    }
+    c->grids.clear();
+    VELO_TRY(build_grids(c));
+    c->have_target = true;
+    return VELO_OK;
+}
+
+int velo_set_source(velo_ctx* c, const float* xyz, int64_t stride, const int32_t* off, int32_t n_rings, int on_device) {
+    if (!c || !off || n_rings < 0) return fail(VELO_ERR_INVALID, "null/negative argument");
+    if (stride < 12) return fail(VELO_ERR_INVALID, "stride_bytes must be >= 12");
+    if (off[0] != 0) return fail(VELO_ERR_INVALID, "ring_offsets[0] must be 0");
+    for (int r = 0; r < n_rings; r++) if (off[r + 1] < off[r]) return fail(VELO_ERR_INVALID, "source ring offsets decrease at ring %d", r);
+    const int n = n_rings > 0 ? off[n_rings] : 0;
+    if (n > 0 && !xyz) return fail(VELO_ERR_INVALID, "null xyz");
+    HIP_TRY(hipSetDevice(c->device));
+    c->have_source = false; c->have_corr = false;
+    c->n_src = n; c->n_src_rings = n_rings;
+    c->h_src_off.assign(off, off + n_rings + 1);
+    VELO_TRY(upload_cloud(c, xyz, stride, n, on_device, c->src));
+    VELO_TRY(c->src_off.reserve((size_t)n_rings + 1));
+    HIP_TRY(hipMemcpyAsync(c->src_off.p, c->h_src_off.data(), sizeof(int) * ((size_t)n_rings + 1), hipMemcpyHostToDevice, c->stream));
+    VELO_TRY(build_query_list(c));
+    c->have_source = true;
+    return VELO_OK;
+}
+
+int velo_set_visual(velo_ctx* c, const velo_match* m, int32_t n) {
+    if (!c || n < 0 || (n > 0 && !m)) return fail(VELO_ERR_INVALID, "bad visual arguments");
+    static_assert(sizeof(VisualMatch) == sizeof(velo_match), "device/host match layout");
+    HIP_TRY(hipSetDevice(c->device));
+    c->n_matches = n;
+    c->h_matches.assign(m, m + n);
+    c->vflags_valid = false;
+    c->h_vflags.clear();
+    if (n > 0) {
+        VELO_TRY(c->vm.reserve((size_t)n));
+        VELO_TRY(c->vflags.reserve((size_t)3 * n));
+        HIP_TRY(hipMemcpyAsync(c->vm.p, c->h_matches.data(), sizeof(velo_match) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemsetAsync(c->vflags.p, 0, (size_t)3 * n, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return VELO_OK;
+}
+
+int velo_associate(velo_ctx* c, const double x[6], int32_t iter, int32_t* n_valid) {
+    if (!c || !x) return fail(VELO_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    return do_associate(c, x, iter, true, true, n_valid);
+}
+
+int velo_get_correspondences(velo_ctx* c, velo_corr* out, int32_t capacity, int32_t* n_queries) {
+    if (!c) return fail(VELO_ERR_INVALID, "null ctx");
+    int qb = 0, qe = 0;
+    if (c->have_corr) q_range(c, &qb, &qe);
+    const int n = qe - qb;
+    if (n_queries) *n_queries = n;
+    if (!out || capacity <= 0 || n == 0) return VELO_OK;
+    if (!c->have_corr) return fail(VELO_ERR_STATE, "no association has run yet");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<float4> p(n), nn(n), v0(n), a1(n);
+    std::vector<int4> a0(n);
+    HIP_TRY(hipMemcpy(p.data(), c->cp.p + qb, sizeof(float4) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(nn.data(), c->cn.p + qb, sizeof(float4) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(v0.data(), c->cv0.p + qb, sizeof(float4) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(a0.data(), c->aux0.p + qb, sizeof(int4) * n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(a1.data(), c->aux1.p + qb, sizeof(float4) * n, hipMemcpyDeviceToHost));
+    const int skip = c->src_skip;
+    int ring = 0;
+    for (int i = 0; i < std::min(n, capacity); i++) {
+        const int qi = qb + i;
+        while (ring + 1 < c->n_src_rings && c->h_q_off[ring + 1] <= qi) ring++;
+        while (c->h_q_off[ring + 1] <= qi && ring + 1 < c->n_src_rings) ring++;
+        velo_corr& o = out[i];
+        std::memset(&o, 0, sizeof(o));
+        int valid; std::memcpy(&valid, &p[i].w, 4);
+        int idx_k; std::memcpy(&idx_k, &a1[i].x, 4);
+        o.valid = valid; o.ring_i = a0[i].x; o.idx_i = a0[i].y; o.ring_j = a0[i].z; o.idx_j = a0[i].w; o.idx_k = idx_k;
+        o.src_ring = ring; o.src_idx = (qi - c->h_q_off[ring]) * skip;
+        o.dist_i = a1[i].y; o.dist_j = a1[i].z;
+        o.p[0] = p[i].x; o.p[1] = p[i].y; o.p[2] = p[i].z;
+        o.n[0] = nn[i].x; o.n[1] = nn[i].y; o.n[2] = nn[i].z;
+        o.v0[0] = v0[i].x; o.v0[1] = v0[i].y; o.v0[2] = v0[i].z;
+    }
+    return VELO_OK;
+}
+
+int velo_build_visual(velo_ctx* c, const double x[6], int32_t iter, int32_t* n_blocks) {
+    if (!c || !x) return fail(VELO_ERR_INVALID, "null argument");
+    if (iter < 1) return fail(VELO_ERR_INVALID, "iter must be >= 1");
+    HIP_TRY(hipSetDevice(c->device));
+    return do_build_visual(c, x, false, iter, n_blocks);
+}
+
+int velo_get_good_matches(velo_ctx* c, velo_good_match* out, int32_t capacity, int32_t* n) {
+    if (!c) return fail(VELO_ERR_INVALID, "null ctx");
+    int count = 0;
+    // emission order of the reference: per match 3D3D|2D2D, 3D2D, 2D3D (velo.h:662-789); matches are cam-major
+    for (int i = 0; i < c->n_matches && (size_t)(3 * i + 2) < c->h_vflags.size(); i++) {
+        for (int s = 0; s < 3; s++) {
+            const unsigned char f = c->h_vflags[3 * i + s];
+            if (!f) continue;
+            if (out && count < capacity) {
+                out[count].cam = c->h_matches[i].cam; out[count].point1 = c->h_matches[i].point1;
+                out[count].point2 = c->h_matches[i].point2; out[count].residual_type = f - 1;
+            }
+            count++;
+        }
+    }
+    if (n) *n = count;
+    return VELO_OK;
+}
+
+int velo_evaluate(velo_ctx* c, const double x[6], double* cost, double JtJ[36], double Jtr[6]) {
+    if (!c || !x) return fail(VELO_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    std::memcpy(c->h_x, x, sizeof(double) * 6);
+    HIP_TRY(hipMemcpyAsync(c->xdev.p, c->h_x, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
+    const EvalArgs A = eval_args(c, c->xdev.p);
+    const EvalPlan plan = eval_plan(A);
+    const int nblocks = plan.total();
+    launch_eval(c, A, plan);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, c->stream, (const LMState*)nullptr, (const double*)c->partials.p, nblocks, c->reduced.p);
+    HIP_TRY(hipGetLastError());
+    double* res = c->reduced.p;
+    if (c->comm) {
+        NCCL_TRY(ncclAllReduce(c->reduced.p, c->reduced.p + kNumAcc, kNumAcc, ncclDouble, ncclSum, c->comm, c->stream));
+        res = c->reduced.p + kNumAcc;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_x + 8, res, sizeof(double) * kNumAcc, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const double* E = c->h_x + 8;
+    if (cost) *cost = E[27];
+    if (JtJ) {
+        int k = 0;
+        for (int i = 0; i < 6; i++) for (int j = i; j < 6; j++) { JtJ[i * 6 + j] = E[k]; JtJ[j * 6 + i] = E[k]; k++; }
+    }
+    if (Jtr) for (int i = 0; i < 6; i++) Jtr[i] = E[21 + i];
+    return VELO_OK;
+}
+
+int velo_evaluate_rows(velo_ctx* c, const double x[6], double* residuals, double* jacobian, int32_t capacity_rows, int32_t* n_rows) {
+    if (!c || !x) return fail(VELO_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    // row layout: visual blocks first (match order, slot order), then valid ICP blocks in query order
+    int qb = 0, qe = 0;
+    if (c->have_corr) q_range(c, &qb, &qe);
+    const int nq = qe - qb;
+    const bool vis = c->vflags_valid && c->shard_rank == 0 && c->n_matches > 0;
+    std::vector<int> h_vis((size_t)3 * (vis ? c->n_matches : 0), -1);
+    int rows = 0;
+    if (vis) {
+        for (size_t s = 0; s < h_vis.size(); s++) {
+            const unsigned char f = c->h_vflags[s];
+            if (!f) continue;
+            h_vis[s] = rows;
+            const int t = f - 1;
+            rows += (t == VELO_RESIDUAL_3D3D) ? 3 : (t == VELO_RESIDUAL_2D2D) ? 1 : 2;
+        }
+    }
+    std::vector<int> h_icp((size_t)std::max(c->n_q, 1), -1);
+    if (nq > 0) {
+        std::vector<float4> p(nq);
+        HIP_TRY(hipMemcpy(p.data(), c->cp.p + qb, sizeof(float4) * nq, hipMemcpyDeviceToHost));
+        for (int i = 0; i < nq; i++) { int valid; std::memcpy(&valid, &p[i].w, 4); if (valid) h_icp[qb + i] = rows++; }
+    }
+    if (n_rows) *n_rows = rows;
+    if (!residuals || !jacobian) return VELO_OK;
+    if (capacity_rows < rows) return fail(VELO_ERR_INVALID, "row capacity %d < %d", capacity_rows, rows);
+    if (rows == 0) return VELO_OK;
+    VELO_TRY(c->row_off_vis.reserve(std::max(h_vis.size(), (size_t)1)));
+    VELO_TRY(c->row_off_icp.reserve(h_icp.size()));
+    VELO_TRY(c->rows_r.reserve((size_t)rows));
+    VELO_TRY(c->rows_J.reserve((size_t)rows * 6));
+    if (!h_vis.empty()) HIP_TRY(hipMemcpy(c->row_off_vis.p, h_vis.data(), sizeof(int) * h_vis.size(), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->row_off_icp.p, h_icp.data(), sizeof(int) * h_icp.size(), hipMemcpyHostToDevice));
+    std::memcpy(c->h_x, x, sizeof(double) * 6);
+    HIP_TRY(hipMemcpyAsync(c->xdev.p, c->h_x, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
+    EvalArgs A = eval_args(c, c->xdev.p);
+    A.rows_r = c->rows_r.p; A.rows_J = c->rows_J.p; A.row_offset_vis = c->row_off_vis.p; A.row_offset_icp = c->row_off_icp.p;
+    launch_eval(c, A, eval_plan(A));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(residuals, c->rows_r.p, sizeof(double) * rows, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(jacobian, c->rows_J.p, sizeof(double) * (size_t)rows * 6, hipMemcpyDeviceToHost));
+    return VELO_OK;
+}
+
+int velo_solve(velo_ctx* c, double x[6], velo_solve_summary* summary) {
+    if (!c || !x) return fail(VELO_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    double xo[6];
+    VELO_TRY(do_solve(c, x, xo, summary, nullptr));
+    for (int k = 0; k < 6; k++) x[k] = xo[k];
+    return VELO_OK;
+}
+
+int velo_frame_to_frame(velo_ctx* c, double x[6], double T[16], velo_summary* summary) {
+    if (!c || !x) return fail(VELO_ERR_INVALID, "null argument");
+    if (!c->have_target || !c->have_source) return fail(VELO_ERR_STATE, "frame_to_frame needs set_target and set_source first");
+    HIP_TRY(hipSetDevice(c->device));
+    velo_summary local;
+    velo_summary* S = summary ? summary : &local;
+    std::memset(S, 0, sizeof(*S));
+    S->n_target = c->n_tgt;
+    c->assoc_events_used = 0;
+    double xc[6];
+    for (int k = 0; k < 6; k++) xc[k] = x[k];
+    bool first = true;
+    for (int iter = 1; iter <= c->P.f2f_iterations; iter++) {                       // velo.h:616
+        VELO_TRY(do_build_visual(c, xc, false, iter, nullptr));                      // velo.h:622-792
+        c->have_corr = false;
+        c->last_n_valid = 0;
+        for (int icp_iter = 0; icp_iter < c->P.icp_iterations; icp_iter++) {        // velo.h:800
+            int nv = 0;
+            VELO_TRY(do_associate(c, xc, iter, false, true, &nv));                   // velo.h:806-894
+            int qb, qe;
+            q_range(c, &qb, &qe);
+            S->n_assoc_rounds++;
+            S->n_queries = c->n_q;
+            const uint64_t nq = (uint64_t)c->n_q;
+            const uint64_t b_assoc = 12ull * nq + 12ull * (uint64_t)c->n_tgt + 28ull * nq;
+            S->assoc_bytes += b_assoc; S->algorithmic_bytes += b_assoc;
+            if (qe > qb) S->assoc_kernel_launches++;
+            velo_solve_summary ss;
+            int evals = 0;
+            VELO_TRY(do_solve(c, first ? xc : xc, xc, &ss, &evals));                 // velo.h:897-902
+            first = false;
+            S->eval_kernel_launches += evals;
+            S->algorithmic_bytes += (uint64_t)ss.evaluations * (36ull * (uint64_t)ss.n_icp_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull);
+            if (S->n_solves < VELO_MAX_SOLVES) S->solves[S->n_solves] = ss;
+            S->n_solves++;
+        }
+    }
+    if (c->timing) {
+        double ms = 0.0;
+        for (int k = 0; k < c->assoc_events_used; k++) {
+            float t = 0.f;
+            HIP_TRY(hipEventElapsedTime(&t, c->assoc_events[k].first, c->assoc_events[k].second));
+            ms += t;
+        }
+        S->assoc_kernel_ms = ms;
+    }
+    for (int k = 0; k < 6; k++) x[k] = xc[k];
+    if (T) velo_pose_vec_to_mat(x, T);
+    return VELO_OK;
+}
+
+int velo_frame_to_frame_batch(velo_ctx** ctxs, int32_t n, double* x, double* T, velo_summary* summaries) {
+    if (!ctxs || n < 0 || (n > 0 && !x)) return fail(VELO_ERR_INVALID, "bad batch arguments");
+    std::vector<int> status((size_t)n, VELO_OK);
+    std::vector<std::string> errs((size_t)n);
+    std::vector<std::thread> th;
+    th.reserve((size_t)n);
+    for (int i = 0; i < n; i++) {
+        th.emplace_back([&, i]() {
+            status[i] = velo_frame_to_frame(ctxs[i], x + 6 * (size_t)i, T ? T + 16 * (size_t)i : nullptr, summaries ? summaries + i : nullptr);
+            if (status[i] != VELO_OK) errs[i] = g_err;
+        });
+    }
+    for (auto& t : th) t.join();
+    for (int i = 0; i < n; i++) if (status[i] != VELO_OK) { g_err = errs[i]; return status[i]; }
+    return VELO_OK;
+}
+
+// util::pose_mat2vec (utility.h:67-82): 6-vector -> 4x4, row-major out.  Column j of R is R(omega) e_j, which is what
+// ceres::AngleAxisToRotationMatrix [3P] writes column-major and utility.h:73-77 transposes back.
+int velo_pose_vec_to_mat(const double x[6], double T[16]) {
+    if (!x || !T) return fail(VELO_ERR_INVALID, "null argument");
+    for (int i = 0; i < 16; i++) T[i] = 0.0;
+    T[15] = 1.0;
+    const double theta2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+    if (theta2 > std::numeric_limits<double>::epsilon()) {
+        const double theta = std::sqrt(theta2), wx = x[0] / theta, wy = x[1] / theta, wz = x[2] / theta;
+        const double c = std::cos(theta), s = std::sin(theta);
+        T[0] = c + wx * wx * (1 - c);       T[4] = wz * s + wx * wy * (1 - c);  T[8] = -wy * s + wx * wz * (1 - c);
+        T[1] = wx * wy * (1 - c) - wz * s;  T[5] = c + wy * wy * (1 - c);       T[9] = wx * s + wy * wz * (1 - c);
+        T[2] = wy * s + wx * wz * (1 - c);  T[6] = -wx * s + wy * wz * (1 - c); T[10] = c + wz * wz * (1 - c);
+    } else {
+        T[0] = 1;      T[4] = x[2];   T[8] = -x[1];
+        T[1] = -x[2];  T[5] = 1;      T[9] = x[0];
+        T[2] = x[1];   T[6] = -x[0];  T[10] = 1;
+    }
+    T[3] = x[3]; T[7] = x[4]; T[11] = x[5];
+    return VELO_OK;
+}
+
+// util::pose_vec2mat (utility.h:83-96): 4x4 -> 6-vector via the quaternion route of ceres::RotationMatrixToAngleAxis [3P]
+int velo_pose_mat_to_vec(const double T[16], double x[6]) {
+    if (!x || !T) return fail(VELO_ERR_INVALID, "null argument");
+    const double R[3][3] = {{T[0], T[1], T[2]}, {T[4], T[5], T[6]}, {T[8], T[9], T[10]}};
+    double q[4] = {0, 0, 0, 0};
+    const double tr = R[0][0] + R[1][1] + R[2][2];
+    if (tr >= 0.0) {
+        double t = std::sqrt(tr + 1.0);
+        q[0] = 0.5 * t; t = 0.5 / t;
+        q[1] = (R[2][1] - R[1][2]) * t; q[2] = (R[0][2] - R[2][0]) * t; q[3] = (R[1][0] - R[0][1]) * t;
+    } else {
+        int i = 0;
+        if (R[1][1] > R[0][0]) i = 1;
+        if (R[2][2] > R[i][i]) i = 2;
+        const int j = (i + 1) % 3, k = (j + 1) % 3;
+        double t = std::sqrt(R[i][i] - R[j][j] - R[k][k] + 1.0);
+        q[i + 1] = 0.5 * t; t = 0.5 / t;
+        q[0] = (R[k][j] - R[j][k]) * t; q[j + 1] = (R[j][i] + R[i][j]) * t; q[k + 1] = (R[k][i] + R[i][k]) * t;
+    }
+    const double s2 = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    if (s2 > 0.0) {
+        const double s = std::sqrt(s2);
+        const double two_theta = 2.0 * ((q[0] < 0.0) ? std::atan2(-s, -q[0]) : std::atan2(s, q[0]));
+        const double k = two_theta / s;
+        x[0] = q[1] * k; x[1] = q[2] * k; x[2] = q[3] * k;
+    } else {
+        x[0] = q[1] * 2.0; x[1] = q[2] * 2.0; x[2] = q[3] * 2.0;
+    }
+    x[3] = T[3]; x[4] = T[7]; x[5] = T[11];
+    return VELO_OK;
+}
+
+int velo_comm_unique_id(char id[128]) {
+    if (!id) return fail(VELO_ERR_INVALID, "null id");
+    static_assert(sizeof(ncclUniqueId) <= 128, "ncclUniqueId larger than the ABI's 128 bytes");
+    ncclUniqueId u;
+    NCCL_TRY(ncclGetUniqueId(&u));
+    std::memset(id, 0, 128);
+    std::memcpy(id, &u, sizeof(u));
+    return VELO_OK;
+}
+
+int velo_comm_init(velo_ctx* c, const char id[128], int32_t rank, int32_t world) {
+    if (!c || !id || world < 1 || rank < 0 || rank >= world) return fail(VELO_ERR_INVALID, "bad comm arguments");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->comm) { NCCL_TRY(ncclCommDestroy(c->comm)); c->comm = nullptr; }
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    NCCL_TRY(ncclCommInitRank(&c->comm, world, u, rank));
+    c->shard_rank = rank; c->shard_world = world;
+    c->have_corr = false;
+    return VELO_OK;
+}
+
+int velo_comm_destroy(velo_ctx* c) {
+    if (!c) return fail(VELO_ERR_INVALID, "null ctx");
+    if (c->comm) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        NCCL_TRY(ncclCommDestroy(c->comm));
+        c->comm = nullptr;
+    }
+    c->shard_rank = 0; c->shard_world = 1;
+    c->have_corr = false;
+    return VELO_OK;
+}
+
+int velo_set_query_shard(velo_ctx* c, int32_t rank, int32_t world) {
+    if (!c || world < 1 || rank < 0 || rank >= world) return fail(VELO_ERR_INVALID, "bad shard arguments");
+    if (c->comm) return fail(VELO_ERR_STATE, "a communicator is attached; its rank/world define the shard");
+    c->shard_rank = rank; c->shard_world = world;
+    c->have_corr = false;
+    return VELO_OK;
+}
+
+int velo_synchronize(velo_ctx* c) {
+    if (!c) return fail(VELO_ERR_INVALID, "null ctx");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VELO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,733 @@
+// velo_kernels.h -- device data layout + HIP kernels of the scan-matching core (gfx950 / CDNA4 only).
+//
+// Kernel map (SURVEY.md section 8(a) rows in brackets):
+//   pack_points_kernel, bbox_kernel, grid_count/scan/scatter  [T1]  target index: uniform grid, cell >= gate radius
+//   assoc_search_kernel                                      [A1-A6] query transform, exact per-ring 1-NN via the
+//                                                                    27-cell neighbourhood, top-2 rings, ring neighbour,
+//                                                                    triangle normal -> correspondence table
+//   visual_gate_kernel                                       [G1]   visual block choice + outlier gate
+//   eval_kernel                                              [R1-R5,L1] residuals + dual-number Jacobians + robust
+//                                                                    weights -> per-workgroup 28-double partial sums
+//   lm_step_kernel                                           [S1]   deterministic final reduction + one trust-region
+//                                                                    Levenberg-Marquardt state transition, on device
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "velo_device_math.h"
+
+namespace velo {
+
+constexpr int kWave = 64;
+constexpr int kNumAcc = 28;           // 21 upper-triangular JtJ + 6 Jtr + cost
+constexpr int kEvalThreads = 256;
+constexpr int kMaxEvalBlocks = 512;
+constexpr int kAssocThreads = 256;
+
+// ---- uniform grid over the target cloud (one per distinct gate radius) ------------------------------------
+struct GridDesc {
+    float ox, oy, oz;       // origin = bbox min
+    float inv_h;            // 1 / cell size; cell size >= 1.01 * gate radius so the 27-neighbourhood is exhaustive
+    int nx, ny, nz;
+    int ncells;
+};
+
+struct GridView {
+    GridDesc d;
+    const int* __restrict__ cell_start;      // [ncells + 1]
+    const float4* __restrict__ sorted;       // [n_finite] x,y,z, w = bits(global target index)
+};
+
+// ---- pose scalars of one association round, computed on the HOST in double with the same libm the CPU
+// restatement uses, so that the float coordinates of the transformed queries are bit-identical (row A1) -----
+struct PoseScalars {
+    double w[3];     // omega
+    double t[3];
+    double c, s;     // cos / sin(theta)
+    double u[3];     // omega / theta
+    double omc;      // 1 - cos(theta)
+    int small;       // theta^2 <= DBL_EPSILON -> first-order branch
+};
+
+__device__ __forceinline__ int cell_coord(float p, float o, float inv_h, int n) {
+    float f = (p - o) * inv_h;
+    f = fminf(fmaxf(f, -2.0f), (float)(n + 1));
+    return (int)floorf(f);
+}
+
+// ---- point packing: (stride-addressed xyz) -> float4 ---------------------------------------------------------
+__global__ void pack_points_kernel(const char* __restrict__ src, int64_t stride, int n, float4* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = (const float*)(src + (int64_t)i * stride);
+    dst[i] = make_float4(p[0], p[1], p[2], 0.0f);
+}
+
+// ring id per point (binary search in ring_offsets) -- the target's gidx -> ring map
+__global__ void ring_of_kernel(const int* __restrict__ off, int n_rings, int n, int* __restrict__ ring_of) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int lo = 0, hi = n_rings;   // find r with off[r] <= i < off[r+1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= i) lo = mid; else hi = mid; }
+    ring_of[i] = lo;
+}
+
+// query list: query i -> global source index.  Ring r contributes ceil(n_r / skip) queries (velo.h:806-807).
+__global__ void query_list_kernel(const int* __restrict__ src_off, const int* __restrict__ q_off, int n_rings,
+                                  int skip, int nq, int* __restrict__ q_src) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    int lo = 0, hi = n_rings;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (q_off[mid] <= i) lo = mid; else hi = mid; }
+    q_src[i] = src_off[lo] + (i - q_off[lo]) * skip;
+}
+
+// ---- bounding box of the finite points: per-block min/max then atomics on order-preserving integer keys ----
+__device__ __forceinline__ unsigned f2key(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__host__ __device__ __forceinline__ float key2f(unsigned k) {
+    unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+#ifdef __HIP_DEVICE_COMPILE__
+    return __uint_as_float(u);
+#else
+    float f; __builtin_memcpy(&f, &u, 4); return f;
+#endif
+}
+__global__ void bbox_kernel(const float4* __restrict__ pts, int n, unsigned* __restrict__ mnmx /* [6]: min xyz, max xyz keys */) {
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float4 p = pts[i];
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+            mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+            mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[k] = fminf(mn[k], __shfl_xor(mn[k], off));
+            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { atomicMin(&mnmx[k], f2key(mn[k])); atomicMax(&mnmx[3 + k], f2key(mx[k])); }
+    }
+}
+
+// ---- grid build: count, exclusive scan (3 kernels), scatter ----------------------------------------------------
+__device__ __forceinline__ int cell_of_point(const GridDesc& g, const float4& p) {
+    int cx = cell_coord(p.x, g.ox, g.inv_h, g.nx), cy = cell_coord(p.y, g.oy, g.inv_h, g.ny), cz = cell_coord(p.z, g.oz, g.inv_h, g.nz);
+    cx = min(max(cx, 0), g.nx - 1); cy = min(max(cy, 0), g.ny - 1); cz = min(max(cz, 0), g.nz - 1);
+    return (cz * g.ny + cy) * g.nx + cx;
+}
+__global__ void grid_count_kernel(GridDesc g, const float4* __restrict__ pts, int n, int* __restrict__ cell_of, int* __restrict__ counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    int c = -1;
+    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) { c = cell_of_point(g, p); atomicAdd(&counts[c], 1); }
+    cell_of[i] = c;
+}
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;                      // per thread
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+__device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
+    __shared__ int wave_sums[kScanThreads / kWave];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+    if (lane == 63) wave_sums[wid] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / kWave; w++) { const int s = wave_sums[w]; if (w < wid) base += s; tot += s; }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+// pass 1: tile-local exclusive scan in place (counts -> local offsets), tile totals out
+__global__ void scan_tiles_kernel(int* __restrict__ data, int n, int* __restrict__ tile_sums) {
+    const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    int v[kScanItems], s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) { v[k] = (base + k < n) ? data[base + k] : 0; s += v[k]; }
+    int total;
+    int ex = block_exclusive_scan(s, &total);
+#pragma unroll
+    for (int k = 0; k < kScanItems; k++) { if (base + k < n) data[base + k] = ex; ex += v[k]; }
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+// pass 2: one workgroup scans the tile totals in place (exclusive) and writes the grand total to data_total
+__global__ void scan_sums_kernel(int* __restrict__ tile_sums, int n_tiles, int* __restrict__ grand_total) {
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int start = 0; start < n_tiles; start += kScanThreads) {
+        const int i = start + threadIdx.x;
+        const int v = (i < n_tiles) ? tile_sums[i] : 0;
+        int total;
+        const int ex = block_exclusive_scan(v, &total);
+        const int carry = carry_s;
+        if (i < n_tiles) tile_sums[i] = ex + carry;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + total;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *grand_total = carry_s;
+}
+// pass 3: add tile offsets; also seed the scatter cursor; element n receives the grand total
+__global__ void scan_add_kernel(int* __restrict__ data, int n, const int* __restrict__ tile_sums, const int* __restrict__ grand_total,
+                                int* __restrict__ cursor) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int v = data[i] + tile_sums[i / kScanTile]; data[i] = v; cursor[i] = v; }
+    else if (i == n) data[n] = *grand_total;
+}
+__global__ void grid_scatter_kernel(const float4* __restrict__ pts, const int* __restrict__ cell_of, int n, int* __restrict__ cursor,
+                                    float4* __restrict__ sorted) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c = cell_of[i];
+    if (c < 0) return;
+    const int slot = atomicAdd(&cursor[c], 1);
+    const float4 p = pts[i];
+    sorted[slot] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+}
+
+// ---- association ------------------------------------------------------------------------------------------------
+// Candidate order inside the scan is irrelevant: candidates are compared through the total order
+//     key = (float bits of d2) << 32 | global target index        (d2 >= 0, so the bit pattern is monotone)
+// and the global index is ring-major, so "lower key" == "closer, ties -> lower ring, then lower index" -- the
+// outcome of the reference's sequential strict-'<' scan over rings (velo.h:825-848) on exact per-ring minima.
+// best1 = min key overall; best2 = min key among candidates whose ring differs from best1's ring.
+struct AssocOut {
+    float4* __restrict__ p;      // xyz of the untransformed source point, w = bits(valid)
+    float4* __restrict__ n;      // unit normal
+    float4* __restrict__ v0;     // plane offset
+    int4* __restrict__ aux0;     // ring_i, idx_i, ring_j, idx_j      (only when want_aux)
+    float4* __restrict__ aux1;   // bits(idx_k), dist_i, dist_j, -
+    int* __restrict__ n_valid;   // atomic counter
+};
+
+__device__ __forceinline__ float dist2_f(float qx, float qy, float qz, float sx, float sy, float sz) {
+    // float L2, accumulated x -> y -> z with separate multiplies and adds (utility.h:51-53, FLANN L2_Simple [3P]);
+    // this file is compiled with -ffp-contract=off so no FMA is formed.
+    const float dx = qx - sx, dy = qy - sy, dz = qz - sz;
+    float r = dx * dx;
+    r = r + dy * dy;
+    r = r + dz * dz;
+    return r;
+}
+
+__device__ __forceinline__ void transform_query(const PoseScalars& P, const float4& p, float* qx, float* qy, float* qz) {
+    // util::transform_point (utility.h:97-103) = ceres::AngleAxisRotatePoint in double, + t, rounded to float
+    const double x = p.x, y = p.y, z = p.z;
+    double r0, r1, r2;
+    if (!P.small) {
+        const double c0 = P.u[1] * z - P.u[2] * y, c1 = P.u[2] * x - P.u[0] * z, c2 = P.u[0] * y - P.u[1] * x;
+        const double tmp = (P.u[0] * x + P.u[1] * y + P.u[2] * z) * P.omc;
+        r0 = x * P.c + c0 * P.s + P.u[0] * tmp;
+        r1 = y * P.c + c1 * P.s + P.u[1] * tmp;
+        r2 = z * P.c + c2 * P.s + P.u[2] * tmp;
+    } else {
+        r0 = x + (P.w[1] * z - P.w[2] * y);
+        r1 = y + (P.w[2] * x - P.w[0] * z);
+        r2 = z + (P.w[0] * y - P.w[1] * x);
+    }
+    *qx = (float)(r0 + P.t[0]);
+    *qy = (float)(r1 + P.t[1]);
+    *qz = (float)(r2 + P.t[2]);
+}
+
+// rows A3 (tail) - A6: from the two winners to (N, v0, valid)
+__device__ __forceinline__ void finish_correspondence(
+    int qi, const float4& psrc, float qx, float qy, float qz, unsigned long long b1, unsigned long long b2, unsigned long long key_inf,
+    const float4* __restrict__ tgt, const int* __restrict__ tgt_off, const int* __restrict__ ring_of, double norm_cond,
+    const AssocOut& out, bool want_aux) {
+    int valid = 0;
+    float nx = 0.f, ny = 0.f, nz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
+    int ring_i = -1, idx_i = 0, ring_j = -1, idx_j = 0, idx_k = 0;
+    float di = 1e18f, dj = 1e18f;
+    if (b1 < key_inf) {
+        const int gi = (int)(unsigned)(b1 & 0xffffffffull);
+        ring_i = ring_of[gi];
+        idx_i = gi - tgt_off[ring_i];
+        di = __uint_as_float((unsigned)(b1 >> 32));
+    }
+    if (b2 < key_inf) {
+        const int gj = (int)(unsigned)(b2 & 0xffffffffull);
+        ring_j = ring_of[gj];
+        idx_j = gj - tgt_off[ring_j];
+        dj = __uint_as_float((unsigned)(b2 >> 32));
+    }
+    if (ring_i >= 0 && ring_j >= 0) {                                   // velo.h:849-851
+        const int base = tgt_off[ring_i];
+        const int n = tgt_off[ring_i + 1] - base;
+        const int k1 = (idx_i + 1) % n, k2 = (idx_i - 1 + n) % n;       // velo.h:852-854
+        const float4 a1 = tgt[base + k1], a2 = tgt[base + k2];
+        const float d1 = dist2_f(a1.x, a1.y, a1.z, qx, qy, qz);         // (np - pointM), same squares
+        const float d2 = dist2_f(a2.x, a2.y, a2.z, qx, qy, qz);
+        idx_k = (d1 < d2) ? k1 : k2;                                    // velo.h:859-863
+        const float4 v0 = tgt[base + idx_i];
+        const float4 v1 = tgt[tgt_off[ring_j] + idx_j];
+        const float4 v2 = (idx_k == k1) ? a1 : a2;
+        const float ax = v1.x - v0.x, ay = v1.y - v0.y, az = v1.z - v0.z;
+        const float bx = v2.x - v0.x, by = v2.y - v0.y, bz = v2.z - v0.z;
+        float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;   // velo.h:872
+        const float nn = sqrtf(cx * cx + cy * cy + cz * cz);            // Eigen norm(): sqrt of the x,y,z sum
+        if (!((double)nn < norm_cond)) {                                // velo.h:873 (float norm vs double constant)
+            nx = cx / nn; ny = cy / nn; nz = cz / nn;                   // velo.h:874
+            vx = v0.x; vy = v0.y; vz = v0.z;
+            valid = 1;
+        }
+    }
+    out.p[qi] = make_float4(psrc.x, psrc.y, psrc.z, __int_as_float(valid));
+    out.n[qi] = make_float4(nx, ny, nz, 0.f);
+    out.v0[qi] = make_float4(vx, vy, vz, 0.f);
+    if (want_aux) {
+        out.aux0[qi] = make_int4(ring_i, idx_i, ring_j, idx_j);
+        out.aux1[qi] = make_float4(__int_as_float(idx_k), di, dj, 0.f);
+    }
+    // one atomic per wave
+    const unsigned long long m = __ballot(valid);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out.n_valid, (int)__popcll(m));
+}
+
+// v0 association search: one lane per query, each lane walks the 9 x-runs of its own 27-cell neighbourhood.
+__global__ void __launch_bounds__(kAssocThreads)
+assoc_search_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
+                    const float4* __restrict__ tgt, const int* __restrict__ tgt_off, const int* __restrict__ ring_of,
+                    unsigned gate_bits, double norm_cond, AssocOut out, int want_aux) {
+    const int qi = q_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = qi < q_end;
+    const unsigned long long key_inf = ((unsigned long long)gate_bits + 1ull) << 32;
+    float4 psrc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    unsigned long long b1 = key_inf, b2 = key_inf;
+    int b1ring = -1;
+    if (active) {
+        psrc = src[q_src[qi]];
+        transform_query(P, psrc, &qx, &qy, &qz);
+        const GridDesc& g = G.d;
+        const int cx = cell_coord(qx, g.ox, g.inv_h, g.nx), cy = cell_coord(qy, g.oy, g.inv_h, g.ny), cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+        const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.ny - 1);
+        const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.nz - 1);
+        if (x0 <= x1) {
+            for (int z = z0; z <= z1; z++) {
+                for (int y = y0; y <= y1; y++) {
+                    const int row = (z * g.ny + y) * g.nx;
+                    const int j0 = G.cell_start[row + x0], j1 = G.cell_start[row + x1 + 1];
+                    for (int j = j0; j < j1; j++) {
+                        const float4 s = G.sorted[j];
+                        const float d2 = dist2_f(qx, qy, qz, s.x, s.y, s.z);
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(s.w);
+                        if (key < b2) {                                  // implies d2 <= gate (keys start at key_inf)
+                            const int ring = ring_of[__float_as_int(s.w)];
+                            if (key < b1) {
+                                if (ring != b1ring) b2 = b1;
+                                b1 = key; b1ring = ring;
+                            } else if (ring != b1ring) {
+                                b2 = key;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (active) finish_correspondence(qi, psrc, qx, qy, qz, b1, b2, key_inf, tgt, tgt_off, ring_of, norm_cond, out, want_aux != 0);
+}
+
+// ---- visual blocks (rows G1, R2-R5) ------------------------------------------------------------------------------------
+// One record per match, three block slots: slot 0 = 3D3D or 2D2D, slot 1 = 3D2D, slot 2 = 2D3D (velo.h order).
+struct VisualMatch {      // device copy of velo_match, floats kept as floats and widened at use (costfunctions.h ctors)
+    float p3_1[3], p3_2[3], p2_1[2], p2_2[2], t_cam[3];
+    int cam, point1, point2;
+    unsigned char d1, d2, pad[2];
+};
+struct VisualParams {
+    double w_3d2d, w_2d2d;
+    double th_3d2d, th_2d2d, th_3d3d;
+    double outlier_reject;
+    int enable_2d2d, enable_3d2d;
+};
+
+// pose at which a sweep evaluates
+struct PoseEval {
+    double t[3];
+    PoseRot fwd;   // R(omega)
+    PoseRot inv;   // R(-omega), cost2D3D only (costfunctions.h:154-160)
+};
+__device__ __forceinline__ void pose_eval_init(const double x[6], PoseEval* P, bool need_inv) {
+    P->t[0] = x[3]; P->t[1] = x[4]; P->t[2] = x[5];
+    pose_rot_init(x, &P->fwd);
+    if (need_inv) { const double m[3] = {-x[0], -x[1], -x[2]}; pose_rot_init(m, &P->inv); }
+}
+
+// residuals r[<=3] and row-major Jacobian J[<=3][6] of one visual block; returns the residual dimension
+__device__ __forceinline__ int visual_block_eval(const PoseEval& P, const VisualMatch& m, int slot, double r[3], double J[18]) {
+    if (slot == 0) {
+        if (m.d1 && m.d2) {
+            const double a[3] = {m.p3_1[0], m.p3_1[1], m.p3_1[2]}, s[3] = {m.p3_2[0], m.p3_2[1], m.p3_2[2]};
+            res_3d3d(P.fwd, P.t, a, s, r, J);
+            return 3;
+        }
+        const double a[2] = {m.p2_1[0], m.p2_1[1]}, s[2] = {m.p2_2[0], m.p2_2[1]}, tc[3] = {m.t_cam[0], m.t_cam[1], m.t_cam[2]};
+        res_2d2d(P.fwd, P.t, a, s, tc, r, J);
+        return 1;
+    }
+    const double tc[3] = {m.t_cam[0], m.t_cam[1], m.t_cam[2]};
+    if (slot == 1) {
+        const double a[3] = {m.p3_1[0], m.p3_1[1], m.p3_1[2]}, s[2] = {m.p2_2[0], m.p2_2[1]};
+        res_3d2d(P.fwd, P.t, a, s, tc, r, J);
+    } else {
+        const double a[3] = {m.p3_2[0], m.p3_2[1], m.p3_2[2]}, s[2] = {m.p2_1[0], m.p2_1[1]};
+        res_2d3d(P.inv, P.t, a, s, tc, r, J);
+    }
+    return 2;
+}
+
+// flags[3*m + slot]: 0 = no block, 1 + residual_type = block present
+__global__ void visual_gate_kernel(const double* __restrict__ xdev, VisualParams V, const VisualMatch* __restrict__ matches, int n, int iter,
+                                   unsigned char* __restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) x[k] = xdev[k];
+    PoseEval P;
+    pose_eval_init(x, &P, true);
+    const VisualMatch m = matches[i];
+    unsigned char f0 = 0, f1 = 0, f2 = 0;
+    bool stop = false;          // a failed gate `continue`s past the remaining residual types of the match
+    double r[3], J[18];
+    const double it = (double)iter;
+    if (m.d1 && m.d2) {                                                      // velo.h:662-693
+        visual_block_eval(P, m, 0, r, J);
+        const double th = V.th_3d3d * V.outlier_reject / it;
+        if (iter > 1 && r[0] * r[0] + r[1] * r[1] + r[2] * r[2] > th * th) stop = true; else f0 = 1 + 0;
+    }
+    if (!stop && !m.d1 && !m.d2 && V.enable_2d2d) {                          // velo.h:694-722
+        visual_block_eval(P, m, 0, r, J);
+        if (iter > 1 && fabs(r[0]) > V.th_2d2d * V.outlier_reject / it) stop = true; else f0 = 1 + 3;
+    }
+    if (V.enable_3d2d) {
+        const double th = V.th_3d2d * V.outlier_reject / it;
+        if (!stop && m.d1) {                                                 // velo.h:724-756
+            visual_block_eval(P, m, 1, r, J);
+            if (iter > 1 && r[0] * r[0] + r[1] * r[1] > th * th) stop = true; else f1 = 1 + 1;
+        }
+        if (!stop && m.d2) {                                                 // velo.h:757-789
+            visual_block_eval(P, m, 2, r, J);
+            if (iter > 1 && r[0] * r[0] + r[1] * r[1] > th * th) stop = true; else f2 = 1 + 2;
+        }
+    }
+    flags[3 * i + 0] = f0; flags[3 * i + 1] = f1; flags[3 * i + 2] = f2;
+}
+
+// ---- LM state (row S1) ------------------------------------------------------------------------------------------------------
+enum { PHASE_INIT = 0, PHASE_CAND = 1 };
+struct LMParams {
+    int max_num_iterations, max_invalid;
+    double function_tolerance, gradient_tolerance, parameter_tolerance;
+    double initial_radius, max_radius, min_radius, min_relative_decrease, min_diag, max_diag;
+};
+struct LMState {
+    double x[6];        // last accepted iterate (the reference's `transform`)
+    double xc[6];       // candidate x + delta
+    double H[21];       // upper triangle of J^T J at x (robustified, unscaled)
+    double g[6];        // J^T r at x
+    double cost;
+    double scale[6];    // Jacobi scaling 1/(1+||J_j||), fixed per solve
+    double diag[6];
+    double radius, decrease, x_norm, model_change, step_norm;
+    double initial_cost;
+    int reuse_diag, invalid, iter, evals, done, termination, phase, pad;
+};
+
+__device__ __forceinline__ int tri(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }   // i <= j
+
+// ---- evaluation sweeps ---------------------------------------------------------------------------------------------------------
+struct EvalArgs {
+    const LMState* __restrict__ state;      // x / xc and the done flag live here
+    const double* __restrict__ x_override;  // when non-null: evaluate at this device x, ignore state (velo_evaluate)
+    const float4* __restrict__ cp;          // correspondences
+    const float4* __restrict__ cn;
+    const float4* __restrict__ cv0;
+    int q_begin, q_end;
+    const VisualMatch* __restrict__ vm;
+    const unsigned char* __restrict__ vflags;
+    int n_matches;                          // 0 on ranks that do not own the visual blocks
+    double loss_a_3dpd, w_3dpd;
+    VisualParams V;
+    double* __restrict__ partials;          // ICP sweep: rows [0, gridDim.x); visual sweep: rows [vis_row0, vis_row0 + gridDim.x)
+    int vis_row0;
+    double* __restrict__ rows_r;            // optional row output
+    double* __restrict__ rows_J;
+    const int* __restrict__ row_offset_vis; // [3*n_matches] row index of each visual slot (exclusive scan of dims)
+    const int* __restrict__ row_offset_icp; // [nq] row index of each query's block (or -1)
+};
+
+// acc += (sr J)^T (sr J), (sr J)^T (sr r): one robustified residual row
+__device__ __forceinline__ void accumulate_row(double acc[kNumAcc], double r, const double Jr[6], double sr) {
+    const double rk = r * sr;
+    double J[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) J[i] = Jr[i] * sr;
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+        for (int j = i; j < 6; j++) acc[k++] += J[i] * J[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) acc[21 + i] += J[i] * rk;
+}
+
+// wave reduction by shuffles, then across the workgroup's waves through LDS; fixed order -> deterministic
+__device__ __forceinline__ void block_reduce_store(double acc[kNumAcc], double* __restrict__ dst /* [28] */) {
+    __shared__ double red[kEvalThreads / kWave][kNumAcc];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kNumAcc; k++) {
+        double v = acc[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) red[wid][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumAcc) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kEvalThreads / kWave; w++) v += red[w][threadIdx.x];
+        dst[threadIdx.x] = v;
+    }
+}
+
+__device__ __forceinline__ bool eval_load_x(const EvalArgs& A, double x[6]) {
+    if (A.x_override) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) x[k] = A.x_override[k];
+        return true;
+    }
+    if (A.state->done) return false;
+    const bool cand = A.state->phase == PHASE_CAND;
+#pragma unroll
+    for (int k = 0; k < 6; k++) x[k] = cand ? A.state->xc[k] : A.state->x[k];
+    return true;
+}
+
+// point-to-plane blocks (row R1 + Scaled(Cauchy(loss_thresh_3DPD), weight_3DPD), velo.h:875-892)
+__global__ void __launch_bounds__(kEvalThreads)
+eval_icp_kernel(EvalArgs A) {
+    double x[6];
+    if (!eval_load_x(A, x)) return;
+    PoseRot R;
+    pose_rot_init(x, &R);
+    const double t[3] = {x[3], x[4], x[5]};
+    double acc[kNumAcc];
+#pragma unroll
+    for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    for (int i = A.q_begin + tid; i < A.q_end; i += nthreads) {
+        const float4 p = A.cp[i];
+        if (__float_as_int(p.w) == 0) continue;
+        const float4 n = A.cn[i], v = A.cv0[i];
+        const double pd[3] = {p.x, p.y, p.z}, nd[3] = {n.x, n.y, n.z}, vd[3] = {v.x, v.y, v.z};
+        double r, J[6];
+        res_3dpd(R, t, pd, nd, vd, &r, J);
+        double rho0, rho1;
+        loss_cauchy(A.loss_a_3dpd, A.w_3dpd, r * r, &rho0, &rho1);
+        acc[27] += 0.5 * rho0;
+        const double sr = sqrt(rho1);
+        accumulate_row(acc, r, J, sr);
+        if (A.rows_r) {
+            const int row = A.row_offset_icp[i];
+            A.rows_r[row] = r * sr;
+#pragma unroll
+            for (int k = 0; k < 6; k++) A.rows_J[(size_t)row * 6 + k] = J[k] * sr;
+        }
+    }
+    block_reduce_store(acc, A.partials + (size_t)blockIdx.x * kNumAcc);
+}
+
+// visual blocks (rows R2-R5; losses velo.h:688,714-717,748-751,781-784)
+__global__ void __launch_bounds__(kEvalThreads)
+eval_visual_kernel(EvalArgs A) {
+    double x[6];
+    if (!eval_load_x(A, x)) return;
+    PoseEval P;
+    pose_eval_init(x, &P, true);
+    double acc[kNumAcc];
+#pragma unroll
+    for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    for (int s = tid; s < 3 * A.n_matches; s += nthreads) {
+        const unsigned char f = A.vflags[s];
+        if (!f) continue;
+        const int mi = s / 3, slot = s - 3 * mi;
+        const VisualMatch m = A.vm[mi];
+        double r[3], J[18];
+        const int d = visual_block_eval(P, m, slot, r, J);
+        double sq = 0.0;
+        for (int k = 0; k < d; k++) sq += r[k] * r[k];
+        double rho0, rho1;
+        const int type = f - 1;
+        if (type == 0) loss_arctan(A.V.th_3d3d, 1.0, sq, &rho0, &rho1);
+        else if (type == 3) loss_arctan(A.V.th_2d2d, A.V.w_2d2d, sq, &rho0, &rho1);
+        else loss_arctan(A.V.th_3d2d, A.V.w_3d2d, sq, &rho0, &rho1);
+        acc[27] += 0.5 * rho0;
+        const double sr = sqrt(rho1);
+        for (int k = 0; k < d; k++) {
+            accumulate_row(acc, r[k], J + 6 * k, sr);
+            if (A.rows_r) {
+                const int row = A.row_offset_vis[s] + k;
+                A.rows_r[row] = r[k] * sr;
+                for (int c = 0; c < 6; c++) A.rows_J[(size_t)row * 6 + c] = J[6 * k + c] * sr;
+            }
+        }
+    }
+    block_reduce_store(acc, A.partials + (size_t)(A.vis_row0 + blockIdx.x) * kNumAcc);
+}
+
+// sums the per-workgroup partials in a fixed order into out[28] (used before the RCCL all-reduce and by velo_evaluate)
+__global__ void reduce_partials_kernel(const LMState* __restrict__ state, const double* __restrict__ partials, int n_blocks, double* __restrict__ out) {
+    if (state && state->done) return;
+    if (threadIdx.x < kNumAcc) {
+        double v = 0.0;
+        for (int b = 0; b < n_blocks; b++) v += partials[(size_t)b * kNumAcc + threadIdx.x];
+        out[threadIdx.x] = v;
+    }
+}
+
+// ---- one trust-region LM state transition --------------------------------------------------------------------------
+__device__ inline bool chol_solve6(const double A[36], const double b[6], double y[6]) {
+    double L[36];
+    for (int i = 0; i < 36; i++) L[i] = 0.0;
+    for (int j = 0; j < 6; j++) {
+        double d = A[j * 6 + j];
+        for (int k = 0; k < j; k++) d -= L[j * 6 + k] * L[j * 6 + k];
+        if (!(d > 0.0) || !isfinite(d)) return false;
+        L[j * 6 + j] = sqrt(d);
+        for (int i = j + 1; i < 6; i++) {
+            double s = A[i * 6 + j];
+            for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
+            L[i * 6 + j] = s / L[j * 6 + j];
+        }
+    }
+    double z[6];
+    for (int i = 0; i < 6; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * z[k]; z[i] = s / L[i * 6 + i]; }
+    for (int i = 5; i >= 0; i--) { double s = z[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * y[k]; y[i] = s / L[i * 6 + i]; }
+    for (int i = 0; i < 6; i++) if (!isfinite(y[i])) return false;
+    return true;
+}
+
+// Computes trust-region steps until one is valid (invalid ones cost an iteration but no evaluation).
+__device__ inline void lm_compute_step(const LMParams& Q, LMState* S) {
+    for (;;) {
+        if (S->iter + 1 > Q.max_num_iterations) { S->done = 1; S->termination = 1; return; }
+        if (S->radius < Q.min_radius) { S->done = 1; S->termination = 0; return; }
+        S->iter++;
+        double Hs[36], gs[6];
+        for (int i = 0; i < 6; i++) {
+            gs[i] = S->g[i] * S->scale[i];
+            for (int j = 0; j < 6; j++) {
+                const double h = (i <= j) ? S->H[tri(i, j)] : S->H[tri(j, i)];
+                Hs[i * 6 + j] = h * S->scale[i] * S->scale[j];
+            }
+        }
+        if (!S->reuse_diag) for (int j = 0; j < 6; j++) S->diag[j] = fmin(fmax(Hs[j * 6 + j], Q.min_diag), Q.max_diag);
+        double A[36];
+        for (int i = 0; i < 36; i++) A[i] = Hs[i];
+        for (int j = 0; j < 6; j++) { const double l = sqrt(S->diag[j] / S->radius); A[j * 6 + j] += l * l; }
+        double y[6], step[6];
+        bool ok = chol_solve6(A, gs, y);
+        S->reuse_diag = 1;
+        double mc = 0.0;
+        if (ok) {
+            double gd = 0.0, dHd = 0.0;
+            for (int i = 0; i < 6; i++) step[i] = -y[i];
+            for (int i = 0; i < 6; i++) { gd += gs[i] * step[i]; for (int j = 0; j < 6; j++) dHd += step[i] * Hs[i * 6 + j] * step[j]; }
+            mc = -(gd + 0.5 * dHd);
+            if (!(mc > 0.0)) ok = false;
+        }
+        if (!ok) {
+            if (++S->invalid >= Q.max_invalid) { S->done = 1; S->termination = 2; return; }
+            S->radius = S->radius / S->decrease; S->decrease *= 2.0; S->reuse_diag = 1;
+            continue;
+        }
+        S->invalid = 0;
+        double dn = 0.0;
+        for (int i = 0; i < 6; i++) { const double d = step[i] * S->scale[i]; S->xc[i] = S->x[i] + d; dn += d * d; }
+        S->step_norm = sqrt(dn);
+        S->model_change = mc;
+        S->phase = PHASE_CAND;
+        return;
+    }
+}
+
+__global__ void lm_begin_kernel(LMState* S, const double* __restrict__ x_in) {
+    if (threadIdx.x == 0) {
+        if (x_in) for (int i = 0; i < 6; i++) S->x[i] = x_in[i];
+        S->phase = PHASE_INIT; S->done = 0; S->termination = 1; S->iter = 0; S->evals = 0; S->invalid = 0; S->reuse_diag = 0;
+    }
+}
+
+// sums: either the per-workgroup partials [n_blocks][28] (single GPU) or an already reduced [1][28] block (after all-reduce)
+__global__ void __launch_bounds__(256)
+lm_step_kernel(LMParams Q, LMState* S, const double* __restrict__ partials, int n_blocks) {
+    if (S->done) return;
+    __shared__ double part[8][kNumAcc];
+    __shared__ double E[kNumAcc];
+    const int t = threadIdx.x;
+    if (t < 8 * kNumAcc) {
+        const int k = t % kNumAcc, p = t / kNumAcc;
+        double v = 0.0;
+        for (int b = p; b < n_blocks; b += 8) v += partials[(size_t)b * kNumAcc + k];
+        part[p][k] = v;
+    }
+    __syncthreads();
+    if (t < kNumAcc) { double v = 0.0; for (int p = 0; p < 8; p++) v += part[p][t]; E[t] = v; }
+    __syncthreads();
+    if (t != 0) return;
+    S->evals++;
+    const double ecost = E[27];
+    if (S->phase == PHASE_INIT) {
+        for (int k = 0; k < 21; k++) S->H[k] = E[k];
+        for (int k = 0; k < 6; k++) S->g[k] = E[21 + k];
+        S->cost = ecost; S->initial_cost = ecost;
+        double xn = 0.0, gm = 0.0;
+        for (int i = 0; i < 6; i++) { xn += S->x[i] * S->x[i]; gm = fmax(gm, fabs(S->g[i])); }
+        S->x_norm = sqrt(xn);
+        if (gm <= Q.gradient_tolerance) { S->done = 1; S->termination = 0; return; }
+        for (int j = 0; j < 6; j++) S->scale[j] = 1.0 / (1.0 + sqrt(S->H[tri(j, j)]));
+        S->radius = Q.initial_radius; S->decrease = 2.0; S->reuse_diag = 0; S->invalid = 0;
+        lm_compute_step(Q, S);
+        return;
+    }
+    // PHASE_CAND: E is the evaluation at xc
+    if (S->step_norm <= Q.parameter_tolerance * (S->x_norm + Q.parameter_tolerance)) { S->done = 1; S->termination = 0; return; }
+    const double cost_change = S->cost - ecost;
+    if (fabs(cost_change) <= Q.function_tolerance * S->cost) { S->done = 1; S->termination = 0; return; }
+    const double q = cost_change / S->model_change;
+    if (q > Q.min_relative_decrease) {
+        double xn = 0.0, gm = 0.0;
+        for (int i = 0; i < 6; i++) { S->x[i] = S->xc[i]; xn += S->x[i] * S->x[i]; }
+        for (int k = 0; k < 21; k++) S->H[k] = E[k];
+        for (int k = 0; k < 6; k++) { S->g[k] = E[21 + k]; gm = fmax(gm, fabs(S->g[k])); }
+        S->cost = ecost; S->x_norm = sqrt(xn);
+        if (gm <= Q.gradient_tolerance) { S->done = 1; S->termination = 0; return; }
+        const double tt = 2.0 * q - 1.0;
+        S->radius = fmin(Q.max_radius, S->radius / fmax(1.0 / 3.0, 1.0 - tt * tt * tt));
+        S->decrease = 2.0; S->reuse_diag = 0;
+    } else {
+        S->radius = S->radius / S->decrease; S->decrease *= 2.0; S->reuse_diag = 1;
+    }
+    lm_compute_step(Q, S);
+}
+
+}  // namespace velo
