@@ -13,6 +13,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -73,9 +74,11 @@ struct DevBuf {
 
 struct Grid {
     GridDesc d{};
-    double gate = 0.0;          // squared-distance gate this grid was sized for
+    double gate = 0.0;          // squared-distance gate the cell size was derived from
+    double h = 0.0;             // cell size
     DevBuf<int> cell_start;     // ncells + 1
-    DevBuf<float4> sorted;
+    DevBuf<float4> sorted;      // cell-sorted copy {x,y,z,bits(gidx)} (+ kGridPad sentinels)
+    DevBuf<int> sring;
     bool built = false;
 };
 
@@ -108,6 +111,8 @@ struct velo_ctx {
     hipStream_t stream = nullptr;
     velo_params P;
     bool timing = false;
+    int assoc_variant = 4;               // 0 = per-lane reference kernel; 1/2/4/8 = waves per 64-query group of the shell walk (VELO_ASSOC_VARIANT)
+    int cluster_w = 3;                   // cluster radius in cells (VELO_CLUSTER_W)
 
     // target (frame2)
     int n_tgt = 0, n_tgt_rings = 0;
@@ -225,11 +230,13 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
     }
     G.d.ox = c->bbox[0]; G.d.oy = c->bbox[1]; G.d.oz = c->bbox[2];
     G.d.inv_h = (float)(1.0 / h);
+    G.h = h;
     G.d.nx = dims[0]; G.d.ny = dims[1]; G.d.nz = dims[2];
     G.d.ncells = dims[0] * dims[1] * dims[2];
     const int nc = G.d.ncells, n = c->n_tgt;
     VELO_TRY(G.cell_start.reserve((size_t)nc + 1));
-    VELO_TRY(G.sorted.reserve((size_t)std::max(n, 1)));
+    const size_t ns = (size_t)n + kGridPad;
+    VELO_TRY(G.sorted.reserve(ns)); VELO_TRY(G.sring.reserve(ns));
     VELO_TRY(c->cursor.reserve((size_t)nc + 1));
     const int n_tiles = cdiv(nc, kScanTile);
     VELO_TRY(c->scan_tiles.reserve((size_t)n_tiles + 1));
@@ -239,37 +246,23 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(n_tiles), dim3(kScanThreads), 0, c->stream, G.cell_start.p, nc, c->scan_tiles.p);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kScanThreads), 0, c->stream, c->scan_tiles.p, n_tiles, c->scan_total.p);
     hipLaunchKernelGGL(scan_add_kernel, dim3(cdiv(nc + 1, 256)), dim3(256), 0, c->stream, G.cell_start.p, nc, c->scan_tiles.p, c->scan_total.p, c->cursor.p);
-    if (n > 0) hipLaunchKernelGGL(grid_scatter_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->tgt.p, c->tgt_cell_of.p, n, c->cursor.p, G.sorted.p);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(cdiv(std::max(n, kGridPad), 256)), dim3(256), 0, c->stream, c->tgt.p, c->tgt_cell_of.p, c->tgt_ring_of.p, n, c->cursor.p,
+                       (const int*)(G.cell_start.p + nc), G.sorted.p, G.sring.p);
     HIP_TRY(hipGetLastError());
     G.built = true;
     return VELO_OK;
 }
 
-// (re)build the grids for the gates of iter = 1..f2f_iterations
+// (re)build THE grid: one fine grid, cell ~ the smallest gate radius among iter = 1..f2f_iterations, serves all gates
 int build_grids(velo_ctx* c) {
-    c->grid_of_iter.assign((size_t)c->P.f2f_iterations + 1, 0);
-    std::vector<double> gates;
-    for (int it = 1; it <= c->P.f2f_iterations; it++) {
-        const double g = gate_of_iter(c->P, it);
-        int found = -1;
-        for (size_t k = 0; k < gates.size(); k++) if (gates[k] == g) found = (int)k;
-        if (found < 0) { gates.push_back(g); found = (int)gates.size() - 1; }
-        c->grid_of_iter[it] = found;
-    }
-    if (c->grids.size() < gates.size()) c->grids.resize(gates.size());
-    for (size_t k = 0; k < gates.size(); k++) VELO_TRY(build_grid(c, c->grids[k], gates[k]));
-    for (size_t k = gates.size(); k < c->grids.size(); k++) c->grids[k].built = false;
-    return VELO_OK;
+    double gmin = gate_of_iter(c->P, 1);
+    for (int it = 2; it <= c->P.f2f_iterations; it++) gmin = std::min(gmin, gate_of_iter(c->P, it));
+    if (const char* e = getenv("VELO_GRID_GATE")) gmin = atof(e);
+    if (c->grids.empty()) c->grids.resize(1);
+    return build_grid(c, c->grids[0], gmin);
 }
 
-Grid* grid_for_iter(velo_ctx* c, int iter) {
-    // any iter is allowed through velo_associate: build on demand if its gate has no grid yet
-    const double g = gate_of_iter(c->P, iter);
-    for (Grid& G : c->grids) if (G.built && G.gate == g) return &G;
-    c->grids.emplace_back();
-    if (build_grid(c, c->grids.back(), g) != VELO_OK) { c->grids.pop_back(); return nullptr; }
-    return &c->grids.back();
-}
+Grid* grid_for_iter(velo_ctx* c, int) { return (!c->grids.empty() && c->grids[0].built) ? &c->grids[0] : nullptr; }
 
 int build_query_list(velo_ctx* c) {
     const int skip = std::max(c->P.icp_skip, 1);
@@ -378,10 +371,9 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         PoseScalars S;
         pose_scalars(x, &S);
         GridView V;
-        V.d = G->d; V.cell_start = G->cell_start.p; V.sorted = G->sorted.p;
+        V.d = G->d; V.cell_start = G->cell_start.p; V.sorted = G->sorted.p; V.sring = G->sring.p;
         AssocOut out;
         out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p;
-        const unsigned gb = gate_bits_of(G->gate);
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
         if (c->timing) {
             if (c->assoc_events_used >= (int)c->assoc_events.size()) {
@@ -392,8 +384,27 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
             ev = &c->assoc_events[c->assoc_events_used++];
             HIP_TRY(hipEventRecord(ev->first, c->stream));
         }
-        hipLaunchKernelGGL(assoc_search_kernel, dim3(cdiv(qe - qb, kAssocThreads)), dim3(kAssocThreads), 0, c->stream,
-                           S, V, c->src.p, c->q_src.p, qb, qe, c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gb, c->P.icp_norm_condition, out, want_aux ? 1 : 0);
+        const int aux = want_aux ? 1 : 0;
+        const int groups = cdiv(qe - qb, 64);
+        const double gate = gate_of_iter(c->P, iter);
+        const unsigned gbits = gate_bits_of(gate);
+        const float h_safe = (float)(G->h * 0.999);
+#define VELO_LAUNCH_V2(NW)                                                                                                         \
+        hipLaunchKernelGGL(assoc_search_v3_kernel<NW>, dim3(groups), dim3(NW * 64), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe, \
+                           c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, c->cluster_w, h_safe, out, aux)
+        switch (c->assoc_variant) {
+            case 0: {
+                const int reach = (int)std::ceil(std::sqrt(std::max(gate, 0.0)) / (G->h * 0.999)) ;
+                hipLaunchKernelGGL(assoc_search_kernel, dim3(cdiv(qe - qb, kAssocThreads)), dim3(kAssocThreads), 0, c->stream,
+                                   S, V, c->src.p, c->q_src.p, qb, qe, c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, std::max(reach, 1), out, aux);
+                break;
+            }
+            case 1: VELO_LAUNCH_V2(1); break;
+            case 2: VELO_LAUNCH_V2(2); break;
+            case 8: VELO_LAUNCH_V2(8); break;
+            default: VELO_LAUNCH_V2(4); break;
+        }
+#undef VELO_LAUNCH_V2
         HIP_TRY(hipGetLastError());
         if (ev) HIP_TRY(hipEventRecord(ev->second, c->stream));
     }
@@ -524,6 +535,8 @@ int velo_create(velo_ctx** out, int device) {
     velo_ctx* c = new velo_ctx();
     c->device = device;
     default_params(&c->P);
+    if (const char* e = getenv("VELO_ASSOC_VARIANT")) c->assoc_variant = atoi(e);
+    if (const char* e = getenv("VELO_CLUSTER_W")) c->cluster_w = std::max(atoi(e), 0);
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipHostMalloc((void**)&c->h_status, sizeof(HostStatus), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&c->h_x, sizeof(double) * 64, hipHostMallocDefault));
@@ -548,7 +561,7 @@ int velo_destroy(velo_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     c->tgt.release(); c->tgt_off.release(); c->tgt_ring_of.release(); c->tgt_cell_of.release();
-    for (Grid& G : c->grids) { G.cell_start.release(); G.sorted.release(); }
+    for (Grid& G : c->grids) { G.cell_start.release(); G.sorted.release(); G.sring.release(); }
     c->scan_tiles.release(); c->cursor.release(); c->scan_total.release(); c->bbox_keys.release();
     c->src.release(); c->src_off.release(); c->q_off.release(); c->q_src.release(); c->staging.release();
     c->cp.release(); c->cn.release(); c->cv0.release(); c->aux0.release(); c->aux1.release(); c->n_valid.release();

@@ -27,15 +27,20 @@ constexpr int kAssocThreads = 256;
 // ---- uniform grid over the target cloud (one per distinct gate radius) ------------------------------------
 struct GridDesc {
     float ox, oy, oz;       // origin = bbox min
-    float inv_h;            // 1 / cell size; cell size >= 1.01 * gate radius so the 27-neighbourhood is exhaustive
+    float inv_h;            // 1 / cell size (one fine grid, cell ~ 1.01 x the smallest gate radius, serves every gate)
     int nx, ny, nz;
     int ncells;
 };
 
+// Cell-sorted copy of the target: float4 {x, y, z, bits(global ring-major target index)} + the point's ring, so that a
+// workgroup can stage whole cell runs into LDS with one coalesced 16-byte load per candidate.  kGridPad sentinel
+// entries (x = +inf) follow the last real point.
+constexpr int kGridPad = 16;
 struct GridView {
     GridDesc d;
     const int* __restrict__ cell_start;      // [ncells + 1]
-    const float4* __restrict__ sorted;       // [n_finite] x,y,z, w = bits(global target index)
+    const float4* __restrict__ sorted;       // [n_finite + kGridPad]
+    const int* __restrict__ sring;           // ring of sorted[j]
 };
 
 // ---- pose scalars of one association round, computed on the HOST in double with the same libm the CPU
@@ -186,15 +191,22 @@ __global__ void scan_add_kernel(int* __restrict__ data, int n, const int* __rest
     if (i < n) { const int v = data[i] + tile_sums[i / kScanTile]; data[i] = v; cursor[i] = v; }
     else if (i == n) data[n] = *grand_total;
 }
-__global__ void grid_scatter_kernel(const float4* __restrict__ pts, const int* __restrict__ cell_of, int n, int* __restrict__ cursor,
-                                    float4* __restrict__ sorted) {
+__global__ void grid_scatter_kernel(const float4* __restrict__ pts, const int* __restrict__ cell_of, const int* __restrict__ ring_of, int n,
+                                    int* __restrict__ cursor, const int* __restrict__ n_finite,
+                                    float4* __restrict__ sorted, int* __restrict__ sring) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < kGridPad) {   // sentinels behind the last real point: +inf coordinates can never pass the gate
+        const int j = *n_finite + i;
+        sorted[j] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __int_as_float(0x7fffffff));
+        sring[j] = 0x7fffffff;
+    }
     if (i >= n) return;
     const int c = cell_of[i];
     if (c < 0) return;
     const int slot = atomicAdd(&cursor[c], 1);
     const float4 p = pts[i];
     sorted[slot] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+    sring[slot] = ring_of[i];
 }
 
 // ---- association ------------------------------------------------------------------------------------------------
@@ -296,11 +308,12 @@ __device__ __forceinline__ void finish_correspondence(
     if ((threadIdx.x & 63) == 0 && m) atomicAdd(out.n_valid, (int)__popcll(m));
 }
 
-// v0 association search: one lane per query, each lane walks the 9 x-runs of its own 27-cell neighbourhood.
+// Reference association search (VELO_ASSOC_VARIANT=0, kept for A/B checks): one lane per query, each lane walks the
+// x-runs of its own (2 reach + 1)^3 cell neighbourhood, reach = ceil(gate radius / cell).
 __global__ void __launch_bounds__(kAssocThreads)
 assoc_search_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
                     const float4* __restrict__ tgt, const int* __restrict__ tgt_off, const int* __restrict__ ring_of,
-                    unsigned gate_bits, double norm_cond, AssocOut out, int want_aux) {
+                    unsigned gate_bits, double norm_cond, int reach, AssocOut out, int want_aux) {
     const int qi = q_begin + blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = qi < q_end;
     const unsigned long long key_inf = ((unsigned long long)gate_bits + 1ull) << 32;
@@ -313,20 +326,20 @@ assoc_search_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, c
         transform_query(P, psrc, &qx, &qy, &qz);
         const GridDesc& g = G.d;
         const int cx = cell_coord(qx, g.ox, g.inv_h, g.nx), cy = cell_coord(qy, g.oy, g.inv_h, g.ny), cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
-        const int y0 = max(cy - 1, 0), y1 = min(cy + 1, g.ny - 1);
-        const int z0 = max(cz - 1, 0), z1 = min(cz + 1, g.nz - 1);
+        const int x0 = max(cx - reach, 0), x1 = min(cx + reach, g.nx - 1);
+        const int y0 = max(cy - reach, 0), y1 = min(cy + reach, g.ny - 1);
+        const int z0 = max(cz - reach, 0), z1 = min(cz + reach, g.nz - 1);
         if (x0 <= x1) {
             for (int z = z0; z <= z1; z++) {
                 for (int y = y0; y <= y1; y++) {
                     const int row = (z * g.ny + y) * g.nx;
                     const int j0 = G.cell_start[row + x0], j1 = G.cell_start[row + x1 + 1];
                     for (int j = j0; j < j1; j++) {
-                        const float4 s = G.sorted[j];
-                        const float d2 = dist2_f(qx, qy, qz, s.x, s.y, s.z);
-                        const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(s.w);
+                        const float4 sp = G.sorted[j];
+                        const float d2 = dist2_f(qx, qy, qz, sp.x, sp.y, sp.z);
+                        const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(sp.w);
                         if (key < b2) {                                  // implies d2 <= gate (keys start at key_inf)
-                            const int ring = ring_of[__float_as_int(s.w)];
+                            const int ring = G.sring[j];
                             if (key < b1) {
                                 if (ring != b1ring) b2 = b1;
                                 b1 = key; b1ring = ring;
@@ -340,6 +353,193 @@ assoc_search_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, c
         }
     }
     if (active) finish_correspondence(qi, psrc, qx, qy, qz, b1, b2, key_inf, tgt, tgt_off, ring_of, norm_cond, out, want_aux != 0);
+}
+
+// ---- running (best1, best2) over distinct rings ---------------------------------------------------------------------
+struct Top2 {
+    unsigned long long b1, b2;
+    int b1ring;
+    float b2d;          // float view of b2's distance field: the cheap per-candidate reject threshold
+};
+__device__ __forceinline__ void top2_update(Top2& t, unsigned long long key, int ring) {
+    if (key < t.b2) {
+        if (key < t.b1) {
+            if (ring != t.b1ring) t.b2 = t.b1;
+            t.b1 = key; t.b1ring = ring;
+        } else if (ring != t.b1ring) {
+            t.b2 = key;
+        }
+        t.b2d = __uint_as_float((unsigned)(t.b2 >> 32));
+    }
+}
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return v;
+}
+
+// ---- association search: LDS-staged shrinking-radius box walk -----------------------------------------------------------
+// A workgroup of NW waves owns 64 consecutive queries; lane i of EVERY wave holds query i (source scans are ring-ordered,
+// so the 64 points are spatial neighbours).  The waves cluster the queries (cells within +-W of a seed lane's cell) and
+// search ONE fine grid (cell ~ the smallest gate radius, shared by all outer iterations) in growing boxes around the
+// cluster's cell bounding box: expansion e = 1, 2, 4, ... cells.  Per phase
+//   1. one thread per grid row of the new shell reads the row's cell offsets (vector loads) -> list of candidate runs,
+//      workgroup prefix sum of their lengths;
+//   2. the runs are copied into an LDS tile by ALL threads with coalesced 16-byte loads (every thread finds its source
+//      run by binary search in the LDS prefix array) -- hundreds of loads in flight instead of a dependent chain;
+//   3. each wave sweeps a slice of the tile: the candidate is read from LDS with one broadcast ds_read_b128 and tested by
+//      all 64 lanes (queries) at once;
+//   4. the waves merge their per-lane (best1, best2) through LDS (top-2-distinct-rings is associative and idempotent).
+// After a phase that covered expansion e every unvisited point is separated from every member query by >= e whole cells,
+// so the walk stops once (e * cell)^2 > max over member lanes of b2d (second-best squared distance, or the gate when a
+// lane has no second ring yet): no unvisited point can enter any lane's result.  In the dense part of a scan this ends
+// after the first phase; the answer is still the exact exhaustive one.
+constexpr int kTileCap = 1024;     // candidates per LDS tile
+
+template <int NW>
+__global__ void __launch_bounds__(NW * 64)
+assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
+                       const float4* __restrict__ tgt, const int* __restrict__ tgt_off, const int* __restrict__ ring_of,
+                       unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, AssocOut out, int want_aux) {
+    constexpr int NT = NW * 64;
+    constexpr int NRUN = 2 * NT;                       // two run slots per row, NT rows per row chunk
+    __shared__ float4 s_cand[kTileCap];
+    __shared__ int s_ring[kTileCap];
+    __shared__ int s_run_j0[NRUN];
+    __shared__ int s_run_off[NRUN + 1];
+    __shared__ int s_wave_tot[NW];
+    __shared__ unsigned long long m1[NW][64], m2[NW][64];
+    __shared__ int mr[NW][64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qi = q_begin + blockIdx.x * 64 + lane;
+    const bool active = qi < q_end;
+    const unsigned long long key_inf = ((unsigned long long)gate_bits + 1ull) << 32;
+    float4 psrc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    Top2 t;
+    t.b1 = key_inf; t.b2 = key_inf; t.b1ring = -1; t.b2d = __uint_as_float(gate_bits + 1u);
+    const GridDesc g = G.d;
+    int cx = 0, cy = 0, cz = 0;
+    if (active) {
+        psrc = src[q_src[qi]];
+        transform_query(P, psrc, &qx, &qy, &qz);
+        cx = cell_coord(qx, g.ox, g.inv_h, g.nx); cy = cell_coord(qy, g.oy, g.inv_h, g.ny); cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
+    }
+    bool pending = active;
+    for (;;) {                                                         // clusters (identical control flow in every wave)
+        const unsigned long long pm = __ballot(pending);
+        if (pm == 0ull) break;
+        const int leader = (int)__ffsll((long long)pm) - 1;
+        const int scx = __builtin_amdgcn_readlane(cx, leader), scy = __builtin_amdgcn_readlane(cy, leader), scz = __builtin_amdgcn_readlane(cz, leader);
+        const bool member = pending && abs(cx - scx) <= cluster_w && abs(cy - scy) <= cluster_w && abs(cz - scz) <= cluster_w;
+        const int big = 1 << 28;
+        const int bx0 = __builtin_amdgcn_readfirstlane(wave_min_i(member ? cx : big)), bx1 = __builtin_amdgcn_readfirstlane(wave_max_i(member ? cx : -big));
+        const int by0 = __builtin_amdgcn_readfirstlane(wave_min_i(member ? cy : big)), by1 = __builtin_amdgcn_readfirstlane(wave_max_i(member ? cy : -big));
+        const int bz0 = __builtin_amdgcn_readfirstlane(wave_min_i(member ? cz : big)), bz1 = __builtin_amdgcn_readfirstlane(wave_max_i(member ? cz : -big));
+        int e_prev = -1;                                               // expansion already covered (-1: nothing yet)
+        for (int e = 1;; e *= 2) {                                     // phases
+            // box of this phase (clipped) and of the previous one (unclipped; empty when e_prev < 0)
+            const int X0 = max(bx0 - e, 0), X1 = min(bx1 + e, g.nx - 1);
+            const int Y0 = max(by0 - e, 0), Y1 = min(by1 + e, g.ny - 1);
+            const int Z0 = max(bz0 - e, 0), Z1 = min(bz1 + e, g.nz - 1);
+            const int px0 = bx0 - e_prev, px1 = bx1 + e_prev, py0 = by0 - e_prev, py1 = by1 + e_prev, pz0 = bz0 - e_prev, pz1 = bz1 + e_prev;
+            const int nyb = Y1 - Y0 + 1, nzb = Z1 - Z0 + 1;
+            const int nrows = (X0 <= X1 && nyb > 0 && nzb > 0) ? nyb * nzb : 0;
+            for (int rbase = 0; rbase < nrows; rbase += NT) {          // row chunks (one row per thread)
+                // ---- 1. run list ----
+                int ja0 = 0, la = 0, jb0 = 0, lb = 0;
+                const int r = rbase + tid;
+                if (r < nrows) {
+                    const int y = Y0 + r % nyb, z = Z0 + r / nyb;
+                    const int row = (z * g.ny + y) * g.nx;
+                    const bool fresh = e_prev < 0 || y < py0 || y > py1 || z < pz0 || z > pz1;
+                    if (fresh) {
+                        ja0 = G.cell_start[row + X0]; la = G.cell_start[row + X1 + 1] - ja0;
+                    } else {                                            // old row: only the cells left of px0 and right of px1 are new
+                        const int a1 = min(px0 - 1, X1), b0 = max(px1 + 1, X0);
+                        if (X0 <= a1) { ja0 = G.cell_start[row + X0]; la = G.cell_start[row + a1 + 1] - ja0; }
+                        if (b0 <= X1) { jb0 = G.cell_start[row + b0]; lb = G.cell_start[row + X1 + 1] - jb0; }
+                    }
+                }
+                // workgroup exclusive scan of (la + lb)
+                const int mine = la + lb;
+                int inc = mine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+                if (lane == 63) s_wave_tot[wid] = inc;
+                __syncthreads();
+                int wbase = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < NW; w++) { const int v = s_wave_tot[w]; if (w < wid) wbase += v; total += v; }
+                const int ex = wbase + inc - mine;
+                s_run_j0[2 * tid] = ja0; s_run_off[2 * tid] = ex;
+                s_run_j0[2 * tid + 1] = jb0; s_run_off[2 * tid + 1] = ex + la;
+                if (tid == 0) s_run_off[NRUN] = total;
+                __syncthreads();
+                // ---- 2./3. tiles ----
+                for (int tbase = 0; tbase < total; tbase += kTileCap) {
+                    const int tn = min(total - tbase, kTileCap);
+                    for (int i = tid; i < tn; i += NT) {
+                        const int slot = tbase + i;
+                        int lo = 0;                                    // largest k with s_run_off[k] <= slot (NRUN is a power of two)
+#pragma unroll
+                        for (int step = NRUN / 2; step > 0; step >>= 1) {
+                            if (s_run_off[lo + step] <= slot) lo += step;
+                        }
+                        const int j = s_run_j0[lo] + (slot - s_run_off[lo]);
+                        s_cand[i] = G.sorted[j];
+                        s_ring[i] = G.sring[j];
+                    }
+                    __syncthreads();
+                    // each wave sweeps a contiguous slice of the tile for all 64 queries
+                    const int per = (tn + NW - 1) / NW;
+                    const int i0 = wid * per, i1 = min(i0 + per, tn);
+                    if (member) {
+#pragma unroll 4
+                        for (int i = i0; i < i1; i++) {
+                            const float4 c = s_cand[i];
+                            const float d2 = dist2_f(qx, qy, qz, c.x, c.y, c.z);
+                            if (d2 <= t.b2d) {
+                                const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(c.w);
+                                top2_update(t, key, s_ring[i]);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            // ---- 4. merge across waves ----
+            if (NW > 1) {
+                m1[wid][lane] = t.b1; m2[wid][lane] = t.b2; mr[wid][lane] = t.b1ring;
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
+                    if (w == wid) continue;
+                    const unsigned long long c1 = m1[w][lane], c2 = m2[w][lane];
+                    if (c1 < t.b2) top2_update(t, c1, mr[w][lane]);
+                    if (c2 < t.b2) top2_update(t, c2, ring_of[(int)(unsigned)(c2 & 0xffffffffull)]);
+                }
+                __syncthreads();
+            }
+            // ---- stop test (identical in every wave: all hold the same merged state) ----
+            const unsigned rw = (unsigned)__builtin_amdgcn_readfirstlane(wave_max_i(member ? (int)__float_as_uint(t.b2d) : 0));
+            const float reach = (float)e * h_safe;
+            if (reach * reach > __uint_as_float(rw)) break;
+            e_prev = e;
+        }
+        pending = pending && !member;
+    }
+    if (NW > 1 && wid != 0) return;
+    if (active) finish_correspondence(qi, psrc, qx, qy, qz, t.b1, t.b2, key_inf, tgt, tgt_off, ring_of, norm_cond, out, want_aux != 0);
 }
 
 // ---- visual blocks (rows G1, R2-R5) ------------------------------------------------------------------------------------
