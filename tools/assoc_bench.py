@@ -13,8 +13,9 @@ variants = sys.argv[2:] or ["0:3", "1:3", "2:3", "4:1", "4:3", "4:6", "8:3"]
 d = synth.scan_to_map(2_000_000) if wl == "c4" else synth.scan_pair()
 ref = None
 for v in variants:
-    av, cw = v.split(":")
+    av, cw, *rest = v.split(":")
     os.environ["VELO_ASSOC_VARIANT"], os.environ["VELO_CLUSTER_W"] = av, cw
+    os.environ["VELO_DEBUG_SKIP"] = rest[0] if rest else "0"
     c = api.Context(0, icp_skip=1)
     t0 = time.perf_counter(); c.set_target(d["tgt_xyz"], d["tgt_off"]); c.synchronize(); t_tgt = time.perf_counter() - t0
     c.set_source(d["src_xyz"], d["src_off"])

@@ -112,7 +112,8 @@ struct velo_ctx {
     velo_params P;
     bool timing = false;
     int assoc_variant = 4;               // 0 = per-lane reference kernel; 1/2/4/8 = waves per 64-query group of the shell walk (VELO_ASSOC_VARIANT)
-    int cluster_w = 3;                   // cluster radius in cells (VELO_CLUSTER_W)
+    int cluster_w = 6;                   // cluster radius in cells (VELO_CLUSTER_W)
+    int debug_skip = 0;                  // timing experiments only (VELO_DEBUG_SKIP): results are wrong when non-zero
 
     // target (frame2)
     int n_tgt = 0, n_tgt_rings = 0;
@@ -141,6 +142,7 @@ struct velo_ctx {
     DevBuf<float4> cp, cn, cv0, aux1;
     DevBuf<int4> aux0;
     DevBuf<int> n_valid;
+    DevBuf<unsigned long long> dbg;
     bool have_corr = false;
     int last_n_valid = 0;
 
@@ -323,6 +325,7 @@ LMParams lm_params(const velo_params& P) {
 }
 
 constexpr int kMaxVisBlocks = 64;
+constexpr int kEvalPerThread = 4;      // nominal residuals per thread of the ICP sweep
 struct EvalPlan { int nb_icp, nb_vis; int total() const { return nb_icp + nb_vis; } };
 
 EvalArgs eval_args(velo_ctx* c, const double* x_override) {
@@ -343,7 +346,7 @@ EvalArgs eval_args(velo_ctx* c, const double* x_override) {
 EvalPlan eval_plan(const EvalArgs& A) {
     EvalPlan E;
     const int nq = A.q_end - A.q_begin;
-    E.nb_icp = nq > 0 ? std::min(std::max(cdiv(nq, kEvalThreads), 1), kMaxEvalBlocks) : 0;
+    E.nb_icp = nq > 0 ? std::min(std::max(cdiv(nq, kEvalThreads * kEvalPerThread), 1), kMaxEvalBlocks) : 0;
     E.nb_vis = A.n_matches > 0 ? std::min(std::max(cdiv(3 * A.n_matches, kEvalThreads), 1), kMaxVisBlocks) : 0;
     return E;
 }
@@ -373,7 +376,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         GridView V;
         V.d = G->d; V.cell_start = G->cell_start.p; V.sorted = G->sorted.p; V.sring = G->sring.p;
         AssocOut out;
-        out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p;
+        out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p; out.dbg = c->dbg.p;
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
         if (c->timing) {
             if (c->assoc_events_used >= (int)c->assoc_events.size()) {
@@ -391,7 +394,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         const float h_safe = (float)(G->h * 0.999);
 #define VELO_LAUNCH_V2(NW)                                                                                                         \
         hipLaunchKernelGGL(assoc_search_v3_kernel<NW>, dim3(groups), dim3(NW * 64), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe, \
-                           c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, c->cluster_w, h_safe, out, aux)
+                           c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, c->cluster_w, h_safe, out, aux, c->debug_skip)
         switch (c->assoc_variant) {
             case 0: {
                 const int reach = (int)std::ceil(std::sqrt(std::max(gate, 0.0)) / (G->h * 0.999)) ;
@@ -470,7 +473,7 @@ int enqueue_lm_iteration(velo_ctx* c, const EvalArgs& A, const EvalPlan& E, cons
 }
 
 // One ceres::Solve on the device.  x_in: host x to start from, or nullptr to continue from the state's x.
-int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summary* S, int* eval_launches) {
+int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summary* S, int* eval_launches, int first_chunk = 6) {
     const LMParams Q = lm_params(c->P);
     const EvalArgs A = eval_args(c, nullptr);
     const EvalPlan E = eval_plan(A);
@@ -480,9 +483,9 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
         HIP_TRY(hipMemcpyAsync(c->xdev.p, c->h_x, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
         xd = c->xdev.p;
     }
-    hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->state.p, xd);
+    hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->state.p, xd, (const int*)(c->have_corr ? c->n_valid.p : nullptr));
     int launched = 0;
-    int chunk = 4;                          // LM iterations per host round trip; later chunks are shorter
+    int chunk = first_chunk;                // LM iterations per host round trip
     const int max_iters = c->P.max_num_iterations + 1;
     for (;;) {
         for (int k = 0; k < chunk; k++) { VELO_TRY(enqueue_lm_iteration(c, A, E, Q)); launched++; }
@@ -490,14 +493,15 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->h_status->s.done) break;
         if (launched > max_iters + 8) return fail(VELO_ERR_STATE, "LM did not terminate after %d sweeps", launched);
-        chunk = 3;
+        chunk = 4;
     }
     const LMState& s = c->h_status->s;
     for (int k = 0; k < 6; k++) x_out[k] = s.x[k];
     if (S) {
         std::memset(S, 0, sizeof(*S));
         S->termination = s.termination; S->lm_iterations = s.iter; S->evaluations = s.evals;
-        S->n_icp_valid = c->have_corr ? c->last_n_valid : 0;
+        c->last_n_valid = s.n_valid;
+        S->n_icp_valid = s.n_valid;
         visual_counts(c, &S->n_visual_blocks, &S->n_visual_residuals);
         if (c->shard_rank != 0) { S->n_visual_blocks = 0; S->n_visual_residuals = 0; }
         S->initial_cost = s.initial_cost; S->final_cost = s.cost;
@@ -537,6 +541,7 @@ int velo_create(velo_ctx** out, int device) {
     default_params(&c->P);
     if (const char* e = getenv("VELO_ASSOC_VARIANT")) c->assoc_variant = atoi(e);
     if (const char* e = getenv("VELO_CLUSTER_W")) c->cluster_w = std::max(atoi(e), 0);
+    if (const char* e = getenv("VELO_DEBUG_SKIP")) c->debug_skip = atoi(e);
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipHostMalloc((void**)&c->h_status, sizeof(HostStatus), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&c->h_x, sizeof(double) * 64, hipHostMallocDefault));
@@ -547,6 +552,8 @@ int velo_create(velo_ctx** out, int device) {
     VELO_TRY(c->xdev.reserve(8));
     VELO_TRY(c->bbox_keys.reserve(6));
     VELO_TRY(c->n_valid.reserve(1));
+    VELO_TRY(c->dbg.reserve(8));
+    HIP_TRY(hipMemsetAsync(c->dbg.p, 0, 64, c->stream));
     HIP_TRY(hipMemsetAsync(c->state.p, 0, sizeof(LMState), c->stream));
     HIP_TRY(hipEventCreate(&c->ev0));
     HIP_TRY(hipEventCreate(&c->ev1));
@@ -559,12 +566,18 @@ int velo_destroy(velo_ctx* c) {
     if (!c) return VELO_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if ((c->debug_skip & 24) && c->dbg.p) {
+        unsigned long long h[8];
+        if (hipMemcpy(h, c->dbg.p, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            fprintf(stderr, "[velo dbg] wave-0 cycles: setup %llu cluster %llu runlist %llu stage %llu sweep %llu sweepbar %llu merge %llu finish %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+        }
+    }
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     c->tgt.release(); c->tgt_off.release(); c->tgt_ring_of.release(); c->tgt_cell_of.release();
     for (Grid& G : c->grids) { G.cell_start.release(); G.sorted.release(); G.sring.release(); }
     c->scan_tiles.release(); c->cursor.release(); c->scan_total.release(); c->bbox_keys.release();
     c->src.release(); c->src_off.release(); c->q_off.release(); c->q_src.release(); c->staging.release();
-    c->cp.release(); c->cn.release(); c->cv0.release(); c->aux0.release(); c->aux1.release(); c->n_valid.release();
+    c->cp.release(); c->cn.release(); c->cv0.release(); c->aux0.release(); c->aux1.release(); c->n_valid.release(); c->dbg.release();
     c->vm.release(); c->vflags.release();
     c->state.release(); c->partials.release(); c->reduced.release(); c->xdev.release();
     c->row_off_vis.release(); c->row_off_icp.release(); c->rows_r.release(); c->rows_J.release();
@@ -631,7 +644,7 @@ int velo_set_target(velo_ctx* c, const float* xyz, int64_t stride, const int32_t
     HIP_TRY(hipMemcpyAsync(c->bbox_keys.p, c->h_int, sizeof(init), hipMemcpyHostToDevice, c->stream));
     if (n > 0) {
         hipLaunchKernelGGL(ring_of_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->tgt_off.p, n_rings, n, c->tgt_ring_of.p);
-        hipLaunchKernelGGL(bbox_kernel, dim3(std::min(cdiv(n, 256), 1024)), dim3(256), 0, c->stream, c->tgt.p, n, c->bbox_keys.p);
+        hipLaunchKernelGGL(bbox_kernel, dim3(std::min(cdiv(n, 256 * 8), 256)), dim3(256), 0, c->stream, c->tgt.p, n, c->bbox_keys.p);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(c->h_int + 8, c->bbox_keys.p, sizeof(init), hipMemcpyDeviceToHost, c->stream));
@@ -856,7 +869,7 @@ int velo_frame_to_frame(velo_ctx* c, double x[6], double T[16], velo_summary* su
         c->last_n_valid = 0;
         for (int icp_iter = 0; icp_iter < c->P.icp_iterations; icp_iter++) {        // velo.h:800
             int nv = 0;
-            VELO_TRY(do_associate(c, xc, iter, false, true, &nv));                   // velo.h:806-894
+            VELO_TRY(do_associate(c, xc, iter, false, false, &nv));                  // velo.h:806-894 (no host sync: the count rides on the LM status)
             int qb, qe;
             q_range(c, &qb, &qe);
             S->n_assoc_rounds++;
@@ -867,7 +880,7 @@ int velo_frame_to_frame(velo_ctx* c, double x[6], double T[16], velo_summary* su
             if (qe > qb) S->assoc_kernel_launches++;
             velo_solve_summary ss;
             int evals = 0;
-            VELO_TRY(do_solve(c, first ? xc : xc, xc, &ss, &evals));                 // velo.h:897-902
+            VELO_TRY(do_solve(c, xc, xc, &ss, &evals, first ? 10 : 4));              // velo.h:897-902
             first = false;
             S->eval_kernel_launches += evals;
             S->algorithmic_bytes += (uint64_t)ss.evaluations * (36ull * (uint64_t)ss.n_icp_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull);

@@ -97,7 +97,8 @@ __host__ __device__ __forceinline__ float key2f(unsigned k) {
     float f; __builtin_memcpy(&f, &u, 4); return f;
 #endif
 }
-__global__ void bbox_kernel(const float4* __restrict__ pts, int n, unsigned* __restrict__ mnmx /* [6]: min xyz, max xyz keys */) {
+__global__ void __launch_bounds__(256)
+bbox_kernel(const float4* __restrict__ pts, int n, unsigned* __restrict__ mnmx /* [6]: min xyz, max xyz keys */) {
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 p = pts[i];
@@ -114,9 +115,15 @@ __global__ void bbox_kernel(const float4* __restrict__ pts, int n, unsigned* __r
             mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off));
         }
     }
-    if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-        for (int k = 0; k < 3; k++) { atomicMin(&mnmx[k], f2key(mn[k])); atomicMax(&mnmx[3 + k], f2key(mx[k])); }
+    __shared__ float red[4][6];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { for (int k = 0; k < 3; k++) { red[wid][k] = mn[k]; red[wid][3 + k] = mx[k]; } }
+    __syncthreads();
+    if (threadIdx.x < 6) {     // one atomic per block and component (same-address atomics serialise)
+        const int k = threadIdx.x;
+        float v = red[0][k];
+        for (int w = 1; w < 4; w++) v = (k < 3) ? fminf(v, red[w][k]) : fmaxf(v, red[w][k]);
+        if (k < 3) atomicMin(&mnmx[k], f2key(v)); else atomicMax(&mnmx[k], f2key(v));
     }
 }
 
@@ -222,6 +229,7 @@ struct AssocOut {
     int4* __restrict__ aux0;     // ring_i, idx_i, ring_j, idx_j      (only when want_aux)
     float4* __restrict__ aux1;   // bits(idx_k), dist_i, dist_j, -
     int* __restrict__ n_valid;   // atomic counter
+    unsigned long long* __restrict__ dbg;   // [8] diagnostic cycle totals (VELO_DEBUG_SKIP & 8)
 };
 
 __device__ __forceinline__ float dist2_f(float qx, float qy, float qz, float sx, float sy, float sz) {
@@ -400,16 +408,20 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // so the walk stops once (e * cell)^2 > max over member lanes of b2d (second-best squared distance, or the gate when a
 // lane has no second ring yet): no unvisited point can enter any lane's result.  In the dense part of a scan this ends
 // after the first phase; the answer is still the exact exhaustive one.
-constexpr int kTileCap = 1024;     // candidates per LDS tile
+constexpr int kTileCap = 512;      // candidates per LDS tile (keeps the workgroup under 20 KB of LDS: 8 workgroups per CU)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int NW>
-__global__ void __launch_bounds__(NW * 64)
+__global__ void __launch_bounds__(NW * 64, 8)
 assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
                        const float4* __restrict__ tgt, const int* __restrict__ tgt_off, const int* __restrict__ ring_of,
-                       unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, AssocOut out, int want_aux) {
+                       unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, AssocOut out, int want_aux, int dbg) {
     constexpr int NT = NW * 64;
     constexpr int NRUN = 2 * NT;                       // two run slots per row, NT rows per row chunk
-    __shared__ float4 s_cand[kTileCap];
+    // tile: candidates stored as PAIRS -- {x0,x1,y0,y1} and {z0,z1,bits(g0),bits(g1)} -- so that the sweep handles two
+    // candidates per packed-f32 instruction after two broadcast ds_read_b128
+    __shared__ float4 s_xy[kTileCap / 2];
+    __shared__ float4 s_zg[kTileCap / 2];
     __shared__ int s_ring[kTileCap];
     __shared__ int s_run_j0[NRUN];
     __shared__ int s_run_off[NRUN + 1];
@@ -420,6 +432,10 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // diagnostic build only (dbg & 8): per-section cycle totals of wave 0, added to out.dbg[0..7]
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = (dbg & 8) ? (long long)__builtin_readcyclecounter() : 0;
+#define VELO_STAMP(k) do { if (dbg & 8) { const long long now__ = (long long)__builtin_readcyclecounter(); tacc[k] += now__ - tlast; tlast = now__; } } while (0)
     const int qi = q_begin + blockIdx.x * 64 + lane;
     const bool active = qi < q_end;
     const unsigned long long key_inf = ((unsigned long long)gate_bits + 1ull) << 32;
@@ -434,6 +450,10 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
         transform_query(P, psrc, &qx, &qy, &qz);
         cx = cell_coord(qx, g.ox, g.inv_h, g.nx); cy = cell_coord(qy, g.oy, g.inv_h, g.ny); cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
     }
+    VELO_STAMP(0);
+    const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+    float* s_xy_f = reinterpret_cast<float*>(s_xy);
+    float* s_zg_f = reinterpret_cast<float*>(s_zg);
     bool pending = active;
     for (;;) {                                                         // clusters (identical control flow in every wave)
         const unsigned long long pm = __ballot(pending);
@@ -445,8 +465,11 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
         const int bx0 = __builtin_amdgcn_readfirstlane(wave_min_i(member ? cx : big)), bx1 = __builtin_amdgcn_readfirstlane(wave_max_i(member ? cx : -big));
         const int by0 = __builtin_amdgcn_readfirstlane(wave_min_i(member ? cy : big)), by1 = __builtin_amdgcn_readfirstlane(wave_max_i(member ? cy : -big));
         const int bz0 = __builtin_amdgcn_readfirstlane(wave_min_i(member ? cz : big)), bz1 = __builtin_amdgcn_readfirstlane(wave_max_i(member ? cz : -big));
+        VELO_STAMP(1);
+        if ((dbg & 16) && tid == 0) atomicAdd(&out.dbg[0], 1ull);
         int e_prev = -1;                                               // expansion already covered (-1: nothing yet)
-        for (int e = 1;; e *= 2) {                                     // phases
+        int e = 1;
+        for (;;) {                                                     // phases: e = 1, then (if needed) the reach the bounds demand
             // box of this phase (clipped) and of the previous one (unclipped; empty when e_prev < 0)
             const int X0 = max(bx0 - e, 0), X1 = min(bx1 + e, g.nx - 1);
             const int Y0 = max(by0 - e, 0), Y1 = min(by1 + e, g.ny - 1);
@@ -454,7 +477,7 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
             const int px0 = bx0 - e_prev, px1 = bx1 + e_prev, py0 = by0 - e_prev, py1 = by1 + e_prev, pz0 = bz0 - e_prev, pz1 = bz1 + e_prev;
             const int nyb = Y1 - Y0 + 1, nzb = Z1 - Z0 + 1;
             const int nrows = (X0 <= X1 && nyb > 0 && nzb > 0) ? nyb * nzb : 0;
-            for (int rbase = 0; rbase < nrows; rbase += NT) {          // row chunks (one row per thread)
+            for (int rbase = 0; rbase < ((dbg & 4) ? 0 : nrows); rbase += NT) {          // row chunks (one row per thread)
                 // ---- 1. run list ----
                 int ja0 = 0, la = 0, jb0 = 0, lb = 0;
                 const int r = rbase + tid;
@@ -485,36 +508,60 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                 s_run_j0[2 * tid + 1] = jb0; s_run_off[2 * tid + 1] = ex + la;
                 if (tid == 0) s_run_off[NRUN] = total;
                 __syncthreads();
+                VELO_STAMP(2);
+                if ((dbg & 16) && tid == 0) { atomicAdd(&out.dbg[1], 1ull); atomicAdd(&out.dbg[2], (unsigned long long)total); if (e_prev >= 0) atomicAdd(&out.dbg[3], (unsigned long long)total); atomicAdd(&out.dbg[4], (unsigned long long)nrows); atomicAdd(&out.dbg[5], (unsigned long long)e); }
+                if (dbg & 2) total = 0;
                 // ---- 2./3. tiles ----
                 for (int tbase = 0; tbase < total; tbase += kTileCap) {
                     const int tn = min(total - tbase, kTileCap);
-                    for (int i = tid; i < tn; i += NT) {
-                        const int slot = tbase + i;
-                        int lo = 0;                                    // largest k with s_run_off[k] <= slot (NRUN is a power of two)
+                    const int tn2 = (tn + 1) & ~1;                     // the sweep consumes pairs
+                    for (int i = tid; i < tn2; i += NT) {
+                        float4 c = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __int_as_float(0x7fffffff));
+                        int cr = 0x7fffffff;
+                        if (i < tn) {
+                            const int slot = tbase + i;
+                            int lo = 0;                                // largest k with s_run_off[k] <= slot (NRUN is a power of two)
 #pragma unroll
-                        for (int step = NRUN / 2; step > 0; step >>= 1) {
-                            if (s_run_off[lo + step] <= slot) lo += step;
+                            for (int step = NRUN / 2; step > 0; step >>= 1) {
+                                if (s_run_off[lo + step] <= slot) lo += step;
+                            }
+                            const int j = s_run_j0[lo] + (slot - s_run_off[lo]);
+                            c = G.sorted[j];
+                            cr = G.sring[j];
                         }
-                        const int j = s_run_j0[lo] + (slot - s_run_off[lo]);
-                        s_cand[i] = G.sorted[j];
-                        s_ring[i] = G.sring[j];
+                        const int pr = i >> 1, hb = i & 1;
+                        s_xy_f[4 * pr + hb] = c.x; s_xy_f[4 * pr + 2 + hb] = c.y;
+                        s_zg_f[4 * pr + hb] = c.z; s_zg_f[4 * pr + 2 + hb] = c.w;
+                        s_ring[i] = cr;
                     }
                     __syncthreads();
-                    // each wave sweeps a contiguous slice of the tile for all 64 queries
-                    const int per = (tn + NW - 1) / NW;
-                    const int i0 = wid * per, i1 = min(i0 + per, tn);
-                    if (member) {
-#pragma unroll 4
-                        for (int i = i0; i < i1; i++) {
-                            const float4 c = s_cand[i];
-                            const float d2 = dist2_f(qx, qy, qz, c.x, c.y, c.z);
-                            if (d2 <= t.b2d) {
-                                const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(c.w);
-                                top2_update(t, key, s_ring[i]);
+                    VELO_STAMP(3);
+                    // each wave sweeps a contiguous slice of the tile's pairs for all 64 queries
+                    const int npairs = tn2 >> 1;
+                    const int per = (npairs + NW - 1) / NW;
+                    const int p0 = wid * per, p1 = min(p0 + per, npairs);
+                    if (member && !(dbg & 1)) {
+#pragma unroll 2
+                        for (int pi = p0; pi < p1; pi++) {
+                            const float4 a = s_xy[pi], bq = s_zg[pi];
+                            const f32x2 cxp = {a.x, a.y}, cyp = {a.z, a.w}, czp = {bq.x, bq.y};
+                            const f32x2 dx = qx2 - cxp, dy = qy2 - cyp, dz = qz2 - czp;
+                            f32x2 d2 = dx * dx;                        // x -> y -> z accumulation, no FMA (file built with -ffp-contract=off)
+                            d2 = d2 + dy * dy;
+                            d2 = d2 + dz * dz;
+                            if (d2.x <= t.b2d) {
+                                const unsigned long long key = ((unsigned long long)__float_as_uint(d2.x) << 32) | (unsigned)__float_as_int(bq.z);
+                                top2_update(t, key, s_ring[2 * pi]);
+                            }
+                            if (d2.y <= t.b2d) {
+                                const unsigned long long key = ((unsigned long long)__float_as_uint(d2.y) << 32) | (unsigned)__float_as_int(bq.w);
+                                top2_update(t, key, s_ring[2 * pi + 1]);
                             }
                         }
                     }
+                    VELO_STAMP(4);
                     __syncthreads();
+                    VELO_STAMP(5);
                 }
             }
             // ---- 4. merge across waves ----
@@ -531,15 +578,23 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                 __syncthreads();
             }
             // ---- stop test (identical in every wave: all hold the same merged state) ----
-            const unsigned rw = (unsigned)__builtin_amdgcn_readfirstlane(wave_max_i(member ? (int)__float_as_uint(t.b2d) : 0));
+            // Every unvisited point is separated from every member query by >= e whole cells.  b2d only shrinks, so the
+            // radius the CURRENT bounds allow is enough for one more phase to finish the cluster.
+            const float rw = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(wave_max_i(member ? (int)__float_as_uint(t.b2d) : 0)));
             const float reach = (float)e * h_safe;
-            if (reach * reach > __uint_as_float(rw)) break;
+            VELO_STAMP(6);
+            if (reach * reach > rw) break;
             e_prev = e;
+            e = max(e + 1, (int)ceilf(sqrtf(rw) / h_safe));
+            if ((float)e * h_safe * ((float)e * h_safe) <= rw) e++;     // rounding guard: the next test must pass
         }
         pending = pending && !member;
     }
     if (NW > 1 && wid != 0) return;
     if (active) finish_correspondence(qi, psrc, qx, qy, qz, t.b1, t.b2, key_inf, tgt, tgt_off, ring_of, norm_cond, out, want_aux != 0);
+    VELO_STAMP(7);
+    if ((dbg & 8) && tid == 0) { for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)&out.dbg[k], (unsigned long long)tacc[k]); }
+#undef VELO_STAMP
 }
 
 // ---- visual blocks (rows G1, R2-R5) ------------------------------------------------------------------------------------
@@ -646,7 +701,7 @@ struct LMState {
     double diag[6];
     double radius, decrease, x_norm, model_change, step_norm;
     double initial_cost;
-    int reuse_diag, invalid, iter, evals, done, termination, phase, pad;
+    int reuse_diag, invalid, iter, evals, done, termination, phase, n_valid;   // n_valid: copy of the association's counter
 };
 
 __device__ __forceinline__ int tri(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }   // i <= j
@@ -688,23 +743,25 @@ __device__ __forceinline__ void accumulate_row(double acc[kNumAcc], double r, co
     for (int i = 0; i < 6; i++) acc[21 + i] += J[i] * rk;
 }
 
-// wave reduction by shuffles, then across the workgroup's waves through LDS; fixed order -> deterministic
+// Workgroup reduction of the 28 accumulators through LDS (fixed order -> deterministic): every thread parks its 28
+// values, then 8 threads per accumulator add 32 entries each and finish with three shuffles.  Row stride 264 doubles
+// keeps the 64-bit reads of one half-wave on distinct bank pairs.
+constexpr int kRedStride = kEvalThreads + 8;
 __device__ __forceinline__ void block_reduce_store(double acc[kNumAcc], double* __restrict__ dst /* [28] */) {
-    __shared__ double red[kEvalThreads / kWave][kNumAcc];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __shared__ double red[kNumAcc * kRedStride];
+    const int tid = threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < kNumAcc; k++) {
-        double v = acc[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) red[wid][k] = v;
-    }
+    for (int k = 0; k < kNumAcc; k++) red[k * kRedStride + tid] = acc[k];
     __syncthreads();
-    if (threadIdx.x < kNumAcc) {
+    if (tid < kNumAcc * 8) {
+        const int k = tid >> 3, part = tid & 7;
         double v = 0.0;
-#pragma unroll
-        for (int w = 0; w < kEvalThreads / kWave; w++) v += red[w][threadIdx.x];
-        dst[threadIdx.x] = v;
+#pragma unroll 8
+        for (int i = 0; i < kEvalThreads / 8; i++) v += red[k * kRedStride + i * 8 + part];
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        if (part == 0) dst[k] = v;
     }
 }
 
@@ -805,25 +862,46 @@ __global__ void reduce_partials_kernel(const LMState* __restrict__ state, const 
 }
 
 // ---- one trust-region LM state transition --------------------------------------------------------------------------
+// 6x6 SPD solve by Cholesky; one reciprocal per pivot, everything else multiplies (the serial critical path of the
+// LM step is divide/sqrt latency)
 __device__ inline bool chol_solve6(const double A[36], const double b[6], double y[6]) {
-    double L[36];
-    for (int i = 0; i < 36; i++) L[i] = 0.0;
+    double L[36], inv[6];
+#pragma unroll
     for (int j = 0; j < 6; j++) {
         double d = A[j * 6 + j];
+#pragma unroll
         for (int k = 0; k < j; k++) d -= L[j * 6 + k] * L[j * 6 + k];
         if (!(d > 0.0) || !isfinite(d)) return false;
-        L[j * 6 + j] = sqrt(d);
+        const double ljj = sqrt(d);
+        L[j * 6 + j] = ljj;
+        inv[j] = 1.0 / ljj;
+#pragma unroll
         for (int i = j + 1; i < 6; i++) {
             double s = A[i * 6 + j];
+#pragma unroll
             for (int k = 0; k < j; k++) s -= L[i * 6 + k] * L[j * 6 + k];
-            L[i * 6 + j] = s / L[j * 6 + j];
+            L[i * 6 + j] = s * inv[j];
         }
     }
     double z[6];
-    for (int i = 0; i < 6; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[i * 6 + k] * z[k]; z[i] = s / L[i * 6 + i]; }
-    for (int i = 5; i >= 0; i--) { double s = z[i]; for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * y[k]; y[i] = s / L[i * 6 + i]; }
-    for (int i = 0; i < 6; i++) if (!isfinite(y[i])) return false;
-    return true;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double s = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= L[i * 6 + k] * z[k];
+        z[i] = s * inv[i];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        double s = z[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) s -= L[k * 6 + i] * y[k];
+        y[i] = s * inv[i];
+    }
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < 6; i++) ok = ok && isfinite(y[i]);
+    return ok;
 }
 
 // Computes trust-region steps until one is valid (invalid ones cost an iteration but no evaluation).
@@ -843,7 +921,8 @@ __device__ inline void lm_compute_step(const LMParams& Q, LMState* S) {
         if (!S->reuse_diag) for (int j = 0; j < 6; j++) S->diag[j] = fmin(fmax(Hs[j * 6 + j], Q.min_diag), Q.max_diag);
         double A[36];
         for (int i = 0; i < 36; i++) A[i] = Hs[i];
-        for (int j = 0; j < 6; j++) { const double l = sqrt(S->diag[j] / S->radius); A[j * 6 + j] += l * l; }
+        const double inv_radius = 1.0 / S->radius;
+        for (int j = 0; j < 6; j++) A[j * 6 + j] += S->diag[j] * inv_radius;      // D^2 = diag / radius
         double y[6], step[6];
         bool ok = chol_solve6(A, gs, y);
         S->reuse_diag = 1;
@@ -870,9 +949,10 @@ __device__ inline void lm_compute_step(const LMParams& Q, LMState* S) {
     }
 }
 
-__global__ void lm_begin_kernel(LMState* S, const double* __restrict__ x_in) {
+__global__ void lm_begin_kernel(LMState* S, const double* __restrict__ x_in, const int* __restrict__ n_valid) {
     if (threadIdx.x == 0) {
         if (x_in) for (int i = 0; i < 6; i++) S->x[i] = x_in[i];
+        S->n_valid = n_valid ? *n_valid : 0;
         S->phase = PHASE_INIT; S->done = 0; S->termination = 1; S->iter = 0; S->evals = 0; S->invalid = 0; S->reuse_diag = 0;
     }
 }
