@@ -1,0 +1,117 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads, exports every symbol include/velo_hip.h declares,
+agrees with the header on struct layout, and FAILS LOUDLY without a GPU (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+import velo_amd  # noqa: F401
+from velo_amd import api, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "velo_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_hip()                       # hipcc cross-compiles gfx950 without a GPU
+    return api.load_library()
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(velo_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = declared_functions()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/velo_hip.h but not exported"
+    assert set(names) == set(api.SIGNATURES), set(names) ^ set(api.SIGNATURES)
+
+
+def test_struct_layouts_match_the_header():
+    src = r'''
+#include <stdio.h>
+#include <stddef.h>
+#include "velo_hip.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu\n", sizeof(velo_params), sizeof(velo_match), sizeof(velo_good_match), sizeof(velo_corr),
+         sizeof(velo_solve_summary), sizeof(velo_summary));
+  printf("%zu %zu %zu %zu\n", offsetof(velo_params, weight_3D2D), offsetof(velo_match, cam), offsetof(velo_corr, p), offsetof(velo_summary, solves));
+  return 0; }
+'''
+    with tempfile.TemporaryDirectory() as td:
+        cfile = os.path.join(td, "probe.c")
+        open(cfile, "w").write(src)
+        exe = os.path.join(td, "probe")
+        subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), cfile, "-o", exe], check=True)  # the header is plain C
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()
+    sizes = [int(v) for v in out]
+    assert sizes[:6] == [C.sizeof(api.VeloParams), api.MATCH_DTYPE.itemsize, api.GOOD_DTYPE.itemsize, api.CORR_DTYPE.itemsize,
+                         C.sizeof(api.VeloSolveSummary), C.sizeof(api.VeloSummary)]
+    assert sizes[6] == api.VeloParams.weight_3D2D.offset
+    assert sizes[7] == api.MATCH_DTYPE.fields["cam"][1]
+    assert sizes[8] == api.CORR_DTYPE.fields["p"][1]
+    assert sizes[9] == api.VeloSummary.solves.offset
+
+
+def test_default_params_are_the_reference_constants(lib):
+    p = api.VeloParams()
+    assert lib.velo_default_params(C.byref(p)) == 0
+    # kitti.h:8-10,20-26,30-32
+    assert (p.icp_skip, p.f2f_iterations, p.icp_iterations) == (200, 2, 3)
+    assert (p.weight_3D2D, p.weight_2D2D, p.weight_3DPD) == (10, 500, 1)
+    assert (p.loss_thresh_3D2D, p.loss_thresh_2D2D, p.loss_thresh_3DPD, p.loss_thresh_3D3D) == (0.01, 0.00002, 0.1, 0.04)
+    assert (p.outlier_reject, p.correspondence_thresh_icp, p.icp_norm_condition) == (5.0, 0.5, 1e-5)
+    assert (p.enable_icp, p.enable_2d2d, p.enable_3d2d) == (1, 1, 1)
+    q, o = api.default_params(), ol.default_params()
+    for name, _ in api.VeloParams._fields_:
+        assert getattr(p, name) == getattr(q, name) == getattr(o, name), name
+
+
+def test_pose_helpers_match_oracle(lib):
+    rng = np.random.default_rng(5)
+    for _ in range(20):
+        x = np.concatenate([rng.normal(size=3) * 0.7, rng.normal(size=3)])
+        T = api.pose_vec_to_mat(x)
+        np.testing.assert_allclose(T, ol.pose_vec_to_mat(x), atol=1e-15)
+        np.testing.assert_allclose(api.pose_mat_to_vec(T), x, atol=1e-13)
+    np.testing.assert_array_equal(api.pose_vec_to_mat(np.zeros(6)), np.eye(4))
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="this check is for boxes without a GPU")
+def test_no_gpu_means_loud_failure_not_fallback(lib):
+    h = C.c_void_p()
+    st = lib.velo_create(C.byref(h), 0)
+    assert st == -5 and not h.value                      # VELO_ERR_NODEVICE
+    assert b"no CPU fallback" in lib.velo_last_error()
+    with pytest.raises(api.VeloError):
+        api.Context(0)
+
+
+def test_argument_validation_without_gpu(lib):
+    assert lib.velo_default_params(None) == -1
+    assert lib.velo_destroy(None) == 0
+    assert lib.velo_pose_vec_to_mat(None, None) == -1
+    assert lib.velo_set_params(None, None) == -1
+    assert lib.velo_version().startswith(b"velo_hip")
+
+
+def test_product_never_touches_the_oracle():
+    """Nothing under the package directory may import, link or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "vision-enhanced-lidar-odometry_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".hpp", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_lib" not in text and "libvelo_oracle" not in text and "velo_oracle" not in text, (dirpath, f)
+    out = subprocess.run(["ldd", build.LIB], capture_output=True, text=True).stdout
+    assert "oracle" not in out

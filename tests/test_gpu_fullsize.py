@@ -1,0 +1,145 @@
+"""-m gpu: BASELINE.json's full sizes (120k-point pair, 2M-point map).  The oracle needs seconds-to-minutes there, so
+parity is checked (a) index-exact on a query SHARD (same shard rule on both sides, full target) and (b) through
+size-independent properties: determinism, idempotence, shard additivity, agreement of two independent kernels
+(per-lane reference kernel vs the LDS-staged shell walk), and recovery of the simulated motion."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+from velo_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pair():
+    return synth.scan_pair()
+
+
+@pytest.fixture(scope="module")
+def full_ctx(hip_lib, pair):
+    c = api.Context(0, icp_skip=1)
+    c.set_target(pair["tgt_xyz"], pair["tgt_off"])
+    c.set_source(pair["src_xyz"], pair["src_off"])
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("iter_,shard", [(1, 3), (2, 11)])
+def test_full_size_shard_is_index_exact(full_ctx, oracle, pair, iter_, shard):
+    world = 16
+    orc = oracle.Oracle(threads=8, icp_skip=1)
+    orc.set_query_shard(shard, world)
+    orc.set_target(pair["tgt_xyz"], pair["tgt_off"])
+    orc.set_source(pair["src_xyz"], pair["src_off"])
+    full_ctx.set_query_shard(shard, world)
+    try:
+        for x in (pair["x0"], pair["x_true"]):
+            assert full_ctx.associate(x, iter_) == orc.associate(x, iter_)
+            a, b = full_ctx.correspondences(), orc.correspondences()
+            assert len(a) == 7500
+            H.assert_corr_equal(a, b)
+            c1, H1, g1 = full_ctx.evaluate(x)
+            c2, H2, g2 = orc.evaluate(x)
+            assert abs(c1 - c2) <= 1e-12 * c2 and H.rel_err(H1, H2) <= 1e-12 and H.rel_err(g1, g2) <= 1e-12
+    finally:
+        full_ctx.set_query_shard(0, 1)
+
+
+def test_full_size_reference_kernel_agrees_with_shell_walk(hip_lib, pair):
+    tables = []
+    for variant in ("0", "4", "1"):
+        os.environ["VELO_ASSOC_VARIANT"] = variant
+        try:
+            c = api.Context(0, icp_skip=1)
+        finally:
+            os.environ.pop("VELO_ASSOC_VARIANT", None)
+        c.set_target(pair["tgt_xyz"], pair["tgt_off"])
+        c.set_source(pair["src_xyz"], pair["src_off"])
+        t = []
+        for it, x in ((1, pair["x0"]), (2, pair["x_true"])):
+            n = c.associate(x, it)
+            t.append((n, c.correspondences()))
+        tables.append(t)
+        c.close()
+    for t in tables[1:]:
+        for (n0, a), (n1, b) in zip(tables[0], t):
+            assert n0 == n1 and n0 > 90000
+            H.assert_corr_equal(a, b)
+
+
+def test_full_size_frame_to_frame_properties(full_ctx, pair):
+    x1, T1, s1 = full_ctx.frame_to_frame(pair["x0"])
+    x2, T2, s2 = full_ctx.frame_to_frame(pair["x0"])
+    assert np.array_equal(x1, x2) and np.array_equal(T1, T2)                      # deterministic, bit for bit
+    assert s1.n_solves == 6 and s1.n_queries == 120000 and s1.n_target == 120000
+    assert all(s1.solves[k].termination == 0 for k in range(6))
+    assert s1.solves[5].final_cost < s1.solves[0].initial_cost
+    # noise-limited recovery of the simulated motion (sigma = 2 cm range noise)
+    assert np.linalg.norm(x1[3:] - pair["x_true"][3:]) < 3e-3 and np.linalg.norm(x1[:3] - pair["x_true"][:3]) < 5e-4
+    # T is the matrix of x (utility.h:67-82) and inverts back
+    np.testing.assert_allclose(api.pose_mat_to_vec(T1), x1, atol=1e-12)
+    # SURVEY.md 8(d) byte accounting
+    want = 6 * (40 * 120000 + 12 * 120000) + sum(s1.solves[k].evaluations * (36 * s1.solves[k].n_icp_valid + 224) for k in range(6))
+    assert s1.algorithmic_bytes == want
+    # a second association at the solution is idempotent
+    n1 = full_ctx.associate(x1, 2)
+    a = full_ctx.correspondences()
+    n2 = full_ctx.associate(x1, 2)
+    assert n1 == n2 and np.array_equal(a, full_ctx.correspondences())
+
+
+def test_full_size_device_resident_inputs_and_stride16(hip_lib, pair, full_ctx):
+    """velo_set_target/source accept device pointers and pcl::PointXYZ's 16-byte stride (zero-copy contract)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    t4 = torch.zeros((120000, 4), dtype=torch.float32, device=dev)
+    t4[:, :3] = torch.from_numpy(pair["tgt_xyz"]).to(dev)
+    s3 = torch.from_numpy(pair["src_xyz"]).to(dev)
+    torch.cuda.synchronize()
+    c = api.Context(0, icp_skip=1)
+    c.set_target(t4, pair["tgt_off"])
+    c.set_source(s3, pair["src_off"])
+    n = c.associate(pair["x_true"], 1)
+    full_ctx.set_query_shard(0, 1)
+    assert n == full_ctx.associate(pair["x_true"], 1)
+    assert np.array_equal(c.correspondences(), full_ctx.correspondences())
+    c.close()
+
+
+def test_batch_of_contexts_matches_single(hip_lib, pair):
+    ctxs = [api.Context(0, icp_skip=4) for _ in range(3)]
+    for c in ctxs:
+        c.set_target(pair["tgt_xyz"], pair["tgt_off"])
+        c.set_source(pair["src_xyz"], pair["src_off"])
+    xs, Ts, Ss = api.frame_to_frame_batch(ctxs, np.tile(pair["x0"], (3, 1)))
+    x_single, _, _ = ctxs[0].frame_to_frame(pair["x0"])
+    for k in range(3):
+        assert np.array_equal(xs[k], x_single) and Ss[k].n_solves == 6
+    for c in ctxs:
+        c.close()
+
+
+def test_scan_to_map_config4_shard_parity_and_solve(hip_lib, oracle):
+    """BASELINE configs[3]: 120k-point scan against a 2M-point accumulated map (1067 rings)."""
+    m = synth.scan_to_map(2_000_000)
+    assert m["tgt_xyz"].shape[0] == 2_000_000 and len(m["tgt_off"]) == 1068
+    c = api.Context(0, icp_skip=1)
+    c.set_target(m["tgt_xyz"], m["tgt_off"])
+    c.set_source(m["src_xyz"], m["src_off"])
+    world, shard = 64, 17
+    orc = oracle.Oracle(threads=8, icp_skip=1)
+    orc.set_query_shard(shard, world)
+    orc.set_target(m["tgt_xyz"], m["tgt_off"])
+    orc.set_source(m["src_xyz"], m["src_off"])
+    c.set_query_shard(shard, world)
+    for it, x in ((1, m["x0"]), (2, m["x_true"])):
+        assert c.associate(x, it) == orc.associate(x, it)
+        H.assert_corr_equal(c.correspondences(), orc.correspondences())
+    c.set_query_shard(0, 1)
+    x, T, s = c.frame_to_frame(m["x0"])
+    assert s.n_target == 2_000_000 and all(s.solves[k].termination == 0 for k in range(6))
+    assert np.linalg.norm(x[3:] - m["x_true"][3:]) < 8e-3 and np.linalg.norm(x[:3] - m["x_true"][:3]) < 1e-3   # map noise
+    c.close()

@@ -1,4 +1,5 @@
-"""Build recipes: the HIP shared library (the product) and, separately, the CPU oracle (the checker).
+"""Build recipe of the HIP shared library (the product).  The CPU checker has its own Makefile next to its source
+and is driven from tests/ and __graft_entry__.build(); nothing in this package touches it.
 
     python -m velo_amd.build            # via the root shim:  python -c "import velo_amd.build as b; b.build_all()"
 
@@ -53,18 +54,8 @@ def build_hip(force: bool = False, verbose: bool = False, extra_flags=()) -> str
     return LIB
 
 
-def build_oracle(force: bool = False) -> str:
-    """Compiles oracle/velo_oracle.cpp (test infrastructure).  Building the checker is not using it."""
-    odir = os.path.join(ROOT, "oracle")
-    out = os.path.join(odir, "_build", "libvelo_oracle.so")
-    deps = [os.path.join(odir, "velo_oracle.cpp"), os.path.join(ROOT, "include", "velo_hip.h"), os.path.join(odir, "Makefile")]
-    if force or _stale(out, deps):
-        subprocess.run(["make", "-C", odir, "-B"], check=True, stdout=subprocess.DEVNULL)
-    return out
-
-
 def build_all(force: bool = False, verbose: bool = False):
-    return build_hip(force, verbose), build_oracle(force)
+    return build_hip(force, verbose)
 
 
 if __name__ == "__main__":
