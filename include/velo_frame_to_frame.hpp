@@ -1,0 +1,171 @@
+// velo_frame_to_frame.hpp -- header-only C++ adaptor: the reference's frameToFrame(...) parameter list
+// (velo.h:598-614, sole caller main.cpp:388-405) on top of the C-ABI of include/velo_hip.h.
+//
+// It is a template over the container types so that it compiles against the reference's own types
+// (pcl::PointCloud<pcl::PointXYZ>::Ptr, pcl::KdTreeFLANN, cv::Point2f, Eigen::Matrix4d) when those headers are present,
+// and against light stand-ins (tests/cpp/standins.hpp) when they are not -- this image has neither PCL, OpenCV nor Eigen.
+// Requirements on the types, all satisfied by the reference's:
+//   CloudPtr   : cloud->size(), cloud->at(i).x/.y/.z                       (pcl::PointCloud<pcl::PointXYZ>::Ptr)
+//   Point2     : p.x, p.y                                                  (cv::Point2f)
+//   Point3     : p.x, p.y, p.z                                             (pcl::PointXYZ)
+//   Mat4       : T(i, j) assignable double                                 (Eigen::Matrix4d)
+//   KdTrees    : ignored -- the per-ring KD-trees (lru.h:17-20) are replaced by the device-side grid index that
+//                velo_set_target builds; the argument is kept so that the call site does not change.
+//
+// What runs where:  this adaptor flattens the reference's nested containers (host), exactly as velo.h:627-654 gathers
+// the per-match operands; residual-type selection + outlier gate (velo.h:662-792), association (velo.h:806-894),
+// residual/Jacobian evaluation (costfunctions.h) and the Ceres solve (velo.h:897-902) run on the GPU behind
+// velo_frame_to_frame().  Errors: the reference reports none; here a failed call throws std::runtime_error with
+// velo_last_error() (the C-ABI itself never throws).
+#ifndef VELO_FRAME_TO_FRAME_HPP_
+#define VELO_FRAME_TO_FRAME_HPP_
+
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "velo_hip.h"
+
+namespace velo_hip {
+
+// same enumerators, same order as the reference's ResidualType (velo.h:3-8)
+enum ResidualType { RESIDUAL_3D3D = VELO_RESIDUAL_3D3D, RESIDUAL_3D2D = VELO_RESIDUAL_3D2D,
+                    RESIDUAL_2D3D = VELO_RESIDUAL_2D3D, RESIDUAL_2D2D = VELO_RESIDUAL_2D2D };
+
+inline void check(int status, const char* what) {
+    if (status != VELO_OK) throw std::runtime_error(std::string(what) + ": " + velo_last_error());
+}
+
+// RAII owner of one velo_ctx (one per host thread, like the reference's single-threaded driver loop).
+class Context {
+public:
+    explicit Context(int device = 0) { check(velo_create(&ctx_, device), "velo_create"); }
+    ~Context() { velo_destroy(ctx_); }
+    Context(const Context&) = delete;
+    Context& operator=(const Context&) = delete;
+    velo_ctx* get() const { return ctx_; }
+    velo_params params() const { velo_params p; check(velo_get_params(ctx_, &p), "velo_get_params"); return p; }
+    void set_params(const velo_params& p) { check(velo_set_params(ctx_, &p), "velo_set_params"); }
+
+    // scans of one frame: a vector of ring clouds, as ScanData::scans holds them (lru.h:8)
+    template <typename CloudPtr>
+    static void flatten(const std::vector<CloudPtr>& rings, std::vector<float>& xyz, std::vector<int32_t>& off) {
+        off.assign(1, 0);
+        size_t n = 0;
+        for (const auto& r : rings) n += r->size();
+        xyz.resize(3 * n);
+        size_t k = 0;
+        for (const auto& r : rings) {
+            for (size_t i = 0; i < r->size(); i++) {
+                const auto& p = r->at(i);
+                xyz[3 * k] = p.x; xyz[3 * k + 1] = p.y; xyz[3 * k + 2] = p.z;
+                k++;
+            }
+            off.push_back((int32_t)k);
+        }
+    }
+    template <typename CloudPtr>
+    void set_target(const std::vector<CloudPtr>& scans_S) {       // replaces scans_S + kd_trees
+        flatten(scans_S, xyz_, off_);
+        check(velo_set_target(ctx_, xyz_.data(), 12, off_.data(), (int32_t)off_.size() - 1, 0), "velo_set_target");
+    }
+    template <typename CloudPtr>
+    void set_source(const std::vector<CloudPtr>& scans_M) {
+        flatten(scans_M, xyz_, off_);
+        check(velo_set_source(ctx_, xyz_.data(), 12, off_.data(), (int32_t)off_.size() - 1, 0), "velo_set_source");
+    }
+
+private:
+    velo_ctx* ctx_ = nullptr;
+    std::vector<float> xyz_;
+    std::vector<int32_t> off_;
+};
+
+// The reference's globals the path reads (kitti.h:3,46-47): number of cameras and cam_trans[cam].
+struct Rig {
+    int num_cams = 2;
+    std::vector<std::array<float, 3>> cam_trans{{{0.f, 0.f, 0.f}}, {{-0.537f, 0.f, 0.f}}};
+};
+
+// frameToFrame, same parameter list and meaning as velo.h:598-614.  `ctx` and `rig` are the two additions (the
+// reference keeps their equivalents in globals).  Returns the 4x4 of the solution like util::pose_mat2vec(transform).
+template <typename Mat4, typename Point2, typename Point3, typename CloudPtr, typename KdTrees>
+Mat4 frameToFrame(Context& ctx, const Rig& rig,
+                  const std::vector<std::vector<std::pair<int, int>>>& matches,
+                  const std::vector<std::vector<std::vector<Point2>>>& keypoints,
+                  const std::vector<std::vector<std::vector<int>>>& keypoint_ids,
+                  const std::map<int, Point3>& landmarks_at_frame,
+                  const std::vector<std::vector<CloudPtr>>& keypoints_with_depth,
+                  const std::vector<std::vector<std::vector<int>>>& has_depth,
+                  const std::vector<CloudPtr>& scans_M,
+                  const std::vector<CloudPtr>& scans_S,
+                  const KdTrees& /*kd_trees: superseded by the device grid*/,
+                  const int frame1, const int frame2,
+                  double transform[6],
+                  std::vector<std::vector<std::pair<int, int>>>& good_matches,
+                  std::vector<std::vector<ResidualType>>& residual_type,
+                  const bool enable_icp) {
+    velo_params P = ctx.params();
+    P.enable_icp = enable_icp ? 1 : 0;                                            // velo.h:806
+    ctx.set_params(P);
+    ctx.set_target(scans_S);
+    ctx.set_source(scans_M);
+
+    // velo.h:622-654: gather, per match, what the residual-type selection needs
+    std::vector<velo_match> recs;
+    for (int cam = 0; cam < rig.num_cams; cam++) {
+        const auto& mc = matches[cam];
+        for (size_t i = 0; i < mc.size(); i++) {
+            const int point1 = mc[i].first, point2 = mc[i].second;
+            const int id = keypoint_ids[cam][frame2][point2];
+            bool d1 = has_depth[cam][frame1][point1] != -1, d2 = has_depth[cam][frame2][point2] != -1;
+            velo_match m;
+            std::memset(&m, 0, sizeof(m));
+            auto lm = landmarks_at_frame.find(id);
+            if (lm != landmarks_at_frame.end()) {                                 // velo.h:634-644
+                m.p3_2[0] = lm->second.x; m.p3_2[1] = lm->second.y; m.p3_2[2] = lm->second.z;
+                d2 = true;
+            } else if (d2) {
+                const auto& p = keypoints_with_depth[cam][frame2]->at(has_depth[cam][frame2][point2]);
+                m.p3_2[0] = p.x; m.p3_2[1] = p.y; m.p3_2[2] = p.z;
+            }
+            if (d1) {
+                const auto& p = keypoints_with_depth[cam][frame1]->at(has_depth[cam][frame1][point1]);
+                m.p3_1[0] = p.x; m.p3_1[1] = p.y; m.p3_1[2] = p.z;
+            }
+            const Point2& a = keypoints[cam][frame1][point1];
+            const Point2& b = keypoints[cam][frame2][point2];
+            m.p2_1[0] = a.x; m.p2_1[1] = a.y; m.p2_2[0] = b.x; m.p2_2[1] = b.y;
+            for (int k = 0; k < 3; k++) m.t_cam[k] = rig.cam_trans[cam][k];
+            m.cam = cam; m.point1 = point1; m.point2 = point2;
+            m.d1 = d1 ? 1 : 0; m.d2 = d2 ? 1 : 0;
+            recs.push_back(m);
+        }
+    }
+    check(velo_set_visual(ctx.get(), recs.empty() ? nullptr : recs.data(), (int32_t)recs.size()), "velo_set_visual");
+
+    double T[16];
+    check(velo_frame_to_frame(ctx.get(), transform, T, nullptr), "velo_frame_to_frame");
+
+    // good_matches / residual_type of the LAST outer iteration (cleared per cam per iter at velo.h:624-625)
+    int32_t n = 0;
+    check(velo_get_good_matches(ctx.get(), nullptr, 0, &n), "velo_get_good_matches");
+    std::vector<velo_good_match> gm((size_t)n);
+    if (n > 0) check(velo_get_good_matches(ctx.get(), gm.data(), n, &n), "velo_get_good_matches");
+    for (int cam = 0; cam < rig.num_cams; cam++) { good_matches[cam].clear(); residual_type[cam].clear(); }
+    for (const auto& g : gm) {
+        good_matches[g.cam].push_back(std::make_pair(g.point1, g.point2));
+        residual_type[g.cam].push_back((ResidualType)g.residual_type);
+    }
+    Mat4 out;
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) out(i, j) = T[i * 4 + j];
+    return out;
+}
+
+}  // namespace velo_hip
+#endif  // VELO_FRAME_TO_FRAME_HPP_

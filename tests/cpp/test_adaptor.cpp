@@ -1,0 +1,94 @@
+// Drives include/velo_frame_to_frame.hpp the way main.cpp:388-405 drives the reference's frameToFrame: nested
+// containers in, transform[6] in/out, good_matches/residual_type out.  Input file written by tests/test_cpp_adaptor.py.
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <vector>
+
+#include "standins.hpp"
+#include "velo_frame_to_frame.hpp"
+
+using namespace standin;
+
+static std::vector<PointCloud::Ptr> read_rings(FILE* f) {
+    int32_t nr;
+    if (fread(&nr, 4, 1, f) != 1) exit(2);
+    std::vector<int32_t> off(nr + 1);
+    if (fread(off.data(), 4, nr + 1, f) != (size_t)nr + 1) exit(2);
+    std::vector<float> xyz(3 * (size_t)off[nr]);
+    if (fread(xyz.data(), 4, xyz.size(), f) != xyz.size()) exit(2);
+    std::vector<PointCloud::Ptr> rings;
+    for (int r = 0; r < nr; r++) {
+        PointCloud::Ptr c(new PointCloud);
+        for (int i = off[r]; i < off[r + 1]; i++) c->push_back(PointXYZ(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
+        rings.push_back(c);
+    }
+    return rings;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) return 1;
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) return 1;
+    std::vector<PointCloud::Ptr> scans_M = read_rings(f), scans_S = read_rings(f);
+    int32_t nm, skip;
+    if (fread(&nm, 4, 1, f) != 1 || fread(&skip, 4, 1, f) != 1) return 2;
+    std::vector<velo_match> recs(nm);
+    if (nm && fread(recs.data(), sizeof(velo_match), nm, f) != (size_t)nm) return 2;
+    double transform[6];
+    if (fread(transform, 8, 6, f) != 6) return 2;
+    fclose(f);
+
+    // rebuild the reference-shaped containers: frame1 = 1 (current), frame2 = 0 (previous)
+    const int num_cams = 2, frame1 = 1, frame2 = 0;
+    std::vector<std::vector<std::pair<int, int>>> matches(num_cams), good_matches(num_cams);
+    std::vector<std::vector<velo_hip::ResidualType>> residual_type(num_cams);
+    std::vector<std::vector<std::vector<Point2f>>> keypoints(num_cams, std::vector<std::vector<Point2f>>(2));
+    std::vector<std::vector<std::vector<int>>> keypoint_ids(num_cams, std::vector<std::vector<int>>(2));
+    std::vector<std::vector<std::vector<int>>> has_depth(num_cams, std::vector<std::vector<int>>(2));
+    std::vector<std::vector<PointCloud::Ptr>> kwd(num_cams, std::vector<PointCloud::Ptr>(2));
+    std::map<int, PointXYZ> landmarks;
+    for (int c = 0; c < num_cams; c++) for (int fr = 0; fr < 2; fr++) kwd[c][fr].reset(new PointCloud);
+    int next_id = 1000;
+    for (int i = 0; i < nm; i++) {
+        const velo_match& m = recs[i];
+        const int c = m.cam;
+        const int k = (int)keypoints[c][frame1].size();
+        keypoints[c][frame1].push_back(Point2f{m.p2_1[0], m.p2_1[1]});
+        keypoints[c][frame2].push_back(Point2f{m.p2_2[0], m.p2_2[1]});
+        const int id = next_id++;
+        keypoint_ids[c][frame1].push_back(id);
+        keypoint_ids[c][frame2].push_back(id);
+        if (m.d1) { has_depth[c][frame1].push_back((int)kwd[c][frame1]->size()); kwd[c][frame1]->push_back(PointXYZ(m.p3_1[0], m.p3_1[1], m.p3_1[2])); }
+        else has_depth[c][frame1].push_back(-1);
+        if (m.d2 && (i % 5 == 0)) {                    // every fifth 3-D point of frame2 arrives as a triangulated landmark
+            landmarks[id] = PointXYZ(m.p3_2[0], m.p3_2[1], m.p3_2[2]);
+            has_depth[c][frame2].push_back(-1);
+        } else if (m.d2) { has_depth[c][frame2].push_back((int)kwd[c][frame2]->size()); kwd[c][frame2]->push_back(PointXYZ(m.p3_2[0], m.p3_2[1], m.p3_2[2])); }
+        else has_depth[c][frame2].push_back(-1);
+        matches[c].push_back(std::make_pair(k, k));
+    }
+    try {
+        velo_hip::Context ctx(0);
+        velo_params P = ctx.params();
+        P.icp_skip = skip;
+        ctx.set_params(P);
+        velo_hip::Rig rig;
+        std::vector<KdTree> kd_trees(scans_S.size());
+        Matrix4d T = velo_hip::frameToFrame<Matrix4d>(ctx, rig, matches, keypoints, keypoint_ids, landmarks, kwd, has_depth,
+                                                      scans_M, scans_S, kd_trees, frame1, frame2, transform, good_matches,
+                                                      residual_type, true);
+        printf("x");
+        for (int i = 0; i < 6; i++) printf(" %.17g", transform[i]);
+        printf("\nT");
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) printf(" %.17g", T(i, j));
+        printf("\n");
+        for (int c = 0; c < num_cams; c++)
+            for (size_t i = 0; i < good_matches[c].size(); i++)
+                printf("g %d %d %d %d\n", c, good_matches[c][i].first, good_matches[c][i].second, (int)residual_type[c][i]);
+    } catch (const std::exception& e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 3;
+    }
+    return 0;
+}

@@ -1,0 +1,69 @@
+"""The header-only C++ adaptor (include/velo_frame_to_frame.hpp) offers the reference's frameToFrame parameter list
+(velo.h:598-614).  CPU: it compiles as plain C++11 against stand-in container types and links to the C-ABI library.
+GPU: driven like main.cpp:388-405 it returns the oracle's pose, good_matches and residual_type."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+import velo_amd  # noqa: F401
+from velo_amd import api, build, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CPP = os.path.join(ROOT, "tests", "cpp")
+
+
+def compile_adaptor(tmp_path) -> str:
+    build.build_hip()
+    exe = str(tmp_path / "test_adaptor")
+    csrc = os.path.dirname(build.LIB)
+    subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", CPP,
+                    os.path.join(CPP, "test_adaptor.cpp"), "-o", exe, "-L", csrc, "-lvelo_hip", f"-Wl,-rpath,{csrc}",
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return exe
+
+
+def write_case(path, d, matches, skip):
+    with open(path, "wb") as f:
+        for xyz, off in ((d["src_xyz"], d["src_off"]), (d["tgt_xyz"], d["tgt_off"])):
+            f.write(struct.pack("i", len(off) - 1))
+            f.write(np.asarray(off, np.int32).tobytes())
+            f.write(np.ascontiguousarray(xyz, np.float32).tobytes())
+        f.write(struct.pack("ii", len(matches), skip))
+        f.write(matches.tobytes())
+        f.write(np.asarray(d["x0"], np.float64).tobytes())
+
+
+def test_adaptor_compiles_as_cxx11(tmp_path):
+    assert os.path.exists(compile_adaptor(tmp_path))
+
+
+@pytest.mark.gpu
+def test_adaptor_matches_oracle(tmp_path, oracle):
+    exe = compile_adaptor(tmp_path)
+    d = H.small_pair(16, 128)
+    m = api.matches_from_dict(synth.stereo_matches(60, mix="all"))
+    per_cam = np.concatenate([np.arange(60), np.arange(60)]).astype(np.int32)     # the C++ side indexes keypoints per camera
+    m["point1"] = per_cam
+    m["point2"] = per_cam
+    case = str(tmp_path / "case.bin")
+    write_case(case, d, m, 2)
+    out = subprocess.run([exe, case], check=True, capture_output=True, text=True).stdout.splitlines()
+    x = np.array([float(v) for v in out[0].split()[1:]])
+    T = np.array([float(v) for v in out[1].split()[1:]]).reshape(4, 4)
+    good = np.array([[int(v) for v in line.split()[1:]] for line in out[2:]]).reshape(-1, 4)
+    orc = oracle.Oracle(icp_skip=2)
+    orc.set_target(d["tgt_xyz"], d["tgt_off"])
+    orc.set_source(d["src_xyz"], d["src_off"])
+    orc.set_visual(m)
+    xo, To, so = orc.frame_to_frame(d["x0"])
+    assert H.pose_close(x, xo), (x, xo)
+    np.testing.assert_allclose(T, To, atol=1e-6)
+    g = orc.good_matches()
+    # the adaptor returns good_matches per camera (cam-major), like the reference's vectors
+    want = np.stack([g["cam"], g["point1"], g["point2"], g["residual_type"]], 1)
+    want = want[np.argsort(want[:, 0], kind="stable")]
+    assert np.array_equal(good, want)
