@@ -392,8 +392,8 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         const double gate = gate_of_iter(c->P, iter);
         const unsigned gbits = gate_bits_of(gate);
         const float h_safe = (float)(G->h * 0.999);
-#define VELO_LAUNCH_V2(NW)                                                                                                         \
-        hipLaunchKernelGGL(assoc_search_v3_kernel<NW>, dim3(groups), dim3(NW * 64), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe, \
+#define VELO_LAUNCH_V2(NW, MINW)                                                                                                   \
+        hipLaunchKernelGGL((assoc_search_v3_kernel<NW, MINW>), dim3(groups), dim3(NW * 64), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe, \
                            c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, c->cluster_w, h_safe, out, aux, c->debug_skip)
         switch (c->assoc_variant) {
             case 0: {
@@ -402,10 +402,14 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                                    S, V, c->src.p, c->q_src.p, qb, qe, c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, std::max(reach, 1), out, aux);
                 break;
             }
-            case 1: VELO_LAUNCH_V2(1); break;
-            case 2: VELO_LAUNCH_V2(2); break;
-            case 8: VELO_LAUNCH_V2(8); break;
-            default: VELO_LAUNCH_V2(4); break;
+            case 1: VELO_LAUNCH_V2(1, 1); break;
+            case 2: VELO_LAUNCH_V2(2, 1); break;
+            case 8: VELO_LAUNCH_V2(8, 8); break;
+            case 45: VELO_LAUNCH_V2(4, 5); break;
+            case 46: VELO_LAUNCH_V2(4, 6); break;
+            case 47: VELO_LAUNCH_V2(4, 7); break;
+            case 48: VELO_LAUNCH_V2(4, 8); break;
+            default: VELO_LAUNCH_V2(4, 6); break;
         }
 #undef VELO_LAUNCH_V2
         HIP_TRY(hipGetLastError());

@@ -411,8 +411,8 @@ __device__ __forceinline__ int wave_max_i(int v) {
 constexpr int kTileCap = 512;      // candidates per LDS tile (keeps the workgroup under 20 KB of LDS: 8 workgroups per CU)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int NW>
-__global__ void __launch_bounds__(NW * 64, 8)
+template <int NW, int MINW>
+__global__ void __launch_bounds__(NW * 64, MINW)
 assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
                        const float4* __restrict__ tgt, const int* __restrict__ tgt_off, const int* __restrict__ ring_of,
                        unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, AssocOut out, int want_aux, int dbg) {
