@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/<tag>/ (written by tools/gpu_profile.sh on the GPU box) into the tracked summaries under profiles/."""
+import collections, csv, glob, json, os, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+lines = []
+f = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+if f:
+    rows = list(csv.DictReader(open(f[0])))
+    with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as o:
+        w = csv.writer(o)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+        for r in rows:
+            w.writerow([r["Name"].split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+    lines.append(f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline  (default batch)")
+    for r in rows[:8]:
+        lines.append(f"  {r['Name'].split('(')[0][:58]:58s} calls {r['Calls']:>6}  avg {float(r['AverageNs'])/1e3:8.1f} us  {r['Percentage']}%")
+b = os.path.join(src, "bench_under_rocprof.json")
+if os.path.exists(b):
+    try:
+        d = json.loads(open(b).read().strip().splitlines()[-1])
+        lines.append(f"bench line under rocprof: value {d['value']:.1f} {d['unit']}, assoc avg launch {d['roofline']['avg_launch_us']:.1f} us (HIP events)")
+    except Exception as e:
+        lines.append(f"(bench line unreadable: {e})")
+for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    f = glob.glob(os.path.join(src, name, "*", "*counter_collection.csv"))
+    if not f:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] == counter:
+            agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    lines.append(f"{counter} per dispatch (KiB as rocprofv3 reports it; gfx950: FETCH_SIZE counts wide coalesced reads at 1/2):")
+    for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:6]:
+        lines.append(f"  {k[:58]:58s} n {len(v):4d}  mean {sum(v)/len(v):12.1f}")
+f = glob.glob(os.path.join(src, "pmc_sq", "*", "*counter_collection.csv"))
+if f:
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f[0])):
+        agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append((r["Dispatch_Id"], float(r["Counter_Value"])))
+    lines.append("SQ counters, sum over XCDs per dispatch, mean over dispatches:")
+    for k in agg:
+        if "assoc" in k or "lm_iter" in k or "eval" in k:
+            parts = []
+            for cn, vals in agg[k].items():
+                per = collections.defaultdict(float)
+                for did, v in vals:
+                    per[did] += v
+                parts.append(f"{cn}={sum(per.values())/len(per):.3g}")
+            lines.append(f"  {k[:50]}: " + " ".join(parts))
+open(os.path.join(dst, f"{tag}_summary.txt"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))

@@ -113,6 +113,7 @@ struct velo_ctx {
     bool timing = false;
     int assoc_variant = 4;               // 0 = per-lane reference kernel; 1/2/4/8 = waves per 64-query group of the shell walk (VELO_ASSOC_VARIANT)
     int cluster_w = 6;                   // cluster radius in cells (VELO_CLUSTER_W)
+    int persistent_wgs = 2048;           // workgroups of the persistent association kernel (VELO_PERSISTENT_WGS)
     int debug_skip = 0;                  // timing experiments only (VELO_DEBUG_SKIP): results are wrong when non-zero
 
     // target (frame2)
@@ -142,7 +143,11 @@ struct velo_ctx {
     DevBuf<float4> cp, cn, cv0, aux1;
     DevBuf<int4> aux0;
     DevBuf<int> n_valid;
-    DevBuf<unsigned long long> dbg;
+    DevBuf<unsigned long long> dbg, wg_times;
+    int wg_times_n = 0;
+    DevBuf<AssocItem> items;             // work queue of the pipelined association
+    DevBuf<int> item_counters;
+    DevBuf<float4> qpos;
     bool have_corr = false;
     int last_n_valid = 0;
 
@@ -157,6 +162,13 @@ struct velo_ctx {
     // LM
     DevBuf<LMState> state;
     DevBuf<double> partials, reduced, xdev;
+    DevBuf<int> ticket;
+    // captured LM chunks (single GPU): key = iterations per chunk; rebuilt when anything baked into the nodes changes
+    hipGraphExec_t chunk_graph[2] = {nullptr, nullptr};
+    int chunk_graph_iters[2] = {0, 0};
+    std::vector<unsigned char> chunk_graph_sig[2];   // bytes of everything baked into the nodes
+    bool use_graphs = true;
+    bool use_fused = true;
     HostStatus* h_status = nullptr;      // pinned
     double* h_x = nullptr;               // pinned, 8 doubles
     int* h_int = nullptr;                // pinned scratch
@@ -376,7 +388,8 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         GridView V;
         V.d = G->d; V.cell_start = G->cell_start.p; V.sorted = G->sorted.p; V.sring = G->sring.p;
         AssocOut out;
-        out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p; out.dbg = c->dbg.p;
+        out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p; out.dbg = c->dbg.p; out.wg_times = nullptr;
+        if (c->debug_skip & 32) { VELO_TRY(c->wg_times.reserve((size_t)2 * cdiv(qe - qb, 64) + 2)); out.wg_times = c->wg_times.p; c->wg_times_n = cdiv(qe - qb, 64); }
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
         if (c->timing) {
             if (c->assoc_events_used >= (int)c->assoc_events.size()) {
@@ -400,6 +413,29 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 const int reach = (int)std::ceil(std::sqrt(std::max(gate, 0.0)) / (G->h * 0.999)) ;
                 hipLaunchKernelGGL(assoc_search_kernel, dim3(cdiv(qe - qb, kAssocThreads)), dim3(kAssocThreads), 0, c->stream,
                                    S, V, c->src.p, c->q_src.p, qb, qe, c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, std::max(reach, 1), out, aux);
+                break;
+            }
+            case 104: case 102: case 108: {   // pipelined: prepare (one item per cluster) + persistent per-cluster search
+                const int nqr = qe - qb;
+                const int shard_cap = (groups / kQShards + 1) * 64;        // worst case: every lane its own cluster
+                VELO_TRY(c->items.reserve((size_t)shard_cap * kQShards));
+                VELO_TRY(c->item_counters.reserve((size_t)2 * kQShards * kQStride));
+                VELO_TRY(c->qpos.reserve((size_t)c->n_q + 64));
+                AssocQueue Q;
+                Q.items = c->items.p; Q.shard_cap = shard_cap; Q.counters = c->item_counters.p; Q.qpos = c->qpos.p;
+                HIP_TRY(hipMemsetAsync(c->item_counters.p, 0, sizeof(int) * 2 * kQShards * kQStride, c->stream));
+                (void)nqr;
+                hipLaunchKernelGGL(assoc_prepare_kernel, dim3(groups), dim3(64), 0, c->stream, S, V.d, c->src.p, c->q_src.p, qb, qe, c->cluster_w, Q);
+                const int wgs = std::min(groups * 4, c->persistent_wgs);
+                if (c->assoc_variant == 102)
+                    hipLaunchKernelGGL((assoc_cluster_kernel<2, 1>), dim3(wgs), dim3(128), 0, c->stream, V, Q, c->src.p, c->q_src.p, qb, qe,
+                                       c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, h_safe, out, aux);
+                else if (c->assoc_variant == 108)
+                    hipLaunchKernelGGL((assoc_cluster_kernel<8, 6>), dim3(wgs), dim3(512), 0, c->stream, V, Q, c->src.p, c->q_src.p, qb, qe,
+                                       c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, h_safe, out, aux);
+                else
+                    hipLaunchKernelGGL((assoc_cluster_kernel<4, 6>), dim3(wgs), dim3(256), 0, c->stream, V, Q, c->src.p, c->q_src.p, qb, qe,
+                                       c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, h_safe, out, aux);
                 break;
             }
             case 1: VELO_LAUNCH_V2(1, 1); break;
@@ -461,6 +497,18 @@ void visual_counts(const velo_ctx* c, int* blocks, int* residuals) {
 
 // enqueue: eval sweep at the state's current point, (all-reduce), LM transition
 int enqueue_lm_iteration(velo_ctx* c, const EvalArgs& A, const EvalPlan& E, const LMParams& Q) {
+    if (!c->comm && c->use_fused) {
+        // fused: [visual sweep] + one launch whose last workgroup reduces and steps
+        EvalArgs B = A;
+        const int nb = std::max(E.nb_icp, 1);
+        if (E.nb_vis > 0) {
+            B.vis_row0 = nb;
+            hipLaunchKernelGGL(eval_visual_kernel, dim3(E.nb_vis), dim3(kEvalThreads), 0, c->stream, B);
+        }
+        hipLaunchKernelGGL(lm_iter_fused_kernel, dim3(nb), dim3(kEvalThreads), 0, c->stream, B, Q, c->state.p, c->ticket.p, nb + E.nb_vis);
+        HIP_TRY(hipGetLastError());
+        return VELO_OK;
+    }
     launch_eval(c, A, E);
     const int nblocks = E.total();
     if (c->comm) {
@@ -473,6 +521,49 @@ int enqueue_lm_iteration(velo_ctx* c, const EvalArgs& A, const EvalPlan& E, cons
         hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, (const double*)c->partials.p, nblocks);
     }
     HIP_TRY(hipGetLastError());
+    return VELO_OK;
+}
+
+// K LM iterations + the status read-back as ONE graph launch (the launch-bound inner loop of the solve).
+int launch_chunk(velo_ctx* c, const EvalArgs& A, const EvalPlan& E, const LMParams& Q, int iters) {
+    const bool graphable = c->use_graphs && !c->comm;
+    if (!graphable) {
+        for (int k = 0; k < iters; k++) VELO_TRY(enqueue_lm_iteration(c, A, E, Q));
+        HIP_TRY(hipMemcpyAsync(&c->h_status->s, c->state.p, sizeof(LMState), hipMemcpyDeviceToHost, c->stream));
+        return VELO_OK;
+    }
+    // signature of everything the captured nodes bake in; a mismatch re-captures that slot
+    std::vector<unsigned char> sig(sizeof(EvalArgs) + sizeof(LMParams) + sizeof(EvalPlan) + sizeof(void*) * 3 + sizeof(int));
+    {
+        unsigned char* w = sig.data();
+        std::memcpy(w, &A, sizeof(EvalArgs)); w += sizeof(EvalArgs);
+        std::memcpy(w, &Q, sizeof(LMParams)); w += sizeof(LMParams);
+        std::memcpy(w, &E, sizeof(EvalPlan)); w += sizeof(EvalPlan);
+        const void* ptrs[3] = {c->state.p, c->ticket.p, c->h_status};
+        std::memcpy(w, ptrs, sizeof(ptrs)); w += sizeof(ptrs);
+        const int fused = c->use_fused ? 1 : 0;
+        std::memcpy(w, &fused, sizeof(int));
+    }
+    int slot = -1;
+    for (int k = 0; k < 2; k++) if (c->chunk_graph[k] && c->chunk_graph_iters[k] == iters && c->chunk_graph_sig[k] == sig) slot = k;
+    if (slot < 0) {
+        slot = (c->chunk_graph[0] && c->chunk_graph_iters[0] != iters) ? 1 : 0;   // slot 0: first-solve chunk size seen first, slot 1: the other
+        if (c->chunk_graph[slot]) { (void)hipGraphExecDestroy(c->chunk_graph[slot]); c->chunk_graph[slot] = nullptr; }
+        hipGraph_t g = nullptr;
+        HIP_TRY(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+        int st = VELO_OK;
+        for (int k = 0; k < iters && st == VELO_OK; k++) st = enqueue_lm_iteration(c, A, E, Q);
+        hipError_t e1 = hipMemcpyAsync(&c->h_status->s, c->state.p, sizeof(LMState), hipMemcpyDeviceToHost, c->stream);
+        hipError_t e2 = hipStreamEndCapture(c->stream, &g);
+        if (st != VELO_OK) { if (g) (void)hipGraphDestroy(g); return st; }
+        if (e1 != hipSuccess || e2 != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); return fail(VELO_ERR_HIP, "graph capture of the LM chunk failed: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2)); }
+        hipError_t e3 = hipGraphInstantiate(&c->chunk_graph[slot], g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e3 != hipSuccess) { c->chunk_graph[slot] = nullptr; return fail(VELO_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(e3)); }
+        c->chunk_graph_iters[slot] = iters;
+        c->chunk_graph_sig[slot] = sig;
+    }
+    HIP_TRY(hipGraphLaunch(c->chunk_graph[slot], c->stream));
     return VELO_OK;
 }
 
@@ -492,11 +583,11 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
     int chunk = first_chunk;                // LM iterations per host round trip
     const int max_iters = c->P.max_num_iterations + 1;
     for (;;) {
-        for (int k = 0; k < chunk; k++) { VELO_TRY(enqueue_lm_iteration(c, A, E, Q)); launched++; }
-        HIP_TRY(hipMemcpyAsync(&c->h_status->s, c->state.p, sizeof(LMState), hipMemcpyDeviceToHost, c->stream));
+        VELO_TRY(launch_chunk(c, A, E, Q, chunk));
+        launched += chunk;
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->h_status->s.done) break;
-        if (launched > max_iters + 8) return fail(VELO_ERR_STATE, "LM did not terminate after %d sweeps", launched);
+        if (launched > max_iters + 16) return fail(VELO_ERR_STATE, "LM did not terminate after %d sweeps", launched);
         chunk = 4;
     }
     const LMState& s = c->h_status->s;
@@ -546,6 +637,9 @@ int velo_create(velo_ctx** out, int device) {
     if (const char* e = getenv("VELO_ASSOC_VARIANT")) c->assoc_variant = atoi(e);
     if (const char* e = getenv("VELO_CLUSTER_W")) c->cluster_w = std::max(atoi(e), 0);
     if (const char* e = getenv("VELO_DEBUG_SKIP")) c->debug_skip = atoi(e);
+    if (const char* e = getenv("VELO_GRAPHS")) c->use_graphs = atoi(e) != 0;
+    if (const char* e = getenv("VELO_PERSISTENT_WGS")) c->persistent_wgs = std::max(atoi(e), 1);
+    if (const char* e = getenv("VELO_FUSED")) c->use_fused = atoi(e) != 0;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipHostMalloc((void**)&c->h_status, sizeof(HostStatus), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&c->h_x, sizeof(double) * 64, hipHostMallocDefault));
@@ -554,6 +648,8 @@ int velo_create(velo_ctx** out, int device) {
     VELO_TRY(c->partials.reserve((size_t)(kMaxEvalBlocks + kMaxVisBlocks) * kNumAcc));
     VELO_TRY(c->reduced.reserve(2 * kNumAcc));
     VELO_TRY(c->xdev.reserve(8));
+    VELO_TRY(c->ticket.reserve(1));
+    HIP_TRY(hipMemsetAsync(c->ticket.p, 0, sizeof(int), c->stream));
     VELO_TRY(c->bbox_keys.reserve(6));
     VELO_TRY(c->n_valid.reserve(1));
     VELO_TRY(c->dbg.reserve(8));
@@ -570,6 +666,19 @@ int velo_destroy(velo_ctx* c) {
     if (!c) return VELO_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if ((c->debug_skip & 32) && c->wg_times.p && c->wg_times_n > 0) {
+        std::vector<unsigned long long> h((size_t)2 * c->wg_times_n);
+        if (hipMemcpy(h.data(), c->wg_times.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            unsigned long long t0 = ~0ull, t1 = 0; std::vector<double> dur, st;
+            for (int i = 0; i < c->wg_times_n; i++) { t0 = std::min(t0, h[2 * i]); t1 = std::max(t1, h[2 * i + 1]); }
+            for (int i = 0; i < c->wg_times_n; i++) { dur.push_back((h[2 * i + 1] - h[2 * i]) * 0.01); st.push_back((h[2 * i] - t0) * 0.01); }
+            std::sort(dur.begin(), dur.end()); std::sort(st.begin(), st.end());
+            auto pc = [&](std::vector<double>& v, double p) { return v[(size_t)(p * (v.size() - 1))]; };
+            double mean = 0; for (double d : dur) mean += d; mean /= dur.size();
+            fprintf(stderr, "[velo dbg] last assoc launch: %d WGs, span %.1f us | WG duration us: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f | WG start us: p50 %.1f p90 %.1f p99 %.1f max %.1f\n",
+                    c->wg_times_n, (t1 - t0) * 0.01, mean, pc(dur, .5), pc(dur, .9), pc(dur, .99), dur.back(), pc(st, .5), pc(st, .9), pc(st, .99), st.back());
+        }
+    }
     if ((c->debug_skip & 24) && c->dbg.p) {
         unsigned long long h[8];
         if (hipMemcpy(h, c->dbg.p, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
@@ -581,9 +690,10 @@ int velo_destroy(velo_ctx* c) {
     for (Grid& G : c->grids) { G.cell_start.release(); G.sorted.release(); G.sring.release(); }
     c->scan_tiles.release(); c->cursor.release(); c->scan_total.release(); c->bbox_keys.release();
     c->src.release(); c->src_off.release(); c->q_off.release(); c->q_src.release(); c->staging.release();
-    c->cp.release(); c->cn.release(); c->cv0.release(); c->aux0.release(); c->aux1.release(); c->n_valid.release(); c->dbg.release();
+    c->cp.release(); c->cn.release(); c->cv0.release(); c->aux0.release(); c->aux1.release(); c->n_valid.release(); c->dbg.release(); c->wg_times.release(); c->items.release(); c->item_counters.release(); c->qpos.release();
     c->vm.release(); c->vflags.release();
-    c->state.release(); c->partials.release(); c->reduced.release(); c->xdev.release();
+    for (int k = 0; k < 2; k++) if (c->chunk_graph[k]) (void)hipGraphExecDestroy(c->chunk_graph[k]);
+    c->state.release(); c->partials.release(); c->reduced.release(); c->xdev.release(); c->ticket.release();
     c->row_off_vis.release(); c->row_off_icp.release(); c->rows_r.release(); c->rows_J.release();
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->h_x) (void)hipHostFree(c->h_x);

@@ -230,6 +230,7 @@ struct AssocOut {
     float4* __restrict__ aux1;   // bits(idx_k), dist_i, dist_j, -
     int* __restrict__ n_valid;   // atomic counter
     unsigned long long* __restrict__ dbg;   // [8] diagnostic cycle totals (VELO_DEBUG_SKIP & 8)
+    unsigned long long* __restrict__ wg_times;   // [2 * groups] start/end s_memrealtime per workgroup (VELO_DEBUG_SKIP & 32)
 };
 
 __device__ __forceinline__ float dist2_f(float qx, float qy, float qz, float sx, float sy, float sz) {
@@ -311,9 +312,10 @@ __device__ __forceinline__ void finish_correspondence(
         out.aux0[qi] = make_int4(ring_i, idx_i, ring_j, idx_j);
         out.aux1[qi] = make_float4(__int_as_float(idx_k), di, dj, 0.f);
     }
-    // one atomic per wave
+    // one atomic per wave, issued by the first lane that is executing this call (lane 0 may be masked off)
     const unsigned long long m = __ballot(valid);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out.n_valid, (int)__popcll(m));
+    const unsigned long long act = __ballot(1);
+    if ((int)(threadIdx.x & 63) == (int)__ffsll((long long)act) - 1 && m) atomicAdd(out.n_valid, (int)__popcll(m));
 }
 
 // Reference association search (VELO_ASSOC_VARIANT=0, kept for A/B checks): one lane per query, each lane walks the
@@ -435,6 +437,7 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
     // diagnostic build only (dbg & 8): per-section cycle totals of wave 0, added to out.dbg[0..7]
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = (dbg & 8) ? (long long)__builtin_readcyclecounter() : 0;
+    if ((dbg & 32) && threadIdx.x == 0) out.wg_times[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #define VELO_STAMP(k) do { if (dbg & 8) { const long long now__ = (long long)__builtin_readcyclecounter(); tacc[k] += now__ - tlast; tlast = now__; } } while (0)
     const int qi = q_begin + blockIdx.x * 64 + lane;
     const bool active = qi < q_end;
@@ -468,7 +471,7 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
         VELO_STAMP(1);
         if ((dbg & 16) && tid == 0) atomicAdd(&out.dbg[0], 1ull);
         int e_prev = -1;                                               // expansion already covered (-1: nothing yet)
-        int e = 1;
+        int e = max(1, dbg >> 8);                                      // first expansion (tuning knob, default 1)
         for (;;) {                                                     // phases: e = 1, then (if needed) the reach the bounds demand
             // box of this phase (clipped) and of the previous one (unclipped; empty when e_prev < 0)
             const int X0 = max(bx0 - e, 0), X1 = min(bx1 + e, g.nx - 1);
@@ -541,12 +544,43 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                     const int per = (npairs + NW - 1) / NW;
                     const int p0 = wid * per, p1 = min(p0 + per, npairs);
                     if (member && !(dbg & 1)) {
-#pragma unroll 2
-                        for (int pi = p0; pi < p1; pi++) {
+                        // 4 pairs (8 candidates) per trip: all LDS reads first, then the packed distance math, then the
+                        // (rare) updates -- keeps 8 ds_read_b128 in flight instead of one dependent read per pair
+                        int pi = p0;
+                        for (; pi + 4 <= p1; pi += 4) {
+                            float4 a[4], bq[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) { a[u] = s_xy[pi + u]; bq[u] = s_zg[pi + u]; }
+                            f32x2 d2[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const f32x2 cxp = {a[u].x, a[u].y}, cyp = {a[u].z, a[u].w}, czp = {bq[u].x, bq[u].y};
+                                const f32x2 dx = qx2 - cxp, dy = qy2 - cyp, dz = qz2 - czp;
+                                f32x2 d = dx * dx;                     // x -> y -> z accumulation, no FMA (-ffp-contract=off)
+                                d = d + dy * dy;
+                                d = d + dz * dz;
+                                d2[u] = d;
+                            }
+                            float dmin = fminf(fminf(fminf(d2[0].x, d2[0].y), fminf(d2[1].x, d2[1].y)), fminf(fminf(d2[2].x, d2[2].y), fminf(d2[3].x, d2[3].y)));
+                            if (dmin <= t.b2d) {                       // some candidate of the 8 may matter for this lane
+#pragma unroll
+                                for (int u = 0; u < 4; u++) {
+                                    if (d2[u].x <= t.b2d) {
+                                        const unsigned long long key = ((unsigned long long)__float_as_uint(d2[u].x) << 32) | (unsigned)__float_as_int(bq[u].z);
+                                        top2_update(t, key, s_ring[2 * (pi + u)]);
+                                    }
+                                    if (d2[u].y <= t.b2d) {
+                                        const unsigned long long key = ((unsigned long long)__float_as_uint(d2[u].y) << 32) | (unsigned)__float_as_int(bq[u].w);
+                                        top2_update(t, key, s_ring[2 * (pi + u) + 1]);
+                                    }
+                                }
+                            }
+                        }
+                        for (; pi < p1; pi++) {
                             const float4 a = s_xy[pi], bq = s_zg[pi];
                             const f32x2 cxp = {a.x, a.y}, cyp = {a.z, a.w}, czp = {bq.x, bq.y};
                             const f32x2 dx = qx2 - cxp, dy = qy2 - cyp, dz = qz2 - czp;
-                            f32x2 d2 = dx * dx;                        // x -> y -> z accumulation, no FMA (file built with -ffp-contract=off)
+                            f32x2 d2 = dx * dx;
                             d2 = d2 + dy * dy;
                             d2 = d2 + dz * dz;
                             if (d2.x <= t.b2d) {
@@ -593,8 +627,278 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
     if (NW > 1 && wid != 0) return;
     if (active) finish_correspondence(qi, psrc, qx, qy, qz, t.b1, t.b2, key_inf, tgt, tgt_off, ring_of, norm_cond, out, want_aux != 0);
     VELO_STAMP(7);
+    if ((dbg & 32) && tid == 0) out.wg_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
     if ((dbg & 8) && tid == 0) { for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)&out.dbg[k], (unsigned long long)tacc[k]); }
 #undef VELO_STAMP
+}
+
+// ---- association as a balanced pipeline: prepare (clusters -> work items) + persistent per-cluster search -----------------
+// The monolithic kernel above walks a group's clusters one after the other, so a 64-query group with several clusters and
+// two phases each is a long latency chain while most workgroups have already left.  Here a cheap prepare kernel (one
+// wave per group) transforms the queries, forms the clusters and appends ONE WORK ITEM PER CLUSTER; a persistent kernel
+// then keeps every workgroup slot busy: workgroups pull items from a global queue, run that cluster's phases (same LDS
+// staged box walk) and finish the correspondences of the cluster's member lanes.
+struct AssocItem {            // 32 bytes
+    int group;                // 64-query group
+    unsigned mask_lo, mask_hi;
+    int bx, by, bz;           // cell bounding box of the members: lo | hi << 16
+    int pad0, pad1;
+};
+// The queue is split into kQShards sub-queues (one returning atomic on ONE word tops out near 90 per microsecond on
+// this chip): group g appends to shard g % kQShards with a single reservation, a workgroup pulls from shard
+// blockIdx % kQShards first and steals from the others when its own runs dry.  Counters sit on separate 128-byte lines.
+constexpr int kQShards = 8;
+constexpr int kQStride = 32;         // ints between counters
+struct AssocQueue {
+    AssocItem* __restrict__ items;   // kQShards regions of shard_cap items
+    int shard_cap;
+    int* __restrict__ counters;      // [s * kQStride] = items in shard s, [(kQShards + s) * kQStride] = dequeue head of shard s
+    float4* __restrict__ qpos;       // transformed query coordinates (float, as the reference rounds them) per query
+};
+
+__global__ void __launch_bounds__(64)
+assoc_prepare_kernel(PoseScalars P, GridDesc g, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
+                     int cluster_w, AssocQueue Q) {
+    const int lane = threadIdx.x;
+    const int group = blockIdx.x;
+    const int qi = q_begin + group * 64 + lane;
+    const bool active = qi < q_end;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    int cx = 0, cy = 0, cz = 0;
+    if (active) {
+        const float4 psrc = src[q_src[qi]];
+        transform_query(P, psrc, &qx, &qy, &qz);
+        cx = cell_coord(qx, g.ox, g.inv_h, g.nx); cy = cell_coord(qy, g.oy, g.inv_h, g.ny); cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
+        Q.qpos[qi] = make_float4(qx, qy, qz, 0.f);
+    }
+    // pass 1: count this group's clusters; one reservation per group in its shard
+    int n_clusters = 0;
+    {
+        bool pending = active;
+        for (;;) {
+            const unsigned long long pm = __ballot(pending);
+            if (pm == 0ull) break;
+            const int leader = (int)__ffsll((long long)pm) - 1;
+            const int scx = __builtin_amdgcn_readlane(cx, leader), scy = __builtin_amdgcn_readlane(cy, leader), scz = __builtin_amdgcn_readlane(cz, leader);
+            const bool member = pending && abs(cx - scx) <= cluster_w && abs(cy - scy) <= cluster_w && abs(cz - scz) <= cluster_w;
+            n_clusters++;
+            pending = pending && !member;
+        }
+    }
+    const int shard = group % kQShards;
+    int base = 0;
+    if (lane == 0 && n_clusters > 0) base = atomicAdd(&Q.counters[shard * kQStride], n_clusters);
+    base = __builtin_amdgcn_readfirstlane(base);
+    // pass 2: write the items
+    bool pending = active;
+    int k = 0;
+    for (;;) {
+        const unsigned long long pm = __ballot(pending);
+        if (pm == 0ull) break;
+        const int leader = (int)__ffsll((long long)pm) - 1;
+        const int scx = __builtin_amdgcn_readlane(cx, leader), scy = __builtin_amdgcn_readlane(cy, leader), scz = __builtin_amdgcn_readlane(cz, leader);
+        const bool member = pending && abs(cx - scx) <= cluster_w && abs(cy - scy) <= cluster_w && abs(cz - scz) <= cluster_w;
+        const unsigned long long mm = __ballot(member);
+        const int big = 1 << 28;
+        const int bx0 = wave_min_i(member ? cx : big), bx1 = wave_max_i(member ? cx : -big);
+        const int by0 = wave_min_i(member ? cy : big), by1 = wave_max_i(member ? cy : -big);
+        const int bz0 = wave_min_i(member ? cz : big), bz1 = wave_max_i(member ? cz : -big);
+        if (lane == 0) {
+            AssocItem it;
+            it.group = group; it.mask_lo = (unsigned)(mm & 0xffffffffull); it.mask_hi = (unsigned)(mm >> 32);
+            // cell coordinates live in [-2, n+1] with n <= 8192: bias by 2 and pack two 16-bit fields
+            it.bx = (bx0 + 2) | ((bx1 + 2) << 16); it.by = (by0 + 2) | ((by1 + 2) << 16); it.bz = (bz0 + 2) | ((bz1 + 2) << 16);
+            it.pad0 = 0; it.pad1 = 0;
+            Q.items[(size_t)shard * Q.shard_cap + base + k] = it;
+        }
+        k++;
+        pending = pending && !member;
+    }
+}
+
+template <int NW, int MINW>
+__global__ void __launch_bounds__(NW * 64, MINW)
+assoc_cluster_kernel(GridView G, AssocQueue Q, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
+                     const float4* __restrict__ tgt, const int* __restrict__ tgt_off, const int* __restrict__ ring_of,
+                     unsigned gate_bits, double norm_cond, float h_safe, AssocOut out, int want_aux) {
+    constexpr int NT = NW * 64;
+    constexpr int NRUN = 2 * NT;
+    __shared__ float4 s_xy[kTileCap / 2];
+    __shared__ float4 s_zg[kTileCap / 2];
+    __shared__ int s_ring[kTileCap];
+    __shared__ int s_run_j0[NRUN];
+    __shared__ int s_run_off[NRUN + 1];
+    __shared__ int s_wave_tot[NW];
+    __shared__ unsigned long long m1[NW][64], m2[NW][64];
+    __shared__ int mr[NW][64];
+    __shared__ int s_item;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned long long key_inf = ((unsigned long long)gate_bits + 1ull) << 32;
+    const GridDesc g = G.d;
+    float* s_xy_f = reinterpret_cast<float*>(s_xy);
+    float* s_zg_f = reinterpret_cast<float*>(s_zg);
+    int shard = blockIdx.x % kQShards, tries = 0;
+
+    for (;;) {                                                         // persistent: pull the next cluster
+        if (tid == 0) {
+            int got = -1;
+            while (tries < kQShards) {
+                const int n = Q.counters[shard * kQStride];
+                int* head = &Q.counters[(kQShards + shard) * kQStride];
+                // plain peek first: an exhausted shard costs no atomic
+                if (__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
+                    const int h = atomicAdd(head, 1);
+                    if (h < n) { got = shard * Q.shard_cap + h; break; }
+                }
+                shard = (shard + 1) % kQShards; tries++;
+            }
+            s_item = got;
+        }
+        __syncthreads();
+        const int item = s_item;
+        __syncthreads();
+        if (item < 0) break;
+        const AssocItem it = Q.items[item];
+        const unsigned long long mm = ((unsigned long long)it.mask_hi << 32) | it.mask_lo;
+        const bool member = (mm >> lane) & 1ull;
+        const int qi = q_begin + it.group * 64 + lane;
+        const int bx0 = (it.bx & 0xffff) - 2, bx1 = (it.bx >> 16) - 2;
+        const int by0 = (it.by & 0xffff) - 2, by1 = (it.by >> 16) - 2;
+        const int bz0 = (it.bz & 0xffff) - 2, bz1 = (it.bz >> 16) - 2;
+        float qx = 0.f, qy = 0.f, qz = 0.f;
+        if (member) { const float4 qp = Q.qpos[qi]; qx = qp.x; qy = qp.y; qz = qp.z; }
+        const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+        Top2 t;
+        t.b1 = key_inf; t.b2 = key_inf; t.b1ring = -1; t.b2d = __uint_as_float(gate_bits + 1u);
+        int e_prev = -1, e = 1;
+        for (;;) {                                                     // phases (see assoc_search_v3_kernel)
+            const int X0 = max(bx0 - e, 0), X1 = min(bx1 + e, g.nx - 1);
+            const int Y0 = max(by0 - e, 0), Y1 = min(by1 + e, g.ny - 1);
+            const int Z0 = max(bz0 - e, 0), Z1 = min(bz1 + e, g.nz - 1);
+            const int px0 = bx0 - e_prev, px1 = bx1 + e_prev, py0 = by0 - e_prev, py1 = by1 + e_prev, pz0 = bz0 - e_prev, pz1 = bz1 + e_prev;
+            const int nyb = Y1 - Y0 + 1, nzb = Z1 - Z0 + 1;
+            const int nrows = (X0 <= X1 && nyb > 0 && nzb > 0) ? nyb * nzb : 0;
+            const float inv_nyb = 1.0f / (float)max(nyb, 1);
+            for (int rbase = 0; rbase < nrows; rbase += NT) {
+                int ja0 = 0, la = 0, jb0 = 0, lb = 0;
+                const int r = rbase + tid;
+                if (r < nrows) {
+                    int zq = (int)(((float)r + 0.5f) * inv_nyb);      // r / nyb for small non-negative ints, fixed up below
+                    zq = (zq * nyb > r) ? zq - 1 : ((zq + 1) * nyb <= r ? zq + 1 : zq);
+                    const int y = Y0 + (r - zq * nyb), z = Z0 + zq;
+                    const int row = (z * g.ny + y) * g.nx;
+                    const bool fresh = e_prev < 0 || y < py0 || y > py1 || z < pz0 || z > pz1;
+                    if (fresh) {
+                        ja0 = G.cell_start[row + X0]; la = G.cell_start[row + X1 + 1] - ja0;
+                    } else {
+                        const int a1 = min(px0 - 1, X1), b0 = max(px1 + 1, X0);
+                        if (X0 <= a1) { ja0 = G.cell_start[row + X0]; la = G.cell_start[row + a1 + 1] - ja0; }
+                        if (b0 <= X1) { jb0 = G.cell_start[row + b0]; lb = G.cell_start[row + X1 + 1] - jb0; }
+                    }
+                }
+                const int mine = la + lb;
+                int inc = mine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+                if (lane == 63) s_wave_tot[wid] = inc;
+                __syncthreads();
+                int wbase = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < NW; w++) { const int v = s_wave_tot[w]; if (w < wid) wbase += v; total += v; }
+                const int ex = wbase + inc - mine;
+                s_run_j0[2 * tid] = ja0; s_run_off[2 * tid] = ex;
+                s_run_j0[2 * tid + 1] = jb0; s_run_off[2 * tid + 1] = ex + la;
+                if (tid == 0) s_run_off[NRUN] = total;
+                __syncthreads();
+                for (int tbase = 0; tbase < total; tbase += kTileCap) {
+                    const int tn = min(total - tbase, kTileCap);
+                    const int tn8 = (tn + 7) & ~7;                     // the sweep consumes 4 pairs per trip
+                    for (int i = tid; i < tn8; i += NT) {
+                        float4 c = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __int_as_float(0x7fffffff));
+                        int cr = 0x7fffffff;
+                        if (i < tn) {
+                            const int slot = tbase + i;
+                            int lo = 0;
+#pragma unroll
+                            for (int step = NRUN / 2; step > 0; step >>= 1) {
+                                if (s_run_off[lo + step] <= slot) lo += step;
+                            }
+                            const int j = s_run_j0[lo] + (slot - s_run_off[lo]);
+                            c = G.sorted[j];
+                            cr = G.sring[j];
+                        }
+                        const int pr = i >> 1, hb = i & 1;
+                        s_xy_f[4 * pr + hb] = c.x; s_xy_f[4 * pr + 2 + hb] = c.y;
+                        s_zg_f[4 * pr + hb] = c.z; s_zg_f[4 * pr + 2 + hb] = c.w;
+                        s_ring[i] = cr;
+                    }
+                    __syncthreads();
+                    const int nquads = tn8 >> 3;                       // groups of 4 pairs
+                    const int per = (nquads + NW - 1) / NW;
+                    const int g0 = wid * per, g1 = min(g0 + per, nquads);
+                    if (member) {
+                        for (int gq = g0; gq < g1; gq++) {
+                            const int pi = gq * 4;
+                            float4 a[4], bq[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) { a[u] = s_xy[pi + u]; bq[u] = s_zg[pi + u]; }
+                            f32x2 d2[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const f32x2 cxp = {a[u].x, a[u].y}, cyp = {a[u].z, a[u].w}, czp = {bq[u].x, bq[u].y};
+                                const f32x2 dx = qx2 - cxp, dy = qy2 - cyp, dz = qz2 - czp;
+                                f32x2 d = dx * dx;                     // x -> y -> z accumulation, no FMA (-ffp-contract=off)
+                                d = d + dy * dy;
+                                d = d + dz * dz;
+                                d2[u] = d;
+                            }
+                            const float dmin = fminf(fminf(fminf(d2[0].x, d2[0].y), fminf(d2[1].x, d2[1].y)), fminf(fminf(d2[2].x, d2[2].y), fminf(d2[3].x, d2[3].y)));
+                            if (dmin <= t.b2d) {
+#pragma unroll
+                                for (int u = 0; u < 4; u++) {
+                                    if (d2[u].x <= t.b2d) {
+                                        const unsigned long long key = ((unsigned long long)__float_as_uint(d2[u].x) << 32) | (unsigned)__float_as_int(bq[u].z);
+                                        top2_update(t, key, s_ring[2 * (pi + u)]);
+                                    }
+                                    if (d2[u].y <= t.b2d) {
+                                        const unsigned long long key = ((unsigned long long)__float_as_uint(d2[u].y) << 32) | (unsigned)__float_as_int(bq[u].w);
+                                        top2_update(t, key, s_ring[2 * (pi + u) + 1]);
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            if (NW > 1) {
+                m1[wid][lane] = t.b1; m2[wid][lane] = t.b2; mr[wid][lane] = t.b1ring;
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
+                    if (w == wid) continue;
+                    const unsigned long long c1 = m1[w][lane], c2 = m2[w][lane];
+                    if (c1 < t.b2) top2_update(t, c1, mr[w][lane]);
+                    if (c2 < t.b2) top2_update(t, c2, ring_of[(int)(unsigned)(c2 & 0xffffffffull)]);
+                }
+                __syncthreads();
+            }
+            const float rw = __uint_as_float((unsigned)__builtin_amdgcn_readfirstlane(wave_max_i(member ? (int)__float_as_uint(t.b2d) : 0)));
+            const float reach = (float)e * h_safe;
+            if (reach * reach > rw) break;
+            e_prev = e;
+            e = max(e + 1, (int)ceilf(sqrtf(rw) / h_safe));
+            if ((float)e * h_safe * ((float)e * h_safe) <= rw) e++;
+        }
+        // rows A3-A6 for the member lanes of this cluster (wave 0 holds the merged state like every other wave)
+        if (wid == 0 && member && qi < q_end) {
+            const float4 psrc = src[q_src[qi]];
+            finish_correspondence(qi, psrc, qx, qy, qz, t.b1, t.b2, key_inf, tgt, tgt_off, ring_of, norm_cond, out, want_aux != 0);
+        }
+    }
 }
 
 // ---- visual blocks (rows G1, R2-R5) ------------------------------------------------------------------------------------
@@ -957,10 +1261,9 @@ __global__ void lm_begin_kernel(LMState* S, const double* __restrict__ x_in, con
     }
 }
 
-// sums: either the per-workgroup partials [n_blocks][28] (single GPU) or an already reduced [1][28] block (after all-reduce)
-__global__ void __launch_bounds__(256)
-lm_step_kernel(LMParams Q, LMState* S, const double* __restrict__ partials, int n_blocks) {
-    if (S->done) return;
+// sums: either the per-workgroup partials [n_blocks][28] (single GPU) or an already reduced [1][28] block (after all-reduce);
+// then ONE LM state transition.  Called by a whole 256-thread workgroup.
+__device__ __forceinline__ void lm_transition(const LMParams& Q, LMState* S, const double* __restrict__ partials, int n_blocks) {
     __shared__ double part[8][kNumAcc];
     __shared__ double E[kNumAcc];
     const int t = threadIdx.x;
@@ -1008,6 +1311,62 @@ lm_step_kernel(LMParams Q, LMState* S, const double* __restrict__ partials, int 
         S->radius = S->radius / S->decrease; S->decrease *= 2.0; S->reuse_diag = 1;
     }
     lm_compute_step(Q, S);
+}
+
+__global__ void __launch_bounds__(256)
+lm_step_kernel(LMParams Q, LMState* S, const double* __restrict__ partials, int n_blocks) {
+    if (S->done) return;
+    lm_transition(Q, S, partials, n_blocks);
+}
+
+// Fused LM iteration (single GPU): the point-to-plane sweep, and the LAST workgroup to arrive performs the final
+// reduction and the LM transition -- one launch per LM iteration instead of two.  Inter-workgroup hand-off by the
+// placement-independent protocol of the CDNA guide (Guideline 16, counter form): every storing wave drains its
+// stores, workgroup barrier, one lane does an agent-scope release then a relaxed agent-scope ticket add; the last
+// arriver does an agent-scope acquire before any thread of its workgroup reads the other workgroups' partial rows.
+// `total_rows` also covers the rows the visual sweep (an earlier launch on the same stream) wrote.
+__global__ void __launch_bounds__(kEvalThreads)
+lm_iter_fused_kernel(EvalArgs A, LMParams Q, LMState* S, int* __restrict__ ticket, int total_rows) {
+    double x[6];
+    if (!eval_load_x(A, x)) return;                      // `done`: nobody touches the ticket
+    PoseRot R;
+    pose_rot_init(x, &R);
+    const double t[3] = {x[3], x[4], x[5]};
+    double acc[kNumAcc];
+#pragma unroll
+    for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    for (int i = A.q_begin + tid; i < A.q_end; i += nthreads) {
+        const float4 p = A.cp[i];
+        if (__float_as_int(p.w) == 0) continue;
+        const float4 n = A.cn[i], v = A.cv0[i];
+        const double pd[3] = {p.x, p.y, p.z}, nd[3] = {n.x, n.y, n.z}, vd[3] = {v.x, v.y, v.z};
+        double r, J[6];
+        res_3dpd(R, t, pd, nd, vd, &r, J);
+        double rho0, rho1;
+        loss_cauchy(A.loss_a_3dpd, A.w_3dpd, r * r, &rho0, &rho1);
+        acc[27] += 0.5 * rho0;
+        accumulate_row(acc, r, J, sqrt(rho1));
+    }
+    block_reduce_store(acc, A.partials + (size_t)blockIdx.x * kNumAcc);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every storing wave drains its stores
+    __syncthreads();
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int prev = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (prev == (int)gridDim.x - 1) ? 1 : 0;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    lm_transition(Q, S, A.partials, total_rows);
 }
 
 }  // namespace velo
