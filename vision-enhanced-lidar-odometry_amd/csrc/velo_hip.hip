@@ -167,7 +167,7 @@ struct velo_ctx {
     hipGraphExec_t chunk_graph[2] = {nullptr, nullptr};
     int chunk_graph_iters[2] = {0, 0};
     std::vector<unsigned char> chunk_graph_sig[2];   // bytes of everything baked into the nodes
-    bool use_graphs = true;
+    bool use_graphs = false;             // LM chunks as hipGraphs (VELO_GRAPHS=1): measured no gain, replay overhead ~ launches saved
     bool use_fused = true;
     HostStatus* h_status = nullptr;      // pinned
     double* h_x = nullptr;               // pinned, 8 doubles
