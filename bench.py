@@ -186,6 +186,14 @@ def main():
         b_launch = assoc_bytes / max(a.steps * B * max(s0.n_assoc_rounds, 1), 1)
         avg_ms = assoc_ms / max(assoc_n, 1)
         achieved = (b_launch / 1e9) / (avg_ms / 1e3) if avg_ms > 0 else 0.0
+        traffic = None          # HBM-side bytes per launch from the committed PMC passes (tools/summarize_traffic.py)
+        import glob
+        tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+        if tf and a.workload == "c2":
+            try:
+                traffic = json.load(open(tf[-1]))["traffic_bytes_per_launch"]
+            except Exception:
+                traffic = None
         line = {
             "metric": "scan-pairs/sec + achieved HBM GB/s, 120k-pt HDL-64E frame-to-frame ICP",
             "value": value, "unit": "scan-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -198,8 +206,8 @@ def main():
                        "valid_correspondences_last_round": int(s0.solves[s0.n_solves - 1].n_icp_valid),
                        "algorithmic_bytes_per_pair": per_pair_bytes},
             "achieved_hbm_GBs_whole_path": per_pair_bytes * value / 1e9,
-            "roofline": {"bound": "hbm", "kernel": "assoc_search_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "assoc_search_v3_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": b_launch,
                          "note": "launch duration from HIP events on the context stream, measured in the timed region"},
             "solution_x": [float(v) for v in x_gpu],

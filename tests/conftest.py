@@ -9,6 +9,14 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+# Load torch's HIP runtime BEFORE the C-ABI library, exactly like bench.py does: both ship a libamdhip64.so.7 / librccl.so.1
+# and the dynamic loader keeps whichever comes first, so fixing the order keeps test and bench processes identical.
+try:
+    import torch  # noqa: F401
+except Exception:      # pragma: no cover
+    torch = None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

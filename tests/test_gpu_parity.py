@@ -239,3 +239,24 @@ def test_tie_breaks_and_wraparound(ctx, oracle):
     assert (a["idx_i"][1], a["idx_k"][1]) == (4, 3)        # neighbours 0 (wrap) and 3: 3 is closer
     assert (a["idx_i"][2], a["idx_k"][2]) == (2, 1)        # equidistant neighbours -> the -1 one
     assert a["valid"][3] == 0 and a["ring_i"][3] == 3 and a["idx_i"][3] == 0 and a["ring_j"][3] == 0   # |N| = 0
+
+
+def test_rccl_path_single_rank(ctx, oracle):
+    """The query-sharded multi-GPU path (RCCL all-reduce of the 28-double block between sweep and LM step) with a
+    1-rank communicator: same launches/collective calls as N ranks, result must equal the plain path and the oracle."""
+    d = H.small_pair(16, 128)
+    orc = oracle.Oracle(threads=4)
+    H.load_both(ctx, orc, d, icp_skip=1)
+    x_plain, _, s_plain = ctx.frame_to_frame(d["x0"])
+    ctx.comm_init(api.comm_unique_id(), 0, 1)
+    try:
+        x_comm, _, s_comm = ctx.frame_to_frame(d["x0"])
+        c1, H1, g1 = ctx.evaluate(d["x_true"])
+    finally:
+        ctx.comm_destroy()
+    x_orc, _, s_orc = orc.frame_to_frame(d["x0"])
+    c2, H2, g2 = orc.evaluate(d["x_true"])          # both sides hold the table of their last association round
+    assert np.array_equal(x_plain, x_comm)
+    assert H.pose_close(x_comm, x_orc)
+    assert [s_comm.solves[k].evaluations for k in range(6)] == [s_orc.solves[k].evaluations for k in range(6)]
+    assert abs(c1 - c2) <= 1e-12 * c2 and H.rel_err(H1, H2) <= 1e-12 and H.rel_err(g1, g2) <= 1e-12

@@ -18,6 +18,7 @@ for v in variants:
     av, cw, *rest = v.split(":")
     os.environ["VELO_ASSOC_VARIANT"], os.environ["VELO_CLUSTER_W"] = av, cw
     os.environ["VELO_DEBUG_SKIP"] = rest[0] if rest else "0"
+    os.environ["VELO_XCD_MAP"] = rest[1] if len(rest) > 1 else "1"
     c = api.Context(0, icp_skip=1)
     c.set_timing(True)
     c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])

@@ -114,6 +114,8 @@ struct velo_ctx {
     int assoc_variant = 4;               // 0 = per-lane reference kernel; 1/2/4/8 = waves per 64-query group of the shell walk (VELO_ASSOC_VARIANT)
     int cluster_w = 6;                   // cluster radius in cells (VELO_CLUSTER_W)
     int persistent_wgs = 2048;           // workgroups of the persistent association kernel (VELO_PERSISTENT_WGS)
+    int xcd_map = 0;                     // XCD-contiguous group mapping of the association kernel (VELO_XCD_MAP=1): measured slower
+                                         // (dense bottom rings all land on one XCD); round-robin placement balances better
     int debug_skip = 0;                  // timing experiments only (VELO_DEBUG_SKIP): results are wrong when non-zero
 
     // target (frame2)
@@ -169,6 +171,7 @@ struct velo_ctx {
     std::vector<unsigned char> chunk_graph_sig[2];   // bytes of everything baked into the nodes
     bool use_graphs = false;             // LM chunks as hipGraphs (VELO_GRAPHS=1): measured no gain, replay overhead ~ launches saved
     bool use_fused = true;
+    int pred_evals[VELO_MAX_SOLVES];     // evaluations each solve of the previous frame_to_frame needed (chunk sizing)
     HostStatus* h_status = nullptr;      // pinned
     double* h_x = nullptr;               // pinned, 8 doubles
     int* h_int = nullptr;                // pinned scratch
@@ -406,8 +409,8 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         const unsigned gbits = gate_bits_of(gate);
         const float h_safe = (float)(G->h * 0.999);
 #define VELO_LAUNCH_V2(NW, MINW)                                                                                                   \
-        hipLaunchKernelGGL((assoc_search_v3_kernel<NW, MINW>), dim3(groups), dim3(NW * 64), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe, \
-                           c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, c->cluster_w, h_safe, out, aux, c->debug_skip)
+        hipLaunchKernelGGL((assoc_search_v3_kernel<NW, MINW>), dim3(c->xcd_map ? ((groups + 7) / 8) * 8 : groups), dim3(NW * 64), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe, \
+                           c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, c->cluster_w, h_safe, out, aux, c->debug_skip, c->xcd_map)
         switch (c->assoc_variant) {
             case 0: {
                 const int reach = (int)std::ceil(std::sqrt(std::max(gate, 0.0)) / (G->h * 0.999)) ;
@@ -588,7 +591,7 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->h_status->s.done) break;
         if (launched > max_iters + 16) return fail(VELO_ERR_STATE, "LM did not terminate after %d sweeps", launched);
-        chunk = 4;
+        chunk = 3;
     }
     const LMState& s = c->h_status->s;
     for (int k = 0; k < 6; k++) x_out[k] = s.x[k];
@@ -627,6 +630,8 @@ int velo_create(velo_ctx** out, int device) {
         return fail(VELO_ERR_NODEVICE, "no HIP device visible: this library has no CPU fallback");
     if (device < 0 || device >= count) return fail(VELO_ERR_INVALID, "device %d out of range (0..%d)", device, count - 1);
     HIP_TRY(hipSetDevice(device));
+    if (getenv("VELO_SPIN")) (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
+    (void)hipGetLastError();
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -634,10 +639,12 @@ int velo_create(velo_ctx** out, int device) {
     velo_ctx* c = new velo_ctx();
     c->device = device;
     default_params(&c->P);
+    for (int k = 0; k < VELO_MAX_SOLVES; k++) c->pred_evals[k] = (k == 0) ? 12 : 5;
     if (const char* e = getenv("VELO_ASSOC_VARIANT")) c->assoc_variant = atoi(e);
     if (const char* e = getenv("VELO_CLUSTER_W")) c->cluster_w = std::max(atoi(e), 0);
     if (const char* e = getenv("VELO_DEBUG_SKIP")) c->debug_skip = atoi(e);
     if (const char* e = getenv("VELO_GRAPHS")) c->use_graphs = atoi(e) != 0;
+    if (const char* e = getenv("VELO_XCD_MAP")) c->xcd_map = atoi(e);
     if (const char* e = getenv("VELO_PERSISTENT_WGS")) c->persistent_wgs = std::max(atoi(e), 1);
     if (const char* e = getenv("VELO_FUSED")) c->use_fused = atoi(e) != 0;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -994,7 +1001,10 @@ int velo_frame_to_frame(velo_ctx* c, double x[6], double T[16], velo_summary* su
             if (qe > qb) S->assoc_kernel_launches++;
             velo_solve_summary ss;
             int evals = 0;
-            VELO_TRY(do_solve(c, xc, xc, &ss, &evals, first ? 10 : 4));              // velo.h:897-902
+            const int solve_idx = std::min(S->n_solves, VELO_MAX_SOLVES - 1);
+            // consecutive frames behave alike: size the first chunk to the evaluations this solve needed last time (+1)
+            VELO_TRY(do_solve(c, xc, xc, &ss, &evals, std::min(std::max(c->pred_evals[solve_idx] + 1, 2), c->P.max_num_iterations + 1)));   // velo.h:897-902
+            c->pred_evals[solve_idx] = ss.evaluations;
             first = false;
             S->eval_kernel_launches += evals;
             S->algorithmic_bytes += (uint64_t)ss.evaluations * (36ull * (uint64_t)ss.n_icp_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull);

@@ -417,7 +417,7 @@ template <int NW, int MINW>
 __global__ void __launch_bounds__(NW * 64, MINW)
 assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
                        const float4* __restrict__ tgt, const int* __restrict__ tgt_off, const int* __restrict__ ring_of,
-                       unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, AssocOut out, int want_aux, int dbg) {
+                       unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, AssocOut out, int want_aux, int dbg, int xcd_map) {
     constexpr int NT = NW * 64;
     constexpr int NRUN = 2 * NT;                       // two run slots per row, NT rows per row chunk
     // tile: candidates stored as PAIRS -- {x0,x1,y0,y1} and {z0,z1,bits(g0),bits(g1)} -- so that the sweep handles two
@@ -437,9 +437,16 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
     // diagnostic build only (dbg & 8): per-section cycle totals of wave 0, added to out.dbg[0..7]
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = (dbg & 8) ? (long long)__builtin_readcyclecounter() : 0;
-    if ((dbg & 32) && threadIdx.x == 0) out.wg_times[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 #define VELO_STAMP(k) do { if (dbg & 8) { const long long now__ = (long long)__builtin_readcyclecounter(); tacc[k] += now__ - tlast; tlast = now__; } } while (0)
-    const int qi = q_begin + blockIdx.x * 64 + lane;
+    // XCD-aware group mapping: workgroups are dealt round-robin over the 8 XCDs, so blockIdx % 8 selects the XCD; give
+    // each XCD one CONTIGUOUS eighth of the ring-ordered groups -- spatial neighbours then share that XCD's 4 MB L2
+    // (cell table rows and candidate cells are re-read by adjacent groups).  Placement affects speed only.
+    const int n_groups = (q_end - q_begin + 63) >> 6;
+    const int per_xcd = (n_groups + 7) >> 3;
+    const int group = xcd_map ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (group >= n_groups || (xcd_map && (int)(blockIdx.x >> 3) >= per_xcd)) return;
+    if ((dbg & 32) && threadIdx.x == 0) out.wg_times[2 * group] = __builtin_amdgcn_s_memrealtime();
+    const int qi = q_begin + group * 64 + lane;
     const bool active = qi < q_end;
     const unsigned long long key_inf = ((unsigned long long)gate_bits + 1ull) << 32;
     float4 psrc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -627,7 +634,7 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
     if (NW > 1 && wid != 0) return;
     if (active) finish_correspondence(qi, psrc, qx, qy, qz, t.b1, t.b2, key_inf, tgt, tgt_off, ring_of, norm_cond, out, want_aux != 0);
     VELO_STAMP(7);
-    if ((dbg & 32) && tid == 0) out.wg_times[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    if ((dbg & 32) && tid == 0) out.wg_times[2 * group + 1] = __builtin_amdgcn_s_memrealtime();
     if ((dbg & 8) && tid == 0) { for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)&out.dbg[k], (unsigned long long)tacc[k]); }
 #undef VELO_STAMP
 }
@@ -1087,8 +1094,11 @@ __global__ void __launch_bounds__(kEvalThreads)
 eval_icp_kernel(EvalArgs A) {
     double x[6];
     if (!eval_load_x(A, x)) return;
-    PoseRot R;
-    pose_rot_init(x, &R);
+    // the point-independent part of the rotation (sqrt, sin, cos and their partials) once per workgroup, not per thread
+    __shared__ PoseRot s_R;
+    if (threadIdx.x == 0) pose_rot_init(x, &s_R);
+    __syncthreads();
+    const PoseRot R = s_R;
     const double t[3] = {x[3], x[4], x[5]};
     double acc[kNumAcc];
 #pragma unroll
@@ -1329,8 +1339,10 @@ __global__ void __launch_bounds__(kEvalThreads)
 lm_iter_fused_kernel(EvalArgs A, LMParams Q, LMState* S, int* __restrict__ ticket, int total_rows) {
     double x[6];
     if (!eval_load_x(A, x)) return;                      // `done`: nobody touches the ticket
-    PoseRot R;
-    pose_rot_init(x, &R);
+    __shared__ PoseRot s_R;                              // rotation constants once per workgroup
+    if (threadIdx.x == 0) pose_rot_init(x, &s_R);
+    __syncthreads();
+    const PoseRot R = s_R;
     const double t[3] = {x[3], x[4], x[5]};
     double acc[kNumAcc];
 #pragma unroll
