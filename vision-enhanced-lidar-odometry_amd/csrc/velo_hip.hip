@@ -231,6 +231,12 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
     G.gate = gate;
     const double radius = std::sqrt(std::max(gate, 0.0));
     double h = std::max(radius * 1.01, 1e-6);
+    // Points lie on surfaces, so points-per-cell grows like N * h^2: for clouds denser than one HDL-64E sweep (accumulated
+    // maps, BASELINE config 4) shrink the cell like N^-1/2 to keep the per-cell population -- and with it the candidates
+    // per query -- at the level the kernel is tuned for.  Any cell size is exact (the box walk handles every gate).
+    const double dense_ref = getenv("VELO_DENSE_REF") ? atof(getenv("VELO_DENSE_REF")) : 150000.0;
+    if (dense_ref > 0.0 && (double)c->n_tgt > dense_ref) h *= std::sqrt(dense_ref / (double)c->n_tgt);
+    h = std::max(h, 1e-6);
     const double ext[3] = {(double)c->bbox[3] - c->bbox[0], (double)c->bbox[4] - c->bbox[1], (double)c->bbox[5] - c->bbox[2]};
     int dims[3];
     for (;;) {   // per-axis <= 8192 cells and <= 2^25 cells in all, else coarsen (still exhaustive: cell >= radius)
@@ -408,9 +414,11 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         const double gate = gate_of_iter(c->P, iter);
         const unsigned gbits = gate_bits_of(gate);
         const float h_safe = (float)(G->h * 0.999);
+        // the clustering radius is a length (VELO_CLUSTER_W is given in cells of the default 0.179 m grid)
+        const int cluster_cells = std::max(1, (int)std::lround((double)c->cluster_w * 0.1785 / G->h));
 #define VELO_LAUNCH_V2(NW, MINW)                                                                                                   \
         hipLaunchKernelGGL((assoc_search_v3_kernel<NW, MINW>), dim3(c->xcd_map ? ((groups + 7) / 8) * 8 : groups), dim3(NW * 64), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe, \
-                           c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, c->cluster_w, h_safe, out, aux, c->debug_skip, c->xcd_map)
+                           c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, cluster_cells, h_safe, out, aux, c->debug_skip, c->xcd_map)
         switch (c->assoc_variant) {
             case 0: {
                 const int reach = (int)std::ceil(std::sqrt(std::max(gate, 0.0)) / (G->h * 0.999)) ;
@@ -428,7 +436,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 Q.items = c->items.p; Q.shard_cap = shard_cap; Q.counters = c->item_counters.p; Q.qpos = c->qpos.p;
                 HIP_TRY(hipMemsetAsync(c->item_counters.p, 0, sizeof(int) * 2 * kQShards * kQStride, c->stream));
                 (void)nqr;
-                hipLaunchKernelGGL(assoc_prepare_kernel, dim3(groups), dim3(64), 0, c->stream, S, V.d, c->src.p, c->q_src.p, qb, qe, c->cluster_w, Q);
+                hipLaunchKernelGGL(assoc_prepare_kernel, dim3(groups), dim3(64), 0, c->stream, S, V.d, c->src.p, c->q_src.p, qb, qe, cluster_cells, Q);
                 const int wgs = std::min(groups * 4, c->persistent_wgs);
                 if (c->assoc_variant == 102)
                     hipLaunchKernelGGL((assoc_cluster_kernel<2, 1>), dim3(wgs), dim3(128), 0, c->stream, V, Q, c->src.p, c->q_src.p, qb, qe,
