@@ -170,7 +170,8 @@ struct velo_ctx {
     int chunk_graph_iters[2] = {0, 0};
     std::vector<unsigned char> chunk_graph_sig[2];   // bytes of everything baked into the nodes
     bool use_graphs = false;             // LM chunks as hipGraphs (VELO_GRAPHS=1): measured no gain, replay overhead ~ launches saved
-    bool use_fused = true;
+    bool use_fused = false;              // one-launch LM iteration (last workgroup reduces + steps), VELO_FUSED=1: measured equal or
+                                         // slightly slower than sweep + lm_step as two launches (release/acquire cost ~ the boundary saved)
     int pred_evals[VELO_MAX_SOLVES];     // evaluations each solve of the previous frame_to_frame needed (chunk sizing)
     HostStatus* h_status = nullptr;      // pinned
     double* h_x = nullptr;               // pinned, 8 doubles
@@ -367,7 +368,8 @@ EvalArgs eval_args(velo_ctx* c, const double* x_override) {
 EvalPlan eval_plan(const EvalArgs& A) {
     EvalPlan E;
     const int nq = A.q_end - A.q_begin;
-    E.nb_icp = nq > 0 ? std::min(std::max(cdiv(nq, kEvalThreads * kEvalPerThread), 1), kMaxEvalBlocks) : 0;
+    static const int per_thread = getenv("VELO_EVAL_PER_THREAD") ? std::max(atoi(getenv("VELO_EVAL_PER_THREAD")), 1) : kEvalPerThread;
+    E.nb_icp = nq > 0 ? std::min(std::max(cdiv(nq, kEvalThreads * per_thread), 1), kMaxEvalBlocks) : 0;
     E.nb_vis = A.n_matches > 0 ? std::min(std::max(cdiv(3 * A.n_matches, kEvalThreads), 1), kMaxVisBlocks) : 0;
     return E;
 }
