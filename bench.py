@@ -13,6 +13,8 @@ Multi-GPU (--mode):
   replicas (default)  every rank registers its own pairs, no data-path collective           -> "scaling": "weak"
   sharded             ONE pair per step, queries split 1/N per rank, RCCL all-reduce of the
                       28-double normal-equation block every LM evaluation (north_star)      -> "scaling": "strong"
+  target-sharded      BASELINE config 5: ONE pair per step, each rank holds a block of whole target rings,
+                      per-query top-2 records all-to-all each association round, then as "sharded"  -> "strong"
 Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -40,7 +42,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas")
+    ap.add_argument("--mode", choices=["replicas", "sharded", "target-sharded"], default="replicas")
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
                     help="c2: 120k pair; c3: + 2000 stereo blocks; c4: 120k scan vs 2M-point map")
     ap.add_argument("--batch", type=int, default=8, help="independent pairs in flight per GPU (one context + stream each)")
@@ -114,9 +116,16 @@ def main():
     torch.cuda.set_device(dev)
 
     d, vis, label = make_workload(a.workload)
-    B = 1 if a.mode == "sharded" else max(1, a.batch)
+    B = 1 if a.mode != "replicas" else max(1, a.batch)
     # inputs resident in HBM before the timed region (torch is only the allocator here)
-    tgt = torch.from_numpy(d["tgt_xyz"]).to(dev)
+    tgt_off, tgt_first_ring, tgt_first_point = d["tgt_off"], 0, 0
+    tgt_np = d["tgt_xyz"]
+    if a.mode == "target-sharded" and world > 1:
+        from velo_amd import shard
+        r0, r1, p0, tgt_off = shard.target_ring_block(d["tgt_off"], rank, world)
+        tgt_first_ring, tgt_first_point = r0, p0
+        tgt_np = d["tgt_xyz"][p0:p0 + int(tgt_off[-1])]
+    tgt = torch.from_numpy(np.ascontiguousarray(tgt_np)).to(dev)
     src = torch.from_numpy(d["src_xyz"]).to(dev)
     torch.cuda.synchronize()
     ctxs = [api.Context(local_rank, icp_skip=1) for _ in range(B)]
@@ -124,16 +133,18 @@ def main():
         c.set_timing(True)
         if vis is not None:
             c.set_visual(vis)
-    if a.mode == "sharded" and world > 1:
+    if a.mode != "replicas" and world > 1:
         uid = [api.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctxs[0].comm_init(uid[0], rank, world)
+        if a.mode == "target-sharded":
+            ctxs[0].comm_set_target_sharded(True)
 
     results = [None] * B
 
     def one_pair(i):
         c = ctxs[i]
-        c.set_target(tgt, d["tgt_off"])
+        c.set_target_part(tgt, tgt_off, tgt_first_ring, tgt_first_point)
         c.set_source(src, d["src_off"])
         results[i] = c.frame_to_frame(d["x0"])
 

@@ -117,6 +117,22 @@ typedef struct velo_corr {
     float v0[3];         /* v0                    velo.h:869 */
 } velo_corr;
 
+/* Target-sharded mode (BASELINE config 5): what one rank knows about a query after searching ONLY the
+ * whole target rings it holds.  Ring ownership is disjoint, so the query's owner merges `world` such records with
+ * best1 = min key1, best2 = min(key1 of the other ranks, key2 of the winner) and builds the plane from the payload. */
+typedef struct velo_partial {
+    uint64_t key1, key2;   /* (float bits of d^2) << 32 | global ring-major point index; "absent" compares above every real key */
+    int32_t ring1, ring2;  /* global ring ids, -1 when absent */
+    int32_t idx1;          /* np_i   (index inside ring1) */
+    int32_t idx_k;         /* np_k   (ring neighbour of np_i, velo.h:852-863) */
+    int32_t idx2;          /* np_j   (index inside ring2) */
+    int32_t pad;
+    float v0[3];           /* scans_S[ring1][idx1] */
+    float v2[3];           /* scans_S[ring1][idx_k] */
+    float v1[3];           /* scans_S[ring2][idx2] */
+    float pad2;
+} velo_partial;
+
 typedef struct velo_solve_summary {
     int32_t termination;       /* VELO_CONVERGENCE / NO_CONVERGENCE / FAILURE */
     int32_t lm_iterations;     /* trust-region iterations, successful or not */
@@ -167,6 +183,11 @@ int velo_set_timing(velo_ctx* ctx, int enable);
  * polyline (kitti.h:158-183).  on_device != 0: xyz is already a device pointer (stays caller-owned, copied). */
 int velo_set_target(velo_ctx* ctx, const float* xyz, int64_t stride_bytes, const int32_t* ring_offsets,
                     int32_t n_rings, int on_device);
+/* Target-sharded variant: this context holds only `n_rings` WHOLE rings of the target (keeps the +-1 ring neighbour of
+ * velo.h:852-856 local); `first_ring` is the global id of the first of them and `first_point` the global ring-major index of
+ * its first point.  ring_offsets are local ([0] == 0).  velo_set_target == velo_set_target_part(..., 0, 0, ...). */
+int velo_set_target_part(velo_ctx* ctx, const float* xyz, int64_t stride_bytes, const int32_t* ring_offsets,
+                         int32_t n_rings, int32_t first_ring, int32_t first_point, int on_device);
 /* Source = frame1 rings (`scans_M`, velo.h:605).  Queries are every icp_skip-th point of each ring (velo.h:807). */
 int velo_set_source(velo_ctx* ctx, const float* xyz, int64_t stride_bytes, const int32_t* ring_offsets,
                     int32_t n_rings, int on_device);
@@ -177,6 +198,15 @@ int velo_set_visual(velo_ctx* ctx, const velo_match* matches, int32_t n);
 /* One association round at pose x with the gate of outer iteration `iter` (1-based): velo.h:806-874.
  * Leaves the correspondence table on the device for velo_evaluate / velo_solve. */
 int velo_associate(velo_ctx* ctx, const double x[6], int32_t iter, int32_t* n_valid);
+/* Target-sharded pieces (tests drive them one by one; with a communicator in target-sharded mode velo_associate runs
+ * them as  partial search -> all-to-all of the record slices -> merge  internally):
+ *   velo_associate_partial: ALL queries against the local rings, one velo_partial per query left on the device;
+ *   velo_get_partials:      copy them to the host;
+ *   velo_merge_partials:    merge `world` host tables (each n_queries records) for THIS context's query share into its
+ *                           correspondence table (rows A3-A6 finished by the query's owner). */
+int velo_associate_partial(velo_ctx* ctx, const double x[6], int32_t iter);
+int velo_get_partials(velo_ctx* ctx, velo_partial* out, int32_t capacity, int32_t* n_queries);
+int velo_merge_partials(velo_ctx* ctx, const velo_partial* const* tables, int32_t world, int32_t* n_valid);
 /* Copies the table back (one record per query, in query order sm-major / smi ascending). */
 int velo_get_correspondences(velo_ctx* ctx, velo_corr* out, int32_t capacity, int32_t* n_queries);
 /* Visual block selection + outlier gate G1 at pose x: velo.h:622-792. */
@@ -212,6 +242,9 @@ int velo_pose_mat_to_vec(const double T[16], double x[6]);  /* util::pose_vec2ma
 int velo_comm_unique_id(char id[128]);
 int velo_comm_init(velo_ctx* ctx, const char id[128], int32_t rank, int32_t world);
 int velo_comm_destroy(velo_ctx* ctx);
+/* enable != 0: the communicator's ranks hold disjoint ring blocks of the target (velo_set_target_part) instead of
+ * replicas; association then exchanges per-query top-2 records (all-to-all) before the query-sharded evaluation. */
+int velo_comm_set_target_sharded(velo_ctx* ctx, int enable);
 /* Restrict this context's queries to share `rank` of `world` WITHOUT a communicator (tests / replicas). */
 int velo_set_query_shard(velo_ctx* ctx, int32_t rank, int32_t world);
 

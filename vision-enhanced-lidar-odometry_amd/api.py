@@ -80,7 +80,11 @@ CORR_DTYPE = np.dtype([
     ("idx_j", np.int32), ("idx_k", np.int32), ("src_ring", np.int32), ("src_idx", np.int32),
     ("dist_i", np.float32), ("dist_j", np.float32),
     ("p", np.float32, 3), ("n", np.float32, 3), ("v0", np.float32, 3)], align=True)
-assert MATCH_DTYPE.itemsize == 68 and GOOD_DTYPE.itemsize == 16 and CORR_DTYPE.itemsize == 76
+PARTIAL_DTYPE = np.dtype([
+    ("key1", np.uint64), ("key2", np.uint64), ("ring1", np.int32), ("ring2", np.int32), ("idx1", np.int32),
+    ("idx_k", np.int32), ("idx2", np.int32), ("pad", np.int32), ("v0", np.float32, 3), ("v2", np.float32, 3),
+    ("v1", np.float32, 3), ("pad2", np.float32)], align=True)
+assert MATCH_DTYPE.itemsize == 68 and GOOD_DTYPE.itemsize == 16 and CORR_DTYPE.itemsize == 76 and PARTIAL_DTYPE.itemsize == 80
 
 
 def matches_from_dict(rec: dict) -> np.ndarray:
@@ -122,9 +126,13 @@ SIGNATURES = {
     "velo_get_params": (C.c_int, [_ctx, _P(VeloParams)]),
     "velo_set_timing": (C.c_int, [_ctx, C.c_int]),
     "velo_set_target": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int]),
+    "velo_set_target_part": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int]),
     "velo_set_source": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int]),
     "velo_set_visual": (C.c_int, [_ctx, C.c_void_p, C.c_int32]),
     "velo_associate": (C.c_int, [_ctx, _dp, C.c_int32, _P(C.c_int32)]),
+    "velo_associate_partial": (C.c_int, [_ctx, _dp, C.c_int32]),
+    "velo_get_partials": (C.c_int, [_ctx, C.c_void_p, C.c_int32, _P(C.c_int32)]),
+    "velo_merge_partials": (C.c_int, [_ctx, _P(C.c_void_p), C.c_int32, _P(C.c_int32)]),
     "velo_get_correspondences": (C.c_int, [_ctx, C.c_void_p, C.c_int32, _P(C.c_int32)]),
     "velo_build_visual": (C.c_int, [_ctx, _dp, C.c_int32, _P(C.c_int32)]),
     "velo_get_good_matches": (C.c_int, [_ctx, C.c_void_p, C.c_int32, _P(C.c_int32)]),
@@ -138,6 +146,7 @@ SIGNATURES = {
     "velo_comm_unique_id": (C.c_int, [C.c_char_p]),
     "velo_comm_init": (C.c_int, [_ctx, C.c_char_p, C.c_int32, C.c_int32]),
     "velo_comm_destroy": (C.c_int, [_ctx]),
+    "velo_comm_set_target_sharded": (C.c_int, [_ctx, C.c_int]),
     "velo_set_query_shard": (C.c_int, [_ctx, C.c_int32, C.c_int32]),
     "velo_synchronize": (C.c_int, [_ctx]),
 }
@@ -238,6 +247,34 @@ class Context:
     def set_target(self, xyz, ring_offsets):
         ptr, stride, off, dev, keep = self._cloud_args(xyz, ring_offsets)
         self._check(self._lib.velo_set_target(self._h, ptr, stride, C.c_void_p(off.ctypes.data), len(off) - 1, dev))
+
+    def set_target_part(self, xyz, ring_offsets, first_ring: int, first_point: int):
+        """Target-sharded mode: this context holds only a block of whole rings (local offsets, [0] == 0)."""
+        ptr, stride, off, dev, keep = self._cloud_args(xyz, ring_offsets)
+        self._check(self._lib.velo_set_target_part(self._h, ptr, stride, C.c_void_p(off.ctypes.data), len(off) - 1,
+                                                   int(first_ring), int(first_point), dev))
+
+    def associate_partial(self, x, iter: int):
+        xv = _dvec(x, 6)
+        self._check(self._lib.velo_associate_partial(self._h, _ptr(xv), int(iter)))
+
+    def partials(self) -> np.ndarray:
+        n = C.c_int32(0)
+        self._check(self._lib.velo_get_partials(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, dtype=PARTIAL_DTYPE)
+        if n.value:
+            self._check(self._lib.velo_get_partials(self._h, C.c_void_p(out.ctypes.data), n.value, C.byref(n)))
+        return out
+
+    def merge_partials(self, tables) -> int:
+        tabs = [np.ascontiguousarray(t, dtype=PARTIAL_DTYPE) for t in tables]
+        arr = (C.c_void_p * len(tabs))(*[t.ctypes.data for t in tabs])
+        n = C.c_int32(0)
+        self._check(self._lib.velo_merge_partials(self._h, arr, len(tabs), C.byref(n)))
+        return n.value
+
+    def comm_set_target_sharded(self, enable: bool):
+        self._check(self._lib.velo_comm_set_target_sharded(self._h, int(bool(enable))))
 
     def set_source(self, xyz, ring_offsets):
         ptr, stride, off, dev, keep = self._cloud_args(xyz, ring_offsets)

@@ -120,6 +120,7 @@ struct velo_ctx {
 
     // target (frame2)
     int n_tgt = 0, n_tgt_rings = 0;
+    int tgt_first_ring = 0, tgt_first_point = 0;   // target-sharded mode: global ids of the first local ring / point
     DevBuf<float4> tgt;
     DevBuf<int> tgt_off, tgt_ring_of, tgt_cell_of;
     std::vector<int> h_tgt_off;
@@ -150,6 +151,10 @@ struct velo_ctx {
     DevBuf<AssocItem> items;             // work queue of the pipelined association
     DevBuf<int> item_counters;
     DevBuf<float4> qpos;
+    DevBuf<PartialRec> partials_rec, partials_all;   // target-sharded mode: my records for all queries / every rank's records for my queries
+    bool have_partials = false;
+    int last_partial_iter = 1;           // gate of the last partial association (the merge needs its key_inf)
+    bool target_sharded = false;
     bool have_corr = false;
     int last_n_valid = 0;
 
@@ -271,7 +276,7 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kScanThreads), 0, c->stream, c->scan_tiles.p, n_tiles, c->scan_total.p);
     hipLaunchKernelGGL(scan_add_kernel, dim3(cdiv(nc + 1, 256)), dim3(256), 0, c->stream, G.cell_start.p, nc, c->scan_tiles.p, c->scan_total.p, c->cursor.p);
     hipLaunchKernelGGL(grid_scatter_kernel, dim3(cdiv(std::max(n, kGridPad), 256)), dim3(256), 0, c->stream, c->tgt.p, c->tgt_cell_of.p, c->tgt_ring_of.p, n, c->cursor.p,
-                       (const int*)(G.cell_start.p + nc), G.sorted.p, G.sring.p);
+                       (const int*)(G.cell_start.p + nc), c->tgt_first_point, G.sorted.p, G.sring.p);
     HIP_TRY(hipGetLastError());
     G.built = true;
     return VELO_OK;
@@ -383,7 +388,7 @@ void launch_eval(velo_ctx* c, EvalArgs A, const EvalPlan& E) {
     }
 }
 
-int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool wait, int* n_valid) {
+int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool wait, int* n_valid, bool partial = false) {
     if (!c->have_target || !c->have_source) return fail(VELO_ERR_STATE, "associate needs set_target and set_source first");
     if (iter < 1) return fail(VELO_ERR_INVALID, "iter must be >= 1");
     if (c->src_skip != std::max(c->P.icp_skip, 1) || (c->n_q > 0) != (c->P.enable_icp != 0 && c->h_q_off[c->n_src_rings] > 0)) VELO_TRY(build_query_list(c));
@@ -391,6 +396,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
     if (!G) return VELO_ERR_HIP;
     int qb, qe;
     q_range(c, &qb, &qe);
+    if (partial) { qb = 0; qe = c->n_q; VELO_TRY(c->partials_rec.reserve((size_t)std::max(c->n_q, 1))); }   // every query against the local rings
     VELO_TRY(c->n_valid.reserve(1));
     HIP_TRY(hipMemsetAsync(c->n_valid.p, 0, sizeof(int), c->stream));
     if (qe > qb) {
@@ -400,6 +406,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         V.d = G->d; V.cell_start = G->cell_start.p; V.sorted = G->sorted.p; V.sring = G->sring.p;
         AssocOut out;
         out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p; out.dbg = c->dbg.p; out.wg_times = nullptr;
+        out.first_ring = c->tgt_first_ring; out.first_point = c->tgt_first_point; out.partial = partial ? c->partials_rec.p : nullptr;
         if (c->debug_skip & 32) { VELO_TRY(c->wg_times.reserve((size_t)2 * cdiv(qe - qb, 64) + 2)); out.wg_times = c->wg_times.p; c->wg_times_n = cdiv(qe - qb, 64); }
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
         if (c->timing) {
@@ -464,6 +471,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         HIP_TRY(hipGetLastError());
         if (ev) HIP_TRY(hipEventRecord(ev->second, c->stream));
     }
+    if (partial) { c->have_partials = true; c->last_partial_iter = iter; if (wait) HIP_TRY(hipStreamSynchronize(c->stream)); return VELO_OK; }
     c->have_corr = true;
     if (wait) {
         HIP_TRY(hipMemcpyAsync(c->h_int, c->n_valid.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -621,6 +629,9 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
 }  // namespace
 
 // =====================================================================================================================
+static int associate_target_sharded(velo_ctx* c, const double x[6], int iter, bool want_aux);
+static int launch_merge(velo_ctx* c, const PartialRec* tables, int world, int stride, int iter, bool want_aux);
+
 extern "C" {
 
 const char* velo_last_error(void) { return g_err.empty() ? g_err_shared.c_str() : g_err.c_str(); }
@@ -707,7 +718,7 @@ int velo_destroy(velo_ctx* c) {
     for (Grid& G : c->grids) { G.cell_start.release(); G.sorted.release(); G.sring.release(); }
     c->scan_tiles.release(); c->cursor.release(); c->scan_total.release(); c->bbox_keys.release();
     c->src.release(); c->src_off.release(); c->q_off.release(); c->q_src.release(); c->staging.release();
-    c->cp.release(); c->cn.release(); c->cv0.release(); c->aux0.release(); c->aux1.release(); c->n_valid.release(); c->dbg.release(); c->wg_times.release(); c->items.release(); c->item_counters.release(); c->qpos.release();
+    c->cp.release(); c->cn.release(); c->cv0.release(); c->aux0.release(); c->aux1.release(); c->n_valid.release(); c->dbg.release(); c->wg_times.release(); c->items.release(); c->item_counters.release(); c->qpos.release(); c->partials_rec.release(); c->partials_all.release();
     c->vm.release(); c->vflags.release();
     for (int k = 0; k < 2; k++) if (c->chunk_graph[k]) (void)hipGraphExecDestroy(c->chunk_graph[k]);
     c->state.release(); c->partials.release(); c->reduced.release(); c->xdev.release(); c->ticket.release();
@@ -751,7 +762,11 @@ int velo_set_timing(velo_ctx* c, int enable) {
 }
 
 int velo_set_target(velo_ctx* c, const float* xyz, int64_t stride, const int32_t* off, int32_t n_rings, int on_device) {
-    if (!c || !off || n_rings < 0) return fail(VELO_ERR_INVALID, "null/negative argument");
+    return velo_set_target_part(c, xyz, stride, off, n_rings, 0, 0, on_device);
+}
+
+int velo_set_target_part(velo_ctx* c, const float* xyz, int64_t stride, const int32_t* off, int32_t n_rings, int32_t first_ring, int32_t first_point, int on_device) {
+    if (!c || !off || n_rings < 0 || first_ring < 0 || first_point < 0) return fail(VELO_ERR_INVALID, "null/negative argument");
     if (stride < 12) return fail(VELO_ERR_INVALID, "stride_bytes must be >= 12");
     if (off[0] != 0) return fail(VELO_ERR_INVALID, "ring_offsets[0] must be 0");
     for (int r = 0; r < n_rings; r++) {
@@ -761,8 +776,9 @@ int velo_set_target(velo_ctx* c, const float* xyz, int64_t stride, const int32_t
     const int n = n_rings > 0 ? off[n_rings] : 0;
     if (n > 0 && !xyz) return fail(VELO_ERR_INVALID, "null xyz");
     HIP_TRY(hipSetDevice(c->device));
-    c->have_target = false; c->have_corr = false;
+    c->have_target = false; c->have_corr = false; c->have_partials = false;
     c->n_tgt = n; c->n_tgt_rings = n_rings;
+    c->tgt_first_ring = first_ring; c->tgt_first_point = first_point;
     c->h_tgt_off.assign(off, off + n_rings + 1);
     VELO_TRY(upload_cloud(c, xyz, stride, n, on_device, c->tgt));
     VELO_TRY(c->tgt_off.reserve((size_t)n_rings + 1));
@@ -774,7 +790,7 @@ int velo_set_target(velo_ctx* c, const float* xyz, int64_t stride, const int32_t
     std::memcpy(c->h_int, init, sizeof(init));
     HIP_TRY(hipMemcpyAsync(c->bbox_keys.p, c->h_int, sizeof(init), hipMemcpyHostToDevice, c->stream));
     if (n > 0) {
-        hipLaunchKernelGGL(ring_of_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->tgt_off.p, n_rings, n, c->tgt_ring_of.p);
+        hipLaunchKernelGGL(ring_of_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->tgt_off.p, n_rings, n, c->tgt_first_ring, c->tgt_ring_of.p);
         hipLaunchKernelGGL(bbox_kernel, dim3(std::min(cdiv(n, 256 * 8), 256)), dim3(256), 0, c->stream, c->tgt.p, n, c->bbox_keys.p);
         HIP_TRY(hipGetLastError());
     }
@@ -833,7 +849,92 @@ int velo_set_visual(velo_ctx* c, const velo_match* m, int32_t n) {
 int velo_associate(velo_ctx* c, const double x[6], int32_t iter, int32_t* n_valid) {
     if (!c || !x) return fail(VELO_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
+    if (c->comm && c->target_sharded) {
+        VELO_TRY(associate_target_sharded(c, x, iter, true));
+        HIP_TRY(hipMemcpyAsync(c->h_int, c->n_valid.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->last_n_valid = c->h_int[0];
+        if (n_valid) *n_valid = c->last_n_valid;
+        return VELO_OK;
+    }
     return do_associate(c, x, iter, true, true, n_valid);
+}
+
+// merge `world` device-resident partial tables (table w at tables + w * stride, records of queries [qb, qe) in order)
+static int launch_merge(velo_ctx* c, const PartialRec* tables, int world, int stride, int iter, bool want_aux) {
+    int qb, qe;
+    q_range(c, &qb, &qe);
+    VELO_TRY(c->n_valid.reserve(1));
+    HIP_TRY(hipMemsetAsync(c->n_valid.p, 0, sizeof(int), c->stream));
+    if (qe > qb) {
+        AssocOut out;
+        out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p;
+        out.dbg = c->dbg.p; out.wg_times = nullptr; out.first_ring = c->tgt_first_ring; out.first_point = c->tgt_first_point; out.partial = nullptr;
+        const unsigned long long key_inf = ((unsigned long long)gate_bits_of(gate_of_iter(c->P, iter)) + 1ull) << 32;
+        hipLaunchKernelGGL(merge_partials_kernel, dim3(cdiv(qe - qb, 256)), dim3(256), 0, c->stream, tables, world, stride, qb, qe,
+                           (const float4*)c->src.p, (const int*)c->q_src.p, key_inf, c->P.icp_norm_condition, out, want_aux ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+    }
+    c->have_corr = true;
+    return VELO_OK;
+}
+
+// target-sharded association with a communicator: partial search over all queries, all-to-all of the record slices
+// (rank r receives, from everybody, the records of ITS query share), merge on the owner
+static int associate_target_sharded(velo_ctx* c, const double x[6], int iter, bool want_aux) {
+    static_assert(sizeof(PartialRec) == sizeof(velo_partial), "partial record layout");
+    VELO_TRY(do_associate(c, x, iter, false, false, nullptr, true));
+    const int W = c->shard_world;
+    int qb, qe;
+    q_range(c, &qb, &qe);
+    int max_share = 0;
+    for (int r = 0; r < W; r++) max_share = std::max(max_share, (int)((int64_t)c->n_q * (r + 1) / W - (int64_t)c->n_q * r / W));
+    VELO_TRY(c->partials_all.reserve((size_t)W * std::max(max_share, 1)));
+    NCCL_TRY(ncclGroupStart());
+    for (int r = 0; r < W; r++) {
+        const int rb = (int)((int64_t)c->n_q * r / W), re = (int)((int64_t)c->n_q * (r + 1) / W);
+        if (re > rb) NCCL_TRY(ncclSend(c->partials_rec.p + rb, (size_t)(re - rb) * sizeof(PartialRec), ncclChar, r, c->comm, c->stream));
+        if (qe > qb) NCCL_TRY(ncclRecv(c->partials_all.p + (size_t)r * max_share, (size_t)(qe - qb) * sizeof(PartialRec), ncclChar, r, c->comm, c->stream));
+    }
+    NCCL_TRY(ncclGroupEnd());
+    return launch_merge(c, c->partials_all.p, W, max_share, iter, want_aux);
+}
+
+int velo_associate_partial(velo_ctx* c, const double x[6], int32_t iter) {
+    if (!c || !x) return fail(VELO_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    return do_associate(c, x, iter, false, true, nullptr, true);
+}
+
+int velo_get_partials(velo_ctx* c, velo_partial* out, int32_t capacity, int32_t* n_queries) {
+    if (!c) return fail(VELO_ERR_INVALID, "null ctx");
+    if (n_queries) *n_queries = c->have_partials ? c->n_q : 0;
+    if (!out || capacity <= 0) return VELO_OK;
+    if (!c->have_partials) return fail(VELO_ERR_STATE, "no partial association has run yet");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, c->partials_rec.p, sizeof(velo_partial) * (size_t)std::min(capacity, c->n_q), hipMemcpyDeviceToHost));
+    return VELO_OK;
+}
+
+int velo_merge_partials(velo_ctx* c, const velo_partial* const* tables, int32_t world, int32_t* n_valid) {
+    if (!c || !tables || world < 1) return fail(VELO_ERR_INVALID, "bad merge arguments");
+    if (!c->have_source) return fail(VELO_ERR_STATE, "merge needs set_source first");
+    HIP_TRY(hipSetDevice(c->device));
+    int qb, qe;
+    q_range(c, &qb, &qe);
+    const int share = std::max(qe - qb, 1);
+    VELO_TRY(c->partials_all.reserve((size_t)world * share));
+    for (int w = 0; w < world; w++) {
+        if (!tables[w]) return fail(VELO_ERR_INVALID, "null table %d", w);
+        if (qe > qb) HIP_TRY(hipMemcpyAsync(c->partials_all.p + (size_t)w * share, tables[w] + qb, sizeof(velo_partial) * (size_t)(qe - qb), hipMemcpyHostToDevice, c->stream));
+    }
+    VELO_TRY(launch_merge(c, c->partials_all.p, world, share, c->last_partial_iter, true));
+    HIP_TRY(hipMemcpyAsync(c->h_int, c->n_valid.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->last_n_valid = c->h_int[0];
+    if (n_valid) *n_valid = c->last_n_valid;
+    return VELO_OK;
 }
 
 int velo_get_correspondences(velo_ctx* c, velo_corr* out, int32_t capacity, int32_t* n_queries) {
@@ -1000,7 +1101,8 @@ int velo_frame_to_frame(velo_ctx* c, double x[6], double T[16], velo_summary* su
         c->last_n_valid = 0;
         for (int icp_iter = 0; icp_iter < c->P.icp_iterations; icp_iter++) {        // velo.h:800
             int nv = 0;
-            VELO_TRY(do_associate(c, xc, iter, false, false, &nv));                  // velo.h:806-894 (no host sync: the count rides on the LM status)
+            if (c->comm && c->target_sharded) VELO_TRY(associate_target_sharded(c, xc, iter, false));
+            else VELO_TRY(do_associate(c, xc, iter, false, false, &nv));             // velo.h:806-894 (no host sync: the count rides on the LM status)
             int qb, qe;
             q_range(c, &qb, &qe);
             S->n_assoc_rounds++;
@@ -1138,6 +1240,13 @@ int velo_comm_destroy(velo_ctx* c) {
         c->comm = nullptr;
     }
     c->shard_rank = 0; c->shard_world = 1;
+    c->have_corr = false;
+    return VELO_OK;
+}
+
+int velo_comm_set_target_sharded(velo_ctx* c, int enable) {
+    if (!c) return fail(VELO_ERR_INVALID, "null ctx");
+    c->target_sharded = enable != 0;
     c->have_corr = false;
     return VELO_OK;
 }

@@ -69,12 +69,14 @@ __global__ void pack_points_kernel(const char* __restrict__ src, int64_t stride,
 }
 
 // ring id per point (binary search in ring_offsets) -- the target's gidx -> ring map
-__global__ void ring_of_kernel(const int* __restrict__ off, int n_rings, int n, int* __restrict__ ring_of) {
+// (a context may hold only a block of whole rings of the target -- target-sharded mode -- so ring ids and point
+//  indices that leave the kernels are GLOBAL: local ring + first_ring, local index + first_point)
+__global__ void ring_of_kernel(const int* __restrict__ off, int n_rings, int n, int first_ring, int* __restrict__ ring_of) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int lo = 0, hi = n_rings;   // find r with off[r] <= i < off[r+1]
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= i) lo = mid; else hi = mid; }
-    ring_of[i] = lo;
+    ring_of[i] = lo + first_ring;
 }
 
 // query list: query i -> global source index.  Ring r contributes ceil(n_r / skip) queries (velo.h:806-807).
@@ -199,7 +201,7 @@ __global__ void scan_add_kernel(int* __restrict__ data, int n, const int* __rest
     else if (i == n) data[n] = *grand_total;
 }
 __global__ void grid_scatter_kernel(const float4* __restrict__ pts, const int* __restrict__ cell_of, const int* __restrict__ ring_of, int n,
-                                    int* __restrict__ cursor, const int* __restrict__ n_finite,
+                                    int* __restrict__ cursor, const int* __restrict__ n_finite, int first_point,
                                     float4* __restrict__ sorted, int* __restrict__ sring) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < kGridPad) {   // sentinels behind the last real point: +inf coordinates can never pass the gate
@@ -212,7 +214,7 @@ __global__ void grid_scatter_kernel(const float4* __restrict__ pts, const int* _
     if (c < 0) return;
     const int slot = atomicAdd(&cursor[c], 1);
     const float4 p = pts[i];
-    sorted[slot] = make_float4(p.x, p.y, p.z, __int_as_float(i));
+    sorted[slot] = make_float4(p.x, p.y, p.z, __int_as_float(i + first_point));
     sring[slot] = ring_of[i];
 }
 
@@ -222,6 +224,7 @@ __global__ void grid_scatter_kernel(const float4* __restrict__ pts, const int* _
 // and the global index is ring-major, so "lower key" == "closer, ties -> lower ring, then lower index" -- the
 // outcome of the reference's sequential strict-'<' scan over rings (velo.h:825-848) on exact per-ring minima.
 // best1 = min key overall; best2 = min key among candidates whose ring differs from best1's ring.
+struct PartialRec;
 struct AssocOut {
     float4* __restrict__ p;      // xyz of the untransformed source point, w = bits(valid)
     float4* __restrict__ n;      // unit normal
@@ -231,6 +234,20 @@ struct AssocOut {
     int* __restrict__ n_valid;   // atomic counter
     unsigned long long* __restrict__ dbg;   // [8] diagnostic cycle totals (VELO_DEBUG_SKIP & 8)
     unsigned long long* __restrict__ wg_times;   // [2 * groups] start/end s_memrealtime per workgroup (VELO_DEBUG_SKIP & 32)
+    int first_ring, first_point;                  // global ids of this context's first target ring / point
+    struct PartialRec* __restrict__ partial;      // target-sharded mode: per-query top-2 record instead of the table
+};
+
+// Target-sharded mode (BASELINE config 5): what one rank knows about a query after searching ITS rings.
+// Rings are disjoint across ranks, so the global winners are: best1 = min key1 over ranks (rank w*), best2 = the smaller
+// of { min key1 over the other ranks, key2 of rank w* }.  The record carries the points the plane needs, so the owner of
+// the query can finish without touching any other rank's cloud.  Same layout as velo_partial in include/velo_hip.h.
+struct PartialRec {
+    unsigned long long key1, key2;     // (d^2 bits << 32 | global index); >= key_inf when absent
+    int ring1, ring2;                  // global ring ids, -1 when absent
+    int idx1, idx_k, idx2, pad;        // np_i, np_k (in ring1), np_j (in ring2)
+    float v0[3], v2[3], v1[3];         // best point, its chosen ring neighbour, second-best point
+    float pad2;
 };
 
 __device__ __forceinline__ float dist2_f(float qx, float qy, float qz, float sx, float sy, float sz) {
@@ -263,51 +280,23 @@ __device__ __forceinline__ void transform_query(const PoseScalars& P, const floa
     *qz = (float)(r2 + P.t[2]);
 }
 
-// rows A3 (tail) - A6: from the two winners to (N, v0, valid)
-__device__ __forceinline__ void finish_correspondence(
-    int qi, const float4& psrc, float qx, float qy, float qz, unsigned long long b1, unsigned long long b2, unsigned long long key_inf,
-    const float4* __restrict__ tgt, const int* __restrict__ tgt_off, const int* __restrict__ ring_of, double norm_cond,
-    const AssocOut& out, bool want_aux) {
-    int valid = 0;
-    float nx = 0.f, ny = 0.f, nz = 0.f, vx = 0.f, vy = 0.f, vz = 0.f;
-    int ring_i = -1, idx_i = 0, ring_j = -1, idx_j = 0, idx_k = 0;
-    float di = 1e18f, dj = 1e18f;
-    if (b1 < key_inf) {
-        const int gi = (int)(unsigned)(b1 & 0xffffffffull);
-        ring_i = ring_of[gi];
-        idx_i = gi - tgt_off[ring_i];
-        di = __uint_as_float((unsigned)(b1 >> 32));
-    }
-    if (b2 < key_inf) {
-        const int gj = (int)(unsigned)(b2 & 0xffffffffull);
-        ring_j = ring_of[gj];
-        idx_j = gj - tgt_off[ring_j];
-        dj = __uint_as_float((unsigned)(b2 >> 32));
-    }
-    if (ring_i >= 0 && ring_j >= 0) {                                   // velo.h:849-851
-        const int base = tgt_off[ring_i];
-        const int n = tgt_off[ring_i + 1] - base;
-        const int k1 = (idx_i + 1) % n, k2 = (idx_i - 1 + n) % n;       // velo.h:852-854
-        const float4 a1 = tgt[base + k1], a2 = tgt[base + k2];
-        const float d1 = dist2_f(a1.x, a1.y, a1.z, qx, qy, qz);         // (np - pointM), same squares
-        const float d2 = dist2_f(a2.x, a2.y, a2.z, qx, qy, qz);
-        idx_k = (d1 < d2) ? k1 : k2;                                    // velo.h:859-863
-        const float4 v0 = tgt[base + idx_i];
-        const float4 v1 = tgt[tgt_off[ring_j] + idx_j];
-        const float4 v2 = (idx_k == k1) ? a1 : a2;
-        const float ax = v1.x - v0.x, ay = v1.y - v0.y, az = v1.z - v0.z;
-        const float bx = v2.x - v0.x, by = v2.y - v0.y, bz = v2.z - v0.z;
-        float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;   // velo.h:872
-        const float nn = sqrtf(cx * cx + cy * cy + cz * cz);            // Eigen norm(): sqrt of the x,y,z sum
-        if (!((double)nn < norm_cond)) {                                // velo.h:873 (float norm vs double constant)
-            nx = cx / nn; ny = cy / nn; nz = cz / nn;                   // velo.h:874
-            vx = v0.x; vy = v0.y; vz = v0.z;
-            valid = 1;
-        }
-    }
+// velo.h:872-874: unit normal of the triangle (v0, v1, v2) in float, or invalid when degenerate (velo.h:873)
+__device__ __forceinline__ int plane_from_points(const float v0[3], const float v1[3], const float v2[3], double norm_cond, float n[3]) {
+    const float ax = v1[0] - v0[0], ay = v1[1] - v0[1], az = v1[2] - v0[2];
+    const float bx = v2[0] - v0[0], by = v2[1] - v0[1], bz = v2[2] - v0[2];
+    const float cx = ay * bz - az * by, cy = az * bx - ax * bz, cz = ax * by - ay * bx;   // velo.h:872
+    const float nn = sqrtf(cx * cx + cy * cy + cz * cz);            // Eigen norm(): sqrt of the x,y,z sum
+    if ((double)nn < norm_cond) return 0;                           // velo.h:873 (float norm vs double constant)
+    n[0] = cx / nn; n[1] = cy / nn; n[2] = cz / nn;                 // velo.h:874
+    return 1;
+}
+
+__device__ __forceinline__ void write_correspondence(int qi, const float4& psrc, int valid, const float n[3], const float v0[3],
+                                                     int ring_i, int idx_i, int ring_j, int idx_j, int idx_k, float di, float dj,
+                                                     const AssocOut& out, bool want_aux) {
     out.p[qi] = make_float4(psrc.x, psrc.y, psrc.z, __int_as_float(valid));
-    out.n[qi] = make_float4(nx, ny, nz, 0.f);
-    out.v0[qi] = make_float4(vx, vy, vz, 0.f);
+    out.n[qi] = valid ? make_float4(n[0], n[1], n[2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
+    out.v0[qi] = valid ? make_float4(v0[0], v0[1], v0[2], 0.f) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (want_aux) {
         out.aux0[qi] = make_int4(ring_i, idx_i, ring_j, idx_j);
         out.aux1[qi] = make_float4(__int_as_float(idx_k), di, dj, 0.f);
@@ -316,6 +305,89 @@ __device__ __forceinline__ void finish_correspondence(
     const unsigned long long m = __ballot(valid);
     const unsigned long long act = __ballot(1);
     if ((int)(threadIdx.x & 63) == (int)__ffsll((long long)act) - 1 && m) atomicAdd(out.n_valid, (int)__popcll(m));
+}
+
+// rows A3 (tail) - A6: from the two winners to (N, v0, valid) -- or, in target-sharded mode, to the partial record
+__device__ __forceinline__ void finish_correspondence(
+    int qi, const float4& psrc, float qx, float qy, float qz, unsigned long long b1, unsigned long long b2, unsigned long long key_inf,
+    const float4* __restrict__ tgt, const int* __restrict__ tgt_off, const int* __restrict__ ring_of, double norm_cond,
+    const AssocOut& out, bool want_aux) {
+    int ring_i = -1, idx_i = 0, ring_j = -1, idx_j = 0, idx_k = 0;
+    float di = 1e18f, dj = 1e18f;
+    float v0[3] = {0.f, 0.f, 0.f}, v1[3] = {0.f, 0.f, 0.f}, v2[3] = {0.f, 0.f, 0.f};
+    if (b1 < key_inf) {
+        const int gi = (int)(unsigned)(b1 & 0xffffffffull) - out.first_point;      // local index
+        ring_i = ring_of[gi];                                                      // global ring id
+        const int base = tgt_off[ring_i - out.first_ring];
+        const int n = tgt_off[ring_i - out.first_ring + 1] - base;
+        idx_i = gi - base;
+        di = __uint_as_float((unsigned)(b1 >> 32));
+        const int k1 = (idx_i + 1) % n, k2 = (idx_i - 1 + n) % n;       // velo.h:852-854
+        const float4 a1 = tgt[base + k1], a2 = tgt[base + k2];
+        const float d1 = dist2_f(a1.x, a1.y, a1.z, qx, qy, qz);         // (np - pointM), same squares
+        const float d2 = dist2_f(a2.x, a2.y, a2.z, qx, qy, qz);
+        idx_k = (d1 < d2) ? k1 : k2;                                    // velo.h:859-863
+        const float4 p0 = tgt[base + idx_i];
+        const float4 p2 = (idx_k == k1) ? a1 : a2;
+        v0[0] = p0.x; v0[1] = p0.y; v0[2] = p0.z; v2[0] = p2.x; v2[1] = p2.y; v2[2] = p2.z;
+    }
+    if (b2 < key_inf) {
+        const int gj = (int)(unsigned)(b2 & 0xffffffffull) - out.first_point;
+        ring_j = ring_of[gj];
+        idx_j = gj - tgt_off[ring_j - out.first_ring];
+        dj = __uint_as_float((unsigned)(b2 >> 32));
+        const float4 p1 = tgt[gj];
+        v1[0] = p1.x; v1[1] = p1.y; v1[2] = p1.z;
+    }
+    if (out.partial) {
+        PartialRec r;
+        r.key1 = b1; r.key2 = b2; r.ring1 = ring_i; r.ring2 = ring_j; r.idx1 = idx_i; r.idx_k = idx_k; r.idx2 = idx_j; r.pad = 0;
+        for (int k = 0; k < 3; k++) { r.v0[k] = v0[k]; r.v2[k] = v2[k]; r.v1[k] = v1[k]; }
+        r.pad2 = 0.f;
+        out.partial[qi] = r;
+        return;
+    }
+    int valid = 0;
+    float n[3] = {0.f, 0.f, 0.f};
+    if (ring_i >= 0 && ring_j >= 0) valid = plane_from_points(v0, v1, v2, norm_cond, n);     // velo.h:849-851,864-874
+    write_correspondence(qi, psrc, valid, n, v0, ring_i, idx_i, ring_j, idx_j, idx_k, di, dj, out, want_aux);
+}
+
+// Owner-side merge of `world` partial tables (one per target shard) for the queries [q_begin, q_end): table w holds
+// records for those queries in order at tables + w * table_stride.  Ring ownership is disjoint, so (see PartialRec):
+// best1 = min key1; best2 = min( key1 of the other ranks, key2 of the winning rank ).
+__global__ void merge_partials_kernel(const PartialRec* __restrict__ tables, int world, int table_stride, int q_begin, int q_end,
+                                      const float4* __restrict__ src, const int* __restrict__ q_src, unsigned long long key_inf,
+                                      double norm_cond, AssocOut out, int want_aux) {
+    const int qi = q_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= q_end) return;
+    const int li = qi - q_begin;
+    unsigned long long k1 = key_inf, k2 = key_inf;
+    int w1 = -1, w2 = -1, second_is_key1 = 0;
+    for (int w = 0; w < world; w++) {
+        const unsigned long long c = tables[(size_t)w * table_stride + li].key1;
+        if (c < k1) { k2 = k1; w2 = w1; second_is_key1 = 1; k1 = c; w1 = w; }
+        else if (c < k2) { k2 = c; w2 = w; second_is_key1 = 1; }
+    }
+    if (w1 >= 0) {
+        const unsigned long long c = tables[(size_t)w1 * table_stride + li].key2;
+        if (c < k2) { k2 = c; w2 = w1; second_is_key1 = 0; }
+    }
+    int ring_i = -1, idx_i = 0, ring_j = -1, idx_j = 0, idx_k = 0, valid = 0;
+    float di = 1e18f, dj = 1e18f, v0[3] = {0.f, 0.f, 0.f}, v1[3] = {0.f, 0.f, 0.f}, v2[3] = {0.f, 0.f, 0.f}, n[3] = {0.f, 0.f, 0.f};
+    if (w1 >= 0 && k1 < key_inf) {
+        const PartialRec r = tables[(size_t)w1 * table_stride + li];
+        ring_i = r.ring1; idx_i = r.idx1; idx_k = r.idx_k; di = __uint_as_float((unsigned)(k1 >> 32));
+        for (int k = 0; k < 3; k++) { v0[k] = r.v0[k]; v2[k] = r.v2[k]; }
+    }
+    if (w2 >= 0 && k2 < key_inf) {
+        const PartialRec r = tables[(size_t)w2 * table_stride + li];
+        dj = __uint_as_float((unsigned)(k2 >> 32));
+        if (second_is_key1) { ring_j = r.ring1; idx_j = r.idx1; for (int k = 0; k < 3; k++) v1[k] = r.v0[k]; }
+        else { ring_j = r.ring2; idx_j = r.idx2; for (int k = 0; k < 3; k++) v1[k] = r.v1[k]; }
+    }
+    if (ring_i >= 0 && ring_j >= 0) valid = plane_from_points(v0, v1, v2, norm_cond, n);
+    write_correspondence(qi, src[q_src[qi]], valid, n, v0, ring_i, idx_i, ring_j, idx_j, idx_k, di, dj, out, want_aux != 0);
 }
 
 // Reference association search (VELO_ASSOC_VARIANT=0, kept for A/B checks): one lane per query, each lane walks the
@@ -614,7 +686,7 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                     if (w == wid) continue;
                     const unsigned long long c1 = m1[w][lane], c2 = m2[w][lane];
                     if (c1 < t.b2) top2_update(t, c1, mr[w][lane]);
-                    if (c2 < t.b2) top2_update(t, c2, ring_of[(int)(unsigned)(c2 & 0xffffffffull)]);
+                    if (c2 < t.b2) top2_update(t, c2, ring_of[(int)(unsigned)(c2 & 0xffffffffull) - out.first_point]);
                 }
                 __syncthreads();
             }
@@ -889,7 +961,7 @@ assoc_cluster_kernel(GridView G, AssocQueue Q, const float4* __restrict__ src, c
                     if (w == wid) continue;
                     const unsigned long long c1 = m1[w][lane], c2 = m2[w][lane];
                     if (c1 < t.b2) top2_update(t, c1, mr[w][lane]);
-                    if (c2 < t.b2) top2_update(t, c2, ring_of[(int)(unsigned)(c2 & 0xffffffffull)]);
+                    if (c2 < t.b2) top2_update(t, c2, ring_of[(int)(unsigned)(c2 & 0xffffffffull) - out.first_point]);
                 }
                 __syncthreads();
             }

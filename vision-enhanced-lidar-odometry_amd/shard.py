@@ -19,6 +19,16 @@ def query_shard_range(n_queries: int, rank: int, world: int):
     return (n_queries * rank) // world, (n_queries * (rank + 1)) // world
 
 
+def target_ring_block(ring_offsets, rank: int, world: int):
+    """Target-sharded mode: rank owns the contiguous block of WHOLE rings [Rs*rank/world, Rs*(rank+1)/world) (keeps the
+    +-1 ring neighbour of velo.h:852-856 local).  Returns (first_ring, last_ring_excl, first_point, local_offsets)."""
+    off = np.asarray(ring_offsets, dtype=np.int64)
+    rs = len(off) - 1
+    r0, r1 = (rs * rank) // world, (rs * (rank + 1)) // world
+    local = (off[r0:r1 + 1] - off[r0]).astype(np.int32)
+    return r0, r1, int(off[r0]), local
+
+
 def pack_normal_equations(cost: float, JtJ: np.ndarray, Jtr: np.ndarray) -> np.ndarray:
     """cost, 6x6, 6 -> the 28-double wire block (row-major upper triangle, then Jtr, then cost)."""
     JtJ = np.asarray(JtJ, dtype=np.float64).reshape(6, 6)
