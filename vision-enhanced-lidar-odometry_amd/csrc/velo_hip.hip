@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -28,6 +29,7 @@ namespace {
 
 thread_local std::string g_err;
 std::string g_err_shared;   // last error of any thread (read by velo_last_error when the caller's own is empty)
+std::mutex g_err_mutex;
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -36,7 +38,7 @@ int fail(int code, const char* fmt, ...) {
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
     g_err = buf;
-    g_err_shared = buf;
+    { std::lock_guard<std::mutex> lk(g_err_mutex); g_err_shared = buf; }
     return code;
 }
 
@@ -410,6 +412,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         if (c->debug_skip & 32) { VELO_TRY(c->wg_times.reserve((size_t)2 * cdiv(qe - qb, 64) + 2)); out.wg_times = c->wg_times.p; c->wg_times_n = cdiv(qe - qb, 64); }
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
         if (c->timing) {
+            if (c->assoc_events_used >= 256) c->assoc_events_used = 0;      // standalone velo_associate calls: recycle
             if (c->assoc_events_used >= (int)c->assoc_events.size()) {
                 hipEvent_t a, b;
                 HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
@@ -634,7 +637,10 @@ static int launch_merge(velo_ctx* c, const PartialRec* tables, int world, int st
 
 extern "C" {
 
-const char* velo_last_error(void) { return g_err.empty() ? g_err_shared.c_str() : g_err.c_str(); }
+const char* velo_last_error(void) {
+    if (g_err.empty()) { std::lock_guard<std::mutex> lk(g_err_mutex); g_err = g_err_shared; }
+    return g_err.c_str();
+}
 const char* velo_version(void) { return "velo_hip 0.1 (gfx950)"; }
 
 int velo_default_params(velo_params* p) {
