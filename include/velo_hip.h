@@ -191,6 +191,16 @@ int velo_set_target_part(velo_ctx* ctx, const float* xyz, int64_t stride_bytes, 
 /* Source = frame1 rings (`scans_M`, velo.h:605).  Queries are every icp_skip-th point of each ring (velo.h:807). */
 int velo_set_source(velo_ctx* ctx, const float* xyz, int64_t stride_bytes, const int32_t* ring_offsets,
                     int32_t n_rings, int on_device);
+/* "Next" row 1 of SURVEY.md 8(f): the step immediately before the path, on the device.  Replaces loadPoints + segmentPoints
+ * (kitti.h:121-185) for one frame: `xyzr` are raw Velodyne records in FILE order (x, y, z, reflectance -> stride 16 for a
+ * KITTI .bin), a new ring starts where x > 0 and the sign of y flips (kitti.h:166), points are stored in the camera-0 frame
+ * (velo_to_cam: row-major 4x4, float arithmetic like pcl::transformPointCloud) and every ring is reordered
+ * new[i] = old[n-1-((i + n/2) % n)] (kitti.h:180).  The result becomes this context's source (as_target == 0) or target. */
+int velo_set_scan_velodyne(velo_ctx* ctx, int32_t as_target, const float* xyzr, int64_t stride_bytes, int32_t n_points,
+                           const float velo_to_cam[16], int on_device);
+/* ring offsets / camera-frame points the context currently holds (for callers that segmented on the device) */
+int velo_get_ring_offsets(velo_ctx* ctx, int32_t of_target, int32_t* out, int32_t capacity, int32_t* n_rings);
+int velo_get_cloud(velo_ctx* ctx, int32_t of_target, float* xyz_out, int32_t capacity_points, int32_t* n_points);
 /* Visual matches of both cameras, in the reference's iteration order cam-major (velo.h:622-627). n may be 0. */
 int velo_set_visual(velo_ctx* ctx, const velo_match* matches, int32_t n);
 

@@ -8,6 +8,7 @@ imported through the root-level shim as ``velo_amd``:
 
 Contents: ``csrc/`` (HIP kernels + the C-ABI shared library, see include/velo_hip.h),
 ``api.py`` (ctypes mirror of that C-ABI -- plumbing for tests/bench, no compute),
-``synth.py`` (seeded HDL-64E / KITTI-layout inputs), ``build.py`` (hipcc / g++ recipes).
+``synth.py`` (seeded HDL-64E / KITTI-layout inputs), ``shard.py`` (multi-GPU host logic), ``odometry.py`` (pose
+hand-off loop around the path), ``build.py`` (hipcc recipe).
 """
-__all__ = ["api", "synth", "build", "shard"]
+__all__ = ["api", "synth", "build", "shard", "odometry"]

@@ -128,6 +128,9 @@ SIGNATURES = {
     "velo_set_target": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int]),
     "velo_set_target_part": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int]),
     "velo_set_source": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int]),
+    "velo_set_scan_velodyne": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int]),
+    "velo_get_ring_offsets": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_int32, _P(C.c_int32)]),
+    "velo_get_cloud": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_int32, _P(C.c_int32)]),
     "velo_set_visual": (C.c_int, [_ctx, C.c_void_p, C.c_int32]),
     "velo_associate": (C.c_int, [_ctx, _dp, C.c_int32, _P(C.c_int32)]),
     "velo_associate_partial": (C.c_int, [_ctx, _dp, C.c_int32]),
@@ -279,6 +282,31 @@ class Context:
     def set_source(self, xyz, ring_offsets):
         ptr, stride, off, dev, keep = self._cloud_args(xyz, ring_offsets)
         self._check(self._lib.velo_set_source(self._h, ptr, stride, C.c_void_p(off.ctypes.data), len(off) - 1, dev))
+
+    def set_scan_velodyne(self, as_target: bool, records, velo_to_cam):
+        """Raw Velodyne records (n,4) float32 in file order (or a torch tensor on the GPU) -> rings on the device."""
+        M = np.ascontiguousarray(np.asarray(velo_to_cam, dtype=np.float32).reshape(4, 4))
+        if hasattr(records, "data_ptr"):
+            ptr, stride, n, dev = C.c_void_p(records.data_ptr()), records.stride(0) * records.element_size(), records.shape[0], 1
+        else:
+            a = np.ascontiguousarray(np.asarray(records, dtype=np.float32))
+            ptr, stride, n, dev = C.c_void_p(a.ctypes.data), a.strides[0], a.shape[0], 0
+        self._check(self._lib.velo_set_scan_velodyne(self._h, int(bool(as_target)), ptr, stride, n, C.c_void_p(M.ctypes.data), dev))
+
+    def ring_offsets(self, of_target: bool) -> np.ndarray:
+        n = C.c_int32(0)
+        self._check(self._lib.velo_get_ring_offsets(self._h, int(bool(of_target)), None, 0, C.byref(n)))
+        out = np.zeros(n.value + 1, dtype=np.int32)
+        self._check(self._lib.velo_get_ring_offsets(self._h, int(bool(of_target)), C.c_void_p(out.ctypes.data), len(out), C.byref(n)))
+        return out
+
+    def cloud(self, of_target: bool) -> np.ndarray:
+        n = C.c_int32(0)
+        self._check(self._lib.velo_get_cloud(self._h, int(bool(of_target)), None, 0, C.byref(n)))
+        out = np.zeros((n.value, 3), dtype=np.float32)
+        if n.value:
+            self._check(self._lib.velo_get_cloud(self._h, int(bool(of_target)), C.c_void_p(out.ctypes.data), n.value, C.byref(n)))
+        return out
 
     def set_visual(self, matches):
         if isinstance(matches, dict):

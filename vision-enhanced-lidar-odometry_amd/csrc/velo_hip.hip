@@ -143,6 +143,7 @@ struct velo_ctx {
     bool have_source = false;
 
     DevBuf<char> staging;                // raw host clouds land here before packing
+    DevBuf<int> seg_flag, seg_excl, seg_ring, seg_off;   // device-side ring segmentation (velo_set_scan_velodyne)
 
     // correspondence table
     DevBuf<float4> cp, cn, cv0, aux1;
@@ -629,6 +630,46 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
     return VELO_OK;
 }
 
+// common tail of every way a target enters the context: ring table, ring ids, bounding box, grid
+int target_finalize(velo_ctx* c) {
+    const int n = c->n_tgt, n_rings = c->n_tgt_rings;
+    for (int r = 0; r < n_rings; r++) if (c->h_tgt_off[r + 1] <= c->h_tgt_off[r]) return fail(VELO_ERR_INVALID, "target ring %d is empty", r);
+    VELO_TRY(c->tgt_off.reserve((size_t)n_rings + 1));
+    VELO_TRY(c->tgt_ring_of.reserve((size_t)std::max(n, 1)));
+    VELO_TRY(c->tgt_cell_of.reserve((size_t)std::max(n, 1)));
+    HIP_TRY(hipMemcpyAsync(c->tgt_off.p, c->h_tgt_off.data(), sizeof(int) * ((size_t)n_rings + 1), hipMemcpyHostToDevice, c->stream));
+    // bbox of the finite points -> host (the only sync of set_target; the grid dimensions are sized from it)
+    unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    std::memcpy(c->h_int, init, sizeof(init));
+    HIP_TRY(hipMemcpyAsync(c->bbox_keys.p, c->h_int, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    if (n > 0) {
+        hipLaunchKernelGGL(ring_of_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->tgt_off.p, n_rings, n, c->tgt_first_ring, c->tgt_ring_of.p);
+        hipLaunchKernelGGL(bbox_kernel, dim3(std::min(cdiv(n, 256 * 8), 256)), dim3(256), 0, c->stream, c->tgt.p, n, c->bbox_keys.p);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_int + 8, c->bbox_keys.p, sizeof(init), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned keys[6];
+    std::memcpy(keys, c->h_int + 8, sizeof(keys));
+    if (keys[0] == 0xffffffffu) {   // no finite point at all
+        for (int k = 0; k < 6; k++) c->bbox[k] = 0.f;
+    } else {
+        for (int k = 0; k < 6; k++) c->bbox[k] = key2f(keys[k]);
+    }
+    c->grids.clear();
+    VELO_TRY(build_grids(c));
+    c->have_target = true;
+    return VELO_OK;
+}
+
+int source_finalize(velo_ctx* c) {
+    VELO_TRY(c->src_off.reserve((size_t)c->n_src_rings + 1));
+    HIP_TRY(hipMemcpyAsync(c->src_off.p, c->h_src_off.data(), sizeof(int) * ((size_t)c->n_src_rings + 1), hipMemcpyHostToDevice, c->stream));
+    VELO_TRY(build_query_list(c));
+    c->have_source = true;
+    return VELO_OK;
+}
+
 }  // namespace
 
 // =====================================================================================================================
@@ -724,6 +765,7 @@ int velo_destroy(velo_ctx* c) {
     for (Grid& G : c->grids) { G.cell_start.release(); G.sorted.release(); G.sring.release(); }
     c->scan_tiles.release(); c->cursor.release(); c->scan_total.release(); c->bbox_keys.release();
     c->src.release(); c->src_off.release(); c->q_off.release(); c->q_src.release(); c->staging.release();
+    c->seg_flag.release(); c->seg_excl.release(); c->seg_ring.release(); c->seg_off.release();
     c->cp.release(); c->cn.release(); c->cv0.release(); c->aux0.release(); c->aux1.release(); c->n_valid.release(); c->dbg.release(); c->wg_times.release(); c->items.release(); c->item_counters.release(); c->qpos.release(); c->partials_rec.release(); c->partials_all.release();
     c->vm.release(); c->vflags.release();
     for (int k = 0; k < 2; k++) if (c->chunk_graph[k]) (void)hipGraphExecDestroy(c->chunk_graph[k]);
@@ -787,32 +829,7 @@ int velo_set_target_part(velo_ctx* c, const float* xyz, int64_t stride, const in
     c->tgt_first_ring = first_ring; c->tgt_first_point = first_point;
     c->h_tgt_off.assign(off, off + n_rings + 1);
     VELO_TRY(upload_cloud(c, xyz, stride, n, on_device, c->tgt));
-    VELO_TRY(c->tgt_off.reserve((size_t)n_rings + 1));
-    VELO_TRY(c->tgt_ring_of.reserve((size_t)std::max(n, 1)));
-    VELO_TRY(c->tgt_cell_of.reserve((size_t)std::max(n, 1)));
-    HIP_TRY(hipMemcpyAsync(c->tgt_off.p, c->h_tgt_off.data(), sizeof(int) * ((size_t)n_rings + 1), hipMemcpyHostToDevice, c->stream));
-    // bbox of the finite points -> host (the only sync of set_target; the grid dimensions are sized from it)
-    unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-    std::memcpy(c->h_int, init, sizeof(init));
-    HIP_TRY(hipMemcpyAsync(c->bbox_keys.p, c->h_int, sizeof(init), hipMemcpyHostToDevice, c->stream));
-    if (n > 0) {
-        hipLaunchKernelGGL(ring_of_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->tgt_off.p, n_rings, n, c->tgt_first_ring, c->tgt_ring_of.p);
-        hipLaunchKernelGGL(bbox_kernel, dim3(std::min(cdiv(n, 256 * 8), 256)), dim3(256), 0, c->stream, c->tgt.p, n, c->bbox_keys.p);
-        HIP_TRY(hipGetLastError());
-    }
-    HIP_TRY(hipMemcpyAsync(c->h_int + 8, c->bbox_keys.p, sizeof(init), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    unsigned keys[6];
-    std::memcpy(keys, c->h_int + 8, sizeof(keys));
-    if (keys[0] == 0xffffffffu) {   // no finite point at all
-        for (int k = 0; k < 6; k++) c->bbox[k] = 0.f;
-    } else {
-        for (int k = 0; k < 6; k++) c->bbox[k] = key2f(keys[k]);
-    }
-    c->grids.clear();
-    VELO_TRY(build_grids(c));
-    c->have_target = true;
-    return VELO_OK;
+    return target_finalize(c);
 }
 
 int velo_set_source(velo_ctx* c, const float* xyz, int64_t stride, const int32_t* off, int32_t n_rings, int on_device) {
@@ -827,10 +844,78 @@ int velo_set_source(velo_ctx* c, const float* xyz, int64_t stride, const int32_t
     c->n_src = n; c->n_src_rings = n_rings;
     c->h_src_off.assign(off, off + n_rings + 1);
     VELO_TRY(upload_cloud(c, xyz, stride, n, on_device, c->src));
-    VELO_TRY(c->src_off.reserve((size_t)n_rings + 1));
-    HIP_TRY(hipMemcpyAsync(c->src_off.p, c->h_src_off.data(), sizeof(int) * ((size_t)n_rings + 1), hipMemcpyHostToDevice, c->stream));
-    VELO_TRY(build_query_list(c));
-    c->have_source = true;
+    return source_finalize(c);
+}
+
+// kitti.h:121-185 on the device ("next" row 1 of SURVEY.md 8(f)): raw Velodyne records (x, y, z, reflectance; any stride
+// >= 12) in file order -> camera-0-frame rings, loaded straight into this context as its source or target.
+int velo_set_scan_velodyne(velo_ctx* c, int32_t as_target, const float* xyzr, int64_t stride, int32_t n, const float velo_to_cam[16], int on_device) {
+    if (!c || n < 0 || (n > 0 && !xyzr) || !velo_to_cam) return fail(VELO_ERR_INVALID, "null/negative argument");
+    if (stride < 12) return fail(VELO_ERR_INVALID, "stride_bytes must be >= 12");
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf<float4>& dst = as_target ? c->tgt : c->src;
+    std::vector<int>& h_off = as_target ? c->h_tgt_off : c->h_src_off;
+    if (as_target) { c->have_target = false; c->have_partials = false; c->tgt_first_ring = 0; c->tgt_first_point = 0; } else c->have_source = false;
+    c->have_corr = false;
+    VELO_TRY(dst.reserve((size_t)std::max(n, 1)));
+    int n_rings = 0;
+    h_off.assign(1, 0);
+    if (n > 0) {
+        const char* rec = (const char*)xyzr;
+        if (!on_device) {
+            const size_t bytes = (size_t)(n - 1) * (size_t)stride + 12;
+            VELO_TRY(c->staging.reserve(bytes));
+            HIP_TRY(hipMemcpyAsync(c->staging.p, xyzr, bytes, hipMemcpyHostToDevice, c->stream));
+            rec = c->staging.p;
+        }
+        VELO_TRY(c->seg_flag.reserve((size_t)n + 2)); VELO_TRY(c->seg_excl.reserve((size_t)n + 2));
+        VELO_TRY(c->seg_ring.reserve((size_t)n + 2)); VELO_TRY(c->seg_off.reserve((size_t)n + 2));
+        VELO_TRY(c->cursor.reserve((size_t)n + 2));
+        const int n_tiles = cdiv(n, kScanTile);
+        VELO_TRY(c->scan_tiles.reserve((size_t)n_tiles + 1));
+        VELO_TRY(c->scan_total.reserve(1));
+        hipLaunchKernelGGL(ring_break_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, rec, stride, n, c->seg_flag.p);
+        HIP_TRY(hipMemcpyAsync(c->seg_excl.p, c->seg_flag.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+        hipLaunchKernelGGL(scan_tiles_kernel, dim3(n_tiles), dim3(kScanThreads), 0, c->stream, c->seg_excl.p, n, c->scan_tiles.p);
+        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kScanThreads), 0, c->stream, c->scan_tiles.p, n_tiles, c->scan_total.p);
+        hipLaunchKernelGGL(scan_add_kernel, dim3(cdiv(n + 1, 256)), dim3(256), 0, c->stream, c->seg_excl.p, n, c->scan_tiles.p, c->scan_total.p, c->cursor.p);
+        hipLaunchKernelGGL(ring_offsets_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const int*)c->seg_excl.p, (const int*)c->seg_flag.p, n,
+                           c->seg_ring.p, c->seg_off.p, c->scan_total.p);
+        Mat34f M;
+        for (int k = 0; k < 12; k++) M.m[k] = velo_to_cam[k];       // rows 0..2 of the row-major 4x4
+        hipLaunchKernelGGL(ring_reorder_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, rec, stride, n, (const int*)c->seg_ring.p, (const int*)c->seg_off.p, M, dst.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(c->h_int, c->scan_total.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        n_rings = c->h_int[0];
+        h_off.resize((size_t)n_rings + 1);
+        HIP_TRY(hipMemcpy(h_off.data(), c->seg_off.p, sizeof(int) * ((size_t)n_rings + 1), hipMemcpyDeviceToHost));
+    }
+    if (as_target) { c->n_tgt = n; c->n_tgt_rings = n_rings; return target_finalize(c); }
+    c->n_src = n; c->n_src_rings = n_rings;
+    return source_finalize(c);
+}
+
+int velo_get_ring_offsets(velo_ctx* c, int32_t of_target, int32_t* out, int32_t capacity, int32_t* n_rings) {
+    if (!c) return fail(VELO_ERR_INVALID, "null ctx");
+    const std::vector<int>& h = of_target ? c->h_tgt_off : c->h_src_off;
+    const int nr = h.empty() ? 0 : (int)h.size() - 1;
+    if (n_rings) *n_rings = nr;
+    if (out) for (int i = 0; i <= nr && i < capacity; i++) out[i] = h[i];
+    return VELO_OK;
+}
+
+// copies the context's camera-frame cloud back (tests): n points, 3 floats each
+int velo_get_cloud(velo_ctx* c, int32_t of_target, float* xyz_out, int32_t capacity_points, int32_t* n_points) {
+    if (!c) return fail(VELO_ERR_INVALID, "null ctx");
+    const int n = of_target ? c->n_tgt : c->n_src;
+    if (n_points) *n_points = n;
+    if (!xyz_out || capacity_points <= 0 || n == 0) return VELO_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<float4> h((size_t)n);
+    HIP_TRY(hipMemcpy(h.data(), of_target ? c->tgt.p : c->src.p, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n && i < capacity_points; i++) { xyz_out[3 * i] = h[i].x; xyz_out[3 * i + 1] = h[i].y; xyz_out[3 * i + 2] = h[i].z; }
     return VELO_OK;
 }
 

@@ -89,6 +89,50 @@ __global__ void query_list_kernel(const int* __restrict__ src_off, const int* __
     q_src[i] = src_off[lo] + (i - q_off[lo]) * skip;
 }
 
+// ---- scan ingestion on the device: KITTI records -> camera-0-frame rings (kitti.h:121-185), "next" row 1 of SURVEY 8(f) ----
+// 1. ring_break_kernel: flag[i] = i > 0 && x_i > 0 && (y_i > 0) != (y_{i-1} > 0)            (kitti.h:164-168, velodyne frame)
+// 2. exclusive scan of the flags (scan_tiles/sums/add above) -> ring id per point, ring count
+// 3. ring_offsets_kernel: off[ring] = first point of that ring (the flagged points), off[n_rings] = n
+// 4. ring_reorder_kernel: camera-frame copy  q = velo_to_cam * p  in float, stored at  new[i] = old[n-1-((i + n/2) % n)]  (kitti.h:178-183)
+__global__ void ring_break_kernel(const char* __restrict__ rec, int64_t stride, int n, int* __restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = (const float*)(rec + (int64_t)i * stride);
+    int f = 0;
+    if (i > 0) {
+        const float* q = (const float*)(rec + (int64_t)(i - 1) * stride);
+        f = (p[0] > 0.f && ((p[1] > 0.f) != (q[1] > 0.f))) ? 1 : 0;
+    }
+    flag[i] = f;
+}
+// ring_id[i] = (exclusive scan of flag)[i] + flag[i]; the flagged points start rings 1.., point 0 starts ring 0
+__global__ void ring_offsets_kernel(const int* __restrict__ excl, const int* __restrict__ flag, int n, int* __restrict__ ring_id, int* __restrict__ off,
+                                    int* __restrict__ n_rings_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = excl[i] + flag[i];
+    ring_id[i] = r;
+    if (i == 0 || flag[i]) off[r] = i;
+    if (i == n - 1) { off[r + 1] = n; *n_rings_out = r + 1; }
+}
+struct Mat34f { float m[12]; };   // rows of velo_to_cam (kitti.h:100-107)
+__global__ void ring_reorder_kernel(const char* __restrict__ rec, int64_t stride, int n, const int* __restrict__ ring_id, const int* __restrict__ off,
+                                    Mat34f M, float4* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* p = (const float*)(rec + (int64_t)i * stride);
+    const float x = p[0], y = p[1], z = p[2];
+    // pcl::transformPointCloud<float> [3P]: linear part column by column, then the translation, all in float
+    const float cx = ((M.m[0] * x + M.m[1] * y) + M.m[2] * z) + M.m[3];
+    const float cy = ((M.m[4] * x + M.m[5] * y) + M.m[6] * z) + M.m[7];
+    const float cz = ((M.m[8] * x + M.m[9] * y) + M.m[10] * z) + M.m[11];
+    const int r = ring_id[i], base = off[r], m = off[r + 1] - base, j = i - base;
+    // new[i'] = old[m-1-((i' + m/2) % m)]  <=>  i' = (m-1-j - m/2) mod m
+    int ip = (m - 1 - j - m / 2) % m;
+    if (ip < 0) ip += m;
+    dst[base + ip] = make_float4(cx, cy, cz, 0.f);
+}
+
 // ---- bounding box of the finite points: per-block min/max then atomics on order-preserving integer keys ----
 __device__ __forceinline__ unsigned f2key(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __host__ __device__ __forceinline__ float key2f(unsigned k) {

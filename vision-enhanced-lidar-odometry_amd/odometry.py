@@ -1,0 +1,67 @@
+"""Pose hand-off around the path ("next" row 2 of SURVEY.md 8(f)): host logic only, mirrors main.cpp:305-331,407-437 and
+kitti.h:202-216.  It makes a standalone LiDAR odometry loop runnable on (synthetic) sequences:
+
+    for every frame k >= 1:   dT   = T[k-2]^-1 T[k-1]            constant-velocity prediction        main.cpp:311-320
+                              x0   = pose_vec2mat(dT)            (a 6-vector despite the name)         main.cpp:331, utility.h:83-96
+                              dpose = frameToFrame(scan k -> scan k-1, x0)                              main.cpp:388-405
+                              T[k] = T[k-1] * dpose                                                     main.cpp:408
+                              agreement = pose_vec2mat(dpose * dT^-1)                                   main.cpp:416-424
+The first frame pair starts from the reference's default transform {0,0,0,0,0,1} (main.cpp:170).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import api
+
+AGREEMENT_T_THRESH = 0.1      # kitti.h:33
+AGREEMENT_R_THRESH = 0.05     # kitti.h:34
+FIRST_GUESS = np.array([0.0, 0.0, 0.0, 0.0, 0.0, 1.0])     # main.cpp:170
+
+
+def kitti_pose_line(T: np.ndarray) -> str:
+    """kitti.h:202-216: the 3x4 of a pose, row-major, operator<< default formatting (6 significant digits)."""
+    return " ".join(f"{float(v):.6g}" for v in np.asarray(T)[:3, :4].reshape(-1)) + " "
+
+
+class LidarOdometer:
+    """Frame-to-frame LiDAR odometry on the device: every scan is segmented on the GPU once per role."""
+
+    def __init__(self, device: int = 0, velo_to_cam=None, **params):
+        from . import synth
+        self.ctx = api.Context(device, **params)
+        self.velo_to_cam = np.asarray(velo_to_cam if velo_to_cam is not None else synth.VELO_TO_CAM, dtype=np.float32)
+        self.poses = []          # ceres_poses_mat (main.cpp:179), camera-0 frame
+        self.prev_records = None
+        self.agreements = []
+        self.summaries = []
+
+    def push(self, records) -> np.ndarray:
+        """records: raw Velodyne (n,4) float32 of the new frame, file order.  Returns the new 4x4 pose."""
+        if self.prev_records is None:
+            self.poses.append(np.eye(4))
+            self.prev_records = records
+            return self.poses[-1]
+        k = len(self.poses)
+        if k > 1:
+            dT = np.linalg.inv(self.poses[k - 2]) @ self.poses[k - 1]         # main.cpp:315-317
+            x0 = api.pose_mat_to_vec(dT)                                       # main.cpp:331
+        else:
+            x0 = FIRST_GUESS.copy()
+            dT = api.pose_vec_to_mat(x0)                                       # main.cpp:319
+        self.ctx.set_scan_velodyne(True, self.prev_records, self.velo_to_cam)  # target = previous frame (sd_prev)
+        self.ctx.set_scan_velodyne(False, records, self.velo_to_cam)           # source = current frame (sd)
+        x, dpose, s = self.ctx.frame_to_frame(x0)
+        self.poses.append(self.poses[k - 1] @ dpose)                           # main.cpp:408
+        self.agreements.append(api.pose_mat_to_vec(dpose @ np.linalg.inv(dT)))  # main.cpp:417
+        self.summaries.append(s)
+        self.prev_records = records
+        return self.poses[-1]
+
+    def write_kitti(self, path: str):
+        with open(path, "w") as f:                                             # main.cpp:758-763
+            for T in self.poses:
+                f.write(kitti_pose_line(T) + "\n")
+
+    def close(self):
+        self.ctx.close()

@@ -340,3 +340,23 @@ def stereo_matches(n_per_cam: int = 1000, seed: int = 3, x_true=None, outlier_fr
         t_cam=CAM_TRANS[cam].astype(np.float32),
     )
     return rec
+
+
+def velodyne_sequence(n_frames: int, scene_seed: int = 0, sigma: float = 0.02, n_beams: int = N_BEAMS, n_azimuth: int = N_AZIMUTH,
+                      step=None):
+    """Raw Velodyne-frame sweeps (n,4 float32 records, reflectance 0) along a gently curving drive + the true sensor poses
+    expressed like the reference's pose chain (camera-0 frame, pose 0 = identity)."""
+    scene = Scene(scene_seed)
+    step = step or dict(yaw=0.01, pitch=0.0005, roll=0.0005, t=(0.8, 0.01, 0.0))
+    T = pose_matrix(0.0, 0.0, 0.0, (-20.0, 0.0, 0.0))
+    T0 = T.copy()
+    C = VELO_TO_CAM.astype(np.float64)
+    frames, poses = [], []
+    for k in range(n_frames):
+        pts = hdl64_scan(scene, T, noise_seed=1000 + k, sigma=sigma, n_beams=n_beams, n_azimuth=n_azimuth)
+        rec = np.zeros((pts.shape[0], 4), dtype=np.float32)
+        rec[:, :3] = pts
+        frames.append(rec)
+        poses.append(C @ np.linalg.inv(T0) @ T @ np.linalg.inv(C))
+        T = T @ pose_matrix(**step)
+    return frames, poses
