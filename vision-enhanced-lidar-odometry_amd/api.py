@@ -162,7 +162,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("VELO_LIB_PATH") or LIB_PATH      # VELO_LIB_PATH: A/B builds on one GPU box
     if not os.path.exists(p):
         raise VeloError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
