@@ -231,9 +231,13 @@ struct KdTree {
     int n = 0;
     static const int kLeaf = 15;
 
+    // pcl::KdTreeFLANN::setInputCloud [3P] copies only the FINITE points into the index and keeps a map back to the
+    // cloud's own indices, so non-finite target points simply can never be returned.
     void build(const float* p, int count) {
-        pts = p; n = count; perm.resize(n); nodes.clear();
-        for (int i = 0; i < n; i++) perm[i] = i;
+        pts = p; nodes.clear(); perm.clear(); perm.reserve(count);
+        for (int i = 0; i < count; i++)
+            if (std::isfinite(p[3 * i]) && std::isfinite(p[3 * i + 1]) && std::isfinite(p[3 * i + 2])) perm.push_back(i);
+        n = (int)perm.size();
         if (n > 0) { nodes.reserve(2 * (n / kLeaf + 1)); build_rec(0, n); }
     }
     int build_rec(int lo, int hi) {

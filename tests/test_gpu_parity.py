@@ -260,3 +260,49 @@ def test_rccl_path_single_rank(ctx, oracle):
     assert H.pose_close(x_comm, x_orc)
     assert [s_comm.solves[k].evaluations for k in range(6)] == [s_orc.solves[k].evaluations for k in range(6)]
     assert abs(c1 - c2) <= 1e-12 * c2 and H.rel_err(H1, H2) <= 1e-12 and H.rel_err(g1, g2) <= 1e-12
+
+
+def test_non_finite_points_and_degenerate_inputs(ctx, oracle):
+    """Non-finite target points are never matched (PCL keeps only finite points in the tree), non-finite queries match
+    nothing, enable_icp = 0 empties the query list (velo.h:806), and argument errors come back as statuses."""
+    d = H.small_pair(8, 64)
+    tgt = d["tgt_xyz"].copy()
+    src = d["src_xyz"].copy()
+    tgt[5] = [np.nan, 0, 0]
+    tgt[100] = [np.inf, 1, 2]
+    tgt[101, 2] = -np.inf
+    src[7] = [np.nan, np.nan, np.nan]
+    src[70, 1] = np.inf
+    orc = oracle.Oracle()
+    for o in (ctx, orc):
+        o.set_params(icp_skip=1)
+        o.set_target(tgt, d["tgt_off"])
+        o.set_source(src, d["src_off"])
+    for it in (1, 2):
+        assert ctx.associate(d["x_true"], it) == orc.associate(d["x_true"], it)
+        a, b = ctx.correspondences(), orc.correspondences()
+        assert a["valid"][7] == 0 and a["valid"][70] == 0
+        keep = np.ones(len(a), bool)
+        keep[[7, 70]] = False                       # p of a NaN query is NaN on both sides; compare the rest bit for bit
+        H.assert_corr_equal(a[keep], b[keep])
+        for f in ("idx_i", "idx_j", "idx_k"):
+            pass
+        used = set()
+        for r, i in zip(a["ring_i"][a["ring_i"] >= 0], a["idx_i"][a["ring_i"] >= 0]):
+            used.add(int(d["tgt_off"][r] + i))
+        assert not ({5, 100, 101} & used)
+    x1, _, s1 = ctx.frame_to_frame(d["x0"])
+    x2, _, s2 = orc.frame_to_frame(d["x0"])
+    assert H.pose_close(x1, x2)
+    # enable_icp = 0: no queries, six solves that converge immediately, x unchanged
+    ctx.set_params(enable_icp=0)
+    x3, _, s3 = ctx.frame_to_frame(d["x0"])
+    assert np.array_equal(x3, d["x0"]) and s3.n_queries == 0 and all(s3.solves[k].evaluations == 1 for k in range(6))
+    ctx.set_params(enable_icp=1)
+    # statuses, not exceptions across the ABI
+    with pytest.raises(api.VeloError):
+        ctx.set_target(d["tgt_xyz"], np.array([0, 10, 10, 20], dtype=np.int32))      # empty ring
+    with pytest.raises(api.VeloError):
+        ctx.set_params(icp_skip=0)
+    with pytest.raises(api.VeloError):
+        ctx.associate(d["x0"], 0)
