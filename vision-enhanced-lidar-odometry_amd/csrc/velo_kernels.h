@@ -1170,25 +1170,37 @@ __device__ __forceinline__ void accumulate_row(double acc[kNumAcc], double r, co
     for (int i = 0; i < 6; i++) acc[21 + i] += J[i] * rk;
 }
 
-// Workgroup reduction of the 28 accumulators through LDS (fixed order -> deterministic): every thread parks its 28
-// values, then 8 threads per accumulator add 32 entries each and finish with three shuffles.  Row stride 264 doubles
-// keeps the 64-bit reads of one half-wave on distinct bank pairs.
-constexpr int kRedStride = kEvalThreads + 8;
+// Workgroup reduction of the 28 accumulators with (almost) no LDS, so that sweep workgroups can share a CU with the
+// LDS-heavy association workgroups of other scan pairs in flight.  Wave level: a halving butterfly -- at mask 32 every
+// lane keeps one half of the (padded to 32) accumulators and ships the other half to its partner, at mask 16 a quarter,
+// ... -- 32 double exchanges instead of 28 x 6; after mask 2 lane L holds accumulator
+//   idx(L) = 16 b5 + 8 b4 + 4 b3 + 2 b2 + b1      (bk = bit k of L), summed over its wave after the mask-1 exchange.
+// Workgroup level: 1 KB of LDS.  Fixed order -> deterministic.
 __device__ __forceinline__ void block_reduce_store(double acc[kNumAcc], double* __restrict__ dst /* [28] */) {
-    __shared__ double red[kNumAcc * kRedStride];
-    const int tid = threadIdx.x;
+    __shared__ double red[kEvalThreads / kWave][32];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    double v[32];
 #pragma unroll
-    for (int k = 0; k < kNumAcc; k++) red[k * kRedStride + tid] = acc[k];
+    for (int k = 0; k < 32; k++) v[k] = (k < kNumAcc) ? acc[k] : 0.0;
+#pragma unroll
+    for (int n = 16, mask = 32; n >= 1; n >>= 1, mask >>= 1) {
+        const bool hi = (lane & mask) != 0;
+#pragma unroll
+        for (int i = 0; i < n; i++) {
+            const double mine = hi ? v[i + n] : v[i];
+            const double send = hi ? v[i] : v[i + n];
+            v[i] = mine + __shfl_xor(send, mask);
+        }
+    }
+    v[0] += __shfl_xor(v[0], 1);
+    const int idx = ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    if ((lane & 1) == 0) red[wid][idx] = v[0];
     __syncthreads();
-    if (tid < kNumAcc * 8) {
-        const int k = tid >> 3, part = tid & 7;
-        double v = 0.0;
-#pragma unroll 8
-        for (int i = 0; i < kEvalThreads / 8; i++) v += red[k * kRedStride + i * 8 + part];
-        v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 4);
-        if (part == 0) dst[k] = v;
+    if (threadIdx.x < kNumAcc) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kEvalThreads / kWave; w++) t += red[w][threadIdx.x];
+        dst[threadIdx.x] = t;
     }
 }
 
