@@ -7,7 +7,7 @@ src = os.path.join(ROOT, "gpurun_out", tag)
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 lines = []
-f = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
+f = sorted(glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv")), key=os.path.getmtime, reverse=True)
 if f:
     rows = list(csv.DictReader(open(f[0])))
     with open(os.path.join(dst, f"{tag}_kernel_stats.csv"), "w") as o:
@@ -26,7 +26,7 @@ if os.path.exists(b):
     except Exception as e:
         lines.append(f"(bench line unreadable: {e})")
 for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    f = glob.glob(os.path.join(src, name, "*", "*counter_collection.csv"))
+    f = sorted(glob.glob(os.path.join(src, name, "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)
     if not f:
         continue
     agg = collections.defaultdict(list)
@@ -36,7 +36,7 @@ for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     lines.append(f"{counter} per dispatch (KiB as rocprofv3 reports it; gfx950: FETCH_SIZE counts wide coalesced reads at 1/2):")
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:6]:
         lines.append(f"  {k[:58]:58s} n {len(v):4d}  mean {sum(v)/len(v):12.1f}")
-f = glob.glob(os.path.join(src, "pmc_sq", "*", "*counter_collection.csv"))
+f = sorted(glob.glob(os.path.join(src, "pmc_sq", "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)
 if f:
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f[0])):

@@ -7,7 +7,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {}
 for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    f = glob.glob(os.path.join(ROOT, "gpurun_out", tag, name, "*", "*counter_collection.csv"))
+    f = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag, name, "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)
     vals = collections.defaultdict(float)
     if f:
         for r in csv.DictReader(open(f[0])):

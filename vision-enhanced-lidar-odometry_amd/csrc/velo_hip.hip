@@ -429,9 +429,11 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         const float h_safe = (float)(G->h * 0.999);
         // the clustering radius is a length (VELO_CLUSTER_W is given in cells of the default 0.179 m grid)
         const int cluster_cells = std::max(1, (int)std::lround((double)c->cluster_w * 0.1785 / G->h));
-#define VELO_LAUNCH_V2(NW, MINW)                                                                                                   \
-        hipLaunchKernelGGL((assoc_search_v3_kernel<NW, MINW>), dim3(c->xcd_map ? ((groups + 7) / 8) * 8 : groups), dim3(NW * 64), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe, \
+#define VELO_LAUNCH_V3(NW, MINW, DBG)                                                                                              \
+        hipLaunchKernelGGL((assoc_search_v3_kernel<NW, MINW, DBG>), dim3(c->xcd_map ? ((groups + 7) / 8) * 8 : groups), dim3(NW * 64), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe, \
                            c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, cluster_cells, h_safe, out, aux, c->debug_skip, c->xcd_map)
+        // the diagnostic hooks (VELO_DEBUG_SKIP != 0) live in a separate instantiation: compiled in, they spill registers
+#define VELO_LAUNCH_V2(NW, MINW) do { if (c->debug_skip) VELO_LAUNCH_V3(NW, MINW, true); else VELO_LAUNCH_V3(NW, MINW, false); } while (0)
         switch (c->assoc_variant) {
             case 0: {
                 const int reach = (int)std::ceil(std::sqrt(std::max(gate, 0.0)) / (G->h * 0.999)) ;
@@ -472,6 +474,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
             default: VELO_LAUNCH_V2(4, 6); break;
         }
 #undef VELO_LAUNCH_V2
+#undef VELO_LAUNCH_V3
         HIP_TRY(hipGetLastError());
         if (ev) HIP_TRY(hipEventRecord(ev->second, c->stream));
     }

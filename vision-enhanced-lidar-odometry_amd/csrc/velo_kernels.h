@@ -529,7 +529,10 @@ __device__ __forceinline__ int wave_max_i(int v) {
 constexpr int kTileCap = 512;      // candidates per LDS tile (keeps the workgroup under 20 KB of LDS: 8 workgroups per CU)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int NW, int MINW>
+// DBG = true compiles the diagnostic hooks selected at run time by `dbg` (bit 0/1/2: skip sweep / tiles / rows, 3: cycle stamps,
+// 4: counters, 5: workgroup times, bits 8+: first expansion); the product instantiation has none of them -- they cost 56 spilled
+// SGPRs and 9 spilled VGPRs when left in.
+template <int NW, int MINW, bool DBG>
 __global__ void __launch_bounds__(NW * 64, MINW)
 assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
                        const float4* __restrict__ tgt, const int* __restrict__ tgt_off, const int* __restrict__ ring_of,
@@ -550,10 +553,10 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // diagnostic build only (dbg & 8): per-section cycle totals of wave 0, added to out.dbg[0..7]
+    // diagnostic build only (DBG && (dbg & 8)): per-section cycle totals of wave 0, added to out.dbg[0..7]
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tlast = (dbg & 8) ? (long long)__builtin_readcyclecounter() : 0;
-#define VELO_STAMP(k) do { if (dbg & 8) { const long long now__ = (long long)__builtin_readcyclecounter(); tacc[k] += now__ - tlast; tlast = now__; } } while (0)
+    long long tlast = (DBG && (dbg & 8)) ? (long long)__builtin_readcyclecounter() : 0;
+#define VELO_STAMP(k) do { if (DBG && (dbg & 8)) { const long long now__ = (long long)__builtin_readcyclecounter(); tacc[k] += now__ - tlast; tlast = now__; } } while (0)
     // XCD-aware group mapping: workgroups are dealt round-robin over the 8 XCDs, so blockIdx % 8 selects the XCD; give
     // each XCD one CONTIGUOUS eighth of the ring-ordered groups -- spatial neighbours then share that XCD's 4 MB L2
     // (cell table rows and candidate cells are re-read by adjacent groups).  Placement affects speed only.
@@ -561,18 +564,17 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
     const int per_xcd = (n_groups + 7) >> 3;
     const int group = xcd_map ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (group >= n_groups || (xcd_map && (int)(blockIdx.x >> 3) >= per_xcd)) return;
-    if ((dbg & 32) && threadIdx.x == 0) out.wg_times[2 * group] = __builtin_amdgcn_s_memrealtime();
+    if ((DBG && (dbg & 32)) && threadIdx.x == 0) out.wg_times[2 * group] = __builtin_amdgcn_s_memrealtime();
     const int qi = q_begin + group * 64 + lane;
     const bool active = qi < q_end;
     const unsigned long long key_inf = ((unsigned long long)gate_bits + 1ull) << 32;
-    float4 psrc = make_float4(0.f, 0.f, 0.f, 0.f);
     float qx = 0.f, qy = 0.f, qz = 0.f;
     Top2 t;
     t.b1 = key_inf; t.b2 = key_inf; t.b1ring = -1; t.b2d = __uint_as_float(gate_bits + 1u);
     const GridDesc g = G.d;
     int cx = 0, cy = 0, cz = 0;
     if (active) {
-        psrc = src[q_src[qi]];
+        const float4 psrc = src[q_src[qi]];                           // re-read at the end instead of living in 4 registers
         transform_query(P, psrc, &qx, &qy, &qz);
         cx = cell_coord(qx, g.ox, g.inv_h, g.nx); cy = cell_coord(qy, g.oy, g.inv_h, g.ny); cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
     }
@@ -592,9 +594,9 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
         const int by0 = __builtin_amdgcn_readfirstlane(wave_min_i(member ? cy : big)), by1 = __builtin_amdgcn_readfirstlane(wave_max_i(member ? cy : -big));
         const int bz0 = __builtin_amdgcn_readfirstlane(wave_min_i(member ? cz : big)), bz1 = __builtin_amdgcn_readfirstlane(wave_max_i(member ? cz : -big));
         VELO_STAMP(1);
-        if ((dbg & 16) && tid == 0) atomicAdd(&out.dbg[0], 1ull);
+        if ((DBG && (dbg & 16)) && tid == 0) atomicAdd(&out.dbg[0], 1ull);
         int e_prev = -1;                                               // expansion already covered (-1: nothing yet)
-        int e = max(1, dbg >> 8);                                      // first expansion (tuning knob, default 1)
+        int e = DBG ? max(1, dbg >> 8) : 1;                                     // first expansion (tuning knob, default 1)
         for (;;) {                                                     // phases: e = 1, then (if needed) the reach the bounds demand
             // box of this phase (clipped) and of the previous one (unclipped; empty when e_prev < 0)
             const int X0 = max(bx0 - e, 0), X1 = min(bx1 + e, g.nx - 1);
@@ -603,7 +605,7 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
             const int px0 = bx0 - e_prev, px1 = bx1 + e_prev, py0 = by0 - e_prev, py1 = by1 + e_prev, pz0 = bz0 - e_prev, pz1 = bz1 + e_prev;
             const int nyb = Y1 - Y0 + 1, nzb = Z1 - Z0 + 1;
             const int nrows = (X0 <= X1 && nyb > 0 && nzb > 0) ? nyb * nzb : 0;
-            for (int rbase = 0; rbase < ((dbg & 4) ? 0 : nrows); rbase += NT) {          // row chunks (one row per thread)
+            for (int rbase = 0; rbase < ((DBG && (dbg & 4)) ? 0 : nrows); rbase += NT) {          // row chunks (one row per thread)
                 // ---- 1. run list ----
                 int ja0 = 0, la = 0, jb0 = 0, lb = 0;
                 const int r = rbase + tid;
@@ -635,8 +637,8 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                 if (tid == 0) s_run_off[NRUN] = total;
                 __syncthreads();
                 VELO_STAMP(2);
-                if ((dbg & 16) && tid == 0) { atomicAdd(&out.dbg[1], 1ull); atomicAdd(&out.dbg[2], (unsigned long long)total); if (e_prev >= 0) atomicAdd(&out.dbg[3], (unsigned long long)total); atomicAdd(&out.dbg[4], (unsigned long long)nrows); atomicAdd(&out.dbg[5], (unsigned long long)e); }
-                if (dbg & 2) total = 0;
+                if ((DBG && (dbg & 16)) && tid == 0) { atomicAdd(&out.dbg[1], 1ull); atomicAdd(&out.dbg[2], (unsigned long long)total); if (e_prev >= 0) atomicAdd(&out.dbg[3], (unsigned long long)total); atomicAdd(&out.dbg[4], (unsigned long long)nrows); atomicAdd(&out.dbg[5], (unsigned long long)e); }
+                if (DBG && (dbg & 2)) total = 0;
                 // ---- 2./3. tiles ----
                 for (int tbase = 0; tbase < total; tbase += kTileCap) {
                     const int tn = min(total - tbase, kTileCap);
@@ -666,7 +668,7 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                     const int npairs = tn2 >> 1;
                     const int per = (npairs + NW - 1) / NW;
                     const int p0 = wid * per, p1 = min(p0 + per, npairs);
-                    if (member && !(dbg & 1)) {
+                    if (member && !(DBG && (dbg & 1))) {
                         // 4 pairs (8 candidates) per trip: all LDS reads first, then the packed distance math, then the
                         // (rare) updates -- keeps 8 ds_read_b128 in flight instead of one dependent read per pair
                         int pi = p0;
@@ -748,10 +750,10 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
         pending = pending && !member;
     }
     if (NW > 1 && wid != 0) return;
-    if (active) finish_correspondence(qi, psrc, qx, qy, qz, t.b1, t.b2, key_inf, tgt, tgt_off, ring_of, norm_cond, out, want_aux != 0);
+    if (active) finish_correspondence(qi, src[q_src[qi]], qx, qy, qz, t.b1, t.b2, key_inf, tgt, tgt_off, ring_of, norm_cond, out, want_aux != 0);
     VELO_STAMP(7);
-    if ((dbg & 32) && tid == 0) out.wg_times[2 * group + 1] = __builtin_amdgcn_s_memrealtime();
-    if ((dbg & 8) && tid == 0) { for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)&out.dbg[k], (unsigned long long)tacc[k]); }
+    if ((DBG && (dbg & 32)) && tid == 0) out.wg_times[2 * group + 1] = __builtin_amdgcn_s_memrealtime();
+    if ((DBG && (dbg & 8)) && tid == 0) { for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)&out.dbg[k], (unsigned long long)tacc[k]); }
 #undef VELO_STAMP
 }
 
