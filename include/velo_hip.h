@@ -261,6 +261,25 @@ int velo_set_query_shard(velo_ctx* ctx, int32_t rank, int32_t world);
 /* Blocks until everything queued on the context's stream is done. */
 int velo_synchronize(velo_ctx* ctx);
 
+/* --- "next" row 3 of SURVEY.md 8(f): the producer of the 3-D keypoints rows R2-R4 consume ---------------- */
+/* projectLidarToCamera (velo.h:329-374) for one camera, on the rings this context holds as source (of_target == 0) or target:
+ * every point is shifted by cam_t (float, = cam_trans[cam]), projected c = (x/z, y/z) in float, kept when z > 0 and c lies in
+ * [bounds[0], bounds[1]) x [bounds[2], bounds[3]) (= min_x, max_x, min_y, max_y of kitti.h:85-97, doubles), and pushed on the
+ * ring's occlusion stack: entries behind it in x and farther in z are popped (velo.h:351-358), the point is dropped when the
+ * stack top is right of it and nearer (velo.h:360-365).  Rings are independent; each is one sequential pass like the reference.
+ * The surviving (`projection`, `scans_valid`) lists stay on the device for velo_depth_association. */
+int velo_project_lidar(velo_ctx* ctx, int32_t of_target, const float cam_t[3], const double bounds[4], int32_t* n_valid_total);
+/* copies the lists back: proj_xy [n][2], points_xyz [n][3] (the un-shifted points, velo.h:368), ring_offsets [n_rings + 1] */
+int velo_get_projection(velo_ctx* ctx, float* proj_xy, float* points_xyz, int32_t capacity_points, int32_t* ring_offsets,
+                        int32_t capacity_offsets, int32_t* n_rings);
+/* featureDepthAssociation (velo.h:376-497) against the last velo_project_lidar: for every keypoint (canonical coordinates,
+ * [n][2] floats) the first ring s whose bracketing segment and that of ring s-1 straddle the keypoint in y and are both
+ * narrower than depth_assoc_thresh (kitti.h:28) gives a 3-D point by the reference's float bilinear interpolation.
+ * has_depth[k] = -1 or the index into kp_with_depth (appended in keypoint order).  The reference's unqualified abs() on the
+ * float widths (velo.h:416,419) is restated as fabs, like the outlier gate. */
+int velo_depth_association(velo_ctx* ctx, const float* keypoints_xy, int32_t n_keypoints, double depth_assoc_thresh,
+                           float* kp_with_depth_xyz, int32_t capacity_points, int32_t* has_depth, int32_t* n_with_depth);
+
 #ifdef __cplusplus
 }
 #endif

@@ -812,4 +812,92 @@ int vo_ring_nn(void* h, int ring, const float* q, int* idx_tree, float* d_tree, 
     return f;
 }
 
+// ---- SURVEY.md 8(f) row 3 restated: projectLidarToCamera (velo.h:329-374) + featureDepthAssociation (velo.h:376-497) ----
+// Stateless: clouds in, lists out.  proj_xy / pts_xyz need room for n points; ring_off_out for n_rings + 1.
+int vo_project_lidar(const float* xyz, int64_t stride, const int32_t* off, int32_t nr, const float* cam_t, const double* bounds,
+                     float* proj_xy, float* pts_xyz, int32_t* ring_off_out) {
+    int out = 0;
+    ring_off_out[0] = 0;
+    for (int s = 0; s < nr; s++) {
+        std::vector<float> cx, cy, pz;            // projection[s] and projected_points (only z is ever read back)
+        std::vector<int> idx;
+        for (int i = off[s]; i < off[s + 1]; i++) {
+            const float* p = (const float*)((const char*)xyz + (int64_t)i * stride);
+            const float ppx = p[0] + cam_t[0], ppy = p[1] + cam_t[1], ppz = p[2] + cam_t[2];     // velo.h:346
+            const float c0 = ppx / ppz, c1 = ppy / ppz;                                          // velo.h:347
+            if (ppz > 0 && (double)c0 >= bounds[0] && (double)c0 < bounds[1] && (double)c1 >= bounds[2] && (double)c1 < bounds[3]) {
+                while (!cx.empty() && c0 < cx.back() && ppz < pz.back()) {                       // velo.h:351-358
+                    cx.pop_back(); cy.pop_back(); pz.pop_back(); idx.pop_back();
+                }
+                if (!cx.empty() && c0 < cx.back() && ppz > pz.back()) continue;                  // velo.h:360-365
+                cx.push_back(c0); cy.push_back(c1); pz.push_back(ppz); idx.push_back(i);
+            }
+        }
+        for (size_t j = 0; j < cx.size(); j++, out++) {
+            const float* p = (const float*)((const char*)xyz + (int64_t)idx[j] * stride);
+            proj_xy[2 * out] = cx[j]; proj_xy[2 * out + 1] = cy[j];
+            pts_xyz[3 * out] = p[0]; pts_xyz[3 * out + 1] = p[1]; pts_xyz[3 * out + 2] = p[2];   // velo.h:368: the un-shifted point
+        }
+        ring_off_out[s + 1] = out;
+    }
+    return out;
+}
+
+static inline float lerp_f(float p1, float p2, float start, float end, float mid) {              // utility.h:20-29
+    const float a = (mid - start) / (end - start);
+    const float b = 1 - a;
+    return p1 * b + p2 * a;
+}
+static inline void lerp_p(const float* p1, const float* p2, float start, float end, float mid, float* o) {   // utility.h:7-19
+    const float a = (mid - start) / (end - start);
+    const float b = 1 - a;
+    o[0] = p1[0] * b + p2[0] * a; o[1] = p1[1] * b + p2[1] * a; o[2] = p1[2] * b + p2[2] * a;
+}
+
+// proj_xy / pts_xyz / ring_off: the lists vo_project_lidar produced.  Returns the number of keypoints that got depth.
+int vo_depth_association(const float* proj_xy, const float* pts_xyz, const int32_t* ring_off, int32_t nr, const float* kps, int32_t nk,
+                         double thresh, float* kp_with_depth, int32_t* has_depth) {
+    int n_out = 0;
+    for (int k = 0; k < nk; k++) {
+        has_depth[k] = -1;
+        const float kx = kps[2 * k], ky = kps[2 * k + 1];
+        int last_interp = -1;
+        for (int s = 0; s < nr; s++) {
+            bool found = false;
+            const int b = ring_off[s], n = ring_off[s + 1] - b;
+            if (n <= 1) { last_interp = -1; continue; }                                           // velo.h:397-400
+            int lo = 0, hi = n - 2, mid = 0;
+            while (lo <= hi) {                                                                    // velo.h:401-407
+                mid = (lo + hi) / 2;
+                if (proj_xy[2 * (b + mid)] > kx) hi = mid - 1;
+                else if (proj_xy[2 * (b + mid + 1)] <= kx) lo = mid + 1;
+                else {
+                    found = true;
+                    if (last_interp != -1) {
+                        const int pb = ring_off[s - 1];
+                        const float* a0 = proj_xy + 2 * (b + mid); const float* a1 = a0 + 2;
+                        const float* b0 = proj_xy + 2 * (pb + last_interp); const float* b1 = b0 + 2;
+                        // velo.h:412-422; abs() on the float widths restated as fabs (gotcha of row G1)
+                        if ((a0[1] > ky) != (b0[1] > ky) && (double)std::fabs(a0[0] - a1[0]) < thresh && (double)std::fabs(b0[0] - b1[0]) < thresh) {
+                            float i1[3], i2[3], o[3];
+                            lerp_p(pts_xyz + 3 * (b + mid), pts_xyz + 3 * (b + mid + 1), a0[0], a1[0], kx, i1);                  // velo.h:447-452
+                            lerp_p(pts_xyz + 3 * (pb + last_interp), pts_xyz + 3 * (pb + last_interp + 1), b0[0], b1[0], kx, i2); // velo.h:453-458
+                            const float i1y = lerp_f(a0[1], a1[1], a0[0], a1[0], kx);                                              // velo.h:459-464
+                            const float i2y = lerp_f(b0[1], b1[1], b0[0], b1[0], kx);                                              // velo.h:465-470
+                            lerp_p(i1, i2, i1y, i2y, ky, o);                                                                       // velo.h:472-477
+                            kp_with_depth[3 * n_out] = o[0]; kp_with_depth[3 * n_out + 1] = o[1]; kp_with_depth[3 * n_out + 2] = o[2];
+                            has_depth[k] = n_out++;                                                                                // velo.h:481-483
+                        }
+                    }
+                    last_interp = mid;
+                    break;
+                }
+            }
+            if (!found) last_interp = -1;                                                         // velo.h:488-490
+            if (has_depth[k] != -1) break;
+        }
+    }
+    return n_out;
+}
+
 }  // extern "C"

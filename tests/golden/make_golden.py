@@ -70,8 +70,22 @@ def functor_vectors():
     return dict(kind=np.array(kinds), c=np.array(consts), x=np.array(xs), r=np.array(rs), J=np.array(Js))
 
 
+def depth_mini():
+    """a 16-ring x 700-azimuth scan, camera 1 (non-zero cam_t), 200 keypoints."""
+    d = synth.scan_pair(n_beams=16, n_azimuth=700)
+    w = synth.cam_window()
+    t = synth.CAM_TRANS[1]
+    proj, pts, off = ol.project_lidar(d["tgt_xyz"], d["tgt_off"], t, w)
+    kps = synth.keypoints_in_window(200, seed=5)
+    kd, has = ol.depth_association(proj, pts, off, kps, synth.DEPTH_ASSOC_THRESH)
+    return dict(xyz=d["tgt_xyz"], off=d["tgt_off"], cam_t=t, window=w, proj_xy=proj, proj_pts=pts, proj_off=off,
+                keypoints=kps, thresh=np.float64(synth.DEPTH_ASSOC_THRESH), kp_with_depth=kd, has_depth=has)
+
+
+FIXTURES = {"mini_pair": mini_pair, "functors": functor_vectors, "depth_mini": depth_mini}
+
 if __name__ == "__main__":
-    np.savez_compressed(os.path.join(HERE, "mini_pair.npz"), **mini_pair())
-    np.savez_compressed(os.path.join(HERE, "functors.npz"), **functor_vectors())
-    for f in ("mini_pair.npz", "functors.npz"):
-        print(f, os.path.getsize(os.path.join(HERE, f)), "bytes")
+    for name in (sys.argv[1:] or list(FIXTURES)):            # python make_golden.py [fixture ...]
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **FIXTURES[name]())
+        print(name + ".npz", os.path.getsize(path), "bytes")

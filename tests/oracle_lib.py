@@ -213,3 +213,39 @@ def pose_mat_to_vec(T):
     x = np.zeros(6)
     lib().vo_pose_mat_to_vec(_d(T, 16).ctypes.data_as(_dp), x.ctypes.data_as(_dp))
     return x
+
+
+# ---- SURVEY.md 8(f) row 3 (stateless oracle functions) -----------------------------------------------------------------
+def project_lidar(xyz, ring_off, cam_t, window):
+    """-> (proj_xy [n,2], points_xyz [n,3], ring_offsets [Rs+1]) per velo.h:329-374."""
+    l = lib()
+    xyz = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+    off = np.ascontiguousarray(ring_off, dtype=np.int32)
+    t = np.ascontiguousarray(cam_t, dtype=np.float32).reshape(3)
+    w = _d(window, 4)
+    n = len(xyz)
+    proj = np.zeros((max(n, 1), 2), dtype=np.float32)
+    pts = np.zeros((max(n, 1), 3), dtype=np.float32)
+    ooff = np.zeros(len(off), dtype=np.int32)
+    l.vo_project_lidar.restype = C.c_int
+    m = l.vo_project_lidar(C.c_void_p(xyz.ctypes.data), C.c_int64(12), C.c_void_p(off.ctypes.data), C.c_int32(len(off) - 1),
+                           C.c_void_p(t.ctypes.data), w.ctypes.data_as(_dp), C.c_void_p(proj.ctypes.data), C.c_void_p(pts.ctypes.data),
+                           C.c_void_p(ooff.ctypes.data))
+    return proj[:m].copy(), pts[:m].copy(), ooff
+
+
+def depth_association(proj_xy, points_xyz, ring_off, keypoints_xy, thresh=0.015):
+    """-> (kp_with_depth [m,3], has_depth [n]) per velo.h:376-497."""
+    l = lib()
+    proj = np.ascontiguousarray(proj_xy, dtype=np.float32).reshape(-1, 2)
+    pts = np.ascontiguousarray(points_xyz, dtype=np.float32).reshape(-1, 3)
+    off = np.ascontiguousarray(ring_off, dtype=np.int32)
+    kp = np.ascontiguousarray(keypoints_xy, dtype=np.float32).reshape(-1, 2)
+    n = len(kp)
+    out = np.zeros((max(n, 1), 3), dtype=np.float32)
+    has = np.full(max(n, 1), -1, dtype=np.int32)
+    l.vo_depth_association.restype = C.c_int
+    m = l.vo_depth_association(C.c_void_p(proj.ctypes.data), C.c_void_p(pts.ctypes.data), C.c_void_p(off.ctypes.data),
+                               C.c_int32(len(off) - 1), C.c_void_p(kp.ctypes.data), C.c_int32(n), C.c_double(thresh),
+                               C.c_void_p(out.ctypes.data), C.c_void_p(has.ctypes.data))
+    return out[:m].copy(), has[:n].copy()

@@ -1,10 +1,12 @@
 """-m gpu: the rows SURVEY.md 8(f) marks "next", each to the same bar as the path:
   row 1  device-side scan ingestion  (kitti.h:121-185)  -- bit-exact against the numpy restatement of the ring segmenter;
-  row 2  pose hand-off / odometry loop (main.cpp:305-331,407-437, kitti.h:202-216) -- same chain as the oracle driven on the CPU."""
+  row 2  pose hand-off / odometry loop (main.cpp:305-331,407-437, kitti.h:202-216) -- same chain as the oracle driven on the CPU;
+  row 3  projectLidarToCamera + featureDepthAssociation (velo.h:329-497) -- bit-exact (float) against the oracle's restatement."""
 import numpy as np
 import pytest
 
 import helpers as H
+import oracle_lib as O
 from velo_amd import api, odometry, synth
 
 pytestmark = pytest.mark.gpu
@@ -82,3 +84,111 @@ def test_odometry_loop_matches_cpu_chain_and_truth(hip_lib, oracle, tmp_path):
     assert len(lines) == 5 and lines[0].split() == ["1", "0", "0", "0", "0", "1", "0", "0", "0", "0", "1", "0"]
     assert all(len(l.split()) == 12 for l in lines)
     odo.close()
+
+
+# ---- row 3: camera projection of the rings + keypoint depth -----------------------------------------------------------------
+def _check_projection(c, xyz, off, cam_t, window, of_target):
+    n = c.project_lidar(of_target, cam_t, window)
+    got = c.projection()
+    want = O.project_lidar(xyz, off, cam_t, window)
+    assert n == len(want[0])
+    assert np.array_equal(got[2], want[2])
+    assert np.array_equal(got[0].view(np.uint32), want[0].view(np.uint32))
+    assert np.array_equal(got[1].view(np.uint32), want[1].view(np.uint32))
+    return want
+
+
+def _check_depth(c, want_proj, kps, thresh):
+    kd, has = c.depth_association(kps, thresh)
+    wkd, whas = O.depth_association(*want_proj, kps, thresh)
+    assert np.array_equal(has, whas)
+    assert np.array_equal(kd.view(np.uint32), wkd.view(np.uint32))
+    return int((has >= 0).sum())
+
+
+@pytest.mark.parametrize("cam", [0, 1])
+def test_projection_and_depth_match_oracle_on_the_street_scan(hip_lib, cam):
+    d = synth.scan_pair()                                   # 64 x 1875
+    w = synth.cam_window()
+    c = api.Context(0)
+    c.set_target(d["tgt_xyz"], d["tgt_off"])
+    c.set_source(d["src_xyz"], d["src_off"])
+    for of_target, xyz, off in ((True, d["tgt_xyz"], d["tgt_off"]), (False, d["src_xyz"], d["src_off"])):
+        want = _check_projection(c, xyz, off, synth.CAM_TRANS[cam], w, of_target)
+        assert _check_depth(c, want, synth.keypoints_in_window(5000, seed=31 + cam), synth.DEPTH_ASSOC_THRESH) > 1000
+    c.close()
+
+
+def test_projection_stack_rules_on_crafted_rings(hip_lib):
+    from test_depth_oracle import crafted_rings
+    xyz, off = crafted_rings(n_rings=150)                    # > 64 rings: the keypoint search carries state across lane chunks
+    w = synth.cam_window()
+    c = api.Context(0)
+    c.set_source(xyz, off)
+    for cam in (0, 1):
+        want = _check_projection(c, xyz, off, synth.CAM_TRANS[cam], w, False)
+        kps = synth.keypoints_in_window(700, seed=3)
+        kps[5] = (np.nan, 0.0)
+        kps[6] = (0.0, np.nan)
+        assert _check_depth(c, want, kps, 0.2) > 50
+        _check_depth(c, want, kps, synth.DEPTH_ASSOC_THRESH)
+        _check_depth(c, want, kps[:1], 0.2)
+    c.close()
+
+
+def test_depth_golden_fixture_and_call_order(hip_lib):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "depth_mini.npz"))
+    c = api.Context(0)
+    with pytest.raises(api.VeloError):
+        c.depth_association(g["keypoints"])                  # nothing projected yet
+    with pytest.raises(api.VeloError):
+        c.project_lidar(True, g["cam_t"], g["window"])       # no target loaded
+    c.set_target(g["xyz"], g["off"])
+    assert c.project_lidar(True, g["cam_t"], g["window"]) == len(g["proj_xy"])
+    xy, pts, off = c.projection()
+    assert np.array_equal(off, g["proj_off"])
+    assert np.array_equal(xy.view(np.uint32), g["proj_xy"].view(np.uint32))
+    assert np.array_equal(pts.view(np.uint32), g["proj_pts"].view(np.uint32))
+    kd, has = c.depth_association(g["keypoints"], float(g["thresh"]))
+    assert np.array_equal(has, g["has_depth"])
+    assert np.array_equal(kd.view(np.uint32), g["kp_with_depth"].view(np.uint32))
+    kd0, has0 = c.depth_association(np.zeros((0, 2), np.float32))
+    assert len(kd0) == 0 and len(has0) == 0
+    # a window nothing falls into: empty lists, no keypoint gets depth
+    assert c.project_lidar(True, g["cam_t"], [5.0, 6.0, 5.0, 6.0]) == 0
+    kd1, has1 = c.depth_association(g["keypoints"])
+    assert len(kd1) == 0 and np.all(has1 == -1)
+    c.close()
+
+
+def test_depth_feeds_the_visual_rows(hip_lib, oracle):
+    """Depth from the device feeds rows R2/R4 like the reference's pipeline does: 3-D keypoints of both frames from the two
+    scans, matched by construction (same keypoints seen from both poses), go through frame_to_frame on both sides."""
+    d = synth.scan_pair(n_beams=64, n_azimuth=1875)
+    w = synth.cam_window()
+    c = api.Context(0, icp_skip=50)
+    o = O.Oracle(icp_skip=50)
+    H.load_both(c, o, d)
+    c.project_lidar(True, synth.CAM_TRANS[0], w)
+    kps = synth.keypoints_in_window(800, seed=77)
+    kd, has = c.depth_association(kps)
+    sel = np.nonzero(has >= 0)[0]
+    assert len(sel) > 200
+    # current-frame 3-D point = the previous-frame one moved by the true motion (x_true maps frame1 -> frame2, so invert it)
+    R = synth.rotvec_to_matrix(d["x_true"][:3])
+    P2 = kd[has[sel]].astype(np.float64)
+    P1 = (P2 - d["x_true"][3:]) @ R
+    q1 = P1[:, :2] / P1[:, 2:3]
+    n = len(sel)
+    rec = dict(cam=np.zeros(n, np.int32), point1=np.arange(n, dtype=np.int32), point2=np.arange(n, dtype=np.int32),
+               d1=np.ones(n, np.uint8), d2=np.ones(n, np.uint8), p3_1=P1.astype(np.float32), p3_2=P2.astype(np.float32),
+               p2_1=q1.astype(np.float32), p2_2=kps[sel], t_cam=np.zeros((n, 3), np.float32))
+    vis = api.matches_from_dict(rec)
+    c.set_visual(vis)
+    o.set_visual(vis)
+    xg, _, sg = c.frame_to_frame(d["x0"])
+    xo, _, so = o.frame_to_frame(d["x0"])
+    assert H.pose_close(xg, xo)
+    assert sg.solves[0].n_visual_blocks == so.solves[0].n_visual_blocks > 0
+    c.close()

@@ -152,6 +152,9 @@ SIGNATURES = {
     "velo_comm_set_target_sharded": (C.c_int, [_ctx, C.c_int]),
     "velo_set_query_shard": (C.c_int, [_ctx, C.c_int32, C.c_int32]),
     "velo_synchronize": (C.c_int, [_ctx]),
+    "velo_project_lidar": (C.c_int, [_ctx, C.c_int32, C.c_void_p, _dp, _P(C.c_int32)]),
+    "velo_get_projection": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, _P(C.c_int32)]),
+    "velo_depth_association": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, _P(C.c_int32)]),
 }
 
 _lib = None
@@ -377,6 +380,43 @@ class Context:
 
     def synchronize(self):
         self._check(self._lib.velo_synchronize(self._h))
+
+    # -- camera projection of a scan + keypoint depth (velo.h:329-497) -------------------------------------------
+    def project_lidar(self, of_target: bool, cam_t, window) -> int:
+        """projectLidarToCamera for one camera on the rings held as source/target; returns the number of kept points."""
+        t = np.ascontiguousarray(np.asarray(cam_t, dtype=np.float32).reshape(-1))
+        if t.size != 3:
+            raise ValueError("cam_t: 3 floats")
+        w = _dvec(window, 4)
+        n = C.c_int32(0)
+        self._check(self._lib.velo_project_lidar(self._h, int(bool(of_target)), C.c_void_p(t.ctypes.data), _ptr(w), C.byref(n)))
+        return n.value
+
+    def projection(self):
+        """(proj_xy [n,2] f32, points_xyz [n,3] f32, ring_offsets [Rs+1] i32) of the last project_lidar."""
+        nr = C.c_int32(0)
+        self._check(self._lib.velo_get_projection(self._h, None, None, 0, None, 0, C.byref(nr)))
+        off = np.zeros(nr.value + 1, dtype=np.int32)
+        self._check(self._lib.velo_get_projection(self._h, None, None, 0, C.c_void_p(off.ctypes.data), off.size, C.byref(nr)))
+        n = int(off[-1])
+        xy = np.zeros((n, 2), dtype=np.float32)
+        pts = np.zeros((n, 3), dtype=np.float32)
+        if n:
+            self._check(self._lib.velo_get_projection(self._h, C.c_void_p(xy.ctypes.data), C.c_void_p(pts.ctypes.data), n,
+                                                      C.c_void_p(off.ctypes.data), off.size, C.byref(nr)))
+        return xy, pts, off
+
+    def depth_association(self, keypoints_xy, thresh: float = 0.015):
+        """featureDepthAssociation against the last project_lidar: (kp_with_depth [m,3] f32, has_depth [n] i32)."""
+        kp = np.ascontiguousarray(np.asarray(keypoints_xy, dtype=np.float32).reshape(-1, 2))
+        n = len(kp)
+        has = np.full(n, -1, dtype=np.int32)
+        out = np.zeros((max(n, 1), 3), dtype=np.float32)
+        m = C.c_int32(0)
+        self._check(self._lib.velo_depth_association(self._h, C.c_void_p(kp.ctypes.data) if n else None, n, float(thresh),
+                                                     C.c_void_p(out.ctypes.data), n, C.c_void_p(has.ctypes.data) if n else None,
+                                                     C.byref(m)))
+        return out[:m.value].copy(), has
 
     # -- multi-GPU -------------------------------------------------------------------------------------------
     def set_query_shard(self, rank: int, world: int):

@@ -22,6 +22,7 @@
 
 #include "../../include/velo_hip.h"
 #include "velo_kernels.h"
+#include "velo_depth_kernels.h"
 
 using namespace velo;
 
@@ -186,6 +187,14 @@ struct velo_ctx {
     int* h_int = nullptr;                // pinned scratch
     DevBuf<int> row_off_vis, row_off_icp;
     DevBuf<double> rows_r, rows_J;
+
+    // camera projection of a scan + keypoint depth association
+    DevBuf<float4> pstack, vstack, kp_point, kp_out;
+    DevBuf<float2> kps;
+    DevBuf<int> proj_off, ring_cnt, kp_flag, kp_excl, kp_has;
+    std::vector<int> h_proj_off, h_ring_cnt;   // offsets of the projected cloud (copied: the cloud may be replaced later)
+    int proj_rings = 0, proj_points = 0, proj_of_target = 0;
+    bool have_projection = false;
 
     // sharding / comm
     int shard_rank = 0, shard_world = 1;
@@ -1357,6 +1366,103 @@ int velo_synchronize(velo_ctx* c) {
     if (!c) return fail(VELO_ERR_INVALID, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return VELO_OK;
+}
+
+// ---- projectLidarToCamera + featureDepthAssociation (velo.h:329-497) ---------------------------------
+int velo_project_lidar(velo_ctx* c, int32_t of_target, const float cam_t[3], const double bounds[4], int32_t* n_valid_total) {
+    if (!c || !cam_t || !bounds) return fail(VELO_ERR_INVALID, "null argument");
+    if (of_target ? !c->have_target : !c->have_source) return fail(VELO_ERR_STATE, "no %s cloud loaded", of_target ? "target" : "source");
+    HIP_TRY(hipSetDevice(c->device));
+    const int n = of_target ? c->n_tgt : c->n_src;
+    const std::vector<int>& h_off = of_target ? c->h_tgt_off : c->h_src_off;
+    const int nr = (int)h_off.size() - 1;
+    c->have_projection = false;
+    c->h_proj_off = h_off;
+    c->proj_rings = nr; c->proj_points = n; c->proj_of_target = of_target ? 1 : 0;
+    c->h_ring_cnt.assign((size_t)std::max(nr, 0), 0);
+    VELO_TRY(c->pstack.reserve((size_t)std::max(n, 1)));
+    VELO_TRY(c->vstack.reserve((size_t)std::max(n, 1)));
+    VELO_TRY(c->ring_cnt.reserve((size_t)std::max(nr, 1)));
+    VELO_TRY(c->proj_off.reserve((size_t)nr + 1));
+    if (nr > 0) {
+        HIP_TRY(hipMemcpyAsync(c->proj_off.p, h_off.data(), sizeof(int) * ((size_t)nr + 1), hipMemcpyHostToDevice, c->stream));
+        CamWindow W;
+        W.tx = cam_t[0]; W.ty = cam_t[1]; W.tz = cam_t[2];
+        W.min_x = bounds[0]; W.max_x = bounds[1]; W.min_y = bounds[2]; W.max_y = bounds[3];
+        hipLaunchKernelGGL(project_ring_kernel, dim3(nr), dim3(256), 0, c->stream, (const float4*)(of_target ? c->tgt.p : c->src.p),
+                           (const int*)c->proj_off.p, nr, W, c->pstack.p, c->vstack.p, c->ring_cnt.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(c->h_ring_cnt.data(), c->ring_cnt.p, sizeof(int) * (size_t)nr, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    c->have_projection = true;
+    if (n_valid_total) {
+        int64_t tot = 0;
+        for (int v : c->h_ring_cnt) tot += v;
+        *n_valid_total = (int32_t)tot;
+    }
+    return VELO_OK;
+}
+
+int velo_get_projection(velo_ctx* c, float* proj_xy, float* points_xyz, int32_t capacity_points, int32_t* ring_offsets,
+                        int32_t capacity_offsets, int32_t* n_rings) {
+    if (!c) return fail(VELO_ERR_INVALID, "null ctx");
+    if (!c->have_projection) return fail(VELO_ERR_STATE, "velo_project_lidar has not run");
+    const int nr = c->proj_rings;
+    if (n_rings) *n_rings = nr;
+    std::vector<int> out_off((size_t)nr + 1, 0);
+    for (int s = 0; s < nr; s++) out_off[s + 1] = out_off[s] + c->h_ring_cnt[s];
+    if (ring_offsets) for (int s = 0; s <= nr && s < capacity_offsets; s++) ring_offsets[s] = out_off[s];
+    if ((!proj_xy && !points_xyz) || capacity_points <= 0 || c->proj_points == 0) return VELO_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<float4> hp((size_t)c->proj_points), hv((size_t)c->proj_points);
+    HIP_TRY(hipMemcpy(hp.data(), c->pstack.p, sizeof(float4) * hp.size(), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(hv.data(), c->vstack.p, sizeof(float4) * hv.size(), hipMemcpyDeviceToHost));
+    for (int s = 0; s < nr; s++)
+        for (int j = 0; j < c->h_ring_cnt[s]; j++) {
+            const int o = out_off[s] + j;
+            if (o >= capacity_points) return VELO_OK;
+            const float4 a = hp[(size_t)c->h_proj_off[s] + j], v = hv[(size_t)c->h_proj_off[s] + j];
+            if (proj_xy) { proj_xy[2 * o] = a.x; proj_xy[2 * o + 1] = a.y; }
+            if (points_xyz) { points_xyz[3 * o] = v.x; points_xyz[3 * o + 1] = v.y; points_xyz[3 * o + 2] = v.z; }
+        }
+    return VELO_OK;
+}
+
+int velo_depth_association(velo_ctx* c, const float* keypoints_xy, int32_t n, double thresh, float* kp_with_depth_xyz,
+                           int32_t capacity_points, int32_t* has_depth, int32_t* n_with_depth) {
+    if (!c || n < 0 || (n > 0 && (!keypoints_xy || !has_depth))) return fail(VELO_ERR_INVALID, "bad keypoint arguments");
+    if (!c->have_projection) return fail(VELO_ERR_STATE, "velo_project_lidar has not run");
+    if (n_with_depth) *n_with_depth = 0;
+    if (n == 0) return VELO_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    VELO_TRY(c->kps.reserve((size_t)n)); VELO_TRY(c->kp_point.reserve((size_t)n)); VELO_TRY(c->kp_out.reserve((size_t)n));
+    VELO_TRY(c->kp_flag.reserve((size_t)n + 2)); VELO_TRY(c->kp_excl.reserve((size_t)n + 2)); VELO_TRY(c->kp_has.reserve((size_t)n));
+    VELO_TRY(c->cursor.reserve((size_t)n + 2));
+    const int n_tiles = cdiv(n, kScanTile);
+    VELO_TRY(c->scan_tiles.reserve((size_t)n_tiles + 1));
+    VELO_TRY(c->scan_total.reserve(1));
+    HIP_TRY(hipMemcpyAsync(c->kps.p, keypoints_xy, sizeof(float2) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(depth_assoc_kernel, dim3(cdiv(n, 4)), dim3(256), 0, c->stream, (const float2*)c->kps.p, n, (const float4*)c->pstack.p,
+                       (const float4*)c->vstack.p, (const int*)c->proj_off.p, (const int*)c->ring_cnt.p, c->proj_rings, thresh, c->kp_point.p, c->kp_flag.p);
+    HIP_TRY(hipMemcpyAsync(c->kp_excl.p, c->kp_flag.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(n_tiles), dim3(kScanThreads), 0, c->stream, c->kp_excl.p, n, c->scan_tiles.p);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kScanThreads), 0, c->stream, c->scan_tiles.p, n_tiles, c->scan_total.p);
+    hipLaunchKernelGGL(scan_add_kernel, dim3(cdiv(n + 1, 256)), dim3(256), 0, c->stream, c->kp_excl.p, n, c->scan_tiles.p, c->scan_total.p, c->cursor.p);
+    hipLaunchKernelGGL(depth_compact_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const int*)c->kp_flag.p, (const int*)c->kp_excl.p,
+                       (const float4*)c->kp_point.p, n, c->kp_has.p, c->kp_out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(has_depth, c->kp_has.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_int, c->scan_total.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int nd = c->h_int[0];
+    if (n_with_depth) *n_with_depth = nd;
+    if (kp_with_depth_xyz && capacity_points > 0 && nd > 0) {
+        std::vector<float4> h((size_t)nd);
+        HIP_TRY(hipMemcpy(h.data(), c->kp_out.p, sizeof(float4) * (size_t)nd, hipMemcpyDeviceToHost));
+        for (int i = 0; i < nd && i < capacity_points; i++) { kp_with_depth_xyz[3 * i] = h[i].x; kp_with_depth_xyz[3 * i + 1] = h[i].y; kp_with_depth_xyz[3 * i + 2] = h[i].z; }
+    }
     return VELO_OK;
 }
 

@@ -34,6 +34,28 @@ VELO_TO_CAM = np.array(
 
 CAM_TRANS = np.array([[0.0, 0.0, 0.0], [-0.537, 0.0, 0.0]], dtype=np.float32)
 
+# KITTI-grey-shaped intrinsics and image size (kitti.h:37-38); the canonical-coordinate window of each camera is computed the
+# way kitti.h:85-97 does it: K^-1 * (0,0,1) and K^-1 * (w,h,1) in float, divided by z, widened to double.
+IMG_WIDTH, IMG_HEIGHT = 1226, 370
+CAM_K = np.array([[718.856, 0.0, 607.1928], [0.0, 718.856, 185.2157], [0.0, 0.0, 1.0]], dtype=np.float32)
+DEPTH_ASSOC_THRESH = 0.015                                   # kitti.h:28
+
+
+def cam_window() -> np.ndarray:
+    """(min_x, max_x, min_y, max_y) as doubles, same for both cameras of the idealised rig."""
+    kinv = np.linalg.inv(CAM_K.astype(np.float64)).astype(np.float32)
+    lo = kinv @ np.array([0.0, 0.0, 1.0], dtype=np.float32)
+    hi = kinv @ np.array([IMG_WIDTH, IMG_HEIGHT, 1.0], dtype=np.float32)
+    return np.array([np.float32(lo[0] / lo[2]), np.float32(hi[0] / hi[2]), np.float32(lo[1] / lo[2]), np.float32(hi[1] / hi[2])],
+                    dtype=np.float64)
+
+
+def keypoints_in_window(n: int, seed: int = 7, window=None) -> np.ndarray:
+    """n synthetic keypoints in canonical coordinates, uniform over the camera window (float32 [n,2])."""
+    w = cam_window() if window is None else np.asarray(window, dtype=np.float64)
+    u = uniform01(seed, 2 * n, stream=9).reshape(n, 2)
+    return np.stack([w[0] + u[:, 0] * (w[1] - w[0]), w[2] + u[:, 1] * (w[3] - w[2])], axis=1).astype(np.float32)
+
 
 # --- counter-based RNG -----------------------------------------------------------------------
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
