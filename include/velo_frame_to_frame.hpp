@@ -24,8 +24,10 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -86,10 +88,14 @@ private:
     std::vector<int32_t> off_;
 };
 
-// The reference's globals the path reads (kitti.h:3,46-47): number of cameras and cam_trans[cam].
+// The reference's globals the path reads (kitti.h:3,46-47): number of cameras and cam_trans[cam]; for the depth rows also
+// the canonical-coordinate window {min_x, max_x, min_y, max_y}[cam] (kitti.h:51,85-97) and depth_assoc_thresh (kitti.h:28).
 struct Rig {
     int num_cams = 2;
     std::vector<std::array<float, 3>> cam_trans{{{0.f, 0.f, 0.f}}, {{-0.537f, 0.f, 0.f}}};
+    std::vector<std::array<double, 4>> window{{{-0.84466541, 0.8608222, -0.25765342, 0.25705326}},
+                                              {{-0.84466541, 0.8608222, -0.25765342, 0.25705326}}};
+    double depth_assoc_thresh = 0.015;
 };
 
 // frameToFrame, same parameter list and meaning as velo.h:598-614.  `ctx` and `rig` are the two additions (the
@@ -165,6 +171,54 @@ Mat4 frameToFrame(Context& ctx, const Rig& rig,
     Mat4 out;
     for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) out(i, j) = T[i * 4 + j];
     return out;
+}
+
+// projectLidarToCamera, velo.h:329-334.  The rings are the ones `ctx` already holds -- `of_target` says in which slot (the
+// frame just loaded for frameToFrame), so nothing is uploaded again; `projection` and `scans_valid` are filled like the
+// reference fills them (one list per ring) for callers that draw or inspect them.  The lists also stay on the device,
+// which is what featureDepthAssociation below searches.
+template <typename Point2, typename Cloud>
+void projectLidarToCamera(Context& ctx, const Rig& rig, bool of_target, std::vector<std::vector<Point2>>& projection,
+                          std::vector<std::shared_ptr<Cloud>>& scans_valid, const int cam) {
+    int32_t n = 0, nr = 0;
+    check(velo_project_lidar(ctx.get(), of_target ? 1 : 0, rig.cam_trans[cam].data(), rig.window[cam].data(), &n), "velo_project_lidar");
+    check(velo_get_projection(ctx.get(), nullptr, nullptr, 0, nullptr, 0, &nr), "velo_get_projection");
+    std::vector<int32_t> off((size_t)nr + 1);
+    std::vector<float> xy(2 * (size_t)n + 2), pts(3 * (size_t)n + 3);
+    check(velo_get_projection(ctx.get(), xy.data(), pts.data(), n, off.data(), nr + 1, &nr), "velo_get_projection");
+    for (int s = 0; s < nr; s++) {
+        projection.push_back(std::vector<Point2>());
+        scans_valid.push_back(std::shared_ptr<Cloud>(new Cloud));
+        for (int j = off[s]; j < off[s + 1]; j++) {
+            Point2 c; c.x = xy[2 * j]; c.y = xy[2 * j + 1];
+            projection.back().push_back(c);
+            typename std::remove_const<typename std::remove_reference<decltype(scans_valid.back()->at(0))>::type>::type p;
+            p.x = pts[3 * j]; p.y = pts[3 * j + 1]; p.z = pts[3 * j + 2];
+            scans_valid.back()->push_back(p);
+        }
+    }
+}
+
+// featureDepthAssociation, velo.h:376-382, against the last projectLidarToCamera of `ctx` (the reference passes the lists
+// back in; here they never left the device).  Appends to keypoints_with_depth, fills and returns has_depth.
+template <typename Point2, typename CloudPtr>
+std::vector<int> featureDepthAssociation(Context& ctx, const Rig& rig, const std::vector<Point2>& keypoints,
+                                         CloudPtr keypoints_with_depth, std::vector<int>& has_depth) {
+    static_assert(sizeof(Point2) == 2 * sizeof(float), "keypoints must be packed (x, y) floats like cv::Point2f");
+    has_depth.assign(keypoints.size(), -1);
+    if (keypoints.empty()) return has_depth;
+    std::vector<int32_t> has(keypoints.size());
+    std::vector<float> xyz(3 * keypoints.size());
+    int32_t n3d = 0;
+    check(velo_depth_association(ctx.get(), &keypoints[0].x, (int32_t)keypoints.size(), rig.depth_assoc_thresh, xyz.data(),
+                                 (int32_t)keypoints.size(), has.data(), &n3d), "velo_depth_association");
+    for (size_t k = 0; k < keypoints.size(); k++) has_depth[k] = has[k];
+    for (int i = 0; i < n3d; i++) {
+        typename std::remove_const<typename std::remove_reference<decltype(keypoints_with_depth->at(0))>::type>::type p;
+        p.x = xyz[3 * i]; p.y = xyz[3 * i + 1]; p.z = xyz[3 * i + 2];
+        keypoints_with_depth->push_back(p);
+    }
+    return has_depth;
 }
 
 }  // namespace velo_hip

@@ -86,6 +86,26 @@ int main(int argc, char** argv) {
         for (int c = 0; c < num_cams; c++)
             for (size_t i = 0; i < good_matches[c].size(); i++)
                 printf("g %d %d %d %d\n", c, good_matches[c][i].first, good_matches[c][i].second, (int)residual_type[c][i]);
+        // the depth rows (main.cpp:594-604) on the target rings the context still holds: the previous frame's keypoints
+        rig.depth_assoc_thresh = 0.2;                  // the 128-azimuth test rings are coarser than KITTI's
+        for (int c = 0; c < num_cams; c++) {
+            std::vector<std::vector<Point2f>> projection;
+            std::vector<PointCloud::Ptr> scans_valid;
+            velo_hip::projectLidarToCamera(ctx, rig, true, projection, scans_valid, c);
+            size_t n_proj = 0;
+            for (size_t s = 0; s < projection.size(); s++) {
+                if (projection[s].size() != scans_valid[s]->size()) return 4;
+                n_proj += projection[s].size();
+            }
+            PointCloud::Ptr kp3(new PointCloud);
+            std::vector<int> hd;
+            velo_hip::featureDepthAssociation(ctx, rig, keypoints[c][frame2], kp3, hd);
+            printf("d %d %zu %zu %zu\n", c, projection.size(), n_proj, kp3->size());
+            for (size_t k = 0; k < hd.size(); k++) {
+                if (hd[k] < 0) printf("h %d %zu -1 0 0 0\n", c, k);
+                else printf("h %d %zu %d %.9g %.9g %.9g\n", c, k, hd[k], kp3->at(hd[k]).x, kp3->at(hd[k]).y, kp3->at(hd[k]).z);
+            }
+        }
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 3;

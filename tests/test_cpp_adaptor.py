@@ -54,7 +54,7 @@ def test_adaptor_matches_oracle(tmp_path, oracle):
     out = subprocess.run([exe, case], check=True, capture_output=True, text=True).stdout.splitlines()
     x = np.array([float(v) for v in out[0].split()[1:]])
     T = np.array([float(v) for v in out[1].split()[1:]]).reshape(4, 4)
-    good = np.array([[int(v) for v in line.split()[1:]] for line in out[2:]]).reshape(-1, 4)
+    good = np.array([[int(v) for v in line.split()[1:]] for line in out[2:] if line.startswith("g ")]).reshape(-1, 4)
     orc = oracle.Oracle(icp_skip=2)
     orc.set_target(d["tgt_xyz"], d["tgt_off"])
     orc.set_source(d["src_xyz"], d["src_off"])
@@ -67,3 +67,20 @@ def test_adaptor_matches_oracle(tmp_path, oracle):
     want = np.stack([g["cam"], g["point1"], g["point2"], g["residual_type"]], 1)
     want = want[np.argsort(want[:, 0], kind="stable")]
     assert np.array_equal(good, want)
+
+    # depth rows through the adaptor: projectLidarToCamera + featureDepthAssociation on the target rings, per camera
+    import oracle_lib as O
+    rig_window = [-0.84466541, 0.8608222, -0.25765342, 0.25705326]          # velo_hip::Rig defaults
+    for cam in (0, 1):
+        proj, pts, off = O.project_lidar(d["tgt_xyz"], d["tgt_off"], synth.CAM_TRANS[cam], rig_window)
+        kps = m["p2_2"][m["cam"] == cam]
+        kd, has = O.depth_association(proj, pts, off, kps, 0.2)
+        assert len(kd) > 5
+        head = [line.split() for line in out if line.startswith(f"d {cam} ")][0]
+        assert [int(v) for v in head[2:]] == [len(off) - 1, len(proj), len(kd)]
+        rows = [line.split() for line in out if line.startswith(f"h {cam} ")]
+        assert len(rows) == len(kps)
+        got_has = np.array([int(r[3]) for r in rows])
+        assert np.array_equal(got_has, has)
+        got_xyz = np.array([[np.float32(v) for v in r[4:7]] for r in rows], dtype=np.float32)[has >= 0]
+        assert np.array_equal(got_xyz.view(np.uint32), kd[has[has >= 0]].view(np.uint32))
