@@ -221,5 +221,49 @@ std::vector<int> featureDepthAssociation(Context& ctx, const Rig& rig, const std
     return has_depth;
 }
 
+// The loop at main.cpp:661-671 -- triangulatePoint (velo.h:1027-1033) for every id in `ids` -- as ONE device call.
+// Per landmark the arguments are the reference's: keypoint_obs2[id][cam] / keypoint_obs3[id][cam] are the per-camera
+// std::map<int frame, observation>, camera_poses[frame][0..5] the pose vectors, landmarks->at(id) the point (read as initial
+// guess when keypoint_added[id], always written), all borrowed for the call.  Observations are flattened in the order the
+// reference adds its residual blocks: 3-D ones camera-major in map order, then 2-D ones camera-major in map order.
+template <typename Obs2, typename Obs3, typename Poses, typename CloudPtr, typename Flags>
+void triangulatePoints(Context& ctx, const Rig& rig, const std::vector<int>& ids, const Obs2& keypoint_obs2, const Obs3& keypoint_obs3,
+                       const Poses& camera_poses, int n_frames, CloudPtr landmarks, const Flags& keypoint_added) {
+    if (ids.empty()) return;
+    std::vector<velo_tri_obs> obs;
+    std::vector<int32_t> off(1, 0);
+    std::vector<float> pts(3 * ids.size());
+    std::vector<uint8_t> init(ids.size());
+    for (size_t l = 0; l < ids.size(); l++) {
+        const int id = ids[l];
+        for (int cam = 0; cam < rig.num_cams; cam++)
+            for (const auto& o3 : keypoint_obs3[id][cam]) {
+                velo_tri_obs o; o.kind = VELO_TRI_OBS_3D; o.frame = o3.first; o.cam = cam;
+                o.s[0] = o3.second.x; o.s[1] = o3.second.y; o.s[2] = o3.second.z;
+                obs.push_back(o);
+            }
+        for (int cam = 0; cam < rig.num_cams; cam++)
+            for (const auto& o2 : keypoint_obs2[id][cam]) {
+                velo_tri_obs o; o.kind = VELO_TRI_OBS_2D; o.frame = o2.first; o.cam = cam;
+                o.s[0] = o2.second.x; o.s[1] = o2.second.y; o.s[2] = 0.f;
+                obs.push_back(o);
+            }
+        off.push_back((int32_t)obs.size());
+        const auto& p = landmarks->at(id);
+        pts[3 * l] = p.x; pts[3 * l + 1] = p.y; pts[3 * l + 2] = p.z;
+        init[l] = keypoint_added[id] ? 1 : 0;
+    }
+    std::vector<double> poses(6 * (size_t)n_frames);
+    for (int f = 0; f < n_frames; f++) for (int i = 0; i < 6; i++) poses[6 * (size_t)f + i] = camera_poses[f][i];
+    std::vector<float> ct(3 * (size_t)rig.num_cams);
+    for (int cam = 0; cam < rig.num_cams; cam++) for (int i = 0; i < 3; i++) ct[3 * (size_t)cam + i] = rig.cam_trans[cam][i];
+    check(velo_triangulate_points(ctx.get(), poses.data(), n_frames, ct.data(), rig.num_cams, obs.empty() ? nullptr : obs.data(), off.data(),
+                                  (int32_t)ids.size(), pts.data(), init.data(), nullptr), "velo_triangulate_points");
+    for (size_t l = 0; l < ids.size(); l++) {
+        auto& p = landmarks->points[ids[l]];
+        p.x = pts[3 * l]; p.y = pts[3 * l + 1]; p.z = pts[3 * l + 2];
+    }
+}
+
 }  // namespace velo_hip
 #endif  // VELO_FRAME_TO_FRAME_HPP_

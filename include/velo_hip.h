@@ -144,6 +144,23 @@ typedef struct velo_solve_summary {
     double final_cost;
 } velo_solve_summary;
 
+/* --- "next" row 4 of SURVEY.md 8(f): batched triangulatePoint (velo.h:1027-1130) ------------------------------ */
+#define VELO_TRI_OBS_3D 0   /* triangulation3D (costfunctions.h:338-375), TrivialLoss (velo.h:1078) */
+#define VELO_TRI_OBS_2D 1   /* triangulation2D (costfunctions.h:288-336), ScaledLoss(CauchyLoss(loss_thresh_3D2D), weight_3D2D) (velo.h:1116-1119) */
+typedef struct velo_tri_obs {  /* one entry of keypoint_obs3[cam] / keypoint_obs2[cam] of one landmark: 24 bytes */
+    int32_t kind;              /* VELO_TRI_OBS_3D / VELO_TRI_OBS_2D */
+    int32_t frame;             /* the map key: index into camera_poses */
+    int32_t cam;               /* camera; a 2-D observation uses cam_trans[cam] */
+    float s[3];                /* 3-D: the observed point (camera-0 frame of `frame`); 2-D: canonical (x, y), s[2] unused */
+} velo_tri_obs;
+typedef struct velo_tri_result {   /* per landmark, optional: 24 bytes */
+    int32_t n_solves;          /* ceres::Solve calls the reference makes for it: 0 (no observation), 1 or 2 (velo.h:1080-1083,1123) */
+    int32_t termination;       /* of the last solve */
+    int32_t lm_iterations;     /* of the last solve */
+    int32_t evaluations;       /* over all solves */
+    double final_cost;
+} velo_tri_result;
+
 typedef struct velo_summary {
     int32_t n_solves;
     int32_t n_assoc_rounds;
@@ -279,6 +296,18 @@ int velo_get_projection(velo_ctx* ctx, float* proj_xy, float* points_xyz, int32_
  * float widths (velo.h:416,419) is restated as fabs, like the outlier gate. */
 int velo_depth_association(velo_ctx* ctx, const float* keypoints_xy, int32_t n_keypoints, double depth_assoc_thresh,
                            float* kp_with_depth_xyz, int32_t capacity_points, int32_t* has_depth, int32_t* n_with_depth);
+
+/* --- "next" row 4: every landmark of a frame triangulated in one call (main.cpp:661-671 loops triangulatePoint over ids) ---
+ * Landmark l owns obs[obs_offsets[l] .. obs_offsets[l+1]).  Residual blocks are added like velo.h:1049-1122: all 3-D
+ * observations in the order given, then all 2-D observations in the order given (pass them cam-major, frame ascending --
+ * the iteration order of the reference's per-camera std::map -- to reproduce its summation order).  Start value: the
+ * current point when initial_guess[l] != 0, else (0, 0, 10) and, if there is a 3-D observation, a first solve on the first
+ * 3-D block alone (velo.h:1080-1083).  The solver is the context's Ceres-default LM (velo_params), 3 unknowns.
+ * camera_poses: [n_frames][6] (angle-axis, translation) as in ceres_poses_vec; cam_trans: [n_cams][3] floats.
+ * points_xyz [n_landmarks][3] is read (initial guesses) and written (float, like pcl::PointXYZ); results may be NULL. */
+int velo_triangulate_points(velo_ctx* ctx, const double* camera_poses, int32_t n_frames, const float* cam_trans, int32_t n_cams,
+                            const velo_tri_obs* obs, const int32_t* obs_offsets, int32_t n_landmarks, float* points_xyz,
+                            const uint8_t* initial_guess, velo_tri_result* results);
 
 #ifdef __cplusplus
 }

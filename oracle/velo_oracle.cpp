@@ -696,6 +696,190 @@ void frame_to_frame(Oracle& o, double x[6], double T[16], velo_summary* sum) {
     if (T) pose_vec_to_mat(x, T);
 }
 
+// ------------------------------------------------------------------------------------------------
+// SURVEY.md 8(f) row 4 restated: triangulatePoint (velo.h:1027-1130) with the functors of costfunctions.h:288-375.
+// One 3-unknown problem per landmark, Jacobians by the same dual numbers as the main path (Jet<3>), the same LM.
+// ------------------------------------------------------------------------------------------------
+// triangulation3D::operator()  costfunctions.h:358-372
+template <typename T> inline void res_tri3d(const double* cam, const double* sv, const T* x, T* r) {
+    T rot[3] = {-T(cam[0]), -T(cam[1]), -T(cam[2])};
+    T m0[3] = {x[0] - T(cam[3]), x[1] - T(cam[4]), x[2] - T(cam[5])}, m[3];
+    angle_axis_rotate_point(rot, m0, m);
+    r[0] = m[0] - T(sv[0]);
+    r[1] = m[1] - T(sv[1]);
+    r[2] = m[2] - T(sv[2]);
+}
+// triangulation2D::operator()  costfunctions.h:315-332
+template <typename T> inline void res_tri2d(const double* cam, const double* sv, const double* t, const T* x, T* r) {
+    T rot[3] = {-T(cam[0]), -T(cam[1]), -T(cam[2])};
+    T m0[3] = {x[0] - T(cam[3]), x[1] - T(cam[4]), x[2] - T(cam[5])}, m[3];
+    angle_axis_rotate_point(rot, m0, m);
+    m[0] += T(t[0]);
+    m[1] += T(t[1]);
+    m[2] += T(t[2]);
+    r[0] = m[0] - T(sv[0]) * m[2];
+    r[1] = m[1] - T(sv[1]) * m[2];
+}
+
+struct TriEval { double cost; double H[9]; double g[3]; };
+struct TriProblem {
+    const double* poses; const float* cam_trans; const velo_tri_obs* obs; int n_obs;
+    bool first_3d_only;          // the solve at velo.h:1080-1083: only the first 3-D block is in the problem
+    Loss loss2d;
+};
+void tri_evaluate(const TriProblem& Q, const double x[3], TriEval* out) {
+    out->cost = 0.0;
+    std::memset(out->H, 0, sizeof(out->H));
+    std::memset(out->g, 0, sizeof(out->g));
+    typedef Jet<3> J3;
+    J3 xj[3];
+    for (int i = 0; i < 3; i++) { xj[i] = J3(x[i]); xj[i].v[i] = 1.0; }
+    for (int pass = 0; pass < 2; pass++) {                 // 3-D blocks first (velo.h:1049-1085), then 2-D (velo.h:1087-1122)
+        for (int k = 0; k < Q.n_obs; k++) {
+            const velo_tri_obs& o = Q.obs[k];
+            if ((o.kind == VELO_TRI_OBS_2D) != (pass == 1)) continue;
+            const double* cam = Q.poses + 6 * (size_t)o.frame;
+            const double sv[3] = {(double)o.s[0], (double)o.s[1], (double)o.s[2]};
+            J3 r[3];
+            int d;
+            Loss L{0, 0.0, 1.0};                           // TrivialLoss (velo.h:1078)
+            if (pass == 0) { res_tri3d<J3>(cam, sv, xj, r); d = 3; }
+            else {
+                const double t[3] = {(double)Q.cam_trans[3 * o.cam], (double)Q.cam_trans[3 * o.cam + 1], (double)Q.cam_trans[3 * o.cam + 2]};
+                res_tri2d<J3>(cam, sv, t, xj, r); d = 2; L = Q.loss2d;
+            }
+            double sq = 0.0;
+            for (int q = 0; q < d; q++) sq += r[q].a * r[q].a;
+            double rho[3];
+            loss_eval(L, sq, rho);
+            out->cost += 0.5 * rho[0];
+            const double sr = std::sqrt(rho[1]);
+            for (int q = 0; q < d; q++) {
+                const double rk = r[q].a * sr;
+                double Jk[3];
+                for (int i = 0; i < 3; i++) Jk[i] = r[q].v[i] * sr;
+                for (int i = 0; i < 3; i++) {
+                    out->g[i] += Jk[i] * rk;
+                    for (int j = 0; j < 3; j++) out->H[i * 3 + j] += Jk[i] * Jk[j];
+                }
+            }
+            if (Q.first_3d_only) return;
+        }
+        if (Q.first_3d_only) return;
+    }
+}
+
+bool chol_solve3(const double A[9], const double b[3], double y[3]) {
+    double L[9];
+    std::memset(L, 0, sizeof(L));
+    for (int j = 0; j < 3; j++) {
+        double d = A[j * 3 + j];
+        for (int k = 0; k < j; k++) d -= L[j * 3 + k] * L[j * 3 + k];
+        if (!(d > 0.0) || !std::isfinite(d)) return false;
+        L[j * 3 + j] = std::sqrt(d);
+        for (int i = j + 1; i < 3; i++) {
+            double sacc = A[i * 3 + j];
+            for (int k = 0; k < j; k++) sacc -= L[i * 3 + k] * L[j * 3 + k];
+            L[i * 3 + j] = sacc / L[j * 3 + j];
+        }
+    }
+    double z[3];
+    for (int i = 0; i < 3; i++) { double sacc = b[i]; for (int k = 0; k < i; k++) sacc -= L[i * 3 + k] * z[k]; z[i] = sacc / L[i * 3 + i]; }
+    for (int i = 2; i >= 0; i--) { double sacc = z[i]; for (int k = i + 1; k < 3; k++) sacc -= L[k * 3 + i] * y[k]; y[i] = sacc / L[i * 3 + i]; }
+    for (int i = 0; i < 3; i++) if (!std::isfinite(y[i])) return false;
+    return true;
+}
+
+// the same trust-region LM as solve() above, 3 unknowns
+void tri_solve(const velo_params& P, const TriProblem& Q, double x[3], velo_tri_result* S) {
+    TriEval E;
+    tri_evaluate(Q, x, &E);
+    S->evaluations++;
+    S->n_solves++;
+    S->lm_iterations = 0;
+    double cost = E.cost;
+    S->final_cost = cost;
+    double x_norm = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    auto gmax = [&](const TriEval& e) { double m = 0; for (int i = 0; i < 3; i++) m = std::max(m, std::fabs(e.g[i])); return m; };
+    if (gmax(E) <= P.gradient_tolerance) { S->termination = VELO_CONVERGENCE; return; }
+    double scale[3];
+    for (int j = 0; j < 3; j++) scale[j] = 1.0 / (1.0 + std::sqrt(E.H[j * 3 + j]));
+    double radius = P.initial_trust_region_radius, decrease = 2.0;
+    bool reuse_diag = false;
+    double diag[3];
+    int invalid = 0;
+    S->termination = VELO_NO_CONVERGENCE;
+    for (int it = 1;; it++) {
+        if (it > P.max_num_iterations) { S->termination = VELO_NO_CONVERGENCE; break; }
+        if (radius < P.min_trust_region_radius) { S->termination = VELO_CONVERGENCE; break; }
+        S->lm_iterations = it;
+        double Hs[9], gs[3];
+        for (int i = 0; i < 3; i++) { gs[i] = E.g[i] * scale[i]; for (int j = 0; j < 3; j++) Hs[i * 3 + j] = E.H[i * 3 + j] * scale[i] * scale[j]; }
+        if (!reuse_diag) for (int j = 0; j < 3; j++) diag[j] = std::min(std::max(Hs[j * 3 + j], P.min_lm_diagonal), P.max_lm_diagonal);
+        double A[9];
+        std::memcpy(A, Hs, sizeof(A));
+        for (int j = 0; j < 3; j++) { const double l = std::sqrt(diag[j] / radius); A[j * 3 + j] += l * l; }
+        double y[3], step[3];
+        bool ok = chol_solve3(A, gs, y);
+        reuse_diag = true;
+        double model_change = 0.0;
+        if (ok) {
+            for (int i = 0; i < 3; i++) step[i] = -y[i];
+            double gd = 0, dHd = 0;
+            for (int i = 0; i < 3; i++) { gd += gs[i] * step[i]; for (int j = 0; j < 3; j++) dHd += step[i] * Hs[i * 3 + j] * step[j]; }
+            model_change = -(gd + 0.5 * dHd);
+            if (!(model_change > 0.0)) ok = false;
+        }
+        if (!ok) {
+            if (++invalid >= P.max_consecutive_invalid_steps) { S->termination = VELO_FAILURE; break; }
+            radius = radius / decrease; decrease *= 2.0; reuse_diag = true;
+            continue;
+        }
+        invalid = 0;
+        double xc[3], dn = 0;
+        for (int i = 0; i < 3; i++) { const double d = step[i] * scale[i]; xc[i] = x[i] + d; dn += d * d; }
+        dn = std::sqrt(dn);
+        TriEval Ec;
+        tri_evaluate(Q, xc, &Ec);
+        S->evaluations++;
+        if (dn <= P.parameter_tolerance * (x_norm + P.parameter_tolerance)) { S->termination = VELO_CONVERGENCE; break; }
+        const double cost_change = cost - Ec.cost;
+        if (std::fabs(cost_change) <= P.function_tolerance * cost) { S->termination = VELO_CONVERGENCE; break; }
+        const double q = cost_change / model_change;
+        if (q > P.min_relative_decrease) {
+            for (int i = 0; i < 3; i++) x[i] = xc[i];
+            cost = Ec.cost; E = Ec;
+            x_norm = std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+            if (gmax(E) <= P.gradient_tolerance) { S->termination = VELO_CONVERGENCE; break; }
+            const double t = 2.0 * q - 1.0;
+            radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
+            radius = std::min(P.max_trust_region_radius, radius);
+            decrease = 2.0; reuse_diag = false;
+        } else {
+            radius = radius / decrease; decrease *= 2.0; reuse_diag = true;
+        }
+    }
+    S->final_cost = cost;
+}
+
+// triangulatePoint  velo.h:1027-1130 for one landmark
+void triangulate_point(const velo_params& P, const double* poses, const float* cam_trans, const velo_tri_obs* obs, int n_obs,
+                       float point[3], bool initial_guess, velo_tri_result* S) {
+    std::memset(S, 0, sizeof(*S));
+    double x[3] = {0, 0, 10};                                // velo.h:1043
+    if (initial_guess) { x[0] = point[0]; x[1] = point[1]; x[2] = point[2]; }   // velo.h:1044-1049
+    TriProblem Q{poses, cam_trans, obs, n_obs, false, Loss{1, P.loss_thresh_3D2D, P.weight_3D2D}};
+    bool any3d = false;
+    for (int k = 0; k < n_obs; k++) any3d = any3d || obs[k].kind == VELO_TRI_OBS_3D;
+    if (!initial_guess && any3d) {                           // velo.h:1080-1083: solve on the first 3-D block alone
+        Q.first_3d_only = true;
+        tri_solve(P, Q, x, S);
+        Q.first_3d_only = false;
+    }
+    if (n_obs > 0) tri_solve(P, Q, x, S);                    // velo.h:1123 (an empty problem returns at once)
+    point[0] = (float)x[0]; point[1] = (float)x[1]; point[2] = (float)x[2];   // velo.h:1124-1126
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -898,6 +1082,28 @@ int vo_depth_association(const float* proj_xy, const float* pts_xyz, const int32
         }
     }
     return n_out;
+}
+
+// every landmark of a frame (the loop at main.cpp:661-671), same shapes as velo_triangulate_points
+int vo_triangulate_points(const velo_params* P, const double* poses, int32_t n_frames, const float* cam_trans, int32_t n_cams,
+                          const velo_tri_obs* obs, const int32_t* off, int32_t n, float* pts, const uint8_t* init, velo_tri_result* res) {
+    (void)n_frames; (void)n_cams;
+    for (int l = 0; l < n; l++) {
+        velo_tri_result r;
+        triangulate_point(*P, poses, cam_trans, obs + off[l], off[l + 1] - off[l], pts + 3 * (size_t)l, init && init[l], &r);
+        if (res) res[l] = r;
+    }
+    return 0;
+}
+// one functor evaluation with its autodiff Jacobian (tests): kind per VELO_TRI_OBS_*, r[3], J[3][3] row-major
+int vo_tri_functor(int kind, const double* cam, const double* sv, const double* t, const double* x, double* r, double* J) {
+    typedef Jet<3> J3;
+    J3 xj[3], rj[3];
+    for (int i = 0; i < 3; i++) { xj[i] = J3(x[i]); xj[i].v[i] = 1.0; }
+    const int d = kind == VELO_TRI_OBS_3D ? 3 : 2;
+    if (d == 3) res_tri3d<J3>(cam, sv, xj, rj); else res_tri2d<J3>(cam, sv, t, xj, rj);
+    for (int q = 0; q < d; q++) { r[q] = rj[q].a; for (int i = 0; i < 3; i++) J[q * 3 + i] = rj[q].v[i]; }
+    return d;
 }
 
 }  // extern "C"

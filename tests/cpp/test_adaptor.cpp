@@ -2,7 +2,9 @@
 // containers in, transform[6] in/out, good_matches/residual_type out.  Input file written by tests/test_cpp_adaptor.py.
 #include <cstdio>
 #include <cstdlib>
+#include <array>
 #include <map>
+#include <string>
 #include <vector>
 
 #include "standins.hpp"
@@ -26,8 +28,53 @@ static std::vector<PointCloud::Ptr> read_rings(FILE* f) {
     return rings;
 }
 
+// second mode: `test_adaptor --tri file` drives velo_hip::triangulatePoints with the containers main.cpp:640-671 holds
+static int run_triangulation(const char* path) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return 1;
+    int32_t n_frames, n_l;
+    if (fread(&n_frames, 4, 1, f) != 1) return 2;
+    std::vector<std::array<double, 6>> poses(n_frames);
+    for (int i = 0; i < n_frames; i++) if (fread(poses[i].data(), 8, 6, f) != 6) return 2;
+    if (fread(&n_l, 4, 1, f) != 1) return 2;
+    std::vector<int32_t> off(n_l + 1);
+    if (fread(off.data(), 4, n_l + 1, f) != (size_t)n_l + 1) return 2;
+    std::vector<velo_tri_obs> obs(off[n_l]);
+    if (!obs.empty() && fread(obs.data(), sizeof(velo_tri_obs), obs.size(), f) != obs.size()) return 2;
+    std::vector<float> p0(3 * (size_t)n_l);
+    std::vector<uint8_t> init(n_l);
+    if (fread(p0.data(), 4, p0.size(), f) != p0.size() || fread(init.data(), 1, n_l, f) != (size_t)n_l) return 2;
+    fclose(f);
+    const int num_cams = 2;
+    std::vector<std::vector<std::map<int, Point2f>>> obs2(n_l, std::vector<std::map<int, Point2f>>(num_cams));
+    std::vector<std::vector<std::map<int, PointXYZ>>> obs3(n_l, std::vector<std::map<int, PointXYZ>>(num_cams));
+    PointCloud::Ptr landmarks(new PointCloud);
+    std::vector<bool> added(n_l);
+    std::vector<int> ids;
+    for (int l = 0; l < n_l; l++) {
+        for (int k = off[l]; k < off[l + 1]; k++) {
+            if (obs[k].kind == VELO_TRI_OBS_3D) obs3[l][obs[k].cam][obs[k].frame] = PointXYZ(obs[k].s[0], obs[k].s[1], obs[k].s[2]);
+            else obs2[l][obs[k].cam][obs[k].frame] = Point2f{obs[k].s[0], obs[k].s[1]};
+        }
+        landmarks->push_back(PointXYZ(p0[3 * l], p0[3 * l + 1], p0[3 * l + 2]));
+        added[l] = init[l] != 0;
+        ids.push_back(l);
+    }
+    try {
+        velo_hip::Context ctx(0);
+        velo_hip::Rig rig;
+        velo_hip::triangulatePoints(ctx, rig, ids, obs2, obs3, poses, n_frames, landmarks, added);
+        for (int l = 0; l < n_l; l++) printf("p %d %.9g %.9g %.9g\n", l, landmarks->at(l).x, landmarks->at(l).y, landmarks->at(l).z);
+    } catch (const std::exception& e) {
+        fprintf(stderr, "error: %s\n", e.what());
+        return 3;
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) return 1;
+    if (argc >= 3 && std::string(argv[1]) == "--tri") return run_triangulation(argv[2]);
     FILE* f = fopen(argv[1], "rb");
     if (!f) return 1;
     std::vector<PointCloud::Ptr> scans_M = read_rings(f), scans_S = read_rings(f);

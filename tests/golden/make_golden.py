@@ -82,7 +82,17 @@ def depth_mini():
                 keypoints=kps, thresh=np.float64(synth.DEPTH_ASSOC_THRESH), kp_with_depth=kd, has_depth=has)
 
 
-FIXTURES = {"mini_pair": mini_pair, "functors": functor_vectors, "depth_mini": depth_mini}
+def triangulation_mini():
+    """64 landmarks over 8 frames with the oracle's points and per-landmark solver summaries."""
+    pr = synth.triangulation_problem(64, n_frames=8, seed=21)
+    pts, res = ol.triangulate_points(pr["camera_poses"], pr["cam_trans"], pr["obs"], pr["obs_offsets"], pr["points0"], pr["initial_guess"])
+    out = {k: pr[k] for k in ("camera_poses", "cam_trans", "obs", "obs_offsets", "points0", "initial_guess")}
+    out["points"] = pts
+    out["results"] = res
+    return out
+
+
+FIXTURES = {"mini_pair": mini_pair, "functors": functor_vectors, "depth_mini": depth_mini, "triangulation_mini": triangulation_mini}
 
 if __name__ == "__main__":
     for name in (sys.argv[1:] or list(FIXTURES)):            # python make_golden.py [fixture ...]

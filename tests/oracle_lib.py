@@ -249,3 +249,30 @@ def depth_association(proj_xy, points_xyz, ring_off, keypoints_xy, thresh=0.015)
                                C.c_int32(len(off) - 1), C.c_void_p(kp.ctypes.data), C.c_int32(n), C.c_double(thresh),
                                C.c_void_p(out.ctypes.data), C.c_void_p(has.ctypes.data))
     return out[:m].copy(), has[:n].copy()
+
+
+# ---- SURVEY.md 8(f) row 4 ----------------------------------------------------------------------------------------------
+def triangulate_points(camera_poses, cam_trans, obs, obs_offsets, points_xyz, initial_guess=None, params=None):
+    """-> (points [n,3] f32, results [n]) per velo.h:1027-1130, one landmark after the other."""
+    from velo_amd.api import TRI_RESULT_DTYPE, pack_triangulation
+    l = lib()
+    poses, ct, ob, off, pts, init = pack_triangulation(camera_poses, cam_trans, obs, obs_offsets, points_xyz, initial_guess)
+    P = params if params is not None else default_params()
+    n = len(off) - 1
+    res = np.zeros(n, dtype=TRI_RESULT_DTYPE)
+    vp = lambda a: C.c_void_p(a.ctypes.data) if a is not None and a.size else None   # noqa: E731
+    l.vo_triangulate_points.restype = C.c_int
+    l.vo_triangulate_points(C.byref(P), vp(poses), C.c_int32(len(poses)), vp(ct), C.c_int32(len(ct)), vp(ob), vp(off), C.c_int32(n),
+                            vp(pts), vp(init), vp(res))
+    return pts, res
+
+
+def tri_functor(kind, cam_pose, s, t, x):
+    """One triangulation functor (costfunctions.h:288-375) with its dual-number Jacobian: (r [d], J [d,3])."""
+    l = lib()
+    r = np.zeros(3)
+    J = np.zeros((3, 3))
+    l.vo_tri_functor.restype = C.c_int
+    d = l.vo_tri_functor(C.c_int(kind), _d(cam_pose, 6).ctypes.data_as(_dp), _d(s, 3).ctypes.data_as(_dp), _d(t, 3).ctypes.data_as(_dp),
+                         _d(x, 3).ctypes.data_as(_dp), r.ctypes.data_as(_dp), J.ctypes.data_as(_dp))
+    return r[:d].copy(), J[:d].copy()

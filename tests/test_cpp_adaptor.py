@@ -84,3 +84,27 @@ def test_adaptor_matches_oracle(tmp_path, oracle):
         assert np.array_equal(got_has, has)
         got_xyz = np.array([[np.float32(v) for v in r[4:7]] for r in rows], dtype=np.float32)[has >= 0]
         assert np.array_equal(got_xyz.view(np.uint32), kd[has[has >= 0]].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_adaptor_triangulates_like_the_oracle(tmp_path):
+    import oracle_lib as O
+    exe = compile_adaptor(tmp_path)
+    pr = synth.triangulation_problem(150, n_frames=8, seed=17)
+    case = str(tmp_path / "tri.bin")
+    with open(case, "wb") as f:
+        f.write(struct.pack("i", len(pr["camera_poses"])))
+        f.write(np.ascontiguousarray(pr["camera_poses"], np.float64).tobytes())
+        f.write(struct.pack("i", len(pr["points0"])))
+        f.write(np.ascontiguousarray(pr["obs_offsets"], np.int32).tobytes())
+        f.write(np.ascontiguousarray(pr["obs"], api.TRI_OBS_DTYPE).tobytes())
+        f.write(np.ascontiguousarray(pr["points0"], np.float32).tobytes())
+        f.write(np.ascontiguousarray(pr["initial_guess"], np.uint8).tobytes())
+    out = subprocess.run([exe, "--tri", case], check=True, capture_output=True, text=True).stdout.splitlines()
+    got = np.array([[np.float32(v) for v in line.split()[2:5]] for line in out if line.startswith("p ")], dtype=np.float32)
+    want, res = O.triangulate_points(pr["camera_poses"], pr["cam_trans"], pr["obs"], pr["obs_offsets"], pr["points0"], pr["initial_guess"])
+    assert got.shape == want.shape
+    conv = res["termination"] == 0
+    scale = np.maximum(1.0, np.linalg.norm(want, axis=1))
+    assert np.all(np.linalg.norm(got - want, axis=1)[conv] / scale[conv] <= 1e-4)
+    assert np.all(got.view(np.uint32) == want.view(np.uint32), axis=1).mean() >= 0.99

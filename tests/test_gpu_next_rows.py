@@ -1,7 +1,9 @@
 """-m gpu: the rows SURVEY.md 8(f) marks "next", each to the same bar as the path:
   row 1  device-side scan ingestion  (kitti.h:121-185)  -- bit-exact against the numpy restatement of the ring segmenter;
   row 2  pose hand-off / odometry loop (main.cpp:305-331,407-437, kitti.h:202-216) -- same chain as the oracle driven on the CPU;
-  row 3  projectLidarToCamera + featureDepthAssociation (velo.h:329-497) -- bit-exact (float) against the oracle's restatement."""
+  row 3  projectLidarToCamera + featureDepthAssociation (velo.h:329-497) -- bit-exact (float) against the oracle's restatement;
+  row 4  batched triangulatePoint (velo.h:1027-1130) -- float32 points within 1e-4 (relative to max(1, |p|)) of the oracle's, solver
+         summaries equal; in practice bit-identical because the device follows the same operation order in double."""
 import numpy as np
 import pytest
 
@@ -191,4 +193,98 @@ def test_depth_feeds_the_visual_rows(hip_lib, oracle):
     xo, _, so = o.frame_to_frame(d["x0"])
     assert H.pose_close(xg, xo)
     assert sg.solves[0].n_visual_blocks == so.solves[0].n_visual_blocks > 0
+    c.close()
+
+
+# ---- row 4: batched landmark triangulation ----------------------------------------------------------------------------------
+TRI_TOL = 1e-4          # |dp| <= TRI_TOL * max(1, |p|): float32 points out of a double LM, same bar as the pose (1e-4 m)
+
+
+def _tri_both(c, pr, **params):
+    args = (pr["camera_poses"], pr["cam_trans"], pr["obs"], pr["obs_offsets"], pr["points0"], pr["initial_guess"])
+    P = O.default_params()
+    if params:
+        c.set_params(**params)
+        for k, v in params.items():
+            setattr(P, k, v)
+    got = c.triangulate_points(*args)
+    want = O.triangulate_points(*args, params=P)
+    return got, want
+
+
+def _assert_tri_close(got, want, min_identical=0.99):
+    (gp, gr), (wp, wr) = got, want
+    scale = np.maximum(1.0, np.linalg.norm(wp, axis=1))
+    # landmarks the solver gave up on (50 iterations / failure) sit on flat valleys: only converged ones are held to the tolerance
+    conv = wr["termination"] == 0
+    d = np.linalg.norm(gp.astype(np.float64) - wp, axis=1) / scale
+    assert np.all(d[conv] <= TRI_TOL), (np.nonzero(d > TRI_TOL)[0][:10], d.max())
+    same = np.all(gp.view(np.uint32) == wp.view(np.uint32), axis=1)
+    assert same.mean() >= min_identical, same.mean()
+    assert np.array_equal(gr["n_solves"], wr["n_solves"])
+    agree = (gr["termination"] == wr["termination"]) & (gr["lm_iterations"] == wr["lm_iterations"]) & (gr["evaluations"] == wr["evaluations"])
+    assert agree.mean() >= min_identical, agree.mean()
+    np.testing.assert_allclose(gr["final_cost"][agree], wr["final_cost"][agree], rtol=1e-9, atol=1e-14)
+
+
+def test_triangulation_matches_oracle(hip_lib):
+    pr = synth.triangulation_problem(3000, n_frames=12, seed=13)
+    c = api.Context(0)
+    got, want = _tri_both(c, pr)
+    _assert_tri_close(got, want)
+    n_obs = np.diff(pr["obs_offsets"])
+    err = np.linalg.norm(got[0] - pr["truth"], axis=1)[n_obs >= 6]
+    assert np.median(err) < 0.1                               # and the points are the landmarks, not just equal to the oracle's
+    # deterministic: the same call again gives the same bits
+    again = c.triangulate_points(pr["camera_poses"], pr["cam_trans"], pr["obs"], pr["obs_offsets"], pr["points0"], pr["initial_guess"])
+    assert np.array_equal(again[0].view(np.uint32), got[0].view(np.uint32))
+    c.close()
+
+
+def test_triangulation_kernels_agree_bit_for_bit(hip_lib, monkeypatch):
+    # one wave per landmark (default) and one thread per landmark sum every accumulator in the same order
+    pr = synth.triangulation_problem(1500, n_frames=40, seed=5)       # up to ~100 observations: more than one 64-lane chunk
+    assert np.diff(pr["obs_offsets"]).max() > 64
+    args = (pr["camera_poses"], pr["cam_trans"], pr["obs"], pr["obs_offsets"], pr["points0"], pr["initial_guess"])
+    out = []
+    for variant in ("1", "0"):
+        monkeypatch.setenv("VELO_TRI_VARIANT", variant)
+        c = api.Context(0)
+        out.append(c.triangulate_points(*args))
+        c.close()
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert np.array_equal(out[0][1], out[1][1])
+    _assert_tri_close(out[0], O.triangulate_points(*args))
+
+
+def test_triangulation_edge_cases(hip_lib):
+    c = api.Context(0)
+    # golden fixture
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "triangulation_mini.npz"))
+    pts, res = c.triangulate_points(g["camera_poses"], g["cam_trans"], g["obs"], g["obs_offsets"], g["points0"], g["initial_guess"])
+    scale = np.maximum(1.0, np.linalg.norm(g["points"], axis=1))
+    assert np.all(np.linalg.norm(pts - g["points"], axis=1) / scale <= TRI_TOL)
+    assert np.array_equal(res["n_solves"], g["results"]["n_solves"])
+    # no initial-guess array at all == all zeros; other solver settings travel through velo_params
+    pr = synth.triangulation_problem(200, n_frames=6, seed=3)
+    pr0 = dict(pr, initial_guess=None)
+    pr1 = dict(pr, initial_guess=np.zeros(200, np.uint8))
+    a = c.triangulate_points(pr0["camera_poses"], pr0["cam_trans"], pr0["obs"], pr0["obs_offsets"], pr0["points0"], None)
+    b = c.triangulate_points(pr1["camera_poses"], pr1["cam_trans"], pr1["obs"], pr1["obs_offsets"], pr1["points0"], pr1["initial_guess"])
+    assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32))
+    got, want = _tri_both(c, pr, max_num_iterations=4, loss_thresh_3D2D=0.02, weight_3D2D=3.0)
+    _assert_tri_close(got, want, min_identical=0.97)
+    assert got[1]["lm_iterations"].max() <= 4
+    # nothing to do / bad input
+    e = c.triangulate_points(pr["camera_poses"], pr["cam_trans"], pr["obs"][:0], np.zeros(1, np.int32), np.zeros((0, 3), np.float32))
+    assert len(e[0]) == 0
+    bad = pr["obs"].copy()
+    bad["frame"][0] = 99
+    with pytest.raises(api.VeloError):
+        c.triangulate_points(pr["camera_poses"], pr["cam_trans"], bad, pr["obs_offsets"], pr["points0"], pr["initial_guess"])
+    bad = pr["obs"].copy()
+    bad["kind"][1] = 7
+    with pytest.raises(api.VeloError):
+        c.triangulate_points(pr["camera_poses"], pr["cam_trans"], bad, pr["obs_offsets"], pr["points0"], pr["initial_guess"])
     c.close()

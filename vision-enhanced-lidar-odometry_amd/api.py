@@ -84,7 +84,12 @@ PARTIAL_DTYPE = np.dtype([
     ("key1", np.uint64), ("key2", np.uint64), ("ring1", np.int32), ("ring2", np.int32), ("idx1", np.int32),
     ("idx_k", np.int32), ("idx2", np.int32), ("pad", np.int32), ("v0", np.float32, 3), ("v2", np.float32, 3),
     ("v1", np.float32, 3), ("pad2", np.float32)], align=True)
+TRI_OBS_DTYPE = np.dtype([("kind", np.int32), ("frame", np.int32), ("cam", np.int32), ("s", np.float32, 3)])
+TRI_RESULT_DTYPE = np.dtype([("n_solves", np.int32), ("termination", np.int32), ("lm_iterations", np.int32),
+                             ("evaluations", np.int32), ("final_cost", np.float64)])
+TRI_OBS_3D, TRI_OBS_2D = 0, 1
 assert MATCH_DTYPE.itemsize == 68 and GOOD_DTYPE.itemsize == 16 and CORR_DTYPE.itemsize == 76 and PARTIAL_DTYPE.itemsize == 80
+assert TRI_OBS_DTYPE.itemsize == 24 and TRI_RESULT_DTYPE.itemsize == 24
 
 
 def matches_from_dict(rec: dict) -> np.ndarray:
@@ -94,6 +99,21 @@ def matches_from_dict(rec: dict) -> np.ndarray:
     for k in ("p3_1", "p3_2", "p2_1", "p2_2", "t_cam", "cam", "point1", "point2", "d1", "d2"):
         m[k] = rec[k]
     return m
+
+
+def pack_triangulation(camera_poses, cam_trans, obs, obs_offsets, points_xyz, initial_guess):
+    """Contiguous, typed copies of the arguments of velo_triangulate_points (shared with the test-side oracle wrapper)."""
+    poses = np.ascontiguousarray(np.asarray(camera_poses, dtype=np.float64).reshape(-1, 6))
+    ct = np.ascontiguousarray(np.asarray(cam_trans, dtype=np.float32).reshape(-1, 3))
+    ob = np.ascontiguousarray(obs, dtype=TRI_OBS_DTYPE)
+    off = np.ascontiguousarray(obs_offsets, dtype=np.int32)
+    pts = np.array(np.asarray(points_xyz, dtype=np.float32).reshape(-1, 3), copy=True, order="C")
+    if len(off) - 1 != len(pts):
+        raise ValueError("obs_offsets must have one more entry than there are landmarks")
+    init = None if initial_guess is None else np.ascontiguousarray(np.asarray(initial_guess).astype(np.uint8))
+    if init is not None and len(init) != len(pts):
+        raise ValueError("initial_guess: one flag per landmark")
+    return poses, ct, ob, off, pts, init
 
 
 def default_params() -> VeloParams:
@@ -155,6 +175,8 @@ SIGNATURES = {
     "velo_project_lidar": (C.c_int, [_ctx, C.c_int32, C.c_void_p, _dp, _P(C.c_int32)]),
     "velo_get_projection": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, _P(C.c_int32)]),
     "velo_depth_association": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_int32, C.c_void_p, _P(C.c_int32)]),
+    "velo_triangulate_points": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
 }
 
 _lib = None
@@ -417,6 +439,19 @@ class Context:
                                                      C.c_void_p(out.ctypes.data), n, C.c_void_p(has.ctypes.data) if n else None,
                                                      C.byref(m)))
         return out[:m.value].copy(), has
+
+    # -- batched landmark triangulation (velo.h:1027-1130) ---------------------------------------------------------
+    def triangulate_points(self, camera_poses, cam_trans, obs, obs_offsets, points_xyz, initial_guess=None):
+        """All landmarks of a frame in one call: (points [n,3] f32, results [n] TRI_RESULT_DTYPE).  `points_xyz` supplies the
+        initial guesses of the landmarks flagged in `initial_guess`; it is not modified."""
+        args = pack_triangulation(camera_poses, cam_trans, obs, obs_offsets, points_xyz, initial_guess)
+        poses, ct, ob, off, pts, init = args
+        n = len(off) - 1
+        res = np.zeros(n, dtype=TRI_RESULT_DTYPE)
+        vp = lambda a: C.c_void_p(a.ctypes.data) if a is not None and a.size else None   # noqa: E731
+        self._check(self._lib.velo_triangulate_points(self._h, vp(poses), len(poses), vp(ct), len(ct), vp(ob), vp(off), n,
+                                                      vp(pts), vp(init), vp(res)))
+        return pts, res
 
     # -- multi-GPU -------------------------------------------------------------------------------------------
     def set_query_shard(self, rank: int, world: int):

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libvelo_hip.so")
 SOURCES = ["velo_hip.hip"]
-HEADERS = ["velo_kernels.h", "velo_depth_kernels.h", "velo_device_math.h", os.path.join(ROOT, "include", "velo_hip.h")]
+HEADERS = ["velo_kernels.h", "velo_depth_kernels.h", "velo_tri_kernels.h", "velo_device_math.h", os.path.join(ROOT, "include", "velo_hip.h")]
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",

@@ -23,6 +23,7 @@
 #include "../../include/velo_hip.h"
 #include "velo_kernels.h"
 #include "velo_depth_kernels.h"
+#include "velo_tri_kernels.h"
 
 using namespace velo;
 
@@ -195,6 +196,16 @@ struct velo_ctx {
     std::vector<int> h_proj_off, h_ring_cnt;   // offsets of the projected cloud (copied: the cloud may be replaced later)
     int proj_rings = 0, proj_points = 0, proj_of_target = 0;
     bool have_projection = false;
+
+    // batched landmark triangulation
+    DevBuf<TriFrame> tri_frames;
+    DevBuf<double> tri_cam_t;
+    DevBuf<velo_tri_obs> tri_obs;
+    DevBuf<int> tri_off;
+    DevBuf<float> tri_pts;
+    DevBuf<unsigned char> tri_init;
+    DevBuf<velo_tri_result> tri_res;
+    int tri_variant = 1;                 // 1 = one wave per landmark (default), 0 = one thread per landmark (VELO_TRI_VARIANT)
 
     // sharding / comm
     int shard_rank = 0, shard_world = 1;
@@ -722,6 +733,7 @@ int velo_create(velo_ctx** out, int device) {
     for (int k = 0; k < VELO_MAX_SOLVES; k++) c->pred_evals[k] = (k == 0) ? 12 : 5;
     if (const char* e = getenv("VELO_ASSOC_VARIANT")) c->assoc_variant = atoi(e);
     if (const char* e = getenv("VELO_CLUSTER_W")) c->cluster_w = std::max(atoi(e), 0);
+    if (const char* e = getenv("VELO_TRI_VARIANT")) c->tri_variant = atoi(e);
     if (const char* e = getenv("VELO_DEBUG_SKIP")) c->debug_skip = atoi(e);
     if (const char* e = getenv("VELO_GRAPHS")) c->use_graphs = atoi(e) != 0;
     if (const char* e = getenv("VELO_XCD_MAP")) c->xcd_map = atoi(e);
@@ -1463,6 +1475,90 @@ int velo_depth_association(velo_ctx* c, const float* keypoints_xy, int32_t n, do
         HIP_TRY(hipMemcpy(h.data(), c->kp_out.p, sizeof(float4) * (size_t)nd, hipMemcpyDeviceToHost));
         for (int i = 0; i < nd && i < capacity_points; i++) { kp_with_depth_xyz[3 * i] = h[i].x; kp_with_depth_xyz[3 * i + 1] = h[i].y; kp_with_depth_xyz[3 * i + 2] = h[i].z; }
     }
+    return VELO_OK;
+}
+
+// ---- batched triangulatePoint (velo.h:1027-1130) ----------------------------------------------------
+int velo_triangulate_points(velo_ctx* c, const double* camera_poses, int32_t n_frames, const float* cam_trans, int32_t n_cams,
+                            const velo_tri_obs* obs, const int32_t* obs_offsets, int32_t n, float* points_xyz,
+                            const uint8_t* initial_guess, velo_tri_result* results) {
+    if (!c || n < 0 || n_frames < 0 || n_cams < 0) return fail(VELO_ERR_INVALID, "null ctx / negative size");
+    if (n == 0) return VELO_OK;
+    if (!obs_offsets || !points_xyz) return fail(VELO_ERR_INVALID, "null offsets / points");
+    if (obs_offsets[0] != 0) return fail(VELO_ERR_INVALID, "obs_offsets[0] must be 0");
+    for (int l = 0; l < n; l++) if (obs_offsets[l + 1] < obs_offsets[l]) return fail(VELO_ERR_INVALID, "obs_offsets must not decrease (landmark %d)", l);
+    const int n_obs = obs_offsets[n];
+    if (n_obs > 0 && (!obs || !camera_poses)) return fail(VELO_ERR_INVALID, "null observations / poses");
+    for (int k = 0; k < n_obs; k++) {
+        const velo_tri_obs& o = obs[k];
+        if (o.kind != VELO_TRI_OBS_3D && o.kind != VELO_TRI_OBS_2D) return fail(VELO_ERR_INVALID, "observation %d: unknown kind %d", k, o.kind);
+        if (o.frame < 0 || o.frame >= n_frames) return fail(VELO_ERR_INVALID, "observation %d: frame %d outside [0, %d)", k, o.frame, n_frames);
+        if (o.kind == VELO_TRI_OBS_2D && (o.cam < 0 || o.cam >= n_cams || !cam_trans)) return fail(VELO_ERR_INVALID, "observation %d: camera %d outside [0, %d)", k, o.cam, n_cams);
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    // per-frame constants in double with the host libm: rot = -pose[0..2] (costfunctions.h:318-320), Rodrigues scalars, R columns
+    std::vector<TriFrame> hf((size_t)std::max(n_frames, 1));
+    for (int f = 0; f < n_frames; f++) {
+        const double* cp = camera_poses + 6 * (size_t)f;
+        const double xr[6] = {-cp[0], -cp[1], -cp[2], 0.0, 0.0, 0.0};
+        PoseScalars S;
+        pose_scalars(xr, &S);
+        TriFrame& F = hf[(size_t)f];
+        std::memset(&F, 0, sizeof(F));
+        for (int k = 0; k < 3; k++) { F.w[k] = S.w[k]; F.u[k] = S.u[k]; F.center[k] = cp[3 + k]; }
+        F.c = S.c; F.s = S.s; F.omc = S.omc; F.small = S.small;
+        for (int j = 0; j < 3; j++) {                                // column j = rotation of e_j, same operation order as the device form
+            double e[3] = {0.0, 0.0, 0.0}, o[3];
+            e[j] = 1.0;
+            if (!F.small) {
+                const double c0 = F.u[1] * e[2] - F.u[2] * e[1], c1 = F.u[2] * e[0] - F.u[0] * e[2], c2 = F.u[0] * e[1] - F.u[1] * e[0];
+                const double tmp = (F.u[0] * e[0] + F.u[1] * e[1] + F.u[2] * e[2]) * F.omc;
+                o[0] = e[0] * F.c + c0 * F.s + F.u[0] * tmp;
+                o[1] = e[1] * F.c + c1 * F.s + F.u[1] * tmp;
+                o[2] = e[2] * F.c + c2 * F.s + F.u[2] * tmp;
+            } else {
+                o[0] = e[0] + (F.w[1] * e[2] - F.w[2] * e[1]);
+                o[1] = e[1] + (F.w[2] * e[0] - F.w[0] * e[2]);
+                o[2] = e[2] + (F.w[0] * e[1] - F.w[1] * e[0]);
+            }
+            F.R[0 * 3 + j] = o[0]; F.R[1 * 3 + j] = o[1]; F.R[2 * 3 + j] = o[2];
+        }
+    }
+    std::vector<double> hct((size_t)std::max(3 * n_cams, 3), 0.0);
+    for (int k = 0; k < 3 * n_cams; k++) hct[(size_t)k] = (double)cam_trans[k];
+    VELO_TRY(c->tri_frames.reserve(hf.size())); VELO_TRY(c->tri_cam_t.reserve(hct.size()));
+    VELO_TRY(c->tri_obs.reserve((size_t)std::max(n_obs, 1))); VELO_TRY(c->tri_off.reserve((size_t)n + 1));
+    VELO_TRY(c->tri_pts.reserve((size_t)3 * n)); VELO_TRY(c->tri_init.reserve((size_t)n)); VELO_TRY(c->tri_res.reserve((size_t)n));
+    HIP_TRY(hipMemcpyAsync(c->tri_frames.p, hf.data(), sizeof(TriFrame) * hf.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->tri_cam_t.p, hct.data(), sizeof(double) * hct.size(), hipMemcpyHostToDevice, c->stream));
+    // blocks enter the problem 3-D first (velo.h:1049-1122): stable partition per landmark, so that block position == index
+    std::vector<velo_tri_obs> hobs((size_t)std::max(n_obs, 1));
+    for (int l = 0; l < n; l++) {
+        int w = obs_offsets[l];
+        for (int pass = 0; pass < 2; pass++)
+            for (int k = obs_offsets[l]; k < obs_offsets[l + 1]; k++)
+                if ((obs[k].kind == VELO_TRI_OBS_2D) == (pass == 1)) hobs[(size_t)w++] = obs[k];
+    }
+    if (n_obs > 0) HIP_TRY(hipMemcpyAsync(c->tri_obs.p, hobs.data(), sizeof(velo_tri_obs) * (size_t)n_obs, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->tri_off.p, obs_offsets, sizeof(int) * ((size_t)n + 1), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->tri_pts.p, points_xyz, sizeof(float) * 3 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    if (initial_guess) HIP_TRY(hipMemcpyAsync(c->tri_init.p, initial_guess, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));                         // hf / hct are stack-owned host vectors
+    TriParams P;
+    P.lm = lm_params(c->P);
+    P.loss_a = c->P.loss_thresh_3D2D; P.loss_w = c->P.weight_3D2D;    // velo.h:1116-1119
+    if (c->tri_variant == 0)     // VELO_TRI_VARIANT=0: one thread per landmark (kept for A/B; same results)
+        hipLaunchKernelGGL(triangulate_kernel, dim3(cdiv(n, 64)), dim3(64), 0, c->stream, (const TriFrame*)c->tri_frames.p, (const double*)c->tri_cam_t.p,
+                           (const velo_tri_obs*)c->tri_obs.p, (const int*)c->tri_off.p, n, P, c->tri_pts.p,
+                           (const unsigned char*)(initial_guess ? c->tri_init.p : nullptr), c->tri_res.p);
+    else
+        hipLaunchKernelGGL(triangulate_wave_kernel, dim3(n), dim3(64), 0, c->stream, (const TriFrame*)c->tri_frames.p, (const double*)c->tri_cam_t.p,
+                           (const velo_tri_obs*)c->tri_obs.p, (const int*)c->tri_off.p, n, P, c->tri_pts.p,
+                           (const unsigned char*)(initial_guess ? c->tri_init.p : nullptr), c->tri_res.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(points_xyz, c->tri_pts.p, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    if (results) HIP_TRY(hipMemcpyAsync(results, c->tri_res.p, sizeof(velo_tri_result) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return VELO_OK;
 }
 

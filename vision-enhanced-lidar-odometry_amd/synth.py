@@ -382,3 +382,55 @@ def velodyne_sequence(n_frames: int, scene_seed: int = 0, sigma: float = 0.02, n
         poses.append(C @ np.linalg.inv(T0) @ T @ np.linalg.inv(C))
         T = T @ pose_matrix(**step)
     return frames, poses
+
+
+def triangulation_problem(n_landmarks: int = 2000, n_frames: int = 12, seed: int = 13, sigma_2d: float = 7e-4, sigma_3d: float = 0.03,
+                          outlier_frac: float = 0.05):
+    """Synthetic input of the landmark triangulation step (main.cpp:640-671): a short camera trajectory, landmarks seen from
+    3..n_frames (frame, camera) pairs as canonical 2-D observations, some of them also with a LiDAR-derived 3-D observation.
+    Observations are listed like the reference adds its residual blocks: 3-D first (camera-major, frame ascending), then 2-D.
+    Returns dict(camera_poses [F,6], cam_trans [2,3], obs (structured: kind, frame, cam, s[3]), obs_offsets [L+1],
+    points0 [L,3] f32 (initial guesses), initial_guess [L] u8, truth [L,3])."""
+    F = n_frames
+    k = np.arange(F, dtype=np.float64)
+    poses = np.stack([0.002 * np.sin(0.7 * k), 0.015 * k, 0.001 * np.cos(0.5 * k), 0.02 * k, 0.01 * np.sin(k), 0.9 * k], axis=1)
+    poses[0] = 0.0                                            # the first pose is the identity (theta == 0 branch)
+    R = [rotvec_to_matrix(p[:3]) for p in poses]
+    u = uniform01(seed, 8 * n_landmarks, stream=0).reshape(n_landmarks, 8)
+    z = 6.0 + 40.0 * u[:, 2]
+    mid = poses[F // 2, 3:]
+    truth = np.stack([(u[:, 0] - 0.5) * 1.2 * z, (u[:, 1] - 0.5) * 0.4 * z, z], axis=1) + mid
+    n_seen = 3 + np.floor(u[:, 3] * (F - 2)).astype(int)      # frames that see the landmark
+    start = np.floor(u[:, 4] * (F - n_seen + 1)).astype(int)
+    kinds, frames, cams, svals, off = [], [], [], [], [0]
+    g = normal01(seed, 10 * n_landmarks * F, stream=1).reshape(n_landmarks, F, 10)
+    ou = uniform01(seed, 2 * n_landmarks * F, stream=2).reshape(n_landmarks, F, 2)
+    tc = CAM_TRANS.astype(np.float64)
+    for l in range(n_landmarks):
+        o3, o2 = [], []
+        if l % 50 == 7:                                       # a landmark nobody observed (empty problem)
+            off.append(off[-1])
+            continue
+        for cam in range(2):
+            for f in range(start[l], start[l] + n_seen[l]):
+                M = R[f].T @ (truth[l] - poses[f, 3:])
+                if M[2] < 1.0:
+                    continue
+                if cam == 0 and l % 3 != 1 and ou[l, f, 0] < 0.4:          # a third of the landmarks never get LiDAR depth
+                    o3.append((0, f, cam, *(M + sigma_3d * g[l, f, 0:3])))
+                Mc = M + tc[cam]
+                q = Mc[:2] / Mc[2] + sigma_2d * g[l, f, 3 + 2 * cam:5 + 2 * cam]
+                if ou[l, f, 1] < outlier_frac:
+                    q = q + 0.05 * g[l, f, 7:9]
+                if l % 11 != 4:                                               # some landmarks have 3-D observations only
+                    o2.append((1, f, cam, q[0], q[1], 0.0))
+        for rec in o3 + o2:
+            kinds.append(rec[0]); frames.append(rec[1]); cams.append(rec[2]); svals.append(rec[3:6])
+        off.append(off[-1] + len(o3) + len(o2))
+    obs = np.zeros(len(kinds), dtype=[("kind", np.int32), ("frame", np.int32), ("cam", np.int32), ("s", np.float32, 3)])
+    obs["kind"], obs["frame"], obs["cam"] = kinds, frames, cams
+    obs["s"] = np.asarray(svals, dtype=np.float32).reshape(-1, 3)
+    init = (u[:, 5] < 0.5).astype(np.uint8)
+    points0 = (truth + 0.5 * normal01(seed, 3 * n_landmarks, stream=3).reshape(n_landmarks, 3)).astype(np.float32)
+    return dict(camera_poses=poses, cam_trans=CAM_TRANS.copy(), obs=obs, obs_offsets=np.asarray(off, dtype=np.int32),
+                points0=points0, initial_guess=init, truth=truth)
