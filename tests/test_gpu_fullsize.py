@@ -50,7 +50,7 @@ def test_full_size_shard_is_index_exact(full_ctx, oracle, pair, iter_, shard):
 
 def test_full_size_reference_kernel_agrees_with_shell_walk(hip_lib, pair):
     tables = []
-    for variant in ("0", "4", "1"):
+    for variant in ("0", "5", "4", "1"):          # per-lane reference, tube (default), box walk with 4 waves / 1 wave
         os.environ["VELO_ASSOC_VARIANT"] = variant
         try:
             c = api.Context(0, icp_skip=1)

@@ -15,7 +15,7 @@ for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
                 vals[r["Dispatch_Id"]] += float(r["Counter_Value"])
     out[counter] = (sum(vals.values()) / len(vals)) if vals else None
 if out["FETCH_SIZE"] is not None and out["WRITE_SIZE"] is not None:
-    res = {"kernel": "assoc_search_v3_kernel", "fetch_KiB_raw": out["FETCH_SIZE"], "write_KiB": out["WRITE_SIZE"],
+    res = {"kernel": "assoc_search_v5_kernel", "fetch_KiB_raw": out["FETCH_SIZE"], "write_KiB": out["WRITE_SIZE"],
            "read_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B)",
            "traffic_bytes_per_launch": (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0,
            "source": f"gpurun_out/{tag}/pmc_fetch + pmc_write (rocprofv3 --pmc, separate passes), bench.py --batch 1"}

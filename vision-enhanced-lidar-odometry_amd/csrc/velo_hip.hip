@@ -115,8 +115,10 @@ struct velo_ctx {
     hipStream_t stream = nullptr;
     velo_params P;
     bool timing = false;
-    int assoc_variant = 4;               // 0 = per-lane reference kernel; 1/2/4/8 = waves per 64-query group of the shell walk (VELO_ASSOC_VARIANT)
-    int cluster_w = 6;                   // cluster radius in cells (VELO_CLUSTER_W)
+    int assoc_variant = -1;              // VELO_ASSOC_VARIANT: -1 = automatic (tube kernel 5 when the gate radius is <= 5 cells, box kernel 4 on
+                                         // density-shrunk grids); 0 = per-lane reference kernel; 1/2/4/8 = waves per group of the box walk; 5 = tube
+    int cluster_w = 6;                   // cluster radius of the box kernels, in cells of the default grid (VELO_CLUSTER_W)
+    bool cluster_w_set = false;          // the tube kernel keeps one cluster per group unless VELO_CLUSTER_W is given
     int persistent_wgs = 2048;           // workgroups of the persistent association kernel (VELO_PERSISTENT_WGS)
     int xcd_map = 0;                     // XCD-contiguous group mapping of the association kernel (VELO_XCD_MAP=1): measured slower
                                          // (dense bottom rings all land on one XCD); round-robin placement balances better
@@ -454,7 +456,12 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                            c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, cluster_cells, h_safe, out, aux, c->debug_skip, c->xcd_map)
         // the diagnostic hooks (VELO_DEBUG_SKIP != 0) live in a separate instantiation: compiled in, they spill registers
 #define VELO_LAUNCH_V2(NW, MINW) do { if (c->debug_skip) VELO_LAUNCH_V3(NW, MINW, true); else VELO_LAUNCH_V3(NW, MINW, false); } while (0)
-        switch (c->assoc_variant) {
+        // Tube kernel (5): candidates per query group -21 % and one cluster per group on the default grid (120k-pt scans: 92 vs
+        // 121 us); its per-query phase 2 enumerates (2e+1)^2 rows per asking query, which loses on density-shrunk grids where
+        // the gate radius is many cells (2M-pt map, e = 15: 1.59 vs 1.45 ms) -- there the box kernel (4) stays.
+        const int reach_cells = (int)std::ceil(std::sqrt(std::max(gate_of_iter(c->P, 1), 0.0)) / (G->h * 0.999));
+        const int variant = c->assoc_variant >= 0 ? c->assoc_variant : (reach_cells <= 5 ? 5 : 4);
+        switch (variant) {
             case 0: {
                 const int reach = (int)std::ceil(std::sqrt(std::max(gate, 0.0)) / (G->h * 0.999)) ;
                 hipLaunchKernelGGL(assoc_search_kernel, dim3(cdiv(qe - qb, kAssocThreads)), dim3(kAssocThreads), 0, c->stream,
@@ -473,15 +480,28 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 (void)nqr;
                 hipLaunchKernelGGL(assoc_prepare_kernel, dim3(groups), dim3(64), 0, c->stream, S, V.d, c->src.p, c->q_src.p, qb, qe, cluster_cells, Q);
                 const int wgs = std::min(groups * 4, c->persistent_wgs);
-                if (c->assoc_variant == 102)
+                if (variant == 102)
                     hipLaunchKernelGGL((assoc_cluster_kernel<2, 1>), dim3(wgs), dim3(128), 0, c->stream, V, Q, c->src.p, c->q_src.p, qb, qe,
                                        c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, h_safe, out, aux);
-                else if (c->assoc_variant == 108)
+                else if (variant == 108)
                     hipLaunchKernelGGL((assoc_cluster_kernel<8, 6>), dim3(wgs), dim3(512), 0, c->stream, V, Q, c->src.p, c->q_src.p, qb, qe,
                                        c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, h_safe, out, aux);
                 else
                     hipLaunchKernelGGL((assoc_cluster_kernel<4, 6>), dim3(wgs), dim3(256), 0, c->stream, V, Q, c->src.p, c->q_src.p, qb, qe,
                                        c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, h_safe, out, aux);
+                break;
+            }
+            case 5: case 55: {   // tube variant: per-row intervals, per-query phase 2 (cluster radius from VELO_CLUSTER_W, 0 = unbounded)
+                const int cw = (c->cluster_w_set && c->cluster_w > 0) ? cluster_cells : (1 << 27);
+                if (c->debug_skip)
+                    hipLaunchKernelGGL((assoc_search_v5_kernel<4, 6, true>), dim3(groups), dim3(256), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe,
+                                       c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux);
+                else if (variant == 55)
+                    hipLaunchKernelGGL((assoc_search_v5_kernel<4, 5, false>), dim3(groups), dim3(256), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe,
+                                       c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux);
+                else
+                    hipLaunchKernelGGL((assoc_search_v5_kernel<4, 6, false>), dim3(groups), dim3(256), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe,
+                                       c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux);
                 break;
             }
             case 1: VELO_LAUNCH_V2(1, 1); break;
@@ -732,7 +752,7 @@ int velo_create(velo_ctx** out, int device) {
     default_params(&c->P);
     for (int k = 0; k < VELO_MAX_SOLVES; k++) c->pred_evals[k] = (k == 0) ? 12 : 5;
     if (const char* e = getenv("VELO_ASSOC_VARIANT")) c->assoc_variant = atoi(e);
-    if (const char* e = getenv("VELO_CLUSTER_W")) c->cluster_w = std::max(atoi(e), 0);
+    if (const char* e = getenv("VELO_CLUSTER_W")) { c->cluster_w = std::max(atoi(e), 0); c->cluster_w_set = true; }
     if (const char* e = getenv("VELO_TRI_VARIANT")) c->tri_variant = atoi(e);
     if (const char* e = getenv("VELO_DEBUG_SKIP")) c->debug_skip = atoi(e);
     if (const char* e = getenv("VELO_GRAPHS")) c->use_graphs = atoi(e) != 0;

@@ -757,6 +757,236 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
 #undef VELO_STAMP
 }
 
+// ---- association search, tube variant (VELO_ASSOC_VARIANT=5) ---------------------------------------------------------------
+// Same machinery as assoc_search_v3_kernel (run list -> LDS tile -> packed sweep -> merge), different candidate set:
+//   * phase 1 does not stage the whole bounding box of the cluster but, for every grid row (y, z), only the x-interval
+//     [min cx - 1, max cx + 1] over the member queries whose cell lies within one row of it -- a tube around the ring segment
+//     instead of its axis-aligned box (LDS atomics build the per-row intervals);
+//   * phase 2 is per query: a member that is not finished after phase 1 asks for ITS OWN reach e_q = ceil(sqrt(b2d_q) / h)
+//     and contributes the rows/intervals of its own cube only; finished members ask for nothing.  Rows subtract the interval
+//     phase 1 already visited.  After phase 2 every member has (e_q h)^2 > b2d_q, so there is never a third phase.
+// Tubes do not blow up with the length of the segment, so the cluster radius can be large (one cluster per group).
+template <int NW, int MINW, bool DBG>
+__global__ void __launch_bounds__(NW * 64, MINW)
+assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
+                       const float4* __restrict__ tgt, const int* __restrict__ tgt_off, const int* __restrict__ ring_of,
+                       unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, AssocOut out, int want_aux) {
+    constexpr int NT = NW * 64;
+    constexpr int NRUN = 2 * NT;
+    __shared__ float4 s_xy[kTileCap / 2];
+    __shared__ float4 s_zg[kTileCap / 2];
+    __shared__ int s_ring[kTileCap];
+    __shared__ int s_run_j0[NRUN];
+    __shared__ int s_run_off[NRUN + 1];
+    __shared__ int s_wave_tot[NW];
+    __shared__ int s_lo[NT], s_hi[NT], s_plo[NT], s_phi[NT];   // per-row x-interval of this phase / of what phase 1 visited
+    __shared__ unsigned long long m1[NW][64], m2[NW][64];
+    __shared__ int mr[NW][64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = (int)blockIdx.x;
+    const int qi = q_begin + group * 64 + lane;
+    const bool active = qi < q_end;
+    const unsigned long long key_inf = ((unsigned long long)gate_bits + 1ull) << 32;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    Top2 t;
+    t.b1 = key_inf; t.b2 = key_inf; t.b1ring = -1; t.b2d = __uint_as_float(gate_bits + 1u);
+    const GridDesc g = G.d;
+    int cx = 0, cy = 0, cz = 0;
+    if (active) {
+        const float4 psrc = src[q_src[qi]];
+        transform_query(P, psrc, &qx, &qy, &qz);
+        cx = cell_coord(qx, g.ox, g.inv_h, g.nx); cy = cell_coord(qy, g.oy, g.inv_h, g.ny); cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
+    }
+    const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+    float* s_xy_f = reinterpret_cast<float*>(s_xy);
+    float* s_zg_f = reinterpret_cast<float*>(s_zg);
+    const int big = 1 << 28;
+    const float reach1 = h_safe * h_safe;                              // (1 cell)^2: what phase 1 guarantees
+    bool pending = active;
+    for (;;) {                                                         // clusters (identical control flow in every wave)
+        const unsigned long long pm = __ballot(pending);
+        if (pm == 0ull) break;
+        const int leader = (int)__ffsll((long long)pm) - 1;
+        const int scx = __builtin_amdgcn_readlane(cx, leader), scy = __builtin_amdgcn_readlane(cy, leader), scz = __builtin_amdgcn_readlane(cz, leader);
+        const bool member = pending && abs(cx - scx) <= cluster_w && abs(cy - scy) <= cluster_w && abs(cz - scz) <= cluster_w;
+        if (DBG && tid == 0) atomicAdd(&out.dbg[0], 1ull);
+        for (int ph = 0; ph < 2; ph++) {
+            // who asks for cells in this phase, and how far
+            bool asks = member;
+            int e = 1;
+            if (ph == 1) {
+                asks = member && !(reach1 > t.b2d);
+                if (__ballot(asks) == 0ull) break;
+                e = max(2, (int)ceilf(sqrtf(t.b2d) / h_safe));
+                if ((float)e * h_safe * ((float)e * h_safe) <= t.b2d) e++;          // rounding guard
+            }
+            const int Y0 = max(__builtin_amdgcn_readfirstlane(wave_min_i(asks ? cy - e : big)), 0);
+            const int Y1 = min(__builtin_amdgcn_readfirstlane(wave_max_i(asks ? cy + e : -big)), g.ny - 1);
+            const int Z0 = max(__builtin_amdgcn_readfirstlane(wave_min_i(asks ? cz - e : big)), 0);
+            const int Z1 = min(__builtin_amdgcn_readfirstlane(wave_max_i(asks ? cz + e : -big)), g.nz - 1);
+            const int nyb = Y1 - Y0 + 1, nzb = Z1 - Z0 + 1;
+            const int nrows = (nyb > 0 && nzb > 0) ? nyb * nzb : 0;
+            for (int rbase = 0; rbase < nrows; rbase += NT) {          // row chunks (one row per thread)
+                // ---- 0. per-row x-intervals ----
+                s_lo[tid] = big; s_hi[tid] = -big;
+                if (ph == 1) { s_plo[tid] = big; s_phi[tid] = -big; }
+                __syncthreads();
+                if (asks) {                                            // the (2e+1)^2 rows of this query's cube, dealt over the waves
+                    const int side = 2 * e + 1;
+                    for (int o = wid; o < side * side; o += NW) {
+                        const int y = cy + (o % side) - e, z = cz + (o / side) - e;
+                        if (y < Y0 || y > Y1 || z < Z0 || z > Z1) continue;
+                        const int r = (z - Z0) * nyb + (y - Y0) - rbase;
+                        if (r >= 0 && r < NT) { atomicMin(&s_lo[r], cx - e); atomicMax(&s_hi[r], cx + e); }
+                    }
+                }
+                if (ph == 1 && member) {                               // what phase 1 staged: the e = 1 tube of ALL members
+                    for (int o = wid; o < 9; o += NW) {
+                        const int y = cy + (o % 3) - 1, z = cz + (o / 3) - 1;
+                        if (y < Y0 || y > Y1 || z < Z0 || z > Z1) continue;
+                        const int r = (z - Z0) * nyb + (y - Y0) - rbase;
+                        if (r >= 0 && r < NT) { atomicMin(&s_plo[r], cx - 1); atomicMax(&s_phi[r], cx + 1); }
+                    }
+                }
+                __syncthreads();
+                // ---- 1. run list ----
+                int ja0 = 0, la = 0, jb0 = 0, lb = 0;
+                const int r = rbase + tid;
+                if (r < nrows) {
+                    const int lo = max(s_lo[tid], 0), hi = min(s_hi[tid], g.nx - 1);
+                    if (lo <= hi) {
+                        const int y = Y0 + r % nyb, z = Z0 + r / nyb;
+                        const int row = (z * g.ny + y) * g.nx;
+                        const int plo = (ph == 1) ? s_plo[tid] : big, phi = (ph == 1) ? s_phi[tid] : -big;
+                        if (plo > phi) {                                // nothing of this row visited yet
+                            ja0 = G.cell_start[row + lo]; la = G.cell_start[row + hi + 1] - ja0;
+                        } else {                                        // only the cells left of plo and right of phi are new
+                            const int a1 = min(plo - 1, hi), b0 = max(phi + 1, lo);
+                            if (lo <= a1) { ja0 = G.cell_start[row + lo]; la = G.cell_start[row + a1 + 1] - ja0; }
+                            if (b0 <= hi) { jb0 = G.cell_start[row + b0]; lb = G.cell_start[row + hi + 1] - jb0; }
+                        }
+                    }
+                }
+                // workgroup exclusive scan of (la + lb)
+                const int mine = la + lb;
+                int inc = mine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+                if (lane == 63) s_wave_tot[wid] = inc;
+                __syncthreads();
+                int wbase = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < NW; w++) { const int v = s_wave_tot[w]; if (w < wid) wbase += v; total += v; }
+                const int ex = wbase + inc - mine;
+                s_run_j0[2 * tid] = ja0; s_run_off[2 * tid] = ex;
+                s_run_j0[2 * tid + 1] = jb0; s_run_off[2 * tid + 1] = ex + la;
+                if (tid == 0) s_run_off[NRUN] = total;
+                __syncthreads();
+                if (DBG && tid == 0) { atomicAdd(&out.dbg[1], 1ull); atomicAdd(&out.dbg[2], (unsigned long long)total); if (ph == 1) atomicAdd(&out.dbg[3], (unsigned long long)total); atomicAdd(&out.dbg[4], (unsigned long long)nrows); }
+                // ---- 2./3. tiles ----
+                for (int tbase = 0; tbase < total; tbase += kTileCap) {
+                    const int tn = min(total - tbase, kTileCap);
+                    const int tn2 = (tn + 1) & ~1;                     // the sweep consumes pairs
+                    for (int i = tid; i < tn2; i += NT) {
+                        float4 c = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __int_as_float(0x7fffffff));
+                        int cr = 0x7fffffff;
+                        if (i < tn) {
+                            const int slot = tbase + i;
+                            int lo = 0;                                // largest k with s_run_off[k] <= slot (NRUN is a power of two)
+#pragma unroll
+                            for (int step = NRUN / 2; step > 0; step >>= 1) {
+                                if (s_run_off[lo + step] <= slot) lo += step;
+                            }
+                            const int j = s_run_j0[lo] + (slot - s_run_off[lo]);
+                            c = G.sorted[j];
+                            cr = G.sring[j];
+                        }
+                        const int pr = i >> 1, hb = i & 1;
+                        s_xy_f[4 * pr + hb] = c.x; s_xy_f[4 * pr + 2 + hb] = c.y;
+                        s_zg_f[4 * pr + hb] = c.z; s_zg_f[4 * pr + 2 + hb] = c.w;
+                        s_ring[i] = cr;
+                    }
+                    __syncthreads();
+                    // each wave sweeps a contiguous slice of the tile's pairs for all 64 queries
+                    const int npairs = tn2 >> 1;
+                    const int per = (npairs + NW - 1) / NW;
+                    const int p0 = wid * per, p1 = min(p0 + per, npairs);
+                    if (member) {
+                        // 4 pairs (8 candidates) per trip: all LDS reads first, then the packed distance math, then the
+                        // (rare) updates -- keeps 8 ds_read_b128 in flight instead of one dependent read per pair
+                        int pi = p0;
+                        for (; pi + 4 <= p1; pi += 4) {
+                            float4 a[4], bq[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) { a[u] = s_xy[pi + u]; bq[u] = s_zg[pi + u]; }
+                            f32x2 d2[4];
+#pragma unroll
+                            for (int u = 0; u < 4; u++) {
+                                const f32x2 cxp = {a[u].x, a[u].y}, cyp = {a[u].z, a[u].w}, czp = {bq[u].x, bq[u].y};
+                                const f32x2 dx = qx2 - cxp, dy = qy2 - cyp, dz = qz2 - czp;
+                                f32x2 d = dx * dx;                     // x -> y -> z accumulation, no FMA (-ffp-contract=off)
+                                d = d + dy * dy;
+                                d = d + dz * dz;
+                                d2[u] = d;
+                            }
+                            float dmin = fminf(fminf(fminf(d2[0].x, d2[0].y), fminf(d2[1].x, d2[1].y)), fminf(fminf(d2[2].x, d2[2].y), fminf(d2[3].x, d2[3].y)));
+                            if (dmin <= t.b2d) {                       // some candidate of the 8 may matter for this lane
+#pragma unroll
+                                for (int u = 0; u < 4; u++) {
+                                    if (d2[u].x <= t.b2d) {
+                                        const unsigned long long key = ((unsigned long long)__float_as_uint(d2[u].x) << 32) | (unsigned)__float_as_int(bq[u].z);
+                                        top2_update(t, key, s_ring[2 * (pi + u)]);
+                                    }
+                                    if (d2[u].y <= t.b2d) {
+                                        const unsigned long long key = ((unsigned long long)__float_as_uint(d2[u].y) << 32) | (unsigned)__float_as_int(bq[u].w);
+                                        top2_update(t, key, s_ring[2 * (pi + u) + 1]);
+                                    }
+                                }
+                            }
+                        }
+                        for (; pi < p1; pi++) {
+                            const float4 a = s_xy[pi], bq = s_zg[pi];
+                            const f32x2 cxp = {a.x, a.y}, cyp = {a.z, a.w}, czp = {bq.x, bq.y};
+                            const f32x2 dx = qx2 - cxp, dy = qy2 - cyp, dz = qz2 - czp;
+                            f32x2 d2 = dx * dx;
+                            d2 = d2 + dy * dy;
+                            d2 = d2 + dz * dz;
+                            if (d2.x <= t.b2d) {
+                                const unsigned long long key = ((unsigned long long)__float_as_uint(d2.x) << 32) | (unsigned)__float_as_int(bq.z);
+                                top2_update(t, key, s_ring[2 * pi]);
+                            }
+                            if (d2.y <= t.b2d) {
+                                const unsigned long long key = ((unsigned long long)__float_as_uint(d2.y) << 32) | (unsigned)__float_as_int(bq.w);
+                                top2_update(t, key, s_ring[2 * pi + 1]);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            // ---- 4. merge across waves ----
+            if (NW > 1) {
+                m1[wid][lane] = t.b1; m2[wid][lane] = t.b2; mr[wid][lane] = t.b1ring;
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
+                    if (w == wid) continue;
+                    const unsigned long long c1 = m1[w][lane], c2 = m2[w][lane];
+                    if (c1 < t.b2) top2_update(t, c1, mr[w][lane]);
+                    if (c2 < t.b2) top2_update(t, c2, ring_of[(int)(unsigned)(c2 & 0xffffffffull) - out.first_point]);
+                }
+                __syncthreads();
+            }
+        }
+        pending = pending && !member;
+    }
+    if (NW > 1 && wid != 0) return;
+    if (active) finish_correspondence(qi, src[q_src[qi]], qx, qy, qz, t.b1, t.b2, key_inf, tgt, tgt_off, ring_of, norm_cond, out, want_aux != 0);
+}
+
 // ---- association as a balanced pipeline: prepare (clusters -> work items) + persistent per-cluster search -----------------
 // The monolithic kernel above walks a group's clusters one after the other, so a 64-query group with several clusters and
 // two phases each is a long latency chain while most workgroups have already left.  Here a cheap prepare kernel (one
