@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Dev tool: association-kernel time per variant, measured with the library's HIP events inside frame_to_frame
 (6 rounds: 3 at gate 0.5, 3 at gate 0.03125), median over repetitions.
-Usage: python tools/assoc_bench.py [c2|c4] [variants...]   variant = assoc_variant:cluster_w[:debug_skip]"""
+Usage: python tools/assoc_bench.py [c2|c4] [variants...]   variant = assoc_variant:cluster_w[:debug_skip[:map]]  (map -> VELO_XCD_MAP for the box kernels, VELO_TUBE_MAP for the tube kernel)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,7 +18,8 @@ for v in variants:
     av, cw, *rest = v.split(":")
     os.environ["VELO_ASSOC_VARIANT"], os.environ["VELO_CLUSTER_W"] = av, cw
     os.environ["VELO_DEBUG_SKIP"] = rest[0] if rest else "0"
-    os.environ["VELO_XCD_MAP"] = rest[1] if len(rest) > 1 else "1"
+    os.environ["VELO_XCD_MAP"] = rest[1] if len(rest) > 1 else "0"
+    os.environ["VELO_TUBE_MAP"] = rest[1] if len(rest) > 1 else "1"
     c = api.Context(0, icp_skip=1)
     c.set_timing(True)
     c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])

@@ -120,7 +120,10 @@ struct velo_ctx {
     int cluster_w = 6;                   // cluster radius of the box kernels, in cells of the default grid (VELO_CLUSTER_W)
     bool cluster_w_set = false;          // the tube kernel keeps one cluster per group unless VELO_CLUSTER_W is given
     int persistent_wgs = 2048;           // workgroups of the persistent association kernel (VELO_PERSISTENT_WGS)
-    int xcd_map = 0;                     // XCD-contiguous group mapping of the association kernel (VELO_XCD_MAP=1): measured slower
+    int xcd_map = 0;                     // box kernels: XCD-contiguous group mapping (VELO_XCD_MAP=1): measured slower
+    int tube_map = -1;                   // tube kernel (VELO_TUBE_MAP): -1 = groups in ring order (default); 1 = XCD k works on the k-th eighth of
+                                         // every ring (a wedge of the scene): L2 hit rate 57 % -> 73 %, yet 8 % SLOWER (the kernel is bound by VALU
+                                         // issue and per-group latency chains, not by L2 misses); 0 = ring order through the same table
                                          // (dense bottom rings all land on one XCD); round-robin placement balances better
     int debug_skip = 0;                  // timing experiments only (VELO_DEBUG_SKIP): results are wrong when non-zero
 
@@ -144,6 +147,8 @@ struct velo_ctx {
     DevBuf<int> src_off, q_off, q_src;
     std::vector<int> h_src_off, h_q_off;
     int src_skip = 0;                    // icp_skip the query list was built with
+    DevBuf<int> group_perm;              // workgroup -> 64-query group, XCD-aware (see build_group_perm)
+    int perm_qb = -1, perm_qe = -1, perm_nq = -1, perm_mode = -1;
     bool have_source = false;
 
     DevBuf<char> staging;                // raw host clouds land here before packing
@@ -343,6 +348,44 @@ int build_query_list(velo_ctx* c) {
     return VELO_OK;
 }
 
+// Workgroup -> group map of the association kernel.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8) and each
+// XCD has its own 4 MB L2, while one launch touches ~17 MB (clouds, sorted copy, cell table, outputs): with groups in ring
+// order every XCD streams the whole scene through its L2 (measured hit rate 57 %).  Here XCD k gets the groups whose queries lie
+// in the k-th eighth of their ring -- a wedge of the scene across ALL rings, so the load stays balanced (the dense bottom
+// rings are shared by all XCDs) and each L2 only has to hold its wedge.  Placement only; results do not depend on it.
+int build_group_perm(velo_ctx* c, int qb, int qe, int mode) {
+    if (c->perm_qb == qb && c->perm_qe == qe && c->perm_nq == c->n_q && c->perm_mode == mode) return VELO_OK;
+    const int groups = cdiv(qe - qb, 64);
+    std::vector<int> perm((size_t)std::max(groups, 1));
+    constexpr int NX = 8;
+    std::vector<std::vector<int>> bucket(NX);
+    int ring = 0;
+    for (int g = 0; g < groups; g++) {
+        const int q = qb + 64 * g + 32;                                  // the group's middle query decides
+        const int qq = std::min(q, qe - 1);
+        while (ring + 1 < (int)c->h_q_off.size() - 1 && c->h_q_off[(size_t)ring + 1] <= qq) ring++;
+        const int len = std::max(c->h_q_off[(size_t)ring + 1] - c->h_q_off[(size_t)ring], 1);
+        const int k = mode == 1 ? std::min(NX - 1, (int)((int64_t)(qq - c->h_q_off[(size_t)ring]) * NX / len)) : g % NX;
+        bucket[(size_t)k].push_back(g);
+    }
+    // blockIdx = slot * 8 + k; a bucket that runs dry is refilled from the fullest one (keeps every group exactly once)
+    std::vector<size_t> next(NX, 0);
+    for (int b = 0; b < groups; b++) {
+        int k = b % NX;
+        if (next[(size_t)k] >= bucket[(size_t)k].size()) {
+            size_t best = 0; int kb = -1;
+            for (int j = 0; j < NX; j++) { const size_t left = bucket[(size_t)j].size() - next[(size_t)j]; if (left > best) { best = left; kb = j; } }
+            k = kb;
+        }
+        perm[(size_t)b] = bucket[(size_t)k][next[(size_t)k]++];
+    }
+    VELO_TRY(c->group_perm.reserve(perm.size()));
+    HIP_TRY(hipMemcpyAsync(c->group_perm.p, perm.data(), sizeof(int) * perm.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));                             // perm is a stack-owned host vector
+    c->perm_qb = qb; c->perm_qe = qe; c->perm_nq = c->n_q; c->perm_mode = mode;
+    return VELO_OK;
+}
+
 void pose_scalars(const double x[6], PoseScalars* S) {
     // the point-independent part of ceres::AngleAxisRotatePoint [3P], in double with the host libm
     std::memset(S, 0, sizeof(*S));
@@ -491,17 +534,23 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                                        c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, h_safe, out, aux);
                 break;
             }
-            case 5: case 55: {   // tube variant: per-row intervals, per-query phase 2 (cluster radius from VELO_CLUSTER_W, 0 = unbounded)
-                const int cw = (c->cluster_w_set && c->cluster_w > 0) ? cluster_cells : (1 << 27);
-                if (c->debug_skip)
-                    hipLaunchKernelGGL((assoc_search_v5_kernel<4, 6, true>), dim3(groups), dim3(256), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe,
-                                       c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux);
-                else if (variant == 55)
-                    hipLaunchKernelGGL((assoc_search_v5_kernel<4, 5, false>), dim3(groups), dim3(256), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe,
-                                       c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux);
-                else
-                    hipLaunchKernelGGL((assoc_search_v5_kernel<4, 6, false>), dim3(groups), dim3(256), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe,
-                                       c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux);
+            case 5: case 55: case 52: case 58: case 51: {   // tube variant: per-row intervals, per-query phase 2 (cluster radius only when VELO_CLUSTER_W is given)
+                // tubes do not grow with the segment, so the cluster radius only has to bound the row box of pathological groups
+                // (a 64-query group straddling a gap in its ring): 96 default cells = 17 m unless VELO_CLUSTER_W says otherwise
+                const int cw = c->cluster_w_set ? (c->cluster_w > 0 ? cluster_cells : 2000)
+                                                : std::max(1, (int)std::lround(96.0 * 0.1785 / G->h));
+                const int* perm = nullptr;
+                if (c->tube_map >= 0) { VELO_TRY(build_group_perm(c, qb, qe, c->tube_map)); perm = c->group_perm.p; }
+#define VELO_LAUNCH_V5(NW, MINW, DBG, PPT)                                                                                         \
+                hipLaunchKernelGGL((assoc_search_v5_kernel<NW, MINW, DBG, PPT>), dim3(groups), dim3(NW * 64), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe, \
+                                   c->tgt.p, c->tgt_off.p, c->n_tgt, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux, perm, c->debug_skip)
+                if (c->debug_skip) VELO_LAUNCH_V5(4, 6, true, 4);
+                else if (variant == 55) VELO_LAUNCH_V5(4, 5, false, 4);
+                else if (variant == 52) VELO_LAUNCH_V5(4, 8, false, 2);
+                else if (variant == 51) VELO_LAUNCH_V5(4, 7, false, 2);
+                else if (variant == 58) VELO_LAUNCH_V5(4, 8, false, 1);
+                else VELO_LAUNCH_V5(4, 6, false, 4);
+#undef VELO_LAUNCH_V5
                 break;
             }
             case 1: VELO_LAUNCH_V2(1, 1); break;
@@ -757,6 +806,7 @@ int velo_create(velo_ctx** out, int device) {
     if (const char* e = getenv("VELO_DEBUG_SKIP")) c->debug_skip = atoi(e);
     if (const char* e = getenv("VELO_GRAPHS")) c->use_graphs = atoi(e) != 0;
     if (const char* e = getenv("VELO_XCD_MAP")) c->xcd_map = atoi(e);
+    if (const char* e = getenv("VELO_TUBE_MAP")) c->tube_map = atoi(e);
     if (const char* e = getenv("VELO_PERSISTENT_WGS")) c->persistent_wgs = std::max(atoi(e), 1);
     if (const char* e = getenv("VELO_FUSED")) c->use_fused = atoi(e) != 0;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));

@@ -397,6 +397,61 @@ __device__ __forceinline__ void finish_correspondence(
     write_correspondence(qi, psrc, valid, n, v0, ring_i, idx_i, ring_j, idx_j, idx_k, di, dj, out, want_aux);
 }
 
+// The same rows with both ring ids already known (the tube kernel tracks them): no ring_of look-up, and the two ring neighbours
+// of the winner are fetched speculatively at gi +- 1 together with the ring bounds -- one memory round trip instead of three
+// dependent ones; only a winner at the end of its ring (2 of ~1,875 points) pays a second load for the wrap-around.
+__device__ __forceinline__ void finish_correspondence_rings(
+    int qi, const float4& psrc, float qx, float qy, float qz, unsigned long long b1, unsigned long long b2, int ring_i_in, int ring_j_in,
+    unsigned long long key_inf, const float4* __restrict__ tgt, const int* __restrict__ tgt_off, int n_tgt_local, double norm_cond,
+    const AssocOut& out, bool want_aux) {
+    int ring_i = -1, idx_i = 0, ring_j = -1, idx_j = 0, idx_k = 0;
+    float di = 1e18f, dj = 1e18f;
+    float v0[3] = {0.f, 0.f, 0.f}, v1[3] = {0.f, 0.f, 0.f}, v2[3] = {0.f, 0.f, 0.f};
+    const bool has1 = b1 < key_inf, has2 = b2 < key_inf;
+    const int gi = has1 ? (int)(unsigned)(b1 & 0xffffffffull) - out.first_point : 0;
+    const int gj = has2 ? (int)(unsigned)(b2 & 0xffffffffull) - out.first_point : 0;
+    // everything that needs no other load first: the two winners, the speculative neighbours, the ring bounds
+    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, a1 = p0, a2 = p0;
+    int base = 0, end = 1, base_j = 0;
+    if (has1) {
+        p0 = tgt[gi]; a1 = tgt[min(gi + 1, n_tgt_local - 1)]; a2 = tgt[max(gi - 1, 0)];
+        base = tgt_off[ring_i_in - out.first_ring]; end = tgt_off[ring_i_in - out.first_ring + 1];
+    }
+    if (has2) { p1 = tgt[gj]; base_j = tgt_off[ring_j_in - out.first_ring]; }
+    if (has1) {
+        ring_i = ring_i_in;
+        const int n = end - base;
+        idx_i = gi - base;
+        di = __uint_as_float((unsigned)(b1 >> 32));
+        const int k1 = (idx_i + 1 == n) ? 0 : idx_i + 1, k2 = (idx_i == 0) ? n - 1 : idx_i - 1;       // velo.h:852-854
+        if (k1 != idx_i + 1) a1 = tgt[base + k1];                       // wrap-around: the speculative neighbour was the next ring's
+        if (k2 != idx_i - 1) a2 = tgt[base + k2];
+        const float d1 = dist2_f(a1.x, a1.y, a1.z, qx, qy, qz);
+        const float d2 = dist2_f(a2.x, a2.y, a2.z, qx, qy, qz);
+        idx_k = (d1 < d2) ? k1 : k2;                                    // velo.h:859-863
+        const float4 p2 = (idx_k == k1) ? a1 : a2;
+        v0[0] = p0.x; v0[1] = p0.y; v0[2] = p0.z; v2[0] = p2.x; v2[1] = p2.y; v2[2] = p2.z;
+    }
+    if (has2) {
+        ring_j = ring_j_in;
+        idx_j = gj - base_j;
+        dj = __uint_as_float((unsigned)(b2 >> 32));
+        v1[0] = p1.x; v1[1] = p1.y; v1[2] = p1.z;
+    }
+    if (out.partial) {
+        PartialRec r;
+        r.key1 = b1; r.key2 = b2; r.ring1 = ring_i; r.ring2 = ring_j; r.idx1 = idx_i; r.idx_k = idx_k; r.idx2 = idx_j; r.pad = 0;
+        for (int k = 0; k < 3; k++) { r.v0[k] = v0[k]; r.v2[k] = v2[k]; r.v1[k] = v1[k]; }
+        r.pad2 = 0.f;
+        out.partial[qi] = r;
+        return;
+    }
+    int valid = 0;
+    float n[3] = {0.f, 0.f, 0.f};
+    if (ring_i >= 0 && ring_j >= 0) valid = plane_from_points(v0, v1, v2, norm_cond, n);     // velo.h:849-851,864-874
+    write_correspondence(qi, psrc, valid, n, v0, ring_i, idx_i, ring_j, idx_j, idx_k, di, dj, out, want_aux);
+}
+
 // Owner-side merge of `world` partial tables (one per target shard) for the queries [q_begin, q_end): table w holds
 // records for those queries in order at tables + w * table_stride.  Ring ownership is disjoint, so (see PartialRec):
 // best1 = min key1; best2 = min( key1 of the other ranks, key2 of the winning rank ).
@@ -484,16 +539,16 @@ assoc_search_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, c
 // ---- running (best1, best2) over distinct rings ---------------------------------------------------------------------
 struct Top2 {
     unsigned long long b1, b2;
-    int b1ring;
+    int b1ring, b2ring; // b2ring is dead (and removed by the compiler) in the kernels that look the second ring up at the end
     float b2d;          // float view of b2's distance field: the cheap per-candidate reject threshold
 };
 __device__ __forceinline__ void top2_update(Top2& t, unsigned long long key, int ring) {
     if (key < t.b2) {
         if (key < t.b1) {
-            if (ring != t.b1ring) t.b2 = t.b1;
+            if (ring != t.b1ring) { t.b2 = t.b1; t.b2ring = t.b1ring; }
             t.b1 = key; t.b1ring = ring;
         } else if (ring != t.b1ring) {
-            t.b2 = key;
+            t.b2 = key; t.b2ring = ring;
         }
         t.b2d = __uint_as_float((unsigned)(t.b2 >> 32));
     }
@@ -570,7 +625,7 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
     const unsigned long long key_inf = ((unsigned long long)gate_bits + 1ull) << 32;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     Top2 t;
-    t.b1 = key_inf; t.b2 = key_inf; t.b1ring = -1; t.b2d = __uint_as_float(gate_bits + 1u);
+    t.b1 = key_inf; t.b2 = key_inf; t.b1ring = -1; t.b2ring = -1; t.b2d = __uint_as_float(gate_bits + 1u);
     const GridDesc g = G.d;
     int cx = 0, cy = 0, cz = 0;
     if (active) {
@@ -766,11 +821,11 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
 //     and contributes the rows/intervals of its own cube only; finished members ask for nothing.  Rows subtract the interval
 //     phase 1 already visited.  After phase 2 every member has (e_q h)^2 > b2d_q, so there is never a third phase.
 // Tubes do not blow up with the length of the segment, so the cluster radius can be large (one cluster per group).
-template <int NW, int MINW, bool DBG>
+template <int NW, int MINW, bool DBG, int PPT>
 __global__ void __launch_bounds__(NW * 64, MINW)
 assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
-                       const float4* __restrict__ tgt, const int* __restrict__ tgt_off, const int* __restrict__ ring_of,
-                       unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, AssocOut out, int want_aux) {
+                       const float4* __restrict__ tgt, const int* __restrict__ tgt_off, int n_tgt_local,
+                       unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, AssocOut out, int want_aux, const int* __restrict__ group_perm, int dbg) {
     constexpr int NT = NW * 64;
     constexpr int NRUN = 2 * NT;
     __shared__ float4 s_xy[kTileCap / 2];
@@ -780,19 +835,29 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
     __shared__ int s_run_off[NRUN + 1];
     __shared__ int s_wave_tot[NW];
     __shared__ int s_lo[NT], s_hi[NT], s_plo[NT], s_phi[NT];   // per-row x-interval of this phase / of what phase 1 visited
-    __shared__ unsigned long long m1[NW][64], m2[NW][64];
-    __shared__ int mr[NW][64];
+    // merge scratch aliases the tile: the barrier that closes the last sweep separates the two uses (NW <= 4)
+    static_assert(NW * 64 * 16 <= (int)sizeof(float4) * (kTileCap / 2) && NW * 64 * 8 <= (int)sizeof(int) * kTileCap, "merge scratch must fit the tile");
+    unsigned long long (*m1)[64] = reinterpret_cast<unsigned long long (*)[64]>(s_xy);
+    unsigned long long (*m2)[64] = m1 + NW;
+    int (*mr)[64] = reinterpret_cast<int (*)[64]>(s_ring);
+    int (*mr2)[64] = mr + NW;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int group = (int)blockIdx.x;
+    // diagnostic instantiation only (DBG && dbg & 8): per-section cycle totals of wave 0, added to out.dbg[0..7]
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = (DBG && (dbg & 8)) ? (long long)__builtin_readcyclecounter() : 0;
+#define VELO_STAMP(k) do { if (DBG && (dbg & 8)) { const long long now__ = (long long)__builtin_readcyclecounter(); tacc[k] += now__ - tlast; tlast = now__; } } while (0)
+    // workgroup -> group through the host-built table (XCD-aware wedges, see build_group_perm); placement affects speed only
+    const int group = group_perm ? group_perm[blockIdx.x] : (int)blockIdx.x;
+    if (DBG && out.wg_times && tid == 0) out.wg_times[2 * group] = __builtin_amdgcn_s_memrealtime();
     const int qi = q_begin + group * 64 + lane;
     const bool active = qi < q_end;
     const unsigned long long key_inf = ((unsigned long long)gate_bits + 1ull) << 32;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     Top2 t;
-    t.b1 = key_inf; t.b2 = key_inf; t.b1ring = -1; t.b2d = __uint_as_float(gate_bits + 1u);
+    t.b1 = key_inf; t.b2 = key_inf; t.b1ring = -1; t.b2ring = -1; t.b2d = __uint_as_float(gate_bits + 1u);
     const GridDesc g = G.d;
     int cx = 0, cy = 0, cz = 0;
     if (active) {
@@ -800,6 +865,7 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
         transform_query(P, psrc, &qx, &qy, &qz);
         cx = cell_coord(qx, g.ox, g.inv_h, g.nx); cy = cell_coord(qy, g.oy, g.inv_h, g.ny); cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
     }
+    VELO_STAMP(0);
     const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
     float* s_xy_f = reinterpret_cast<float*>(s_xy);
     float* s_zg_f = reinterpret_cast<float*>(s_zg);
@@ -812,7 +878,7 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
         const int leader = (int)__ffsll((long long)pm) - 1;
         const int scx = __builtin_amdgcn_readlane(cx, leader), scy = __builtin_amdgcn_readlane(cy, leader), scz = __builtin_amdgcn_readlane(cz, leader);
         const bool member = pending && abs(cx - scx) <= cluster_w && abs(cy - scy) <= cluster_w && abs(cz - scz) <= cluster_w;
-        if (DBG && tid == 0) atomicAdd(&out.dbg[0], 1ull);
+        if (DBG && (dbg & 16) && tid == 0) atomicAdd(&out.dbg[0], 1ull);
         for (int ph = 0; ph < 2; ph++) {
             // who asks for cells in this phase, and how far
             bool asks = member;
@@ -829,36 +895,44 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
             const int Z1 = min(__builtin_amdgcn_readfirstlane(wave_max_i(asks ? cz + e : -big)), g.nz - 1);
             const int nyb = Y1 - Y0 + 1, nzb = Z1 - Z0 + 1;
             const int nrows = (nyb > 0 && nzb > 0) ? nyb * nzb : 0;
-            for (int rbase = 0; rbase < nrows; rbase += NT) {          // row chunks (one row per thread)
+            const float rcp_nyb = 1.0f / (float)max(nyb, 1);
+            for (int rbase = 0; rbase < ((DBG && (dbg & 4)) ? 0 : nrows); rbase += NT) {          // row chunks (one row per thread)
                 // ---- 0. per-row x-intervals ----
                 s_lo[tid] = big; s_hi[tid] = -big;
                 if (ph == 1) { s_plo[tid] = big; s_phi[tid] = -big; }
                 __syncthreads();
-                if (asks) {                                            // the (2e+1)^2 rows of this query's cube, dealt over the waves
-                    const int side = 2 * e + 1;
-                    for (int o = wid; o < side * side; o += NW) {
-                        const int y = cy + (o % side) - e, z = cz + (o / side) - e;
-                        if (y < Y0 || y > Y1 || z < Z0 || z > Z1) continue;
-                        const int r = (z - Z0) * nyb + (y - Y0) - rbase;
-                        if (r >= 0 && r < NT) { atomicMin(&s_lo[r], cx - e); atomicMax(&s_hi[r], cx + e); }
+                if (asks) {                                            // the (2e+1)^2 rows of this query's cube: z-layers dealt over the waves
+                    for (int z = cz - e + wid; z <= cz + e; z += NW) {
+                        if (z < Z0 || z > Z1) continue;
+                        const int rz = (z - Z0) * nyb - Y0 - rbase;
+                        for (int y = max(cy - e, Y0); y <= min(cy + e, Y1); y++) {
+                            const int r = rz + y;
+                            if (r >= 0 && r < NT) { atomicMin(&s_lo[r], cx - e); atomicMax(&s_hi[r], cx + e); }
+                        }
                     }
                 }
                 if (ph == 1 && member) {                               // what phase 1 staged: the e = 1 tube of ALL members
-                    for (int o = wid; o < 9; o += NW) {
-                        const int y = cy + (o % 3) - 1, z = cz + (o / 3) - 1;
-                        if (y < Y0 || y > Y1 || z < Z0 || z > Z1) continue;
-                        const int r = (z - Z0) * nyb + (y - Y0) - rbase;
-                        if (r >= 0 && r < NT) { atomicMin(&s_plo[r], cx - 1); atomicMax(&s_phi[r], cx + 1); }
+                    for (int z = cz - 1 + wid; z <= cz + 1; z += NW) {
+                        if (z < Z0 || z > Z1) continue;
+                        const int rz = (z - Z0) * nyb - Y0 - rbase;
+                        for (int y = max(cy - 1, Y0); y <= min(cy + 1, Y1); y++) {
+                            const int r = rz + y;
+                            if (r >= 0 && r < NT) { atomicMin(&s_plo[r], cx - 1); atomicMax(&s_phi[r], cx + 1); }
+                        }
                     }
                 }
                 __syncthreads();
+                VELO_STAMP(1);
                 // ---- 1. run list ----
                 int ja0 = 0, la = 0, jb0 = 0, lb = 0;
                 const int r = rbase + tid;
                 if (r < nrows) {
                     const int lo = max(s_lo[tid], 0), hi = min(s_hi[tid], g.nx - 1);
                     if (lo <= hi) {
-                        const int y = Y0 + r % nyb, z = Z0 + r / nyb;
+                        // r / nyb without the integer-division sequence: r < 2^24 (bounded cluster radius), one float multiply + fix-up
+                        int zq = (int)((float)r * rcp_nyb), yr = r - zq * nyb;
+                        if (yr < 0) { zq--; yr += nyb; } else if (yr >= nyb) { zq++; yr -= nyb; }
+                        const int y = Y0 + yr, z = Z0 + zq;
                         const int row = (z * g.ny + y) * g.nx;
                         const int plo = (ph == 1) ? s_plo[tid] : big, phi = (ph == 1) ? s_phi[tid] : -big;
                         if (plo > phi) {                                // nothing of this row visited yet
@@ -885,11 +959,13 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                 s_run_j0[2 * tid + 1] = jb0; s_run_off[2 * tid + 1] = ex + la;
                 if (tid == 0) s_run_off[NRUN] = total;
                 __syncthreads();
-                if (DBG && tid == 0) { atomicAdd(&out.dbg[1], 1ull); atomicAdd(&out.dbg[2], (unsigned long long)total); if (ph == 1) atomicAdd(&out.dbg[3], (unsigned long long)total); atomicAdd(&out.dbg[4], (unsigned long long)nrows); }
+                VELO_STAMP(2);
+                if (DBG && (dbg & 2)) total = 0;
+                if (DBG && (dbg & 16) && tid == 0) { atomicAdd(&out.dbg[1], 1ull); atomicAdd(&out.dbg[2], (unsigned long long)total); if (ph == 1) atomicAdd(&out.dbg[3], (unsigned long long)total); atomicAdd(&out.dbg[4], (unsigned long long)nrows); }
                 // ---- 2./3. tiles ----
                 for (int tbase = 0; tbase < total; tbase += kTileCap) {
                     const int tn = min(total - tbase, kTileCap);
-                    const int tn2 = (tn + 1) & ~1;                     // the sweep consumes pairs
+                    const int tn2 = (tn + 2 * PPT - 1) / (2 * PPT) * (2 * PPT);   // the sweep consumes trips of PPT pairs; +inf sentinels pad
                     for (int i = tid; i < tn2; i += NT) {
                         float4 c = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __int_as_float(0x7fffffff));
                         int cr = 0x7fffffff;
@@ -910,21 +986,21 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                         s_ring[i] = cr;
                     }
                     __syncthreads();
-                    // each wave sweeps a contiguous slice of the tile's pairs for all 64 queries
+                    VELO_STAMP(3);
+                    // Trips of PPT pairs (2 PPT candidates) are dealt round-robin over the waves, so every wave samples the whole
+                    // tile instead of one quarter of it -- its bounds tighten as fast as the best rows allow.  Per trip: all LDS
+                    // reads first (coordinates AND ring ids), then the packed distance math, then the (rare) updates.
                     const int npairs = tn2 >> 1;
-                    const int per = (npairs + NW - 1) / NW;
-                    const int p0 = wid * per, p1 = min(p0 + per, npairs);
-                    if (member) {
-                        // 4 pairs (8 candidates) per trip: all LDS reads first, then the packed distance math, then the
-                        // (rare) updates -- keeps 8 ds_read_b128 in flight instead of one dependent read per pair
-                        int pi = p0;
-                        for (; pi + 4 <= p1; pi += 4) {
-                            float4 a[4], bq[4];
+                    if (member && !(DBG && (dbg & 1))) {
+                        const int2* s_ring2 = reinterpret_cast<const int2*>(s_ring);
+                        for (int pi = wid * PPT; pi < npairs; pi += NW * PPT) {
+                            float4 a[PPT], bq[PPT];
+                            int2 rg[PPT];
 #pragma unroll
-                            for (int u = 0; u < 4; u++) { a[u] = s_xy[pi + u]; bq[u] = s_zg[pi + u]; }
-                            f32x2 d2[4];
+                            for (int u = 0; u < PPT; u++) { a[u] = s_xy[pi + u]; bq[u] = s_zg[pi + u]; rg[u] = s_ring2[pi + u]; }
+                            f32x2 d2[PPT];
 #pragma unroll
-                            for (int u = 0; u < 4; u++) {
+                            for (int u = 0; u < PPT; u++) {
                                 const f32x2 cxp = {a[u].x, a[u].y}, cyp = {a[u].z, a[u].w}, czp = {bq[u].x, bq[u].y};
                                 const f32x2 dx = qx2 - cxp, dy = qy2 - cyp, dz = qz2 - czp;
                                 f32x2 d = dx * dx;                     // x -> y -> z accumulation, no FMA (-ffp-contract=off)
@@ -932,59 +1008,52 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                                 d = d + dz * dz;
                                 d2[u] = d;
                             }
-                            float dmin = fminf(fminf(fminf(d2[0].x, d2[0].y), fminf(d2[1].x, d2[1].y)), fminf(fminf(d2[2].x, d2[2].y), fminf(d2[3].x, d2[3].y)));
-                            if (dmin <= t.b2d) {                       // some candidate of the 8 may matter for this lane
+                            float dmin = fminf(d2[0].x, d2[0].y);
 #pragma unroll
-                                for (int u = 0; u < 4; u++) {
+                            for (int u = 1; u < PPT; u++) dmin = fminf(dmin, fminf(d2[u].x, d2[u].y));
+                            if (dmin <= t.b2d) {                       // some candidate of the trip may matter for this lane
+#pragma unroll
+                                for (int u = 0; u < PPT; u++) {
                                     if (d2[u].x <= t.b2d) {
                                         const unsigned long long key = ((unsigned long long)__float_as_uint(d2[u].x) << 32) | (unsigned)__float_as_int(bq[u].z);
-                                        top2_update(t, key, s_ring[2 * (pi + u)]);
+                                        top2_update(t, key, rg[u].x);
                                     }
                                     if (d2[u].y <= t.b2d) {
                                         const unsigned long long key = ((unsigned long long)__float_as_uint(d2[u].y) << 32) | (unsigned)__float_as_int(bq[u].w);
-                                        top2_update(t, key, s_ring[2 * (pi + u) + 1]);
+                                        top2_update(t, key, rg[u].y);
                                     }
                                 }
                             }
                         }
-                        for (; pi < p1; pi++) {
-                            const float4 a = s_xy[pi], bq = s_zg[pi];
-                            const f32x2 cxp = {a.x, a.y}, cyp = {a.z, a.w}, czp = {bq.x, bq.y};
-                            const f32x2 dx = qx2 - cxp, dy = qy2 - cyp, dz = qz2 - czp;
-                            f32x2 d2 = dx * dx;
-                            d2 = d2 + dy * dy;
-                            d2 = d2 + dz * dz;
-                            if (d2.x <= t.b2d) {
-                                const unsigned long long key = ((unsigned long long)__float_as_uint(d2.x) << 32) | (unsigned)__float_as_int(bq.z);
-                                top2_update(t, key, s_ring[2 * pi]);
-                            }
-                            if (d2.y <= t.b2d) {
-                                const unsigned long long key = ((unsigned long long)__float_as_uint(d2.y) << 32) | (unsigned)__float_as_int(bq.w);
-                                top2_update(t, key, s_ring[2 * pi + 1]);
-                            }
-                        }
                     }
+                    VELO_STAMP(4);
                     __syncthreads();
+                    VELO_STAMP(5);
                 }
             }
             // ---- 4. merge across waves ----
             if (NW > 1) {
-                m1[wid][lane] = t.b1; m2[wid][lane] = t.b2; mr[wid][lane] = t.b1ring;
+                m1[wid][lane] = t.b1; m2[wid][lane] = t.b2; mr[wid][lane] = t.b1ring; mr2[wid][lane] = t.b2ring;
                 __syncthreads();
 #pragma unroll
                 for (int w = 0; w < NW; w++) {
                     if (w == wid) continue;
                     const unsigned long long c1 = m1[w][lane], c2 = m2[w][lane];
                     if (c1 < t.b2) top2_update(t, c1, mr[w][lane]);
-                    if (c2 < t.b2) top2_update(t, c2, ring_of[(int)(unsigned)(c2 & 0xffffffffull) - out.first_point]);
+                    if (c2 < t.b2) top2_update(t, c2, mr2[w][lane]);
                 }
                 __syncthreads();
             }
+            VELO_STAMP(6);
         }
         pending = pending && !member;
     }
     if (NW > 1 && wid != 0) return;
-    if (active) finish_correspondence(qi, src[q_src[qi]], qx, qy, qz, t.b1, t.b2, key_inf, tgt, tgt_off, ring_of, norm_cond, out, want_aux != 0);
+    if (active) finish_correspondence_rings(qi, src[q_src[qi]], qx, qy, qz, t.b1, t.b2, t.b1ring, t.b2ring, key_inf, tgt, tgt_off, n_tgt_local, norm_cond, out, want_aux != 0);
+    VELO_STAMP(7);
+    if (DBG && out.wg_times && tid == 0) out.wg_times[2 * group + 1] = __builtin_amdgcn_s_memrealtime();
+    if (DBG && (dbg & 8) && tid == 0) { for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)&out.dbg[k], (unsigned long long)tacc[k]); }
+#undef VELO_STAMP
 }
 
 // ---- association as a balanced pipeline: prepare (clusters -> work items) + persistent per-cluster search -----------------
@@ -1127,7 +1196,7 @@ assoc_cluster_kernel(GridView G, AssocQueue Q, const float4* __restrict__ src, c
         if (member) { const float4 qp = Q.qpos[qi]; qx = qp.x; qy = qp.y; qz = qp.z; }
         const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
         Top2 t;
-        t.b1 = key_inf; t.b2 = key_inf; t.b1ring = -1; t.b2d = __uint_as_float(gate_bits + 1u);
+        t.b1 = key_inf; t.b2 = key_inf; t.b1ring = -1; t.b2ring = -1; t.b2d = __uint_as_float(gate_bits + 1u);
         int e_prev = -1, e = 1;
         for (;;) {                                                     // phases (see assoc_search_v3_kernel)
             const int X0 = max(bx0 - e, 0), X1 = min(bx1 + e, g.nx - 1);
