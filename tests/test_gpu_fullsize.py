@@ -70,6 +70,37 @@ def test_full_size_reference_kernel_agrees_with_shell_walk(hip_lib, pair):
             H.assert_corr_equal(a, b)
 
 
+def test_warm_started_rounds_equal_cold_rounds(hip_lib, pair, monkeypatch):
+    """Rounds after the first start from the previous round's winners (AssocOut::prev).  Seeds are ordinary candidates entered
+    early, so every table must equal the one of a context that never has seeds -- also when the pose jumps, the gate shrinks
+    (iter 2), grows again, or the source / target is replaced in between."""
+    monkeypatch.setenv("VELO_WARM_START", "1")
+    warm = api.Context(0, icp_skip=1)
+    monkeypatch.setenv("VELO_WARM_START", "0")
+    cold = api.Context(0, icp_skip=1)
+    for c in (warm, cold):
+        c.set_target(pair["tgt_xyz"], pair["tgt_off"])
+        c.set_source(pair["src_xyz"], pair["src_off"])
+    x0, x1 = pair["x0"], pair["x_true"]
+    seq = [(1, x0), (1, x0 + 0.3 * (x1 - x0)), (1, x0 + 0.9 * (x1 - x0)), (2, x1), (2, x1 + 1e-4), (2, x1),
+           (1, np.array([0.02, -0.01, 0.03, 0.4, -0.3, 1.5])), (2, x0), (1, x1)]
+    for it, x in seq:
+        assert warm.associate(x, it) == cold.associate(x, it)
+        assert warm.correspondences().tobytes() == cold.correspondences().tobytes()
+    # swap the roles of the two scans: stale seeds must not survive a new source / target
+    for c in (warm, cold):
+        c.set_target(pair["src_xyz"], pair["src_off"])
+        c.set_source(pair["tgt_xyz"], pair["tgt_off"])
+    for it, x in ((1, np.zeros(6)), (2, np.zeros(6))):
+        assert warm.associate(x, it) == cold.associate(x, it)
+        assert warm.correspondences().tobytes() == cold.correspondences().tobytes()
+    xa, Ta, sa = warm.frame_to_frame(np.zeros(6))
+    xb, Tb, sb = cold.frame_to_frame(np.zeros(6))
+    assert np.array_equal(xa, xb) and np.array_equal(Ta, Tb)
+    warm.close()
+    cold.close()
+
+
 def test_full_size_frame_to_frame_properties(full_ctx, pair):
     x1, T1, s1 = full_ctx.frame_to_frame(pair["x0"])
     x2, T2, s2 = full_ctx.frame_to_frame(pair["x0"])

@@ -115,8 +115,8 @@ struct velo_ctx {
     hipStream_t stream = nullptr;
     velo_params P;
     bool timing = false;
-    int assoc_variant = -1;              // VELO_ASSOC_VARIANT: -1 = automatic (tube kernel 5 when the gate radius is <= 5 cells, box kernel 4 on
-                                         // density-shrunk grids); 0 = per-lane reference kernel; 1/2/4/8 = waves per group of the box walk; 5 = tube
+    int assoc_variant = -1;              // VELO_ASSOC_VARIANT: -1 = default (tube kernel 5); 0 = per-lane reference kernel; 1/2/4/8 = waves per group
+                                         // of the box walk; 5 = tube kernel
     int cluster_w = 6;                   // cluster radius of the box kernels, in cells of the default grid (VELO_CLUSTER_W)
     bool cluster_w_set = false;          // the tube kernel keeps one cluster per group unless VELO_CLUSTER_W is given
     int persistent_wgs = 2048;           // workgroups of the persistent association kernel (VELO_PERSISTENT_WGS)
@@ -147,6 +147,9 @@ struct velo_ctx {
     DevBuf<int> src_off, q_off, q_src;
     std::vector<int> h_src_off, h_q_off;
     int src_skip = 0;                    // icp_skip the query list was built with
+    DevBuf<int4> prev_pair;              // tube kernel warm start: last round's winners per query (-1 = none); reset with every new source / target
+    bool prev_ready = false;             // prev_pair holds n_q initialised entries for the current source and target
+    int warm_start = 1;                  // VELO_WARM_START=0 turns the seeds off (A/B; results are identical either way)
     DevBuf<int> group_perm;              // workgroup -> 64-query group, XCD-aware (see build_group_perm)
     int perm_qb = -1, perm_qe = -1, perm_nq = -1, perm_mode = -1;
     bool have_source = false;
@@ -325,6 +328,7 @@ Grid* grid_for_iter(velo_ctx* c, int) { return (!c->grids.empty() && c->grids[0]
 
 int build_query_list(velo_ctx* c) {
     const int skip = std::max(c->P.icp_skip, 1);
+    c->prev_ready = false;                                            // seeds are indexed by query
     c->h_q_off.assign((size_t)c->n_src_rings + 1, 0);
     for (int r = 0; r < c->n_src_rings; r++) {
         const int n = c->h_src_off[r + 1] - c->h_src_off[r];
@@ -475,6 +479,15 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         AssocOut out;
         out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p; out.dbg = c->dbg.p; out.wg_times = nullptr;
         out.first_ring = c->tgt_first_ring; out.first_point = c->tgt_first_point; out.partial = partial ? c->partials_rec.p : nullptr;
+        out.prev = nullptr;
+        if (c->warm_start) {
+            if (!c->prev_ready) {                                     // first round after a new source or target: no seeds yet
+                VELO_TRY(c->prev_pair.reserve((size_t)std::max(c->n_q, 1)));
+                HIP_TRY(hipMemsetAsync(c->prev_pair.p, 0xff, sizeof(int4) * (size_t)std::max(c->n_q, 1), c->stream));
+                c->prev_ready = true;
+            }
+            out.prev = c->prev_pair.p;
+        }
         if (c->debug_skip & 32) { VELO_TRY(c->wg_times.reserve((size_t)2 * cdiv(qe - qb, 64) + 2)); out.wg_times = c->wg_times.p; c->wg_times_n = cdiv(qe - qb, 64); }
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
         if (c->timing) {
@@ -499,11 +512,10 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                            c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, cluster_cells, h_safe, out, aux, c->debug_skip, c->xcd_map)
         // the diagnostic hooks (VELO_DEBUG_SKIP != 0) live in a separate instantiation: compiled in, they spill registers
 #define VELO_LAUNCH_V2(NW, MINW) do { if (c->debug_skip) VELO_LAUNCH_V3(NW, MINW, true); else VELO_LAUNCH_V3(NW, MINW, false); } while (0)
-        // Tube kernel (5): candidates per query group -21 % and one cluster per group on the default grid (120k-pt scans: 92 vs
-        // 121 us); its per-query phase 2 enumerates (2e+1)^2 rows per asking query, which loses on density-shrunk grids where
-        // the gate radius is many cells (2M-pt map, e = 15: 1.59 vs 1.45 ms) -- there the box kernel (4) stays.
-        const int reach_cells = (int)std::ceil(std::sqrt(std::max(gate_of_iter(c->P, 1), 0.0)) / (G->h * 0.999));
-        const int variant = c->assoc_variant >= 0 ? c->assoc_variant : (reach_cells <= 5 ? 5 : 4);
+        // Default = tube kernel (5) with warm start.  120k-pt scans: 69 us per launch averaged over the 6 rounds of a call (box
+        // kernel 4: 121 us); 2M-pt map: 535 us vs 1.49 ms -- its cold first round is slower there (density-shrunk grid, gate radius
+        // = 15 cells, every query asks for a (2e+1)^2-row box: 1.59 vs 1.45 ms) but the five warm rounds need tiny boxes.
+        const int variant = c->assoc_variant >= 0 ? c->assoc_variant : 5;
         switch (variant) {
             case 0: {
                 const int reach = (int)std::ceil(std::sqrt(std::max(gate, 0.0)) / (G->h * 0.999)) ;
@@ -725,6 +737,7 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
 // common tail of every way a target enters the context: ring table, ring ids, bounding box, grid
 int target_finalize(velo_ctx* c) {
     const int n = c->n_tgt, n_rings = c->n_tgt_rings;
+    c->prev_ready = false;                                            // seeds refer to points of the old target
     for (int r = 0; r < n_rings; r++) if (c->h_tgt_off[r + 1] <= c->h_tgt_off[r]) return fail(VELO_ERR_INVALID, "target ring %d is empty", r);
     VELO_TRY(c->tgt_off.reserve((size_t)n_rings + 1));
     VELO_TRY(c->tgt_ring_of.reserve((size_t)std::max(n, 1)));
@@ -807,6 +820,7 @@ int velo_create(velo_ctx** out, int device) {
     if (const char* e = getenv("VELO_GRAPHS")) c->use_graphs = atoi(e) != 0;
     if (const char* e = getenv("VELO_XCD_MAP")) c->xcd_map = atoi(e);
     if (const char* e = getenv("VELO_TUBE_MAP")) c->tube_map = atoi(e);
+    if (const char* e = getenv("VELO_WARM_START")) c->warm_start = atoi(e);
     if (const char* e = getenv("VELO_PERSISTENT_WGS")) c->persistent_wgs = std::max(atoi(e), 1);
     if (const char* e = getenv("VELO_FUSED")) c->use_fused = atoi(e) != 0;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -1054,7 +1068,7 @@ static int launch_merge(velo_ctx* c, const PartialRec* tables, int world, int st
     if (qe > qb) {
         AssocOut out;
         out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p;
-        out.dbg = c->dbg.p; out.wg_times = nullptr; out.first_ring = c->tgt_first_ring; out.first_point = c->tgt_first_point; out.partial = nullptr;
+        out.dbg = c->dbg.p; out.wg_times = nullptr; out.first_ring = c->tgt_first_ring; out.first_point = c->tgt_first_point; out.partial = nullptr; out.prev = nullptr;
         const unsigned long long key_inf = ((unsigned long long)gate_bits_of(gate_of_iter(c->P, iter)) + 1ull) << 32;
         hipLaunchKernelGGL(merge_partials_kernel, dim3(cdiv(qe - qb, 256)), dim3(256), 0, c->stream, tables, world, stride, qb, qe,
                            (const float4*)c->src.p, (const int*)c->q_src.p, key_inf, c->P.icp_norm_condition, out, want_aux ? 1 : 0);

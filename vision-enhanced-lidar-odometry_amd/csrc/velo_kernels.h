@@ -280,6 +280,8 @@ struct AssocOut {
     unsigned long long* __restrict__ wg_times;   // [2 * groups] start/end s_memrealtime per workgroup (VELO_DEBUG_SKIP & 32)
     int first_ring, first_point;                  // global ids of this context's first target ring / point
     struct PartialRec* __restrict__ partial;      // target-sharded mode: per-query top-2 record instead of the table
+    int4* __restrict__ prev;                      // tube kernel: {local index of best1, of best2, ring1, ring2} of the last round (-1: none);
+                                                  // read as warm-start seeds, rewritten at the end (same entry, same workgroup), or null
 };
 
 // Target-sharded mode (BASELINE config 5): what one rank knows about a query after searching ITS rings.
@@ -438,6 +440,7 @@ __device__ __forceinline__ void finish_correspondence_rings(
         dj = __uint_as_float((unsigned)(b2 >> 32));
         v1[0] = p1.x; v1[1] = p1.y; v1[2] = p1.z;
     }
+    if (out.prev) out.prev[qi] = make_int4(has1 ? gi : -1, has2 ? gj : -1, ring_i, ring_j);   // seeds of the next round
     if (out.partial) {
         PartialRec r;
         r.key1 = b1; r.key2 = b2; r.ring1 = ring_i; r.ring2 = ring_j; r.idx1 = idx_i; r.idx_k = idx_k; r.idx2 = idx_j; r.pad = 0;
@@ -817,10 +820,12 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
 //   * phase 1 does not stage the whole bounding box of the cluster but, for every grid row (y, z), only the x-interval
 //     [min cx - 1, max cx + 1] over the member queries whose cell lies within one row of it -- a tube around the ring segment
 //     instead of its axis-aligned box (LDS atomics build the per-row intervals);
-//   * phase 2 is per query: a member that is not finished after phase 1 asks for ITS OWN reach e_q = ceil(sqrt(b2d_q) / h)
-//     and contributes the rows/intervals of its own cube only; finished members ask for nothing.  Rows subtract the interval
-//     phase 1 already visited.  After phase 2 every member has (e_q h)^2 > b2d_q, so there is never a third phase.
+//   * phase 2 is per query: a member whose current bound reaches beyond what phase 1 visited for it asks for the cell box of
+//     ITS OWN bound sphere and contributes the rows/intervals of that box only; finished members ask for nothing.  Rows
+//     subtract the interval phase 1 already visited.  After phase 2 every member has seen its whole bound sphere, so there
+//     is never a third phase.
 // Tubes do not blow up with the length of the segment, so the cluster radius can be large (one cluster per group).
+//   * rounds after the first are warm-started from the previous round's winners (AssocOut::prev).
 template <int NW, int MINW, bool DBG, int PPT>
 __global__ void __launch_bounds__(NW * 64, MINW)
 assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
@@ -864,13 +869,29 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
         const float4 psrc = src[q_src[qi]];
         transform_query(P, psrc, &qx, &qy, &qz);
         cx = cell_coord(qx, g.ox, g.inv_h, g.nx); cy = cell_coord(qy, g.oy, g.inv_h, g.ny); cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
+        // Warm start: the two winners of the previous round (same source, same target, slightly different pose) are real
+        // candidates of this round, so entering them first changes nothing in the result (top-2 is idempotent) but starts the
+        // search with a tight second-best bound: almost every later candidate fails the cheap trip test and the per-query
+        // second phase is rarely needed.  Seeds beyond the current gate are dropped like any other candidate.
+        if (out.prev && !(DBG && (dbg & 512))) {
+            const int4 pv = out.prev[qi];
+            if (pv.x >= 0) {
+                const float4 c = tgt[pv.x];
+                const float d = dist2_f(c.x, c.y, c.z, qx, qy, qz);
+                if (__float_as_uint(d) <= gate_bits) top2_update(t, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(pv.x + out.first_point), pv.z);
+            }
+            if (pv.y >= 0) {
+                const float4 c = tgt[pv.y];
+                const float d = dist2_f(c.x, c.y, c.z, qx, qy, qz);
+                if (__float_as_uint(d) <= gate_bits) top2_update(t, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(pv.y + out.first_point), pv.w);
+            }
+        }
     }
     VELO_STAMP(0);
     const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
     float* s_xy_f = reinterpret_cast<float*>(s_xy);
     float* s_zg_f = reinterpret_cast<float*>(s_zg);
     const int big = 1 << 28;
-    const float reach1 = h_safe * h_safe;                              // (1 cell)^2: what phase 1 guarantees
     bool pending = active;
     for (;;) {                                                         // clusters (identical control flow in every wave)
         const unsigned long long pm = __ballot(pending);
@@ -879,20 +900,31 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
         const int scx = __builtin_amdgcn_readlane(cx, leader), scy = __builtin_amdgcn_readlane(cy, leader), scz = __builtin_amdgcn_readlane(cz, leader);
         const bool member = pending && abs(cx - scx) <= cluster_w && abs(cy - scy) <= cluster_w && abs(cz - scz) <= cluster_w;
         if (DBG && (dbg & 16) && tid == 0) atomicAdd(&out.dbg[0], 1ull);
+        // Per-query cell boxes.  Everything closer to the query than r = sqrt(b2d) lies in the cells [cell(q - r), cell(q + r)] per
+        // axis (the cell function is monotone; r is padded against rounding).  Phase 1 visits that box clipped to the query's
+        // own cell +- 1: with warm-start seeds r is a few centimetres and the box is 1-2 cells per axis instead of 3, without
+        // seeds it is the +-1 neighbourhood.  A query is finished when the box of its CURRENT bound lies inside what phase 1
+        // visited for it; the others ask phase 2 for the box of their current bound.
+        const float r1 = sqrtf(t.b2d) * 1.0001f + 1e-6f;
+        const int p1x0 = max(cell_coord(qx - r1, g.ox, g.inv_h, g.nx), cx - 1), p1x1 = min(cell_coord(qx + r1, g.ox, g.inv_h, g.nx), cx + 1);
+        const int p1y0 = max(cell_coord(qy - r1, g.oy, g.inv_h, g.ny), cy - 1), p1y1 = min(cell_coord(qy + r1, g.oy, g.inv_h, g.ny), cy + 1);
+        const int p1z0 = max(cell_coord(qz - r1, g.oz, g.inv_h, g.nz), cz - 1), p1z1 = min(cell_coord(qz + r1, g.oz, g.inv_h, g.nz), cz + 1);
         for (int ph = 0; ph < 2; ph++) {
-            // who asks for cells in this phase, and how far
+            // who asks for cells in this phase, and which box
             bool asks = member;
-            int e = 1;
+            int bx0 = p1x0, bx1 = p1x1, by0 = p1y0, by1 = p1y1, bz0 = p1z0, bz1 = p1z1;
             if (ph == 1) {
-                asks = member && !(reach1 > t.b2d);
+                const float r2 = sqrtf(t.b2d) * 1.0001f + 1e-6f;
+                bx0 = cell_coord(qx - r2, g.ox, g.inv_h, g.nx); bx1 = cell_coord(qx + r2, g.ox, g.inv_h, g.nx);
+                by0 = cell_coord(qy - r2, g.oy, g.inv_h, g.ny); by1 = cell_coord(qy + r2, g.oy, g.inv_h, g.ny);
+                bz0 = cell_coord(qz - r2, g.oz, g.inv_h, g.nz); bz1 = cell_coord(qz + r2, g.oz, g.inv_h, g.nz);
+                asks = member && !(bx0 >= p1x0 && bx1 <= p1x1 && by0 >= p1y0 && by1 <= p1y1 && bz0 >= p1z0 && bz1 <= p1z1);
                 if (__ballot(asks) == 0ull) break;
-                e = max(2, (int)ceilf(sqrtf(t.b2d) / h_safe));
-                if ((float)e * h_safe * ((float)e * h_safe) <= t.b2d) e++;          // rounding guard
             }
-            const int Y0 = max(__builtin_amdgcn_readfirstlane(wave_min_i(asks ? cy - e : big)), 0);
-            const int Y1 = min(__builtin_amdgcn_readfirstlane(wave_max_i(asks ? cy + e : -big)), g.ny - 1);
-            const int Z0 = max(__builtin_amdgcn_readfirstlane(wave_min_i(asks ? cz - e : big)), 0);
-            const int Z1 = min(__builtin_amdgcn_readfirstlane(wave_max_i(asks ? cz + e : -big)), g.nz - 1);
+            const int Y0 = max(__builtin_amdgcn_readfirstlane(wave_min_i(asks ? by0 : big)), 0);
+            const int Y1 = min(__builtin_amdgcn_readfirstlane(wave_max_i(asks ? by1 : -big)), g.ny - 1);
+            const int Z0 = max(__builtin_amdgcn_readfirstlane(wave_min_i(asks ? bz0 : big)), 0);
+            const int Z1 = min(__builtin_amdgcn_readfirstlane(wave_max_i(asks ? bz1 : -big)), g.nz - 1);
             const int nyb = Y1 - Y0 + 1, nzb = Z1 - Z0 + 1;
             const int nrows = (nyb > 0 && nzb > 0) ? nyb * nzb : 0;
             const float rcp_nyb = 1.0f / (float)max(nyb, 1);
@@ -901,23 +933,23 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                 s_lo[tid] = big; s_hi[tid] = -big;
                 if (ph == 1) { s_plo[tid] = big; s_phi[tid] = -big; }
                 __syncthreads();
-                if (asks) {                                            // the (2e+1)^2 rows of this query's cube: z-layers dealt over the waves
-                    for (int z = cz - e + wid; z <= cz + e; z += NW) {
+                if (asks) {                                            // the rows of this query's box: z-layers dealt over the waves
+                    for (int z = bz0 + wid; z <= bz1; z += NW) {
                         if (z < Z0 || z > Z1) continue;
                         const int rz = (z - Z0) * nyb - Y0 - rbase;
-                        for (int y = max(cy - e, Y0); y <= min(cy + e, Y1); y++) {
+                        for (int y = max(by0, Y0); y <= min(by1, Y1); y++) {
                             const int r = rz + y;
-                            if (r >= 0 && r < NT) { atomicMin(&s_lo[r], cx - e); atomicMax(&s_hi[r], cx + e); }
+                            if (r >= 0 && r < NT) { atomicMin(&s_lo[r], bx0); atomicMax(&s_hi[r], bx1); }
                         }
                     }
                 }
-                if (ph == 1 && member) {                               // what phase 1 staged: the e = 1 tube of ALL members
-                    for (int z = cz - 1 + wid; z <= cz + 1; z += NW) {
+                if (ph == 1 && member) {                               // what phase 1 staged: the phase-1 boxes of ALL members
+                    for (int z = p1z0 + wid; z <= p1z1; z += NW) {
                         if (z < Z0 || z > Z1) continue;
                         const int rz = (z - Z0) * nyb - Y0 - rbase;
-                        for (int y = max(cy - 1, Y0); y <= min(cy + 1, Y1); y++) {
+                        for (int y = max(p1y0, Y0); y <= min(p1y1, Y1); y++) {
                             const int r = rz + y;
-                            if (r >= 0 && r < NT) { atomicMin(&s_plo[r], cx - 1); atomicMax(&s_phi[r], cx + 1); }
+                            if (r >= 0 && r < NT) { atomicMin(&s_plo[r], p1x0); atomicMax(&s_phi[r], p1x1); }
                         }
                     }
                 }
@@ -1049,6 +1081,16 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
         pending = pending && !member;
     }
     if (NW > 1 && wid != 0) return;
+    if (DBG && (dbg & 128)) {                                          // diagnostic: finish without the gathers (wrong results)
+        if (active) { out.p[qi] = make_float4(qx, qy, qz, 0.f); out.n[qi] = make_float4((float)(t.b1 >> 32), (float)(t.b2 >> 32), 0.f, 0.f); out.v0[qi] = make_float4(0.f, 0.f, 0.f, 0.f); }
+    } else if (DBG && (dbg & 256)) {                                   // diagnostic: gathers but a trivial write and no counter
+        if (active) {
+            const float4 ps = src[q_src[qi]];
+            const int gi = (int)(unsigned)(t.b1 & 0xffffffffull) % max(n_tgt_local, 1), gj = (int)(unsigned)(t.b2 & 0xffffffffull) % max(n_tgt_local, 1);
+            const float4 p0 = tgt[gi], p1 = tgt[gj], a1 = tgt[min(gi + 1, n_tgt_local - 1)], a2 = tgt[max(gi - 1, 0)];
+            out.p[qi] = make_float4(ps.x + p0.x + p1.x, a1.y + a2.y, qz, 0.f);
+        }
+    } else
     if (active) finish_correspondence_rings(qi, src[q_src[qi]], qx, qy, qz, t.b1, t.b2, t.b1ring, t.b2ring, key_inf, tgt, tgt_off, n_tgt_local, norm_cond, out, want_aux != 0);
     VELO_STAMP(7);
     if (DBG && out.wg_times && tid == 0) out.wg_times[2 * group + 1] = __builtin_amdgcn_s_memrealtime();
