@@ -556,12 +556,14 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
 #define VELO_LAUNCH_V5(NW, MINW, DBG, PPT)                                                                                         \
                 hipLaunchKernelGGL((assoc_search_v5_kernel<NW, MINW, DBG, PPT>), dim3(groups), dim3(NW * 64), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe, \
                                    c->tgt.p, c->tgt_off.p, c->n_tgt, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux, perm, c->debug_skip)
-                if (c->debug_skip) VELO_LAUNCH_V5(4, 6, true, 4);
+                // default: 5 waves/SIMD (96 VGPRs, no spills, no scratch traffic), 2 candidate pairs per trip.  Measured on C2:
+                // 62 us; 6 waves + 2 pairs (5 spilled VGPRs) 65; 7 waves + 2 pairs 64; 5 waves + 4 pairs 66; 6 waves + 4 pairs 71
+                if (c->debug_skip) VELO_LAUNCH_V5(4, 5, true, 2);
                 else if (variant == 55) VELO_LAUNCH_V5(4, 5, false, 4);
-                else if (variant == 52) VELO_LAUNCH_V5(4, 8, false, 2);
+                else if (variant == 52) VELO_LAUNCH_V5(4, 6, false, 2);
                 else if (variant == 51) VELO_LAUNCH_V5(4, 7, false, 2);
-                else if (variant == 58) VELO_LAUNCH_V5(4, 8, false, 1);
-                else VELO_LAUNCH_V5(4, 6, false, 4);
+                else if (variant == 58) VELO_LAUNCH_V5(4, 6, false, 4);
+                else VELO_LAUNCH_V5(4, 5, false, 2);
 #undef VELO_LAUNCH_V5
                 break;
             }

@@ -815,6 +815,24 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
 #undef VELO_STAMP
 }
 
+// Cells that can hold a point closer than r to the query: [cell(q - r), cell(q + r)] per axis (the cell function is monotone);
+// clip = additionally restricted to the query's own cell +- 1 (what phase 1 of the tube kernel visits).  Cheap enough (6 cell
+// computations) to be recomputed where it is needed instead of living in 6 registers across the sweep.
+struct CellBox { int x0, x1, y0, y1, z0, z1; };
+__device__ __forceinline__ CellBox query_box(const GridDesc& g, float qx, float qy, float qz, int cx, int cy, int cz, float r, bool clip) {
+    asm volatile("" : "+v"(r));     // opaque to CSE / loop-invariant hoisting: recomputing IS the point (6 registers less across the sweep)
+    CellBox b;
+    b.x0 = cell_coord(qx - r, g.ox, g.inv_h, g.nx); b.x1 = cell_coord(qx + r, g.ox, g.inv_h, g.nx);
+    b.y0 = cell_coord(qy - r, g.oy, g.inv_h, g.ny); b.y1 = cell_coord(qy + r, g.oy, g.inv_h, g.ny);
+    b.z0 = cell_coord(qz - r, g.oz, g.inv_h, g.nz); b.z1 = cell_coord(qz + r, g.oz, g.inv_h, g.nz);
+    if (clip) {
+        b.x0 = max(b.x0, cx - 1); b.x1 = min(b.x1, cx + 1);
+        b.y0 = max(b.y0, cy - 1); b.y1 = min(b.y1, cy + 1);
+        b.z0 = max(b.z0, cz - 1); b.z1 = min(b.z1, cz + 1);
+    }
+    return b;
+}
+
 // ---- association search, tube variant (VELO_ASSOC_VARIANT=5) ---------------------------------------------------------------
 // Same machinery as assoc_search_v3_kernel (run list -> LDS tile -> packed sweep -> merge), different candidate set:
 //   * phase 1 does not stage the whole bounding box of the cluster but, for every grid row (y, z), only the x-interval
@@ -833,6 +851,7 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                        unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, AssocOut out, int want_aux, const int* __restrict__ group_perm, int dbg) {
     constexpr int NT = NW * 64;
     constexpr int NRUN = 2 * NT;
+    static_assert(kTileCap % (2 * PPT) == 0, "the tile must hold whole trips (the padding of the last trip stays inside it)");
     __shared__ float4 s_xy[kTileCap / 2];
     __shared__ float4 s_zg[kTileCap / 2];
     __shared__ int s_ring[kTileCap];
@@ -905,26 +924,25 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
         // own cell +- 1: with warm-start seeds r is a few centimetres and the box is 1-2 cells per axis instead of 3, without
         // seeds it is the +-1 neighbourhood.  A query is finished when the box of its CURRENT bound lies inside what phase 1
         // visited for it; the others ask phase 2 for the box of their current bound.
-        const float r1 = sqrtf(t.b2d) * 1.0001f + 1e-6f;
-        const int p1x0 = max(cell_coord(qx - r1, g.ox, g.inv_h, g.nx), cx - 1), p1x1 = min(cell_coord(qx + r1, g.ox, g.inv_h, g.nx), cx + 1);
-        const int p1y0 = max(cell_coord(qy - r1, g.oy, g.inv_h, g.ny), cy - 1), p1y1 = min(cell_coord(qy + r1, g.oy, g.inv_h, g.ny), cy + 1);
-        const int p1z0 = max(cell_coord(qz - r1, g.oz, g.inv_h, g.nz), cz - 1), p1z1 = min(cell_coord(qz + r1, g.oz, g.inv_h, g.nz), cz + 1);
+        const float r1 = sqrtf(t.b2d) * 1.0001f + 1e-6f;               // bound radius phase 1 works with (padded against rounding)
         for (int ph = 0; ph < 2; ph++) {
-            // who asks for cells in this phase, and which box
+            // who asks for cells in this phase, and with which radius
             bool asks = member;
-            int bx0 = p1x0, bx1 = p1x1, by0 = p1y0, by1 = p1y1, bz0 = p1z0, bz1 = p1z1;
+            float rq = r1;
             if (ph == 1) {
-                const float r2 = sqrtf(t.b2d) * 1.0001f + 1e-6f;
-                bx0 = cell_coord(qx - r2, g.ox, g.inv_h, g.nx); bx1 = cell_coord(qx + r2, g.ox, g.inv_h, g.nx);
-                by0 = cell_coord(qy - r2, g.oy, g.inv_h, g.ny); by1 = cell_coord(qy + r2, g.oy, g.inv_h, g.ny);
-                bz0 = cell_coord(qz - r2, g.oz, g.inv_h, g.nz); bz1 = cell_coord(qz + r2, g.oz, g.inv_h, g.nz);
-                asks = member && !(bx0 >= p1x0 && bx1 <= p1x1 && by0 >= p1y0 && by1 <= p1y1 && bz0 >= p1z0 && bz1 <= p1z1);
+                rq = sqrtf(t.b2d) * 1.0001f + 1e-6f;
+                const CellBox b2 = query_box(g, qx, qy, qz, cx, cy, cz, rq, false), b1 = query_box(g, qx, qy, qz, cx, cy, cz, r1, true);
+                asks = member && !(b2.x0 >= b1.x0 && b2.x1 <= b1.x1 && b2.y0 >= b1.y0 && b2.y1 <= b1.y1 && b2.z0 >= b1.z0 && b2.z1 <= b1.z1);
                 if (__ballot(asks) == 0ull) break;
             }
-            const int Y0 = max(__builtin_amdgcn_readfirstlane(wave_min_i(asks ? by0 : big)), 0);
-            const int Y1 = min(__builtin_amdgcn_readfirstlane(wave_max_i(asks ? by1 : -big)), g.ny - 1);
-            const int Z0 = max(__builtin_amdgcn_readfirstlane(wave_min_i(asks ? bz0 : big)), 0);
-            const int Z1 = min(__builtin_amdgcn_readfirstlane(wave_max_i(asks ? bz1 : -big)), g.nz - 1);
+            int Y0, Y1, Z0, Z1;
+            {
+                const CellBox bb = query_box(g, qx, qy, qz, cx, cy, cz, rq, ph == 0);
+                Y0 = max(__builtin_amdgcn_readfirstlane(wave_min_i(asks ? bb.y0 : big)), 0);
+                Y1 = min(__builtin_amdgcn_readfirstlane(wave_max_i(asks ? bb.y1 : -big)), g.ny - 1);
+                Z0 = max(__builtin_amdgcn_readfirstlane(wave_min_i(asks ? bb.z0 : big)), 0);
+                Z1 = min(__builtin_amdgcn_readfirstlane(wave_max_i(asks ? bb.z1 : -big)), g.nz - 1);
+            }
             const int nyb = Y1 - Y0 + 1, nzb = Z1 - Z0 + 1;
             const int nrows = (nyb > 0 && nzb > 0) ? nyb * nzb : 0;
             const float rcp_nyb = 1.0f / (float)max(nyb, 1);
@@ -934,22 +952,24 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                 if (ph == 1) { s_plo[tid] = big; s_phi[tid] = -big; }
                 __syncthreads();
                 if (asks) {                                            // the rows of this query's box: z-layers dealt over the waves
-                    for (int z = bz0 + wid; z <= bz1; z += NW) {
+                    const CellBox bb = query_box(g, qx, qy, qz, cx, cy, cz, rq, ph == 0);
+                    for (int z = bb.z0 + wid; z <= bb.z1; z += NW) {
                         if (z < Z0 || z > Z1) continue;
                         const int rz = (z - Z0) * nyb - Y0 - rbase;
-                        for (int y = max(by0, Y0); y <= min(by1, Y1); y++) {
+                        for (int y = max(bb.y0, Y0); y <= min(bb.y1, Y1); y++) {
                             const int r = rz + y;
-                            if (r >= 0 && r < NT) { atomicMin(&s_lo[r], bx0); atomicMax(&s_hi[r], bx1); }
+                            if (r >= 0 && r < NT) { atomicMin(&s_lo[r], bb.x0); atomicMax(&s_hi[r], bb.x1); }
                         }
                     }
                 }
                 if (ph == 1 && member) {                               // what phase 1 staged: the phase-1 boxes of ALL members
-                    for (int z = p1z0 + wid; z <= p1z1; z += NW) {
+                    const CellBox b1 = query_box(g, qx, qy, qz, cx, cy, cz, r1, true);
+                    for (int z = b1.z0 + wid; z <= b1.z1; z += NW) {
                         if (z < Z0 || z > Z1) continue;
                         const int rz = (z - Z0) * nyb - Y0 - rbase;
-                        for (int y = max(p1y0, Y0); y <= min(p1y1, Y1); y++) {
+                        for (int y = max(b1.y0, Y0); y <= min(b1.y1, Y1); y++) {
                             const int r = rz + y;
-                            if (r >= 0 && r < NT) { atomicMin(&s_plo[r], p1x0); atomicMax(&s_phi[r], p1x1); }
+                            if (r >= 0 && r < NT) { atomicMin(&s_plo[r], b1.x0); atomicMax(&s_phi[r], b1.x1); }
                         }
                     }
                 }
