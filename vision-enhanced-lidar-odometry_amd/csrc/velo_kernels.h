@@ -1583,6 +1583,16 @@ __device__ __forceinline__ bool eval_load_x(const EvalArgs& A, double x[6]) {
 // point-to-plane blocks (row R1 + Scaled(Cauchy(loss_thresh_3DPD), weight_3DPD), velo.h:875-892)
 __global__ void __launch_bounds__(kEvalThreads)
 eval_icp_kernel(EvalArgs A) {
+    // The correspondences do not depend on the pose: the first kPre strided rows of this thread are requested BEFORE the LM
+    // state (written by the previous launch) is read and the rotation constants are set up, so both latencies overlap.
+    constexpr int kPre = 4;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    float4 pp[kPre], pn[kPre], pv[kPre];
+#pragma unroll
+    for (int k = 0; k < kPre; k++) {
+        const int i = min(A.q_begin + tid + k * nthreads, A.q_end - 1);
+        pp[k] = A.cp[i]; pn[k] = A.cn[i]; pv[k] = A.cv0[i];
+    }
     double x[6];
     if (!eval_load_x(A, x)) return;
     // the point-independent part of the rotation (sqrt, sin, cos and their partials) once per workgroup, not per thread
@@ -1594,11 +1604,15 @@ eval_icp_kernel(EvalArgs A) {
     double acc[kNumAcc];
 #pragma unroll
     for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
-    for (int i = A.q_begin + tid; i < A.q_end; i += nthreads) {
-        const float4 p = A.cp[i];
+    int it = 0;
+    for (int i = A.q_begin + tid; i < A.q_end; i += nthreads, it++) {
+        float4 p, n, v;
+        if (it < kPre) {                                     // (compile-time indices after unrolling the first kPre trips)
+            p = pp[0]; n = pn[0]; v = pv[0];
+#pragma unroll
+            for (int k = 1; k < kPre; k++) if (it == k) { p = pp[k]; n = pn[k]; v = pv[k]; }
+        } else { p = A.cp[i]; n = A.cn[i]; v = A.cv0[i]; }
         if (__float_as_int(p.w) == 0) continue;
-        const float4 n = A.cn[i], v = A.cv0[i];
         const double pd[3] = {p.x, p.y, p.z}, nd[3] = {n.x, n.y, n.z}, vd[3] = {v.x, v.y, v.z};
         double r, J[6];
         res_3dpd(R, t, pd, nd, vd, &r, J);
@@ -1764,7 +1778,8 @@ __global__ void lm_begin_kernel(LMState* S, const double* __restrict__ x_in, con
 
 // sums: either the per-workgroup partials [n_blocks][28] (single GPU) or an already reduced [1][28] block (after all-reduce);
 // then ONE LM state transition.  Called by a whole 256-thread workgroup.
-__device__ __forceinline__ void lm_transition(const LMParams& Q, LMState* S, const double* __restrict__ partials, int n_blocks) {
+__device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* S, const double* E);
+__device__ __forceinline__ void lm_transition(const LMParams& Q, LMState* Sg, const double* __restrict__ partials, int n_blocks) {
     __shared__ double part[8][kNumAcc];
     __shared__ double E[kNumAcc];
     const int t = threadIdx.x;
@@ -1778,6 +1793,14 @@ __device__ __forceinline__ void lm_transition(const LMParams& Q, LMState* S, con
     if (t < kNumAcc) { double v = 0.0; for (int p = 0; p < 8; p++) v += part[p][t]; E[t] = v; }
     __syncthreads();
     if (t != 0) return;
+    // the transition is ~300 dependent double operations on the state: run it on a private copy (one batch of loads, one batch
+    // of stores) instead of walking the global struct field by field with a wait after every access
+    LMState L = *Sg;
+    lm_transition_local(Q, &L, E);
+    *Sg = L;
+}
+
+__device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* S, const double* E) {
     S->evals++;
     const double ecost = E[27];
     if (S->phase == PHASE_INIT) {
