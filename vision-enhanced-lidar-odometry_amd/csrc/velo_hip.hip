@@ -160,7 +160,9 @@ struct velo_ctx {
     // correspondence table
     DevBuf<float4> cp, cn, cv0, aux1;
     DevBuf<int4> aux0;
-    DevBuf<int> n_valid;
+    DevBuf<int> n_valid;                 // two counters used alternately: the association kernel of one round clears the counter of
+    int nv_idx = 0;                      // the next, so no fill launch (and no 18 us launch gap behind it) per round
+    bool nv_clean[2] = {false, false};   // counter is zero on the stream's timeline
     DevBuf<unsigned long long> dbg, wg_times;
     int wg_times_n = 0;
     DevBuf<AssocItem> items;             // work queue of the pipelined association
@@ -232,6 +234,15 @@ int q_range(const velo_ctx* c, int* b, int* e) {
     const int64_t nq = c->n_q;
     *b = (int)(nq * c->shard_rank / c->shard_world);
     *e = (int)(nq * (c->shard_rank + 1) / c->shard_world);
+    return VELO_OK;
+}
+
+// next valid-counter: returns with c->nv_idx switched to a counter that is zero at this point of the stream
+int next_valid_counter(velo_ctx* c) {
+    VELO_TRY(c->n_valid.reserve(2));
+    c->nv_idx ^= 1;
+    if (!c->nv_clean[c->nv_idx]) HIP_TRY(hipMemsetAsync(c->n_valid.p + c->nv_idx, 0, sizeof(int), c->stream));
+    c->nv_clean[c->nv_idx] = false;      // about to be counted into
     return VELO_OK;
 }
 
@@ -469,17 +480,16 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
     int qb, qe;
     q_range(c, &qb, &qe);
     if (partial) { qb = 0; qe = c->n_q; VELO_TRY(c->partials_rec.reserve((size_t)std::max(c->n_q, 1))); }   // every query against the local rings
-    VELO_TRY(c->n_valid.reserve(1));
-    HIP_TRY(hipMemsetAsync(c->n_valid.p, 0, sizeof(int), c->stream));
+    VELO_TRY(next_valid_counter(c));
     if (qe > qb) {
         PoseScalars S;
         pose_scalars(x, &S);
         GridView V;
         V.d = G->d; V.cell_start = G->cell_start.p; V.sorted = G->sorted.p; V.sring = G->sring.p;
         AssocOut out;
-        out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p; out.dbg = c->dbg.p; out.wg_times = nullptr;
+        out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p + c->nv_idx; out.dbg = c->dbg.p; out.wg_times = nullptr;
         out.first_ring = c->tgt_first_ring; out.first_point = c->tgt_first_point; out.partial = partial ? c->partials_rec.p : nullptr;
-        out.prev = nullptr;
+        out.prev = nullptr; out.n_valid_next = nullptr;
         if (c->warm_start) {
             if (!c->prev_ready) {                                     // first round after a new source or target: no seeds yet
                 VELO_TRY(c->prev_pair.reserve((size_t)std::max(c->n_q, 1)));
@@ -551,6 +561,8 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 // (a 64-query group straddling a gap in its ring): 96 default cells = 17 m unless VELO_CLUSTER_W says otherwise
                 const int cw = c->cluster_w_set ? (c->cluster_w > 0 ? cluster_cells : 2000)
                                                 : std::max(1, (int)std::lround(96.0 * 0.1785 / G->h));
+                out.n_valid_next = c->n_valid.p + (c->nv_idx ^ 1);      // the tube kernel clears it for the next round
+                c->nv_clean[c->nv_idx ^ 1] = true;
                 const int* perm = nullptr;
                 if (c->tube_map >= 0) { VELO_TRY(build_group_perm(c, qb, qe, c->tube_map)); perm = c->group_perm.p; }
 #define VELO_LAUNCH_V5(NW, MINW, DBG, PPT)                                                                                         \
@@ -584,7 +596,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
     if (partial) { c->have_partials = true; c->last_partial_iter = iter; if (wait) HIP_TRY(hipStreamSynchronize(c->stream)); return VELO_OK; }
     c->have_corr = true;
     if (wait) {
-        HIP_TRY(hipMemcpyAsync(c->h_int, c->n_valid.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->h_int, c->n_valid.p + c->nv_idx, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->last_n_valid = c->h_int[0];
         if (n_valid) *n_valid = c->last_n_valid;
@@ -709,7 +721,7 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
         HIP_TRY(hipMemcpyAsync(c->xdev.p, c->h_x, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
         xd = c->xdev.p;
     }
-    hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->state.p, xd, (const int*)(c->have_corr ? c->n_valid.p : nullptr));
+    hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->state.p, xd, (const int*)(c->have_corr ? c->n_valid.p + c->nv_idx : nullptr));
     int launched = 0;
     int chunk = first_chunk;                // LM iterations per host round trip
     const int max_iters = c->P.max_num_iterations + 1;
@@ -836,7 +848,7 @@ int velo_create(velo_ctx** out, int device) {
     VELO_TRY(c->ticket.reserve(1));
     HIP_TRY(hipMemsetAsync(c->ticket.p, 0, sizeof(int), c->stream));
     VELO_TRY(c->bbox_keys.reserve(6));
-    VELO_TRY(c->n_valid.reserve(1));
+    VELO_TRY(c->n_valid.reserve(2));
     VELO_TRY(c->dbg.reserve(8));
     HIP_TRY(hipMemsetAsync(c->dbg.p, 0, 64, c->stream));
     HIP_TRY(hipMemsetAsync(c->state.p, 0, sizeof(LMState), c->stream));
@@ -1052,7 +1064,7 @@ int velo_associate(velo_ctx* c, const double x[6], int32_t iter, int32_t* n_vali
     HIP_TRY(hipSetDevice(c->device));
     if (c->comm && c->target_sharded) {
         VELO_TRY(associate_target_sharded(c, x, iter, true));
-        HIP_TRY(hipMemcpyAsync(c->h_int, c->n_valid.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->h_int, c->n_valid.p + c->nv_idx, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->last_n_valid = c->h_int[0];
         if (n_valid) *n_valid = c->last_n_valid;
@@ -1065,12 +1077,11 @@ int velo_associate(velo_ctx* c, const double x[6], int32_t iter, int32_t* n_vali
 static int launch_merge(velo_ctx* c, const PartialRec* tables, int world, int stride, int iter, bool want_aux) {
     int qb, qe;
     q_range(c, &qb, &qe);
-    VELO_TRY(c->n_valid.reserve(1));
-    HIP_TRY(hipMemsetAsync(c->n_valid.p, 0, sizeof(int), c->stream));
+    VELO_TRY(next_valid_counter(c));
     if (qe > qb) {
         AssocOut out;
-        out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p;
-        out.dbg = c->dbg.p; out.wg_times = nullptr; out.first_ring = c->tgt_first_ring; out.first_point = c->tgt_first_point; out.partial = nullptr; out.prev = nullptr;
+        out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p + c->nv_idx;
+        out.dbg = c->dbg.p; out.wg_times = nullptr; out.first_ring = c->tgt_first_ring; out.first_point = c->tgt_first_point; out.partial = nullptr; out.prev = nullptr; out.n_valid_next = nullptr;
         const unsigned long long key_inf = ((unsigned long long)gate_bits_of(gate_of_iter(c->P, iter)) + 1ull) << 32;
         hipLaunchKernelGGL(merge_partials_kernel, dim3(cdiv(qe - qb, 256)), dim3(256), 0, c->stream, tables, world, stride, qb, qe,
                            (const float4*)c->src.p, (const int*)c->q_src.p, key_inf, c->P.icp_norm_condition, out, want_aux ? 1 : 0);
@@ -1131,7 +1142,7 @@ int velo_merge_partials(velo_ctx* c, const velo_partial* const* tables, int32_t 
         if (qe > qb) HIP_TRY(hipMemcpyAsync(c->partials_all.p + (size_t)w * share, tables[w] + qb, sizeof(velo_partial) * (size_t)(qe - qb), hipMemcpyHostToDevice, c->stream));
     }
     VELO_TRY(launch_merge(c, c->partials_all.p, world, share, c->last_partial_iter, true));
-    HIP_TRY(hipMemcpyAsync(c->h_int, c->n_valid.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->h_int, c->n_valid.p + c->nv_idx, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->last_n_valid = c->h_int[0];
     if (n_valid) *n_valid = c->last_n_valid;

@@ -276,6 +276,7 @@ struct AssocOut {
     int4* __restrict__ aux0;     // ring_i, idx_i, ring_j, idx_j      (only when want_aux)
     float4* __restrict__ aux1;   // bits(idx_k), dist_i, dist_j, -
     int* __restrict__ n_valid;   // atomic counter
+    int* __restrict__ n_valid_next;   // tube kernel: the counter of the NEXT round, cleared here (or null)
     unsigned long long* __restrict__ dbg;   // [8] diagnostic cycle totals (VELO_DEBUG_SKIP & 8)
     unsigned long long* __restrict__ wg_times;   // [2 * groups] start/end s_memrealtime per workgroup (VELO_DEBUG_SKIP & 32)
     int first_ring, first_point;                  // global ids of this context's first target ring / point
@@ -875,6 +876,7 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
 #define VELO_STAMP(k) do { if (DBG && (dbg & 8)) { const long long now__ = (long long)__builtin_readcyclecounter(); tacc[k] += now__ - tlast; tlast = now__; } } while (0)
     // workgroup -> group through the host-built table (XCD-aware wedges, see build_group_perm); placement affects speed only
     const int group = group_perm ? group_perm[blockIdx.x] : (int)blockIdx.x;
+    if (out.n_valid_next && blockIdx.x == 0 && tid == 0) *out.n_valid_next = 0;   // its last reader ran before this launch (same stream)
     if (DBG && out.wg_times && tid == 0) out.wg_times[2 * group] = __builtin_amdgcn_s_memrealtime();
     const int qi = q_begin + group * 64 + lane;
     const bool active = qi < q_end;
