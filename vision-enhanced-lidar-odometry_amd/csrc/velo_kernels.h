@@ -885,29 +885,47 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
     Top2 t;
     t.b1 = key_inf; t.b2 = key_inf; t.b1ring = -1; t.b2ring = -1; t.b2d = __uint_as_float(gate_bits + 1u);
     const GridDesc g = G.d;
-    int cx = 0, cy = 0, cz = 0;
-    if (active) {
-        const float4 psrc = src[q_src[qi]];
-        transform_query(P, psrc, &qx, &qy, &qz);
-        cx = cell_coord(qx, g.ox, g.inv_h, g.nx); cy = cell_coord(qy, g.oy, g.inv_h, g.ny); cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
-        // Warm start: the two winners of the previous round (same source, same target, slightly different pose) are real
-        // candidates of this round, so entering them first changes nothing in the result (top-2 is idempotent) but starts the
-        // search with a tight second-best bound: almost every later candidate fails the cheap trip test and the per-query
-        // second phase is rarely needed.  Seeds beyond the current gate are dropped like any other candidate.
-        if (out.prev && !(DBG && (dbg & 512))) {
-            const int4 pv = out.prev[qi];
-            if (pv.x >= 0) {
-                const float4 c = tgt[pv.x];
-                const float d = dist2_f(c.x, c.y, c.z, qx, qy, qz);
-                if (__float_as_uint(d) <= gate_bits) top2_update(t, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(pv.x + out.first_point), pv.z);
+    // Set-up once per GROUP, not once per wave: wave 0 transforms the 64 queries (double precision) and enters the warm-start
+    // seeds, the other waves pick the result up from LDS (scratch aliases the tile, which is not in use yet).
+    {
+        float* sq = reinterpret_cast<float*>(s_xy);                              // [3][64] transformed query
+        unsigned long long* sb = reinterpret_cast<unsigned long long*>(s_zg);   // [2][64] best1 / best2 keys
+        int* sr = s_ring;                                                        // [2][64] their rings
+        if (wid == 0) {
+            if (active) {
+                const float4 psrc = src[q_src[qi]];
+                transform_query(P, psrc, &qx, &qy, &qz);
+                // Warm start: the two winners of the previous round (same source, same target, slightly different pose) are real
+                // candidates of this round, so entering them first changes nothing in the result (top-2 is idempotent) but starts the
+                // search with a tight second-best bound: almost every later candidate fails the cheap trip test and the per-query
+                // second phase is rarely needed.  Seeds beyond the current gate are dropped like any other candidate.
+                if (out.prev && !(DBG && (dbg & 512))) {
+                    const int4 pv = out.prev[qi];
+                    if (pv.x >= 0) {
+                        const float4 c = tgt[pv.x];
+                        const float d = dist2_f(c.x, c.y, c.z, qx, qy, qz);
+                        if (__float_as_uint(d) <= gate_bits) top2_update(t, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(pv.x + out.first_point), pv.z);
+                    }
+                    if (pv.y >= 0) {
+                        const float4 c = tgt[pv.y];
+                        const float d = dist2_f(c.x, c.y, c.z, qx, qy, qz);
+                        if (__float_as_uint(d) <= gate_bits) top2_update(t, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(pv.y + out.first_point), pv.w);
+                    }
+                }
             }
-            if (pv.y >= 0) {
-                const float4 c = tgt[pv.y];
-                const float d = dist2_f(c.x, c.y, c.z, qx, qy, qz);
-                if (__float_as_uint(d) <= gate_bits) top2_update(t, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(pv.y + out.first_point), pv.w);
-            }
+            sq[lane] = qx; sq[64 + lane] = qy; sq[128 + lane] = qz;
+            sb[lane] = t.b1; sb[64 + lane] = t.b2; sr[lane] = t.b1ring; sr[64 + lane] = t.b2ring;
         }
+        __syncthreads();
+        if (wid != 0) {
+            qx = sq[lane]; qy = sq[64 + lane]; qz = sq[128 + lane];
+            t.b1 = sb[lane]; t.b2 = sb[64 + lane]; t.b1ring = sr[lane]; t.b2ring = sr[64 + lane];
+            t.b2d = __uint_as_float((unsigned)(t.b2 >> 32));
+        }
+        __syncthreads();                                                         // the tile may be overwritten from here on
     }
+    int cx = 0, cy = 0, cz = 0;
+    if (active) { cx = cell_coord(qx, g.ox, g.inv_h, g.nx); cy = cell_coord(qy, g.oy, g.inv_h, g.ny); cz = cell_coord(qz, g.oz, g.inv_h, g.nz); }
     VELO_STAMP(0);
     const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
     float* s_xy_f = reinterpret_cast<float*>(s_xy);
