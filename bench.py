@@ -191,6 +191,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # SURVEY 8(d) asks for the single-pair latency next to the throughput: a short untimed-by-the-contract leg, one pair in flight
+    single = None
+    if world == 1 and a.mode == "replicas" and B > 1:
+        for _ in range(3):
+            one_pair(0)
+        ctxs[0].synchronize()
+        t1 = time.perf_counter()
+        n1 = 20
+        for _ in range(n1):
+            one_pair(0)
+        ctxs[0].synchronize()
+        lat = (time.perf_counter() - t1) / n1
+        single = {"pairs_in_flight": 1, "ms_per_pair": 1e3 * lat, "pairs_per_s": 1.0 / lat}
+
     pairs_per_rank = a.steps * B
     total_pairs = pairs_per_rank * (world if a.mode == "replicas" else 1)
     value = total_pairs / dt
@@ -230,6 +244,8 @@ def main():
                          "note": "launch duration from HIP events on the context stream, measured in the timed region"},
             "solution_x": [float(v) for v in x_gpu],
         }
+        if single is not None:
+            line["single_pair"] = single
         if not a.no_cpu_baseline:
             cb = cpu_baseline(d, vis, a.cpu_sample_skip)
             xo = np.array(cb.pop("x"))
