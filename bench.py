@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
                     help="c2: 120k pair; c3: + 2000 stereo blocks; c4: 120k scan vs 2M-point map")
     ap.add_argument("--batch", type=int, default=8, help="independent pairs in flight per GPU (one context + stream each)")
+    ap.add_argument("--threads-per-pair", dest="batch_api", action="store_false",
+                    help="drive every pair from its own host thread (frame_to_frame) instead of velo_frame_to_frame_batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL)")
     ap.add_argument("--force-device", type=int, default=None, help="testing only: every rank uses this device (with --dist-backend gloo)")
@@ -149,17 +151,27 @@ def main():
 
     results = [None] * B
 
-    def one_pair(i):
+    def load_pair(i):
         c = ctxs[i]
         c.set_target_part(tgt, tgt_off, tgt_first_ring, tgt_first_point)
         c.set_source(src, d["src_off"])
-        results[i] = c.frame_to_frame(d["x0"])
+
+    def one_pair(i):
+        load_pair(i)
+        results[i] = ctxs[i].frame_to_frame(d["x0"])
 
     pool = ThreadPoolExecutor(max_workers=B) if B > 1 else None
+    x0s = np.tile(np.asarray(d["x0"], dtype=np.float64), (B, 1))
 
     def step():
         if pool is None:
             one_pair(0)
+        elif a.batch_api:
+            # index builds of the B pairs from B host threads, then the B registrations through the library's batch entry point
+            list(pool.map(load_pair, range(B)))
+            xs, Ts, Ss = api.frame_to_frame_batch(ctxs, x0s)
+            for i in range(B):
+                results[i] = (xs[i], Ts[i], Ss[i])
         else:
             list(pool.map(one_pair, range(B)))
 

@@ -174,3 +174,41 @@ def test_scan_to_map_config4_shard_parity_and_solve(hip_lib, oracle):
     assert s.n_target == 2_000_000 and all(s.solves[k].termination == 0 for k in range(6))
     assert np.linalg.norm(x[3:] - m["x_true"][3:]) < 8e-3 and np.linalg.norm(x[:3] - m["x_true"][:3]) < 1e-3   # map noise
     c.close()
+
+
+def test_batch_entry_point_equals_single_calls(hip_lib, monkeypatch):
+    """velo_frame_to_frame_batch advances the contexts in lock-step with shared LM launches; every context must get exactly what
+    a call of its own gives (same kernels' arithmetic, different launch structure), also with different pairs in one batch,
+    and the thread-per-context fallback must agree too."""
+    pairs = [H.small_pair(16, 128), H.small_pair(32, 200), H.small_pair(16, 96, scene_seed=3), H.small_pair(24, 160), H.small_pair(16, 128)]
+    # two of the five contexts also carry stereo matches (the visual sweep joins the shared launches)
+    visuals = [None, api.matches_from_dict(synth.stereo_matches(40, mix="all")), None, api.matches_from_dict(synth.stereo_matches(25, seed=8)), None]
+    singles = []
+    for d, v in zip(pairs, visuals):
+        c = api.Context(0, icp_skip=1)
+        c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])
+        if v is not None:
+            c.set_visual(v)
+        singles.append(c.frame_to_frame(d["x0"]))
+        c.close()
+    for lockstep in ("1", "0"):
+        monkeypatch.setenv("VELO_BATCH_LOCKSTEP", lockstep)
+        ctxs = [api.Context(0, icp_skip=1) for _ in pairs]
+        for c, d, v in zip(ctxs, pairs, visuals):
+            c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])
+            if v is not None:
+                c.set_visual(v)
+        for rep in range(2):                                  # second call: warm-start tables and chunk predictions carry over
+            xs, Ts, Ss = api.frame_to_frame_batch(ctxs, [d["x0"] for d in pairs])
+            for i, (x1, T1, s1) in enumerate(singles):
+                assert np.array_equal(xs[i], x1), (lockstep, rep, i)
+                assert np.array_equal(Ts[i], T1)
+                assert Ss[i].n_solves == s1.n_solves
+                for k in range(s1.n_solves):
+                    a, b = Ss[i].solves[k], s1.solves[k]
+                    assert (a.termination, a.lm_iterations, a.evaluations, a.n_icp_valid, a.n_visual_blocks, a.n_visual_residuals) == \
+                        (b.termination, b.lm_iterations, b.evaluations, b.n_icp_valid, b.n_visual_blocks, b.n_visual_residuals)
+                    assert a.final_cost == b.final_cost and a.initial_cost == b.initial_cost
+                assert Ss[i].algorithmic_bytes == s1.algorithmic_bytes
+        for c in ctxs:
+            c.close()

@@ -475,7 +475,8 @@ def comm_unique_id() -> bytes:
 
 
 def frame_to_frame_batch(ctxs, x0s):
-    """B independent scan pairs in flight, one context (and host thread inside the library) each."""
+    """B independent scan pairs in flight, one context each.  The library advances them in lock-step on one stream with shared LM
+    launches when it can (same device and parameters, no communicator, no visual blocks), else with a host thread per context."""
     lib = load_library()
     n = len(ctxs)
     arr = (_ctx * n)(*[c.handle for c in ctxs])

@@ -9,6 +9,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <array>
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>
@@ -218,6 +219,14 @@ struct velo_ctx {
     DevBuf<unsigned char> tri_init;
     DevBuf<velo_tri_result> tri_res;
     int tri_variant = 1;                 // 1 = one wave per landmark (default), 0 = one thread per landmark (VELO_TRI_VARIANT)
+
+    // lock-step batch driver (velo_frame_to_frame_batch): scratch owned by the FIRST context of a batch
+    DevBuf<LMBatchItem> batch_items;
+    DevBuf<LMState> batch_states;
+    DevBuf<double> batch_x;
+    void* h_batch = nullptr;             // pinned: items, x, states
+    size_t h_batch_bytes = 0;
+    int batch_lockstep = 1;              // VELO_BATCH_LOCKSTEP=0: one host thread per context instead (A/B)
 
     // sharding / comm
     int shard_rank = 0, shard_world = 1;
@@ -837,6 +846,7 @@ int velo_create(velo_ctx** out, int device) {
     if (const char* e = getenv("VELO_WARM_START")) c->warm_start = atoi(e);
     if (const char* e = getenv("VELO_PERSISTENT_WGS")) c->persistent_wgs = std::max(atoi(e), 1);
     if (const char* e = getenv("VELO_FUSED")) c->use_fused = atoi(e) != 0;
+    if (const char* e = getenv("VELO_BATCH_LOCKSTEP")) c->batch_lockstep = atoi(e);
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(hipHostMalloc((void**)&c->h_status, sizeof(HostStatus), hipHostMallocDefault));
     HIP_TRY(hipHostMalloc((void**)&c->h_x, sizeof(double) * 64, hipHostMallocDefault));
@@ -893,6 +903,8 @@ int velo_destroy(velo_ctx* c) {
     for (int k = 0; k < 2; k++) if (c->chunk_graph[k]) (void)hipGraphExecDestroy(c->chunk_graph[k]);
     c->state.release(); c->partials.release(); c->reduced.release(); c->xdev.release(); c->ticket.release();
     c->row_off_vis.release(); c->row_off_icp.release(); c->rows_r.release(); c->rows_J.release();
+    if (c->h_batch) (void)hipHostFree(c->h_batch);
+    c->batch_items.release(); c->batch_states.release(); c->batch_x.release();
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->h_x) (void)hipHostFree(c->h_x);
     if (c->h_int) (void)hipHostFree(c->h_int);
@@ -1306,7 +1318,6 @@ int velo_frame_to_frame(velo_ctx* c, double x[6], double T[16], velo_summary* su
     c->assoc_events_used = 0;
     double xc[6];
     for (int k = 0; k < 6; k++) xc[k] = x[k];
-    bool first = true;
     for (int iter = 1; iter <= c->P.f2f_iterations; iter++) {                       // velo.h:616
         VELO_TRY(do_build_visual(c, xc, false, iter, nullptr));                      // velo.h:622-792
         c->have_corr = false;
@@ -1329,7 +1340,6 @@ int velo_frame_to_frame(velo_ctx* c, double x[6], double T[16], velo_summary* su
             // consecutive frames behave alike: size the first chunk to the evaluations this solve needed last time (+1)
             VELO_TRY(do_solve(c, xc, xc, &ss, &evals, std::min(std::max(c->pred_evals[solve_idx] + 1, 2), c->P.max_num_iterations + 1)));   // velo.h:897-902
             c->pred_evals[solve_idx] = ss.evaluations;
-            first = false;
             S->eval_kernel_launches += evals;
             S->algorithmic_bytes += (uint64_t)ss.evaluations * (36ull * (uint64_t)ss.n_icp_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull);
             if (S->n_solves < VELO_MAX_SOLVES) S->solves[S->n_solves] = ss;
@@ -1350,8 +1360,172 @@ int velo_frame_to_frame(velo_ctx* c, double x[6], double T[16], velo_summary* su
     return VELO_OK;
 }
 
+// Lock-step batch: every context does what velo_frame_to_frame does, in the same order and with the same kernels' arithmetic,
+// but the n contexts advance together on ONE stream and share launches in the LM phase: one sweep launch covers the
+// point-to-plane residuals of all contexts (blockIdx.y = context), one launch steps all n LM states, one copy brings all n
+// states back per chunk.  With a host thread per context (the fallback) a step of 8 pairs is 8 x 84 small LM launches that each
+// fill half the chip and stall behind the other contexts' association kernels; here it is 84 launches that fill it.
+// Conditions: same device, same parameters, no communicator, default kernels -- anything else falls back.
+static bool batch_can_lockstep(velo_ctx** ctxs, int n) {
+    if (n < 2 || !ctxs[0] || !ctxs[0]->batch_lockstep) return false;
+    for (int i = 0; i < n; i++) {
+        const velo_ctx* c = ctxs[i];
+        if (!c || c->device != ctxs[0]->device || c->comm || c->use_fused || c->use_graphs) return false;
+        if (!c->have_target || !c->have_source || c->shard_world != 1) return false;
+        if (std::memcmp(&c->P, &ctxs[0]->P, sizeof(velo_params)) != 0) return false;
+        for (int j = 0; j < i; j++) if (ctxs[j] == c) return false;
+    }
+    return true;
+}
+
+static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo_summary* summaries) {
+    velo_ctx* c0 = ctxs[0];
+    HIP_TRY(hipSetDevice(c0->device));
+    const velo_params P = c0->P;
+    const LMParams Q = lm_params(P);
+    // everything queued on the contexts' own streams (set_target / set_source) must be done before the shared stream uses it
+    for (int i = 0; i < n; i++) HIP_TRY(hipStreamSynchronize(ctxs[i]->stream));
+    std::vector<hipStream_t> own((size_t)n);
+    for (int i = 0; i < n; i++) { own[(size_t)i] = ctxs[i]->stream; ctxs[i]->stream = c0->stream; }
+    struct Restore { velo_ctx** c; std::vector<hipStream_t>& s; int n; ~Restore() { for (int i = 0; i < n; i++) c[i]->stream = s[(size_t)i]; } } restore{ctxs, own, n};
+    hipStream_t bs = c0->stream;
+    // pinned + device scratch
+    const size_t need = (size_t)n * (sizeof(LMBatchItem) + sizeof(LMState) + 8 * sizeof(double));
+    if (c0->h_batch_bytes < need) {
+        if (c0->h_batch) (void)hipHostFree(c0->h_batch);
+        c0->h_batch = nullptr; c0->h_batch_bytes = 0;
+        HIP_TRY(hipHostMalloc(&c0->h_batch, need, hipHostMallocDefault));
+        c0->h_batch_bytes = need;
+    }
+    LMBatchItem* h_items = (LMBatchItem*)c0->h_batch;
+    LMState* h_states = (LMState*)(h_items + n);
+    double* h_x = (double*)(h_states + n);
+    VELO_TRY(c0->batch_items.reserve((size_t)n)); VELO_TRY(c0->batch_states.reserve((size_t)n)); VELO_TRY(c0->batch_x.reserve((size_t)8 * n));
+
+    std::vector<velo_summary> local((size_t)n);
+    std::vector<velo_summary*> S((size_t)n);
+    std::vector<std::array<double, 6>> xc((size_t)n);
+    for (int i = 0; i < n; i++) {
+        S[(size_t)i] = summaries ? summaries + i : &local[(size_t)i];
+        std::memset(S[(size_t)i], 0, sizeof(velo_summary));
+        S[(size_t)i]->n_target = ctxs[i]->n_tgt;
+        ctxs[i]->assoc_events_used = 0;
+        for (int k = 0; k < 6; k++) xc[(size_t)i][(size_t)k] = x[6 * (size_t)i + k];
+    }
+    const int max_iters = P.max_num_iterations + 1;
+    for (int iter = 1; iter <= P.f2f_iterations; iter++) {                              // velo.h:616
+        for (int i = 0; i < n; i++) {
+            VELO_TRY(do_build_visual(ctxs[i], xc[(size_t)i].data(), false, iter, nullptr));   // velo.h:622-792
+            ctxs[i]->have_corr = false; ctxs[i]->last_n_valid = 0;
+        }
+        for (int icp_iter = 0; icp_iter < P.icp_iterations; icp_iter++) {               // velo.h:800
+            int nb_max = 0, nbv_max = 0, first_chunk = 2;
+            for (int i = 0; i < n; i++) {
+                velo_ctx* c = ctxs[i];
+                int nv = 0;
+                VELO_TRY(do_associate(c, xc[(size_t)i].data(), iter, false, false, &nv));   // velo.h:806-894, on the shared stream
+                int qb, qe;
+                q_range(c, &qb, &qe);
+                velo_summary* Si = S[(size_t)i];
+                Si->n_assoc_rounds++; Si->n_queries = c->n_q;
+                const uint64_t nq = (uint64_t)c->n_q;
+                const uint64_t b_assoc = 12ull * nq + 12ull * (uint64_t)c->n_tgt + 28ull * nq;
+                Si->assoc_bytes += b_assoc; Si->algorithmic_bytes += b_assoc;
+                if (qe > qb) Si->assoc_kernel_launches++;
+                LMBatchItem& it = h_items[i];
+                it.A = eval_args(c, nullptr);
+                const EvalPlan E = eval_plan(it.A);
+                it.S = c->state.p; it.xd = c0->batch_x.p + 8 * (size_t)i;
+                it.n_valid = c->have_corr ? c->n_valid.p + c->nv_idx : nullptr;
+                it.nb_icp = E.nb_icp; it.nb_vis = E.nb_vis; it.n_rows = E.total();
+                it.A.vis_row0 = E.nb_icp;
+                nb_max = std::max(nb_max, E.nb_icp); nbv_max = std::max(nbv_max, E.nb_vis);
+                for (int k = 0; k < 6; k++) h_x[8 * (size_t)i + k] = xc[(size_t)i][(size_t)k];
+                const int solve_idx = std::min(Si->n_solves, VELO_MAX_SOLVES - 1);
+                first_chunk = std::max(first_chunk, std::min(c->pred_evals[solve_idx] + 1, max_iters));
+            }
+            HIP_TRY(hipMemcpyAsync(c0->batch_items.p, h_items, sizeof(LMBatchItem) * (size_t)n, hipMemcpyHostToDevice, bs));
+            HIP_TRY(hipMemcpyAsync(c0->batch_x.p, h_x, sizeof(double) * 8 * (size_t)n, hipMemcpyHostToDevice, bs));
+            hipLaunchKernelGGL(lm_begin_batch_kernel, dim3(n), dim3(64), 0, bs, (const LMBatchItem*)c0->batch_items.p);
+            int launched = 0, chunk = first_chunk;
+            for (;;) {                                                                  // one ceres::Solve per context, velo.h:897-902
+                for (int k = 0; k < chunk; k++) {
+                    if (nb_max > 0) hipLaunchKernelGGL(eval_icp_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, (const LMBatchItem*)c0->batch_items.p);
+                    if (nbv_max > 0) hipLaunchKernelGGL(eval_visual_batch_kernel, dim3(nbv_max, n), dim3(kEvalThreads), 0, bs, (const LMBatchItem*)c0->batch_items.p);
+                    hipLaunchKernelGGL(lm_step_batch_kernel, dim3(n), dim3(256), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p);
+                }
+                hipLaunchKernelGGL(lm_gather_states_kernel, dim3(n), dim3(128), 0, bs, (const LMBatchItem*)c0->batch_items.p, c0->batch_states.p);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(h_states, c0->batch_states.p, sizeof(LMState) * (size_t)n, hipMemcpyDeviceToHost, bs));
+                launched += chunk;
+                HIP_TRY(hipStreamSynchronize(bs));
+                bool all_done = true;
+                for (int i = 0; i < n; i++) all_done = all_done && h_states[i].done != 0;
+                if (all_done) break;
+                if (launched > max_iters + 16) return fail(VELO_ERR_STATE, "LM did not terminate after %d sweeps", launched);
+                chunk = 3;
+            }
+            for (int i = 0; i < n; i++) {
+                velo_ctx* c = ctxs[i];
+                const LMState& st = h_states[i];
+                velo_summary* Si = S[(size_t)i];
+                for (int k = 0; k < 6; k++) xc[(size_t)i][(size_t)k] = st.x[k];
+                velo_solve_summary ss;
+                std::memset(&ss, 0, sizeof(ss));
+                ss.termination = st.termination; ss.lm_iterations = st.iter; ss.evaluations = st.evals;
+                c->last_n_valid = st.n_valid; ss.n_icp_valid = st.n_valid;
+                visual_counts(c, &ss.n_visual_blocks, &ss.n_visual_residuals);
+                ss.initial_cost = st.initial_cost; ss.final_cost = st.cost;
+                const int solve_idx = std::min(Si->n_solves, VELO_MAX_SOLVES - 1);
+                c->pred_evals[solve_idx] = ss.evaluations;
+                Si->eval_kernel_launches += st.evals;
+                Si->algorithmic_bytes += (uint64_t)ss.evaluations * (36ull * (uint64_t)ss.n_icp_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull);
+                if (Si->n_solves < VELO_MAX_SOLVES) Si->solves[Si->n_solves] = ss;
+                Si->n_solves++;
+            }
+        }
+    }
+    for (int i = 0; i < n; i++) {
+        velo_ctx* c = ctxs[i];
+        if (c->timing) {
+            double ms = 0.0;
+            for (int k = 0; k < c->assoc_events_used; k++) {
+                float t = 0.f;
+                HIP_TRY(hipEventElapsedTime(&t, c->assoc_events[k].first, c->assoc_events[k].second));
+                ms += t;
+            }
+            S[(size_t)i]->assoc_kernel_ms = ms;
+        }
+        for (int k = 0; k < 6; k++) x[6 * (size_t)i + k] = xc[(size_t)i][(size_t)k];
+        if (T) velo_pose_vec_to_mat(x + 6 * (size_t)i, T + 16 * (size_t)i);
+    }
+    return VELO_OK;
+}
+
 int velo_frame_to_frame_batch(velo_ctx** ctxs, int32_t n, double* x, double* T, velo_summary* summaries) {
     if (!ctxs || n < 0 || (n > 0 && !x)) return fail(VELO_ERR_INVALID, "bad batch arguments");
+    if (batch_can_lockstep(ctxs, n)) {
+        // G lock-step groups, one host thread and one stream each: while one group is in its (chip-filling) association
+        // launches or waits for a status copy, another group's LM launches run -- the groups hide each other's bubbles
+        // Measured on C2 (pairs/s, 3 runs each): 8 contexts: 1 group 1,425, 2 groups 1,790-1,920, 4 groups 1,990-2,200, one thread per
+        // context 1,600; 16 contexts: 2 groups 2,010-2,110, 4 groups 1,420-1,510 (four association kernels interleave), 8 groups 1,740-1,780.
+        static const int groups_env = getenv("VELO_BATCH_GROUPS") ? std::max(atoi(getenv("VELO_BATCH_GROUPS")), 1) : 0;
+        const int G = groups_env > 0 ? std::min(groups_env, n / 2) : (n >= 12 ? 2 : std::min(4, n / 2));
+        if (G <= 1) return f2f_batch_lockstep(ctxs, n, x, T, summaries);
+        std::vector<int> gst((size_t)G, VELO_OK);
+        std::vector<std::string> gerr((size_t)G);
+        std::vector<std::thread> gth;
+        for (int gi = 0; gi < G; gi++) {
+            const int b = (int)((int64_t)n * gi / G), e = (int)((int64_t)n * (gi + 1) / G);
+            gth.emplace_back([&, gi, b, e]() {
+                gst[(size_t)gi] = f2f_batch_lockstep(ctxs + b, e - b, x + 6 * (size_t)b, T ? T + 16 * (size_t)b : nullptr, summaries ? summaries + b : nullptr);
+                if (gst[(size_t)gi] != VELO_OK) gerr[(size_t)gi] = g_err;
+            });
+        }
+        for (auto& t : gth) t.join();
+        for (int gi = 0; gi < G; gi++) if (gst[(size_t)gi] != VELO_OK) { g_err = gerr[(size_t)gi]; return gst[(size_t)gi]; }
+        return VELO_OK;
+    }
     std::vector<int> status((size_t)n, VELO_OK);
     std::vector<std::string> errs((size_t)n);
     std::vector<std::thread> th;

@@ -1601,12 +1601,11 @@ __device__ __forceinline__ bool eval_load_x(const EvalArgs& A, double x[6]) {
 }
 
 // point-to-plane blocks (row R1 + Scaled(Cauchy(loss_thresh_3DPD), weight_3DPD), velo.h:875-892)
-__global__ void __launch_bounds__(kEvalThreads)
-eval_icp_kernel(EvalArgs A) {
+__device__ __forceinline__ void eval_icp_body(const EvalArgs& A, const int bx, const int nbx) {
     // The correspondences do not depend on the pose: the first kPre strided rows of this thread are requested BEFORE the LM
     // state (written by the previous launch) is read and the rotation constants are set up, so both latencies overlap.
     constexpr int kPre = 4;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    const int tid = bx * blockDim.x + threadIdx.x, nthreads = nbx * blockDim.x;
     float4 pp[kPre], pn[kPre], pv[kPre];
 #pragma unroll
     for (int k = 0; k < kPre; k++) {
@@ -1648,12 +1647,32 @@ eval_icp_kernel(EvalArgs A) {
             for (int k = 0; k < 6; k++) A.rows_J[(size_t)row * 6 + k] = J[k] * sr;
         }
     }
-    block_reduce_store(acc, A.partials + (size_t)blockIdx.x * kNumAcc);
+    block_reduce_store(acc, A.partials + (size_t)bx * kNumAcc);
 }
 
-// visual blocks (rows R2-R5; losses velo.h:688,714-717,748-751,781-784)
 __global__ void __launch_bounds__(kEvalThreads)
-eval_visual_kernel(EvalArgs A) {
+eval_icp_kernel(EvalArgs A) { eval_icp_body(A, blockIdx.x, gridDim.x); }
+
+// ---- several contexts in one launch (velo_frame_to_frame_batch): blockIdx.y = context -------------------------------------------
+// Each context keeps its own state, partial sums and correspondence table; the batch only shares LAUNCHES, so a sweep over 8
+// contexts is one kernel of ~950 workgroups instead of 8 kernels of 118 that each leave half the chip idle.
+struct LMBatchItem {
+    EvalArgs A;            // A.state / A.partials are this context's
+    LMState* S;
+    const double* xd;      // x to start the solve from (device)
+    const int* n_valid;    // association counter of this round
+    int nb_icp;            // workgroups of this context's point-to-plane sweep
+    int nb_vis;            // workgroups of its visual sweep (A.vis_row0 = nb_icp)
+    int n_rows;            // rows of partial sums the LM step reduces
+};
+__global__ void __launch_bounds__(kEvalThreads)
+eval_icp_batch_kernel(const LMBatchItem* __restrict__ items) {
+    const LMBatchItem& it = items[blockIdx.y];
+    if ((int)blockIdx.x >= it.nb_icp) return;
+    eval_icp_body(it.A, blockIdx.x, it.nb_icp);
+}
+// visual blocks (rows R2-R5; losses velo.h:688,714-717,748-751,781-784)
+__device__ __forceinline__ void eval_visual_body(const EvalArgs& A, const int bx, const int nbx) {
     double x[6];
     if (!eval_load_x(A, x)) return;
     PoseEval P;
@@ -1661,7 +1680,7 @@ eval_visual_kernel(EvalArgs A) {
     double acc[kNumAcc];
 #pragma unroll
     for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    const int tid = bx * blockDim.x + threadIdx.x, nthreads = nbx * blockDim.x;
     for (int s = tid; s < 3 * A.n_matches; s += nthreads) {
         const unsigned char f = A.vflags[s];
         if (!f) continue;
@@ -1687,7 +1706,16 @@ eval_visual_kernel(EvalArgs A) {
             }
         }
     }
-    block_reduce_store(acc, A.partials + (size_t)(A.vis_row0 + blockIdx.x) * kNumAcc);
+    block_reduce_store(acc, A.partials + (size_t)(A.vis_row0 + bx) * kNumAcc);
+}
+
+__global__ void __launch_bounds__(kEvalThreads)
+eval_visual_kernel(EvalArgs A) { eval_visual_body(A, blockIdx.x, gridDim.x); }
+__global__ void __launch_bounds__(kEvalThreads)
+eval_visual_batch_kernel(const LMBatchItem* __restrict__ items) {
+    const LMBatchItem& it = items[blockIdx.y];
+    if ((int)blockIdx.x >= it.nb_vis) return;
+    eval_visual_body(it.A, blockIdx.x, it.nb_vis);
 }
 
 // sums the per-workgroup partials in a fixed order into out[28] (used before the RCCL all-reduce and by velo_evaluate)
@@ -1861,6 +1889,27 @@ __global__ void __launch_bounds__(256)
 lm_step_kernel(LMParams Q, LMState* S, const double* __restrict__ partials, int n_blocks) {
     if (S->done) return;
     lm_transition(Q, S, partials, n_blocks);
+}
+__global__ void lm_begin_batch_kernel(const LMBatchItem* __restrict__ items) {
+    const LMBatchItem& it = items[blockIdx.x];
+    LMState* S = it.S;
+    if (threadIdx.x == 0) {
+        if (it.xd) for (int i = 0; i < 6; i++) S->x[i] = it.xd[i];
+        S->n_valid = it.n_valid ? *it.n_valid : 0;
+        S->phase = PHASE_INIT; S->done = 0; S->termination = 1; S->iter = 0; S->evals = 0; S->invalid = 0; S->reuse_diag = 0;
+    }
+}
+__global__ void __launch_bounds__(256)
+lm_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items) {
+    const LMBatchItem& it = items[blockIdx.x];
+    if (it.S->done) return;
+    lm_transition(Q, it.S, it.A.partials, it.n_rows);
+}
+// all states of the batch into one contiguous block (one D2H copy per chunk instead of one per context)
+__global__ void lm_gather_states_kernel(const LMBatchItem* __restrict__ items, LMState* __restrict__ out) {
+    const unsigned* src = reinterpret_cast<const unsigned*>(items[blockIdx.x].S);
+    unsigned* dst = reinterpret_cast<unsigned*>(out + blockIdx.x);
+    for (int k = threadIdx.x; k < (int)(sizeof(LMState) / 4); k += blockDim.x) dst[k] = src[k];
 }
 
 // Fused LM iteration (single GPU): the point-to-plane sweep, and the LAST workgroup to arrive performs the final
