@@ -239,6 +239,12 @@ def test_tie_breaks_and_wraparound(ctx, oracle):
     assert (a["idx_i"][1], a["idx_k"][1]) == (4, 3)        # neighbours 0 (wrap) and 3: 3 is closer
     assert (a["idx_i"][2], a["idx_k"][2]) == (2, 1)        # equidistant neighbours -> the -1 one
     assert a["valid"][3] == 0 and a["ring_i"][3] == 3 and a["idx_i"][3] == 0 and a["ring_j"][3] == 0   # |N| = 0
+    # the same ties when the round is warm-started from the previous round's winners (seeds enter before the grid candidates):
+    # exact multiples of 1/8 keep the distances tied after these translations too
+    for xs in (np.array([0, 0, 0, u, 0, 0], dtype=np.float64), np.zeros(6), np.array([0, 0, 0, 0, 0, u], dtype=np.float64), np.zeros(6)):
+        for it in (1, 2):
+            assert ctx.associate(xs, it) == orc.associate(xs, it)
+            H.assert_corr_equal(ctx.correspondences(), orc.correspondences())
 
 
 def test_rccl_path_single_rank(ctx, oracle):
