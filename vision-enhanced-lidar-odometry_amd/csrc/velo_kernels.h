@@ -971,9 +971,12 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                 s_lo[tid] = big; s_hi[tid] = -big;
                 if (ph == 1) { s_plo[tid] = big; s_phi[tid] = -big; }
                 __syncthreads();
+                // z-layers that have rows in this chunk (rows are z-major): a query only walks those layers of its box, so a box
+                // that spans several chunks costs its rows once, not once per chunk
+                const int zc0 = Z0 + (int)((float)rbase * rcp_nyb) - 1, zc1 = Z0 + (int)((float)(rbase + NT - 1) * rcp_nyb) + 1;
                 if (asks) {                                            // the rows of this query's box: z-layers dealt over the waves
                     const CellBox bb = query_box(g, qx, qy, qz, cx, cy, cz, rq, ph == 0);
-                    for (int z = bb.z0 + wid; z <= bb.z1; z += NW) {
+                    for (int z = max(bb.z0, zc0) + wid; z <= min(bb.z1, zc1); z += NW) {
                         if (z < Z0 || z > Z1) continue;
                         const int rz = (z - Z0) * nyb - Y0 - rbase;
                         for (int y = max(bb.y0, Y0); y <= min(bb.y1, Y1); y++) {
@@ -984,7 +987,7 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                 }
                 if (ph == 1 && member) {                               // what phase 1 staged: the phase-1 boxes of ALL members
                     const CellBox b1 = query_box(g, qx, qy, qz, cx, cy, cz, r1, true);
-                    for (int z = b1.z0 + wid; z <= b1.z1; z += NW) {
+                    for (int z = max(b1.z0, zc0) + wid; z <= min(b1.z1, zc1); z += NW) {
                         if (z < Z0 || z > Z1) continue;
                         const int rz = (z - Z0) * nyb - Y0 - rbase;
                         for (int y = max(b1.y0, Y0); y <= min(b1.y1, Y1); y++) {
