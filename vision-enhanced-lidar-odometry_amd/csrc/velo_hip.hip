@@ -151,6 +151,9 @@ struct velo_ctx {
     DevBuf<int4> prev_pair;              // tube kernel warm start: last round's winners per query (-1 = none); reset with every new source / target
     bool prev_ready = false;             // prev_pair holds n_q initialised entries for the current source and target
     int warm_start = 1;                  // VELO_WARM_START=0 turns the seeds off (A/B; results are identical either way)
+    int asker_rows = -1;                 // tube kernel (VELO_ASKER_ROWS): phase 2 goes query by query when the asking queries' boxes have more
+                                         // rows than this in total.  -1 = by target density: never on a regular scan (120k points: the tile pass
+                                         // is 62 vs 105-115 us), always when the grid had to be density-shrunk (2M-point map: 244 vs 420 us)
     DevBuf<int> group_perm;              // workgroup -> 64-query group, XCD-aware (see build_group_perm)
     int perm_qb = -1, perm_qe = -1, perm_nq = -1, perm_mode = -1;
     bool have_source = false;
@@ -535,6 +538,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         // kernel 4: 121 us); 2M-pt map: 535 us vs 1.49 ms -- its cold first round is slower there (density-shrunk grid, gate radius
         // = 15 cells, every query asks for a (2e+1)^2-row box: 1.59 vs 1.45 ms) but the five warm rounds need tiny boxes.
         const int variant = c->assoc_variant >= 0 ? c->assoc_variant : 5;
+        const int reach_cells = (int)std::ceil(std::sqrt(std::max(gate_of_iter(c->P, 1), 0.0)) / (G->h * 0.999));   // > 5: density-shrunk grid
         switch (variant) {
             case 0: {
                 const int reach = (int)std::ceil(std::sqrt(std::max(gate, 0.0)) / (G->h * 0.999)) ;
@@ -565,26 +569,27 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                                        c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, h_safe, out, aux);
                 break;
             }
-            case 5: case 55: case 52: case 58: case 51: {   // tube variant: per-row intervals, per-query phase 2 (cluster radius only when VELO_CLUSTER_W is given)
+            case 5: case 55: case 52: case 59: {   // tube variant: per-row intervals, per-query phase 2 (cluster radius only when VELO_CLUSTER_W is given)
                 // tubes do not grow with the segment, so the cluster radius only has to bound the row box of pathological groups
                 // (a 64-query group straddling a gap in its ring): 96 default cells = 17 m unless VELO_CLUSTER_W says otherwise
                 const int cw = c->cluster_w_set ? (c->cluster_w > 0 ? cluster_cells : 2000)
                                                 : std::max(1, (int)std::lround(96.0 * 0.1785 / G->h));
                 out.n_valid_next = c->n_valid.p + (c->nv_idx ^ 1);      // the tube kernel clears it for the next round
                 c->nv_clean[c->nv_idx ^ 1] = true;
+                const int asker_rows = c->asker_rows >= 0 ? c->asker_rows : (reach_cells > 5 ? 0 : (1 << 30));
                 const int* perm = nullptr;
                 if (c->tube_map >= 0) { VELO_TRY(build_group_perm(c, qb, qe, c->tube_map)); perm = c->group_perm.p; }
-#define VELO_LAUNCH_V5(NW, MINW, DBG, PPT)                                                                                         \
-                hipLaunchKernelGGL((assoc_search_v5_kernel<NW, MINW, DBG, PPT>), dim3(groups), dim3(NW * 64), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe, \
-                                   c->tgt.p, c->tgt_off.p, c->n_tgt, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux, perm, c->debug_skip)
+#define VELO_LAUNCH_V5(NW, MINW, DBG, PPT, ASKER)                                                                                         \
+                hipLaunchKernelGGL((assoc_search_v5_kernel<NW, MINW, DBG, PPT, ASKER>), dim3(groups), dim3(NW * 64), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe, \
+                                   c->tgt.p, c->tgt_off.p, c->n_tgt, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux, perm, c->debug_skip, asker_rows)
                 // default: 5 waves/SIMD (96 VGPRs, no spills, no scratch traffic), 2 candidate pairs per trip.  Measured on C2:
                 // 62 us; 6 waves + 2 pairs (5 spilled VGPRs) 65; 7 waves + 2 pairs 64; 5 waves + 4 pairs 66; 6 waves + 4 pairs 71
-                if (c->debug_skip) VELO_LAUNCH_V5(4, 5, true, 2);
-                else if (variant == 55) VELO_LAUNCH_V5(4, 5, false, 4);
-                else if (variant == 52) VELO_LAUNCH_V5(4, 6, false, 2);
-                else if (variant == 51) VELO_LAUNCH_V5(4, 7, false, 2);
-                else if (variant == 58) VELO_LAUNCH_V5(4, 6, false, 4);
-                else VELO_LAUNCH_V5(4, 5, false, 2);
+                if (c->debug_skip) VELO_LAUNCH_V5(4, 5, true, 2, true);
+                else if (variant == 55) VELO_LAUNCH_V5(4, 5, false, 4, true);
+                else if (variant == 52) VELO_LAUNCH_V5(4, 6, false, 2, true);
+                else if (variant == 59) VELO_LAUNCH_V5(4, 5, false, 2, false);   // phase 2 through the row/tile machinery (A/B)
+                else if (asker_rows >= (1 << 30)) VELO_LAUNCH_V5(4, 5, false, 2, false);   // regular grid: instantiation without the query-by-query code (no spills)
+                else VELO_LAUNCH_V5(4, 5, false, 2, true);
 #undef VELO_LAUNCH_V5
                 break;
             }
@@ -844,6 +849,7 @@ int velo_create(velo_ctx** out, int device) {
     if (const char* e = getenv("VELO_XCD_MAP")) c->xcd_map = atoi(e);
     if (const char* e = getenv("VELO_TUBE_MAP")) c->tube_map = atoi(e);
     if (const char* e = getenv("VELO_WARM_START")) c->warm_start = atoi(e);
+    if (const char* e = getenv("VELO_ASKER_ROWS")) c->asker_rows = atoi(e);
     if (const char* e = getenv("VELO_PERSISTENT_WGS")) c->persistent_wgs = std::max(atoi(e), 1);
     if (const char* e = getenv("VELO_FUSED")) c->use_fused = atoi(e) != 0;
     if (const char* e = getenv("VELO_BATCH_LOCKSTEP")) c->batch_lockstep = atoi(e);

@@ -834,6 +834,13 @@ __device__ __forceinline__ CellBox query_box(const GridDesc& g, float qx, float 
     return b;
 }
 
+__device__ __forceinline__ void top2_merge_xor(Top2& t, int mask) {
+    const unsigned long long o1 = __shfl_xor(t.b1, mask), o2 = __shfl_xor(t.b2, mask);
+    const int r1 = __shfl_xor(t.b1ring, mask), r2 = __shfl_xor(t.b2ring, mask);
+    if (o1 < t.b2) top2_update(t, o1, r1);
+    if (o2 < t.b2) top2_update(t, o2, r2);
+}
+
 // ---- association search, tube variant (VELO_ASSOC_VARIANT=5) ---------------------------------------------------------------
 // Same machinery as assoc_search_v3_kernel (run list -> LDS tile -> packed sweep -> merge), different candidate set:
 //   * phase 1 does not stage the whole bounding box of the cluster but, for every grid row (y, z), only the x-interval
@@ -845,11 +852,11 @@ __device__ __forceinline__ CellBox query_box(const GridDesc& g, float qx, float 
 //     is never a third phase.
 // Tubes do not blow up with the length of the segment, so the cluster radius can be large (one cluster per group).
 //   * rounds after the first are warm-started from the previous round's winners (AssocOut::prev).
-template <int NW, int MINW, bool DBG, int PPT>
+template <int NW, int MINW, bool DBG, int PPT, bool ASKER>
 __global__ void __launch_bounds__(NW * 64, MINW)
 assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
                        const float4* __restrict__ tgt, const int* __restrict__ tgt_off, int n_tgt_local,
-                       unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, AssocOut out, int want_aux, const int* __restrict__ group_perm, int dbg) {
+                       unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, AssocOut out, int want_aux, const int* __restrict__ group_perm, int dbg, int asker_rows) {
     constexpr int NT = NW * 64;
     constexpr int NRUN = 2 * NT;
     static_assert(kTileCap % (2 * PPT) == 0, "the tile must hold whole trips (the padding of the last trip stays inside it)");
@@ -945,6 +952,7 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
         // seeds it is the +-1 neighbourhood.  A query is finished when the box of its CURRENT bound lies inside what phase 1
         // visited for it; the others ask phase 2 for the box of their current bound.
         const float r1 = sqrtf(t.b2d) * 1.0001f + 1e-6f;               // bound radius phase 1 works with (padded against rounding)
+        bool asker_phase = false;
         for (int ph = 0; ph < 2; ph++) {
             // who asks for cells in this phase, and with which radius
             bool asks = member;
@@ -953,7 +961,18 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                 rq = sqrtf(t.b2d) * 1.0001f + 1e-6f;
                 const CellBox b2 = query_box(g, qx, qy, qz, cx, cy, cz, rq, false), b1 = query_box(g, qx, qy, qz, cx, cy, cz, r1, true);
                 asks = member && !(b2.x0 >= b1.x0 && b2.x1 <= b1.x1 && b2.y0 >= b1.y0 && b2.y1 <= b1.y1 && b2.z0 >= b1.z0 && b2.z1 <= b1.z1);
-                if (__ballot(asks) == 0ull) break;
+                if (__ballot(asks) == 0ull || (DBG && (dbg & 1024))) break;         // dbg & 1024: diagnostic, no second phase (wrong results)
+                if (ASKER) {
+                    // Two ways through phase 2.  Few askers with small boxes (a 120k-point scan: ~10 per group, <= 81 rows each, a few
+                    // new points): the row/tile machinery below takes all their rows in one parallel pass.  Many askers with big
+                    // boxes (2M-point map on its density-shrunk grid: every query, up to 961 rows each): the union tube makes all
+                    // 64 lanes test thousands of candidates that matter to one query each -- then one query at a time is cheaper.
+                    const int rows_mine = asks ? (b2.y1 - b2.y0 + 1) * (b2.z1 - b2.z0 + 1) : 0;
+                    int rows_all = rows_mine;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) rows_all += __shfl_xor(rows_all, off);
+                    if (rows_all > asker_rows) { asker_phase = true; break; }
+                }
             }
             int Y0, Y1, Z0, Z1;
             {
@@ -1118,6 +1137,93 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                     if (c2 < t.b2) top2_update(t, c2, mr2[w][lane]);
                 }
                 __syncthreads();
+            }
+            VELO_STAMP(6);
+        }
+        if (ASKER && asker_phase) {
+            // ---- phase 2, one asking query at a time ("asker-centric") ---------------------------------------------------------------
+            // After phase 1 few queries still need cells (those whose second ring is farther than a cell), each a large box of its own
+            // that shares little with the others'.  Pushing them through the row/tile machinery costs ~10 barriers and a mostly
+            // empty tile per chunk; instead the askers are dealt over the waves and a wave turns ALL 64 LANES on ONE query: the
+            // lanes take the rows of its box (cell offsets -> runs -> wave prefix sum), then each lane tests its own share of the
+            // candidates against that one query, starting from the query's current bounds (so nearly everything is pruned), and
+            // six xor-shuffle merges pool the lanes' top-2 states.  Cells phase 1 already staged are simply tested again
+            // (top-2 is idempotent).  No workgroup barrier until the results are handed to the other waves.
+            const float rq = sqrtf(t.b2d) * 1.0001f + 1e-6f;
+            bool asks;
+            {
+                const CellBox b2 = query_box(g, qx, qy, qz, cx, cy, cz, rq, false), b1 = query_box(g, qx, qy, qz, cx, cy, cz, r1, true);
+                asks = member && !(b2.x0 >= b1.x0 && b2.x1 <= b1.x1 && b2.y0 >= b1.y0 && b2.y1 <= b1.y1 && b2.z0 >= b1.z0 && b2.z1 <= b1.z1);
+            }
+            unsigned long long am = __ballot(asks);
+            if (DBG && (dbg & 1024)) am = 0ull;
+            if (am != 0ull) {
+                // LPA lanes per asker (64: one asker per wave at a time; 16 -- four at a time -- measured slower on the map: 314 vs 244 us)
+                constexpr int LPA = 64;
+                const int sg = lane / LPA, sl = lane % LPA;
+                int* w_j0 = s_run_j0 + wid * 128 + sg * (LPA + 1);     // this sub-group's run list (16 rows at a time)
+                int* w_off = s_run_off + wid * 128 + sg * (LPA + 1);
+                if (asks) s_lo[(int)__popcll(am & ((1ull << lane) - 1ull))] = lane;   // rank -> lane (every wave writes the same values)
+                __syncthreads();
+                const int n_ask = (int)__popcll(am);
+                const int nq_w = (n_ask - wid + NW - 1) / NW;          // askers of this wave: ranks wid, wid + NW, ...
+                for (int p0 = 0; p0 < nq_w; p0 += 64 / LPA) {
+                    const int q = p0 + sg;
+                    const bool on = q < nq_w;
+                    const int la = on ? s_lo[q * NW + wid] : 0;
+                    // the asker's query and current state, broadcast to the lanes of its sub-group
+                    const float ax = __shfl(qx, la), ay = __shfl(qy, la), az = __shfl(qz, la), ar = __shfl(rq, la);
+                    Top2 tl;
+                    tl.b1 = __shfl(t.b1, la); tl.b2 = __shfl(t.b2, la); tl.b1ring = __shfl(t.b1ring, la); tl.b2ring = __shfl(t.b2ring, la);
+                    tl.b2d = __uint_as_float((unsigned)(tl.b2 >> 32));
+                    const CellBox bb = query_box(g, ax, ay, az, 0, 0, 0, ar, false);
+                    const int x0 = max(bb.x0, 0), x1 = min(bb.x1, g.nx - 1);
+                    const int y0 = max(bb.y0, 0), y1 = min(bb.y1, g.ny - 1), z0 = max(bb.z0, 0), z1 = min(bb.z1, g.nz - 1);
+                    const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+                    const int nrows_a = (on && x0 <= x1 && ny > 0 && nz > 0) ? ny * nz : 0;
+                    const float rcp_ny = 1.0f / (float)max(ny, 1);
+                    for (int r0 = 0; r0 < nrows_a; r0 += LPA) {
+                        const int r = r0 + sl;
+                        int j0 = 0, len = 0;
+                        if (r < nrows_a) {
+                            int zq = (int)((float)r * rcp_ny), yr = r - zq * ny;
+                            if (yr < 0) { zq--; yr += ny; } else if (yr >= ny) { zq++; yr -= ny; }
+                            const int row = ((z0 + zq) * g.ny + (y0 + yr)) * g.nx;
+                            j0 = G.cell_start[row + x0]; len = G.cell_start[row + x1 + 1] - j0;
+                        }
+                        int inc = len;
+#pragma unroll
+                        for (int off = 1; off < LPA; off <<= 1) { const int v = __shfl_up(inc, off, LPA); if (sl >= off) inc += v; }
+                        const int total = __shfl(inc, LPA - 1, LPA);
+                        w_j0[sl] = j0; w_off[sl] = inc - len;
+                        if (sl == 0) w_off[LPA] = total;
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (DBG && (dbg & 16) && sl == 0) { atomicAdd(&out.dbg[2], (unsigned long long)total); atomicAdd(&out.dbg[3], (unsigned long long)total); atomicAdd(&out.dbg[4], (unsigned long long)min(LPA, nrows_a - r0)); }
+                        for (int slot = sl; slot < total; slot += LPA) {
+                            int lo = 0;                                // largest i with w_off[i] <= slot
+#pragma unroll
+                            for (int step = LPA / 2; step > 0; step >>= 1) { if (w_off[lo + step] <= slot) lo += step; }
+                            const int j = w_j0[lo] + (slot - w_off[lo]);
+                            const float4 c = G.sorted[j];
+                            const float d = dist2_f(ax, ay, az, c.x, c.y, c.z);
+                            if (d <= tl.b2d) top2_update(tl, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(c.w), G.sring[j]);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();               // the run list is rewritten by the next rows
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    }
+#pragma unroll
+                    for (int m = 1; m < LPA; m <<= 1) top2_merge_xor(tl, m);     // the sub-group's lanes now hold the asker's result
+                    if (on && sl == 0) { m1[0][la] = tl.b1; m2[0][la] = tl.b2; mr[0][la] = tl.b1ring; mr2[0][la] = tl.b2ring; }
+                }
+                __syncthreads();                                       // results of all waves' askers are in LDS
+                if (asks) {
+                    t.b1 = m1[0][lane]; t.b2 = m2[0][lane]; t.b1ring = mr[0][lane]; t.b2ring = mr2[0][lane];
+                    t.b2d = __uint_as_float((unsigned)(t.b2 >> 32));
+                }
+                __syncthreads();                                       // the scratch aliases the tile of the next cluster
             }
             VELO_STAMP(6);
         }
