@@ -1149,12 +1149,20 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
             // candidates against that one query, starting from the query's current bounds (so nearly everything is pruned), and
             // six xor-shuffle merges pool the lanes' top-2 states.  Cells phase 1 already staged are simply tested again
             // (top-2 is idempotent).  No workgroup barrier until the results are handed to the other waves.
-            const float rq = sqrtf(t.b2d) * 1.0001f + 1e-6f;
+            // Two stages: first every asker looks no farther than 4 cells (a query that starts without a second ring -- bound = the
+            // gate, 15 cells on the shrunk grid -- usually finds one nearby and shrinks its bound), then only the queries whose bound
+            // still reaches beyond those 4 cells search their full sphere.
+            const float cap = 4.0f * h_safe;
             bool asks;
             {
-                const CellBox b2 = query_box(g, qx, qy, qz, cx, cy, cz, rq, false), b1 = query_box(g, qx, qy, qz, cx, cy, cz, r1, true);
+                const float rq0 = sqrtf(t.b2d) * 1.0001f + 1e-6f;
+                const CellBox b2 = query_box(g, qx, qy, qz, cx, cy, cz, rq0, false), b1 = query_box(g, qx, qy, qz, cx, cy, cz, r1, true);
                 asks = member && !(b2.x0 >= b1.x0 && b2.x1 <= b1.x1 && b2.y0 >= b1.y0 && b2.y1 <= b1.y1 && b2.z0 >= b1.z0 && b2.z1 <= b1.z1);
             }
+            for (int stage = 0; stage < 2; stage++) {
+            const float rnow = sqrtf(t.b2d) * 1.0001f + 1e-6f;
+            const float rq = stage == 0 ? fminf(rnow, cap) : rnow;
+            if (stage == 1) asks = asks && rnow > cap;                 // the others have seen their whole bound sphere in stage 0
             unsigned long long am = __ballot(asks);
             if (DBG && (dbg & 1024)) am = 0ull;
             if (am != 0ull) {
@@ -1224,6 +1232,7 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                     t.b2d = __uint_as_float((unsigned)(t.b2 >> 32));
                 }
                 __syncthreads();                                       // the scratch aliases the tile of the next cluster
+            }
             }
             VELO_STAMP(6);
         }
