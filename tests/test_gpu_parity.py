@@ -312,3 +312,25 @@ def test_non_finite_points_and_degenerate_inputs(ctx, oracle):
         ctx.set_params(icp_skip=0)
     with pytest.raises(api.VeloError):
         ctx.associate(d["x0"], 0)
+
+
+def test_small_problem_single_launch_solve_is_bit_identical(hip_lib, monkeypatch):
+    """Problems whose sweep fits a few workgroups (the reference's icp_skip = 200) run a whole solve in one single-workgroup launch
+    (lm_solve_small_kernel); it walks the same virtual blocks with the same arithmetic, so poses, costs and iteration counts
+    equal the launch-per-iteration path bit for bit."""
+    d = synth.scan_pair(n_beams=64, n_azimuth=1875)
+    vis = api.matches_from_dict(synth.stereo_matches(40, mix="all"))
+    out = []
+    for small in ("1", "0"):
+        monkeypatch.setenv("VELO_SMALL_SOLVE", small)
+        c = api.Context(0)                                   # reference constants: icp_skip = 200 -> 640 queries
+        c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"]); c.set_visual(vis)
+        out.append(c.frame_to_frame(d["x0"]))
+        c.close()
+    (x1, T1, s1), (x0, T0, s0) = out
+    assert s1.n_queries == 640
+    assert np.array_equal(x1, x0) and np.array_equal(T1, T0)
+    for k in range(s1.n_solves):
+        a, b = s1.solves[k], s0.solves[k]
+        assert (a.termination, a.lm_iterations, a.evaluations, a.n_icp_valid, a.n_visual_blocks) == (b.termination, b.lm_iterations, b.evaluations, b.n_icp_valid, b.n_visual_blocks)
+        assert a.initial_cost == b.initial_cost and a.final_cost == b.final_cost

@@ -151,6 +151,7 @@ struct velo_ctx {
     DevBuf<int4> prev_pair;              // tube kernel warm start: last round's winners per query (-1 = none); reset with every new source / target
     bool prev_ready = false;             // prev_pair holds n_q initialised entries for the current source and target
     int warm_start = 1;                  // VELO_WARM_START=0 turns the seeds off (A/B; results are identical either way)
+    int small_solve = 1;                 // VELO_SMALL_SOLVE=0: small problems go through the launch-per-iteration path too (A/B, identical results)
     int asker_rows = -1;                 // tube kernel (VELO_ASKER_ROWS): phase 2 goes query by query when the asking queries' boxes have more
                                          // rows than this in total.  -1 = by target density: never on a regular scan (120k points: the tile pass
                                          // is 62 vs 105-115 us), always when the grid had to be density-shrunk (2M-point map: 244 vs 420 us)
@@ -735,6 +736,16 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
         HIP_TRY(hipMemcpyAsync(c->xdev.p, c->h_x, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
         xd = c->xdev.p;
     }
+    const int max_iters_all = c->P.max_num_iterations + 1;
+    if (!c->comm && !c->use_fused && !c->use_graphs && c->small_solve && E.total() >= 1 && E.total() <= kSmallRows) {
+        // small problem (the reference's icp_skip = 200): the whole solve in one single-workgroup launch, one status copy
+        hipLaunchKernelGGL(lm_solve_small_kernel, dim3(1), dim3(kEvalThreads), 0, c->stream, A, Q, c->state.p, xd,
+                           (const int*)(c->have_corr ? c->n_valid.p + c->nv_idx : nullptr), E.nb_icp, E.nb_vis, max_iters_all + 2);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&c->h_status->s, c->state.p, sizeof(LMState), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (!c->h_status->s.done) return fail(VELO_ERR_STATE, "LM did not terminate after %d sweeps", max_iters_all + 2);
+    } else {
     hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->state.p, xd, (const int*)(c->have_corr ? c->n_valid.p + c->nv_idx : nullptr));
     int launched = 0;
     int chunk = first_chunk;                // LM iterations per host round trip
@@ -746,6 +757,7 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
         if (c->h_status->s.done) break;
         if (launched > max_iters + 16) return fail(VELO_ERR_STATE, "LM did not terminate after %d sweeps", launched);
         chunk = 3;
+    }
     }
     const LMState& s = c->h_status->s;
     for (int k = 0; k < 6; k++) x_out[k] = s.x[k];
@@ -849,6 +861,7 @@ int velo_create(velo_ctx** out, int device) {
     if (const char* e = getenv("VELO_XCD_MAP")) c->xcd_map = atoi(e);
     if (const char* e = getenv("VELO_TUBE_MAP")) c->tube_map = atoi(e);
     if (const char* e = getenv("VELO_WARM_START")) c->warm_start = atoi(e);
+    if (const char* e = getenv("VELO_SMALL_SOLVE")) c->small_solve = atoi(e);
     if (const char* e = getenv("VELO_ASKER_ROWS")) c->asker_rows = atoi(e);
     if (const char* e = getenv("VELO_PERSISTENT_WGS")) c->persistent_wgs = std::max(atoi(e), 1);
     if (const char* e = getenv("VELO_FUSED")) c->use_fused = atoi(e) != 0;

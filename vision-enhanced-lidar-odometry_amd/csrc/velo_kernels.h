@@ -2030,6 +2030,65 @@ __global__ void lm_gather_states_kernel(const LMBatchItem* __restrict__ items, L
     for (int k = threadIdx.x; k < (int)(sizeof(LMState) / 4); k += blockDim.x) dst[k] = src[k];
 }
 
+// A whole ceres::Solve in ONE single-workgroup launch, for problems whose sweep is at most kSmallRows workgroups anyway (the
+// reference's own configuration: icp_skip = 200 -> 640 queries = one workgroup).  There a solve is ~8 LM iterations x two
+// launches of a few microseconds of work each plus host round trips: pure launch latency (1.1 ms per frame_to_frame call).
+// Here the workgroup walks the virtual blocks of the sweep one after the other -- the SAME eval bodies with the same block
+// index and block count, so every partial row is bit-identical to the multi-launch path -- reduces them in the same order,
+// thread 0 does the transition, and the loop continues on the device.  State and partial rows live in LDS for the duration.
+constexpr int kSmallRows = 4;
+__global__ void __launch_bounds__(kEvalThreads)
+lm_solve_small_kernel(EvalArgs A, LMParams Q, LMState* Sg, const double* __restrict__ x_in, const int* __restrict__ n_valid,
+                      int nb_icp, int nb_vis, int max_sweeps) {
+    __shared__ double rows[kSmallRows][kNumAcc];
+    __shared__ double part[8][kNumAcc];
+    __shared__ double E[kNumAcc];
+    __shared__ double s_x[6];
+    __shared__ LMState sL;
+    __shared__ int s_done;
+    const int t = threadIdx.x;
+    if (t == 0) {                                            // lm_begin_kernel
+        LMState L = *Sg;
+        if (x_in) for (int i = 0; i < 6; i++) L.x[i] = x_in[i];
+        L.n_valid = n_valid ? *n_valid : 0;
+        L.phase = PHASE_INIT; L.done = 0; L.termination = 1; L.iter = 0; L.evals = 0; L.invalid = 0; L.reuse_diag = 0;
+        sL = L;
+        for (int i = 0; i < 6; i++) s_x[i] = L.x[i];
+        s_done = 0;
+    }
+    __syncthreads();
+    EvalArgs B = A;
+    B.x_override = s_x;                                      // the sweeps read the point from LDS, not from the global state
+    B.partials = &rows[0][0];
+    B.vis_row0 = nb_icp;
+    const int n_rows = nb_icp + nb_vis;
+    for (int sweep = 0; sweep < max_sweeps; sweep++) {
+        if (s_done) break;
+        for (int bx = 0; bx < nb_icp; bx++) eval_icp_body(B, bx, nb_icp);
+        for (int bx = 0; bx < nb_vis; bx++) eval_visual_body(B, bx, nb_vis);
+        __syncthreads();
+        if (t < 8 * kNumAcc) {                               // the reduction of lm_transition, same order
+            const int k = t % kNumAcc, p = t / kNumAcc;
+            double v = 0.0;
+            for (int b = p; b < n_rows; b += 8) v += rows[b][k];
+            part[p][k] = v;
+        }
+        __syncthreads();
+        if (t < kNumAcc) { double v = 0.0; for (int p = 0; p < 8; p++) v += part[p][t]; E[t] = v; }
+        __syncthreads();
+        if (t == 0) {
+            LMState L = sL;
+            lm_transition_local(Q, &L, E);
+            sL = L;
+            const bool cand = L.phase == PHASE_CAND;
+            for (int i = 0; i < 6; i++) s_x[i] = cand ? L.xc[i] : L.x[i];
+            s_done = L.done;
+        }
+        __syncthreads();
+    }
+    if (t == 0) *Sg = sL;
+}
+
 // Fused LM iteration (single GPU): the point-to-plane sweep, and the LAST workgroup to arrive performs the final
 // reduction and the LM transition -- one launch per LM iteration instead of two.  Inter-workgroup hand-off by the
 // placement-independent protocol of the CDNA guide (Guideline 16, counter form): every storing wave drains its
