@@ -334,3 +334,36 @@ def test_small_problem_single_launch_solve_is_bit_identical(hip_lib, monkeypatch
         a, b = s1.solves[k], s0.solves[k]
         assert (a.termination, a.lm_iterations, a.evaluations, a.n_icp_valid, a.n_visual_blocks) == (b.termination, b.lm_iterations, b.evaluations, b.n_icp_valid, b.n_visual_blocks)
         assert a.initial_cost == b.initial_cost and a.final_cost == b.final_cost
+
+
+@pytest.mark.parametrize("env", [{}, {"VELO_ASKER_ROWS": "0"}, {"VELO_CLUSTER_W": "2"}, {"VELO_DENSE_REF": "300"},
+                                 {"VELO_DENSE_REF": "300", "VELO_ASKER_ROWS": "0"}, {"VELO_WARM_START": "0"}])
+def test_association_random_geometry_all_paths(hip_lib, oracle, monkeypatch, env):
+    """Every way through the tube kernel (tile pass / query-by-query second phase, one or many clusters, regular or
+    density-shrunk grid, with or without seeds) against the oracle on clouds that look nothing like a street scan: ragged
+    rings, dense clumps next to voids, points far outside the bulk, repeated rounds at moving poses."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    rng = np.random.default_rng(12)
+    n_rings = 23
+    lens = rng.integers(1, 140, n_rings)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    centres = rng.uniform(-4, 4, (6, 3))
+    which = rng.integers(0, 6, off[-1])
+    tgt = (centres[which] + rng.normal(0, 0.35, (off[-1], 3)) * rng.choice([0.1, 1.0, 3.0], (off[-1], 1))).astype(np.float32)
+    tgt[rng.integers(0, off[-1], 5)] += np.float32(40.0)                      # far outliers stretch the bounding box
+    slens = rng.integers(1, 90, 17)
+    soff = np.concatenate([[0], np.cumsum(slens)]).astype(np.int32)
+    src = (centres[rng.integers(0, 6, soff[-1])] + rng.normal(0, 0.5, (soff[-1], 3))).astype(np.float32)
+    c = api.Context(0, icp_skip=1)
+    o = oracle.Oracle(icp_skip=1)
+    for obj in (c, o):
+        obj.set_target(tgt, off)
+        obj.set_source(src, soff)
+    poses = [np.zeros(6), np.array([0.01, -0.02, 0.015, 0.05, -0.03, 0.02]), np.array([0.01, -0.02, 0.015, 0.051, -0.03, 0.02]),
+             np.array([0.3, 0.1, -0.2, 1.0, -0.5, 0.3]), np.zeros(6)]
+    for it in (1, 2, 1):
+        for x in poses:
+            assert c.associate(x, it) == o.associate(x, it)
+            H.assert_corr_equal(c.correspondences(), o.correspondences())
+    c.close()
