@@ -108,3 +108,38 @@ def test_adaptor_triangulates_like_the_oracle(tmp_path):
     scale = np.maximum(1.0, np.linalg.norm(want, axis=1))
     assert np.all(np.linalg.norm(got - want, axis=1)[conv] / scale[conv] <= 1e-4)
     assert np.all(got.view(np.uint32) == want.view(np.uint32), axis=1).mean() >= 0.99
+
+
+def compile_ceres_cost(tmp_path) -> str:
+    build.build_hip()
+    exe = str(tmp_path / "test_ceres_cost")
+    csrc = os.path.dirname(build.LIB)
+    subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), "-I", CPP,
+                    os.path.join(CPP, "test_ceres_cost.cpp"), "-o", exe, "-L", csrc, "-lvelo_hip", f"-Wl,-rpath,{csrc}",
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return exe
+
+
+def test_ceres_cost_adaptor_compiles_as_cxx11(tmp_path):
+    assert os.path.exists(compile_ceres_cost(tmp_path))
+
+
+@pytest.mark.gpu
+def test_ceres_cost_adaptor_rows_match_oracle(tmp_path, oracle):
+    """Seam 3: the batched ceres::CostFunction (include/velo_ceres_cost.hpp) returns the robustified rows of all current blocks:
+    residuals and row-major Jacobian equal the oracle's, with and without the Jacobian requested."""
+    exe = compile_ceres_cost(tmp_path)
+    d = H.small_pair(16, 128)
+    m = api.matches_from_dict(synth.stereo_matches(30, mix="all"))
+    case, outp = str(tmp_path / "case.bin"), str(tmp_path / "rows.bin")
+    write_case(case, d, m, 2)
+    subprocess.run([exe, case, outp], check=True, capture_output=True, text=True)
+    raw = np.fromfile(outp, dtype=np.float64)
+    n = int(raw[0])
+    r, J = raw[1:1 + n], raw[1 + n:1 + 7 * n].reshape(n, 6)
+    orc = oracle.Oracle(icp_skip=2)
+    orc.set_target(d["tgt_xyz"], d["tgt_off"]); orc.set_source(d["src_xyz"], d["src_off"]); orc.set_visual(m)
+    orc.associate(d["x0"], 1); orc.build_visual(d["x0"], 1)
+    ro, Jo = orc.evaluate_rows(d["x0"])
+    assert n == len(ro) > 100
+    assert H.rel_err(r, ro) <= 1e-12 and H.rel_err(J, Jo) <= 1e-12
