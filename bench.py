@@ -237,9 +237,12 @@ def main():
         traffic = None          # HBM-side bytes per launch from the committed PMC passes (tools/summarize_traffic.py)
         import glob
         tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+        sq = None
         if tf and a.workload == "c2":
             try:
-                traffic = json.load(open(tf[-1]))["traffic_bytes_per_launch"]
+                tj = json.load(open(tf[-1]))
+                traffic = tj["traffic_bytes_per_launch"]
+                sq = tj.get("sq_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -264,6 +267,12 @@ def main():
         }
         if single is not None:
             line["single_pair"] = single
+        if sq and sq.get("SQ_INSTS_VALU"):
+            # the bound that binds: VALU issue.  1024 SIMDs, one wave-instruction per 4 cycles each (packed-f32 and f64 ops take 8)
+            t_alone = (single or {}).get("assoc_avg_launch_us", avg_ms * 1e3) * 1e-6
+            line["roofline"]["valu"] = {"wave_insts_per_launch": sq["SQ_INSTS_VALU"], "salu": sq.get("SQ_INSTS_SALU"), "lds": sq.get("SQ_INSTS_LDS"),
+                                        "issue_slots_per_launch_at_2p4GHz": 1024 * 2.4e9 / 4 * t_alone,
+                                        "note": "from the committed PMC pass (profiles/*_traffic.json); launch time = the kernel alone"}
         if not a.no_cpu_baseline:
             cb = cpu_baseline(d, vis, a.cpu_sample_skip)
             xo = np.array(cb.pop("x"))

@@ -19,5 +19,13 @@ if out["FETCH_SIZE"] is not None and out["WRITE_SIZE"] is not None:
            "read_correction": "x2 (gfx950 FETCH_SIZE counts 128-B requests at 64 B)",
            "traffic_bytes_per_launch": (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0,
            "source": f"gpurun_out/{tag}/pmc_fetch + pmc_write (rocprofv3 --pmc, separate passes), bench.py --batch 1"}
+    # instruction counters of the same kernel (pmc_sq pass): the bound that actually binds (the data is L2 / Infinity-Cache resident)
+    f = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag, "pmc_sq", "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)
+    if f:
+        per = collections.defaultdict(lambda: collections.defaultdict(float))
+        for r in csv.DictReader(open(f[0])):
+            if "assoc_search" in r["Kernel_Name"]:
+                per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        res["sq_per_launch"] = {k: sum(v.values()) / len(v) for k, v in per.items()}
     json.dump(res, open(os.path.join(ROOT, "profiles", f"{tag}_traffic.json"), "w"), indent=1)
     print(res)
