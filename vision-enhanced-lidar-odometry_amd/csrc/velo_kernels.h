@@ -867,6 +867,8 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
     __shared__ int s_run_off[NRUN + 1];
     __shared__ int s_wave_tot[NW];
     __shared__ int s_lo[NT], s_hi[NT], s_plo[NT], s_phi[NT];   // per-row x-interval of this phase / of what phase 1 visited
+    __shared__ int s_box[2][6][64];                            // per-query cell box of phase 1 / phase 2 (x0, x1, y0, y1, z0, z1)
+    __shared__ int s_phase[8];                                 // Y0, Y1, Z0, Z1, asking-lane mask (lo, hi), total rows asked for
     // merge scratch aliases the tile: the barrier that closes the last sweep separates the two uses (NW <= 4)
     static_assert(NW * 64 * 16 <= (int)sizeof(float4) * (kTileCap / 2) && NW * 64 * 8 <= (int)sizeof(int) * kTileCap, "merge scratch must fit the tile");
     unsigned long long (*m1)[64] = reinterpret_cast<unsigned long long (*)[64]>(s_xy);
@@ -954,34 +956,45 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
         const float r1 = sqrtf(t.b2d) * 1.0001f + 1e-6f;               // bound radius phase 1 works with (padded against rounding)
         bool asker_phase = false;
         for (int ph = 0; ph < 2; ph++) {
-            // who asks for cells in this phase, and with which radius
-            bool asks = member;
-            float rq = r1;
-            if (ph == 1) {
-                rq = sqrtf(t.b2d) * 1.0001f + 1e-6f;
-                const CellBox b2 = query_box(g, qx, qy, qz, cx, cy, cz, rq, false), b1 = query_box(g, qx, qy, qz, cx, cy, cz, r1, true);
-                asks = member && !(b2.x0 >= b1.x0 && b2.x1 <= b1.x1 && b2.y0 >= b1.y0 && b2.y1 <= b1.y1 && b2.z0 >= b1.z0 && b2.z1 <= b1.z1);
-                if (__ballot(asks) == 0ull || (DBG && (dbg & 1024))) break;         // dbg & 1024: diagnostic, no second phase (wrong results)
-                if (ASKER) {
-                    // Two ways through phase 2.  Few askers with small boxes (a 120k-point scan: ~10 per group, <= 81 rows each, a few
-                    // new points): the row/tile machinery below takes all their rows in one parallel pass.  Many askers with big
-                    // boxes (2M-point map on its density-shrunk grid: every query, up to 961 rows each): the union tube makes all
-                    // 64 lanes test thousands of candidates that matter to one query each -- then one query at a time is cheaper.
-                    const int rows_mine = asks ? (b2.y1 - b2.y0 + 1) * (b2.z1 - b2.z0 + 1) : 0;
-                    int rows_all = rows_mine;
+            // Who asks for cells in this phase, with which box, and the (y, z) extent of all boxes: worked out by wave 0 only and
+            // published through LDS (s_box, s_phase) -- the four waves hold identical states here, three of them would only
+            // repeat ~250 VALU instructions of cell arithmetic and wave reductions per phase.
+            if (wid == 0) {
+                bool asks0 = member;
+                CellBox bb;
+                int rows_all = 0;
+                if (ph == 0) bb = query_box(g, qx, qy, qz, cx, cy, cz, r1, true);
+                else {
+                    const float rq = sqrtf(t.b2d) * 1.0001f + 1e-6f;
+                    bb = query_box(g, qx, qy, qz, cx, cy, cz, rq, false);
+                    asks0 = member && !(bb.x0 >= s_box[0][0][lane] && bb.x1 <= s_box[0][1][lane] && bb.y0 >= s_box[0][2][lane] &&
+                                        bb.y1 <= s_box[0][3][lane] && bb.z0 >= s_box[0][4][lane] && bb.z1 <= s_box[0][5][lane]);
+                    rows_all = asks0 ? (bb.y1 - bb.y0 + 1) * (bb.z1 - bb.z0 + 1) : 0;
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) rows_all += __shfl_xor(rows_all, off);
-                    if (rows_all > asker_rows) { asker_phase = true; break; }
+                }
+                s_box[ph][0][lane] = bb.x0; s_box[ph][1][lane] = bb.x1; s_box[ph][2][lane] = bb.y0;
+                s_box[ph][3][lane] = bb.y1; s_box[ph][4][lane] = bb.z0; s_box[ph][5][lane] = bb.z1;
+                const unsigned long long am0 = __ballot(asks0);
+                const int y0 = wave_min_i(asks0 ? bb.y0 : big), y1 = wave_max_i(asks0 ? bb.y1 : -big);
+                const int z0 = wave_min_i(asks0 ? bb.z0 : big), z1 = wave_max_i(asks0 ? bb.z1 : -big);
+                if (lane == 0) {
+                    s_phase[0] = max(y0, 0); s_phase[1] = min(y1, g.ny - 1); s_phase[2] = max(z0, 0); s_phase[3] = min(z1, g.nz - 1);
+                    s_phase[4] = (int)(unsigned)(am0 & 0xffffffffull); s_phase[5] = (int)(unsigned)(am0 >> 32); s_phase[6] = rows_all;
                 }
             }
-            int Y0, Y1, Z0, Z1;
-            {
-                const CellBox bb = query_box(g, qx, qy, qz, cx, cy, cz, rq, ph == 0);
-                Y0 = max(__builtin_amdgcn_readfirstlane(wave_min_i(asks ? bb.y0 : big)), 0);
-                Y1 = min(__builtin_amdgcn_readfirstlane(wave_max_i(asks ? bb.y1 : -big)), g.ny - 1);
-                Z0 = max(__builtin_amdgcn_readfirstlane(wave_min_i(asks ? bb.z0 : big)), 0);
-                Z1 = min(__builtin_amdgcn_readfirstlane(wave_max_i(asks ? bb.z1 : -big)), g.nz - 1);
+            __syncthreads();
+            const unsigned long long am_ph = ((unsigned long long)(unsigned)s_phase[5] << 32) | (unsigned long long)(unsigned)s_phase[4];
+            const bool asks = ((am_ph >> lane) & 1ull) != 0ull;
+            if (ph == 1) {
+                if (am_ph == 0ull || (DBG && (dbg & 1024))) break;                   // dbg & 1024: diagnostic, no second phase (wrong results)
+                // Two ways through phase 2.  Few askers with small boxes (a 120k-point scan: ~10 per group, <= 81 rows each, a few new
+                // points): the row/tile machinery below takes all their rows in one parallel pass.  Many askers with big boxes (2M-point
+                // map on its density-shrunk grid: every query, up to 961 rows each): the union tube makes all 64 lanes test thousands
+                // of candidates that matter to one query each -- then one query at a time is cheaper.
+                if (ASKER && s_phase[6] > asker_rows) { asker_phase = true; break; }
             }
+            const int Y0 = s_phase[0], Y1 = s_phase[1], Z0 = s_phase[2], Z1 = s_phase[3];
             const int nyb = Y1 - Y0 + 1, nzb = Z1 - Z0 + 1;
             const int nrows = (nyb > 0 && nzb > 0) ? nyb * nzb : 0;
             const float rcp_nyb = 1.0f / (float)max(nyb, 1);
@@ -994,24 +1007,26 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                 // that spans several chunks costs its rows once, not once per chunk
                 const int zc0 = Z0 + (int)((float)rbase * rcp_nyb) - 1, zc1 = Z0 + (int)((float)(rbase + NT - 1) * rcp_nyb) + 1;
                 if (asks) {                                            // the rows of this query's box: z-layers dealt over the waves
-                    const CellBox bb = query_box(g, qx, qy, qz, cx, cy, cz, rq, ph == 0);
-                    for (int z = max(bb.z0, zc0) + wid; z <= min(bb.z1, zc1); z += NW) {
+                    const int bx0 = s_box[ph][0][lane], bx1 = s_box[ph][1][lane], by0 = s_box[ph][2][lane], by1 = s_box[ph][3][lane];
+                    const int bz0 = s_box[ph][4][lane], bz1 = s_box[ph][5][lane];
+                    for (int z = max(bz0, zc0) + wid; z <= min(bz1, zc1); z += NW) {
                         if (z < Z0 || z > Z1) continue;
                         const int rz = (z - Z0) * nyb - Y0 - rbase;
-                        for (int y = max(bb.y0, Y0); y <= min(bb.y1, Y1); y++) {
+                        for (int y = max(by0, Y0); y <= min(by1, Y1); y++) {
                             const int r = rz + y;
-                            if (r >= 0 && r < NT) { atomicMin(&s_lo[r], bb.x0); atomicMax(&s_hi[r], bb.x1); }
+                            if (r >= 0 && r < NT) { atomicMin(&s_lo[r], bx0); atomicMax(&s_hi[r], bx1); }
                         }
                     }
                 }
                 if (ph == 1 && member) {                               // what phase 1 staged: the phase-1 boxes of ALL members
-                    const CellBox b1 = query_box(g, qx, qy, qz, cx, cy, cz, r1, true);
-                    for (int z = max(b1.z0, zc0) + wid; z <= min(b1.z1, zc1); z += NW) {
+                    const int bx0 = s_box[0][0][lane], bx1 = s_box[0][1][lane], by0 = s_box[0][2][lane], by1 = s_box[0][3][lane];
+                    const int bz0 = s_box[0][4][lane], bz1 = s_box[0][5][lane];
+                    for (int z = max(bz0, zc0) + wid; z <= min(bz1, zc1); z += NW) {
                         if (z < Z0 || z > Z1) continue;
                         const int rz = (z - Z0) * nyb - Y0 - rbase;
-                        for (int y = max(b1.y0, Y0); y <= min(b1.y1, Y1); y++) {
+                        for (int y = max(by0, Y0); y <= min(by1, Y1); y++) {
                             const int r = rz + y;
-                            if (r >= 0 && r < NT) { atomicMin(&s_plo[r], b1.x0); atomicMax(&s_phi[r], b1.x1); }
+                            if (r >= 0 && r < NT) { atomicMin(&s_plo[r], bx0); atomicMax(&s_phi[r], bx1); }
                         }
                     }
                 }
