@@ -215,6 +215,11 @@ int velo_set_source(velo_ctx* ctx, const float* xyz, int64_t stride_bytes, const
  * new[i] = old[n-1-((i + n/2) % n)] (kitti.h:180).  The result becomes this context's source (as_target == 0) or target. */
 int velo_set_scan_velodyne(velo_ctx* ctx, int32_t as_target, const float* xyzr, int64_t stride_bytes, int32_t n_points,
                            const float velo_to_cam[16], int on_device);
+/* The scan cache of the odometry loop (replaces the ScansLRU look-up of the previous frame, lru.h:31-61, main.cpp:233,380): the cloud
+ * this context holds as SOURCE (frame k, already segmented on the device) becomes its TARGET for the next registration -- device
+ * buffers are swapped, nothing is uploaded or segmented again; only the target index (ring ids, grid) is built.  Afterwards the
+ * context has no source until the next velo_set_source / velo_set_scan_velodyne(as_target = 0). */
+int velo_source_to_target(velo_ctx* ctx);
 /* ring offsets / camera-frame points the context currently holds (for callers that segmented on the device) */
 int velo_get_ring_offsets(velo_ctx* ctx, int32_t of_target, int32_t* out, int32_t capacity, int32_t* n_rings);
 int velo_get_cloud(velo_ctx* ctx, int32_t of_target, float* xyz_out, int32_t capacity_points, int32_t* n_points);

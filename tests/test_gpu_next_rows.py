@@ -55,6 +55,31 @@ def test_device_segmenter_feeds_the_path_like_host_rings(hip_lib):
     c2.close()
 
 
+def test_source_promoted_to_target_equals_a_fresh_upload(hip_lib):
+    """The scan cache of the loop: frame k, segmented on the device as source, becomes the target of the next registration
+    without another upload (velo_source_to_target) -- same cloud, same ring table, same index, same result bit for bit."""
+    scene = synth.Scene(0)
+    f0 = records_of(synth.hdl64_scan(scene, synth.pose_matrix(0, 0, 0, (0, 0, 0)), noise_seed=1, n_beams=32, n_azimuth=400))
+    f1 = records_of(synth.hdl64_scan(scene, synth.pose_matrix(**synth.TRUE_MOTION), noise_seed=2, n_beams=32, n_azimuth=400))
+    a, b = api.Context(0, icp_skip=1), api.Context(0, icp_skip=1)
+    with pytest.raises(api.VeloError):
+        a.source_to_target()                                  # nothing to promote yet
+    a.set_scan_velodyne(False, f0, synth.VELO_TO_CAM)
+    a.source_to_target()
+    with pytest.raises(api.VeloError):
+        a.frame_to_frame(synth.INITIAL_GUESS)                 # the source slot is empty now
+    a.set_scan_velodyne(False, f1, synth.VELO_TO_CAM)
+    b.set_scan_velodyne(True, f0, synth.VELO_TO_CAM)
+    b.set_scan_velodyne(False, f1, synth.VELO_TO_CAM)
+    assert np.array_equal(a.ring_offsets(True), b.ring_offsets(True))
+    assert np.array_equal(a.cloud(True).view(np.uint32), b.cloud(True).view(np.uint32))
+    xa, Ta, sa = a.frame_to_frame(synth.INITIAL_GUESS)
+    xb, Tb, sb = b.frame_to_frame(synth.INITIAL_GUESS)
+    assert np.array_equal(xa, xb) and np.array_equal(Ta, Tb)
+    a.close()
+    b.close()
+
+
 def test_odometry_loop_matches_cpu_chain_and_truth(hip_lib, oracle, tmp_path):
     frames, truth = synth.velodyne_sequence(5, n_beams=32, n_azimuth=400)
     odo = odometry.LidarOdometer(0, icp_skip=1)

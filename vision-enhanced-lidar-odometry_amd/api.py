@@ -149,6 +149,7 @@ SIGNATURES = {
     "velo_set_target_part": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int]),
     "velo_set_source": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int]),
     "velo_set_scan_velodyne": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int]),
+    "velo_source_to_target": (C.c_int, [_ctx]),
     "velo_get_ring_offsets": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_int32, _P(C.c_int32)]),
     "velo_get_cloud": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_int32, _P(C.c_int32)]),
     "velo_set_visual": (C.c_int, [_ctx, C.c_void_p, C.c_int32]),
@@ -324,6 +325,10 @@ class Context:
         out = np.zeros(n.value + 1, dtype=np.int32)
         self._check(self._lib.velo_get_ring_offsets(self._h, int(bool(of_target)), C.c_void_p(out.ctypes.data), len(out), C.byref(n)))
         return out
+
+    def source_to_target(self):
+        """The device-resident source scan becomes the target of the next registration (no upload, no second segmentation)."""
+        self._check(self._lib.velo_source_to_target(self._h))
 
     def cloud(self, of_target: bool) -> np.ndarray:
         n = C.c_int32(0)

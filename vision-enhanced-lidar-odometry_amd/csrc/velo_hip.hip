@@ -1049,6 +1049,19 @@ int velo_set_scan_velodyne(velo_ctx* c, int32_t as_target, const float* xyzr, in
     return source_finalize(c);
 }
 
+int velo_source_to_target(velo_ctx* c) {
+    if (!c) return fail(VELO_ERR_INVALID, "null ctx");
+    if (!c->have_source) return fail(VELO_ERR_STATE, "no source cloud to promote");
+    HIP_TRY(hipSetDevice(c->device));
+    std::swap(c->tgt.p, c->src.p); std::swap(c->tgt.cap, c->src.cap);
+    c->h_tgt_off = c->h_src_off;
+    c->n_tgt = c->n_src; c->n_tgt_rings = c->n_src_rings;
+    c->tgt_first_ring = 0; c->tgt_first_point = 0;
+    c->have_source = false; c->have_target = false; c->have_corr = false; c->have_partials = false;
+    c->n_src = 0; c->n_src_rings = 0; c->n_q = 0; c->h_src_off.assign(1, 0); c->h_q_off.assign(1, 0);
+    return target_finalize(c);
+}
+
 int velo_get_ring_offsets(velo_ctx* c, int32_t of_target, int32_t* out, int32_t capacity, int32_t* n_rings) {
     if (!c) return fail(VELO_ERR_INVALID, "null ctx");
     const std::vector<int>& h = of_target ? c->h_tgt_off : c->h_src_off;

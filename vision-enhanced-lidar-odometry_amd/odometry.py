@@ -25,7 +25,9 @@ def kitti_pose_line(T: np.ndarray) -> str:
 
 
 class LidarOdometer:
-    """Frame-to-frame LiDAR odometry on the device: every scan is segmented on the GPU once per role."""
+    """Frame-to-frame LiDAR odometry on the device.  Every scan is uploaded and segmented ONCE, as the source of its own
+    registration; for the next frame it is promoted to target on the device (`velo_source_to_target`, the role the reference's
+    ScansLRU cache plays for sd_prev, main.cpp:233,380) -- only its search index is built then."""
 
     def __init__(self, device: int = 0, velo_to_cam=None, **params):
         from . import synth
@@ -41,6 +43,7 @@ class LidarOdometer:
         if self.prev_records is None:
             self.poses.append(np.eye(4))
             self.prev_records = records
+            self.ctx.set_scan_velodyne(False, records, self.velo_to_cam)       # frame 0 waits on the device as "source"
             return self.poses[-1]
         k = len(self.poses)
         if k > 1:
@@ -49,7 +52,7 @@ class LidarOdometer:
         else:
             x0 = FIRST_GUESS.copy()
             dT = api.pose_vec_to_mat(x0)                                       # main.cpp:319
-        self.ctx.set_scan_velodyne(True, self.prev_records, self.velo_to_cam)  # target = previous frame (sd_prev)
+        self.ctx.source_to_target()                                            # target = previous frame (sd_prev), already on the device
         self.ctx.set_scan_velodyne(False, records, self.velo_to_cam)           # source = current frame (sd)
         x, dpose, s = self.ctx.frame_to_frame(x0)
         self.poses.append(self.poses[k - 1] @ dpose)                           # main.cpp:408
