@@ -82,6 +82,10 @@ public:
         check(velo_set_source(ctx_, xyz_.data(), 12, off_.data(), (int32_t)off_.size() - 1, 0), "velo_set_source");
     }
 
+    // the scan held as source (frame k) becomes the target of the next registration without another upload: the role of
+    // scans_lru.get(frame - 1) in the reference's loop (main.cpp:380)
+    void source_to_target() { check(velo_source_to_target(ctx_), "velo_source_to_target"); }
+
 private:
     velo_ctx* ctx_ = nullptr;
     std::vector<float> xyz_;
