@@ -1547,13 +1547,13 @@ int velo_frame_to_frame_batch(velo_ctx** ctxs, int32_t n, double* x, double* T, 
         std::vector<int> gst((size_t)G, VELO_OK);
         std::vector<std::string> gerr((size_t)G);
         std::vector<std::thread> gth;
-        for (int gi = 0; gi < G; gi++) {
+        auto run_group = [&](int gi) {
             const int b = (int)((int64_t)n * gi / G), e = (int)((int64_t)n * (gi + 1) / G);
-            gth.emplace_back([&, gi, b, e]() {
-                gst[(size_t)gi] = f2f_batch_lockstep(ctxs + b, e - b, x + 6 * (size_t)b, T ? T + 16 * (size_t)b : nullptr, summaries ? summaries + b : nullptr);
-                if (gst[(size_t)gi] != VELO_OK) gerr[(size_t)gi] = g_err;
-            });
-        }
+            gst[(size_t)gi] = f2f_batch_lockstep(ctxs + b, e - b, x + 6 * (size_t)b, T ? T + 16 * (size_t)b : nullptr, summaries ? summaries + b : nullptr);
+            if (gst[(size_t)gi] != VELO_OK) gerr[(size_t)gi] = g_err;
+        };
+        for (int gi = 1; gi < G; gi++) gth.emplace_back(run_group, gi);
+        run_group(0);                                            // the calling thread drives the first group itself
         for (auto& t : gth) t.join();
         for (int gi = 0; gi < G; gi++) if (gst[(size_t)gi] != VELO_OK) { g_err = gerr[(size_t)gi]; return gst[(size_t)gi]; }
         return VELO_OK;
