@@ -5,6 +5,8 @@
 //     for iter:  visual gate kernel;  for icp_iter:  association kernel;  LM solve = chunks of
 //     [eval sweep -> (RCCL all-reduce) -> lm_step] launches that early-exit on the device-side `done` flag,
 // with one small D2H status copy per chunk (the only host synchronisation inside a solve).
+// velo_frame_to_frame_batch advances several contexts in lock-step groups with shared LM launches (f2f_batch_lockstep);
+// problems whose sweep is a few workgroups run a whole solve in one launch (lm_solve_small_kernel).
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 

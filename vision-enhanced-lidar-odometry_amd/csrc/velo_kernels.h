@@ -569,7 +569,8 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return v;
 }
 
-// ---- association search: LDS-staged shrinking-radius box walk -----------------------------------------------------------
+// ---- association search: LDS-staged shrinking-radius box walk (VELO_ASSOC_VARIANT=4; superseded by the tube kernel below, ----
+// ---- kept for A/B and as the second independent implementation the parity tests compare against) ---------------------------
 // A workgroup of NW waves owns 64 consecutive queries; lane i of EVERY wave holds query i (source scans are ring-ordered,
 // so the 64 points are spatial neighbours).  The waves cluster the queries (cells within +-W of a seed lane's cell) and
 // search ONE fine grid (cell ~ the smallest gate radius, shared by all outer iterations) in growing boxes around the
