@@ -313,3 +313,29 @@ def test_triangulation_edge_cases(hip_lib):
     with pytest.raises(api.VeloError):
         c.triangulate_points(pr["camera_poses"], pr["cam_trans"], bad, pr["obs_offsets"], pr["points0"], pr["initial_guess"])
     c.close()
+
+
+@pytest.mark.gpu
+def test_device_memory_returns_after_destroy():
+    """Create / upload / solve / promote / destroy cycles leave device memory where it was (every buffer a context owns,
+    including the grid of each replaced target and the warm-start table, goes with the context)."""
+    import torch
+    d = synth.scan_pair(n_beams=16, n_azimuth=400)
+
+    def cycle():
+        ctxs = [api.Context(0, icp_skip=1) for _ in range(2)]
+        for c in ctxs:
+            c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])
+        api.frame_to_frame_batch(ctxs, [d["x0"]] * 2)
+        for _ in range(4):                      # a new target per frame must reuse / free the old grid
+            ctxs[0].source_to_target(); ctxs[0].set_source(d["src_xyz"], d["src_off"])
+        ctxs[0].frame_to_frame(d["x0"])
+        for c in ctxs: c.close()
+
+    for _ in range(3): cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for _ in range(25): cycle()
+    torch.cuda.synchronize()
+    drift = free0 - torch.cuda.mem_get_info(0)[0]
+    assert drift < 4 << 20, f"device memory drift {drift / 1e6:.1f} MB over 25 cycles"

@@ -67,6 +67,12 @@ template <typename T>
 struct DevBuf {
     T* p = nullptr;
     size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap) { o.p = nullptr; o.cap = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept { if (this != &o) { release(); p = o.p; cap = o.cap; o.p = nullptr; o.cap = 0; } return *this; }
+    ~DevBuf() { release(); }             // every buffer a context owns goes with it (velo_destroy -> delete)
     int reserve(size_t n) {
         if (n <= cap) return VELO_OK;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
@@ -803,7 +809,7 @@ int target_finalize(velo_ctx* c) {
     } else {
         for (int k = 0; k < 6; k++) c->bbox[k] = key2f(keys[k]);
     }
-    c->grids.clear();
+    for (Grid& G : c->grids) G.built = false;                         // keep the buffers: a new target of the same size rebuilds in place
     VELO_TRY(build_grids(c));
     c->have_target = true;
     return VELO_OK;
