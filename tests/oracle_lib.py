@@ -15,12 +15,16 @@ from velo_amd.api import (CORR_DTYPE, GOOD_DTYPE, MATCH_DTYPE, VeloParams, VeloS
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "libvelo_oracle.so")
+# VELO_ORACLE_SO: load another build of the same source instead (the ASan/UBSan one of `make -C oracle asan`, see tests/README)
+ORACLE_SO_OVERRIDE = os.environ.get("VELO_ORACLE_SO")
 
 _dp = C.POINTER(C.c_double)
 _lib = None
 
 
 def build_oracle(force: bool = False) -> str:
+    if ORACLE_SO_OVERRIDE:
+        return ORACLE_SO_OVERRIDE
     src = os.path.join(ORACLE_DIR, "velo_oracle.cpp")
     hdr = os.path.join(ROOT, "include", "velo_hip.h")
     if (force or not os.path.exists(ORACLE_SO)
