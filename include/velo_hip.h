@@ -37,6 +37,8 @@ extern "C" {
 #define VELO_RESIDUAL_3D2D 1
 #define VELO_RESIDUAL_2D3D 2
 #define VELO_RESIDUAL_2D2D 3
+/* velo_functor.kind only: the ICP functor cost3DPD (costfunctions.h:17-55), which has no ResidualType value */
+#define VELO_FUNCTOR_3DPD 4
 
 /* ceres::TerminationType [3P] for one LM solve (velo.h:902) */
 #define VELO_CONVERGENCE 0
@@ -252,6 +254,20 @@ int velo_evaluate(velo_ctx* ctx, const double x[6], double* cost, double JtJ[36]
  * jacobian[n_res*6], robustifier already applied.  Order: visual blocks, then ICP blocks (velo.h order). */
 int velo_evaluate_rows(velo_ctx* ctx, const double x[6], double* residuals, double* jacobian,
                        int32_t capacity_rows, int32_t* n_rows);
+/* Seam 2 (the functor concept, costfunctions.h:17-220: `template<class T> bool operator()(const T* x, T* residual) const`
+ * instantiated by ceres::AutoDiffCostFunction<F, dim, 6>) by value: n functors at one pose in one launch.
+ * kind = VELO_RESIDUAL_* or VELO_FUNCTOR_3DPD; c = the functor's constructor arguments widened to double, in the reference's
+ * order: cost3D3D m(3) s(3) (costfunctions.h:62-74) | cost3D2D m(3) s(2) t(3) (94-110) | cost2D3D m(3) s(2) t(3) (134-150)
+ * | cost2D2D m(2) s(2) t(3) (176-190) | cost3DPD point(3) normal(3) offset(3) (19-37).
+ * residuals: n x 3 doubles (rows beyond the functor's dimension are 0), the RAW residuals -- no loss applied;
+ * jacobians: n x 18 doubles, row-major dim x 6 per functor = what autodiff returns (may be NULL). */
+typedef struct velo_functor {
+    int32_t kind;
+    int32_t reserved;
+    double c[9];
+} velo_functor;   /* 80 bytes */
+int velo_evaluate_functors(velo_ctx* ctx, const velo_functor* functors, int32_t n, const double x[6],
+                           double* residuals, double* jacobians);
 /* One ceres::Solve (velo.h:897-902) on the current blocks, x in/out. */
 int velo_solve(velo_ctx* ctx, double x[6], velo_solve_summary* summary);
 

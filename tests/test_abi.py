@@ -46,6 +46,7 @@ int main(void) {
   printf("%zu %zu %zu %zu %zu %zu\n", sizeof(velo_params), sizeof(velo_match), sizeof(velo_good_match), sizeof(velo_corr),
          sizeof(velo_solve_summary), sizeof(velo_summary));
   printf("%zu %zu %zu %zu\n", offsetof(velo_params, weight_3D2D), offsetof(velo_match, cam), offsetof(velo_corr, p), offsetof(velo_summary, solves));
+  printf("%zu %zu %zu %zu %zu\n", sizeof(velo_tri_obs), sizeof(velo_tri_result), sizeof(velo_partial), sizeof(velo_functor), offsetof(velo_functor, c));
   return 0; }
 '''
     with tempfile.TemporaryDirectory() as td:
@@ -61,6 +62,8 @@ int main(void) {
     assert sizes[7] == api.MATCH_DTYPE.fields["cam"][1]
     assert sizes[8] == api.CORR_DTYPE.fields["p"][1]
     assert sizes[9] == api.VeloSummary.solves.offset
+    assert sizes[10:15] == [api.TRI_OBS_DTYPE.itemsize, api.TRI_RESULT_DTYPE.itemsize, api.PARTIAL_DTYPE.itemsize,
+                            api.FUNCTOR_DTYPE.itemsize, api.FUNCTOR_DTYPE.fields["c"][1]]
 
 
 def test_default_params_are_the_reference_constants(lib):

@@ -143,3 +143,35 @@ def test_ceres_cost_adaptor_rows_match_oracle(tmp_path, oracle):
     ro, Jo = orc.evaluate_rows(d["x0"])
     assert n == len(ro) > 100
     assert H.rel_err(r, ro) <= 1e-12 and H.rel_err(J, Jo) <= 1e-12
+
+
+def compile_functor_batch(tmp_path) -> str:
+    build.build_hip()
+    exe = str(tmp_path / "test_functor_batch")
+    csrc = os.path.dirname(build.LIB)
+    subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-Wno-missing-field-initializers", "-I", os.path.join(ROOT, "include"), "-I", CPP,
+                    os.path.join(CPP, "test_functor_batch.cpp"), "-o", exe, "-L", csrc, "-lvelo_hip", f"-Wl,-rpath,{csrc}",
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return exe
+
+
+def test_functor_batch_adaptor_compiles_as_cxx11(tmp_path):
+    assert os.path.exists(compile_functor_batch(tmp_path))
+
+
+@pytest.mark.gpu
+def test_functor_batch_adaptor_matches_golden_vectors(tmp_path):
+    """Seam 2 through the C++ packers: the committed functor vectors (tests/golden/functors.npz), one pose per run."""
+    exe = compile_functor_batch(tmp_path)
+    f = np.load(os.path.join(ROOT, "tests", "golden", "functors.npz"))
+    for k, x in enumerate(np.unique(f["x"], axis=0)):
+        sel = np.all(f["x"] == x, axis=1)
+        n = int(sel.sum())
+        case, outp = str(tmp_path / f"fn{k}.bin"), str(tmp_path / f"fn{k}.out")
+        rec = np.concatenate([f["kind"][sel].astype(np.float64)[:, None], f["c"][sel]], axis=1)
+        with open(case, "wb") as fh:
+            fh.write(np.float64(n).tobytes()); fh.write(np.ascontiguousarray(rec).tobytes()); fh.write(np.asarray(x, np.float64).tobytes())
+        subprocess.run([exe, case, outp], check=True, capture_output=True)
+        got = np.fromfile(outp, dtype=np.float64).reshape(n, 21)
+        np.testing.assert_allclose(got[:, :3], f["r"][sel], rtol=1e-13, atol=1e-14)
+        np.testing.assert_allclose(got[:, 3:].reshape(n, 3, 6), f["J"][sel], rtol=1e-12, atol=1e-13)

@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import helpers as H
+import oracle_lib as O
 from velo_amd import api, synth
 
 pytestmark = pytest.mark.gpu
@@ -366,4 +367,35 @@ def test_association_random_geometry_all_paths(hip_lib, oracle, monkeypatch, env
         for x in poses:
             assert c.associate(x, it) == o.associate(x, it)
             H.assert_corr_equal(c.correspondences(), o.correspondences())
+    c.close()
+
+
+@pytest.mark.gpu
+def test_functor_batch_matches_oracle_autodiff(hip_lib):
+    """velo_evaluate_functors (seam 2 by value): 5 functor kinds x 400 random constant sets at large, tiny and zero
+    rotations against the oracle's dual-number evaluation; rows beyond a functor's dimension are zero; bad kinds are refused."""
+    rng = np.random.default_rng(77)
+    ncon = {0: 6, 1: 8, 2: 8, 3: 7, 4: 9}
+    dim = {0: 3, 1: 2, 2: 2, 3: 1, 4: 1}
+    n = 2000
+    kinds = rng.integers(0, 5, size=n).astype(np.int32)
+    consts = np.zeros((n, 9))
+    for i, k in enumerate(kinds):
+        consts[i, :ncon[k]] = rng.normal(size=ncon[k]) * (0.3 if k == 3 else 3.0)
+    c = api.Context(0)
+    for w_scale in (0.0, 1e-9, 1e-4, 0.3, 2.5):
+        x = np.concatenate([rng.normal(size=3) * w_scale, rng.normal(size=3)])
+        r, J = c.evaluate_functors(kinds, consts, x)
+        r_only, none = c.evaluate_functors(kinds, consts, x, want_jacobian=False)
+        assert none is None and np.array_equal(r, r_only)
+        for i in range(0, n, 7):
+            ro, Jo = O.functor(int(kinds[i]), consts[i], x)
+            d = dim[int(kinds[i])]
+            np.testing.assert_allclose(r[i, :d], ro, rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(J[i, :d], Jo, rtol=1e-11, atol=1e-12)
+            assert not r[i, d:].any() and not J[i, d:].any()
+    r0, J0 = c.evaluate_functors(np.zeros(0, np.int32), np.zeros((0, 9)), np.zeros(6))
+    assert r0.shape == (0, 3)
+    with pytest.raises(api.VeloError):
+        c.evaluate_functors([5], np.zeros((1, 9)), np.zeros(6))
     c.close()

@@ -88,8 +88,10 @@ TRI_OBS_DTYPE = np.dtype([("kind", np.int32), ("frame", np.int32), ("cam", np.in
 TRI_RESULT_DTYPE = np.dtype([("n_solves", np.int32), ("termination", np.int32), ("lm_iterations", np.int32),
                              ("evaluations", np.int32), ("final_cost", np.float64)])
 TRI_OBS_3D, TRI_OBS_2D = 0, 1
+FUNCTOR_DTYPE = np.dtype([("kind", np.int32), ("reserved", np.int32), ("c", np.float64, 9)])
+FUNCTOR_3DPD = 4
 assert MATCH_DTYPE.itemsize == 68 and GOOD_DTYPE.itemsize == 16 and CORR_DTYPE.itemsize == 76 and PARTIAL_DTYPE.itemsize == 80
-assert TRI_OBS_DTYPE.itemsize == 24 and TRI_RESULT_DTYPE.itemsize == 24
+assert TRI_OBS_DTYPE.itemsize == 24 and TRI_RESULT_DTYPE.itemsize == 24 and FUNCTOR_DTYPE.itemsize == 80
 
 
 def matches_from_dict(rec: dict) -> np.ndarray:
@@ -162,6 +164,7 @@ SIGNATURES = {
     "velo_get_good_matches": (C.c_int, [_ctx, C.c_void_p, C.c_int32, _P(C.c_int32)]),
     "velo_evaluate": (C.c_int, [_ctx, _dp, _dp, _dp, _dp]),
     "velo_evaluate_rows": (C.c_int, [_ctx, _dp, _dp, _dp, C.c_int32, _P(C.c_int32)]),
+    "velo_evaluate_functors": (C.c_int, [_ctx, C.c_void_p, C.c_int32, _dp, _dp, _dp]),
     "velo_solve": (C.c_int, [_ctx, _dp, _P(VeloSolveSummary)]),
     "velo_frame_to_frame": (C.c_int, [_ctx, _dp, _dp, _P(VeloSummary)]),
     "velo_frame_to_frame_batch": (C.c_int, [_P(_ctx), C.c_int32, _dp, _dp, _P(VeloSummary)]),
@@ -389,6 +392,22 @@ class Context:
         J = np.zeros((n.value, 6))
         if n.value:
             self._check(self._lib.velo_evaluate_rows(self._h, _ptr(xv), _ptr(r), _ptr(J), n.value, C.byref(n)))
+        return r, J
+
+    def evaluate_functors(self, kinds, consts, x, want_jacobian: bool = True):
+        """Seam 2 by value: raw residuals [n,3] and autodiff-equal Jacobians [n,3,6] of n functors (kind 0..3 = ResidualType
+        order, 4 = cost3DPD; consts [n,<=9] = constructor arguments in the reference's order) at pose x."""
+        kinds = np.asarray(kinds, dtype=np.int32).reshape(-1)
+        consts = np.asarray(consts, dtype=np.float64)
+        consts = consts.reshape(len(kinds), consts.size // max(len(kinds), 1))
+        rec = np.zeros(len(kinds), dtype=FUNCTOR_DTYPE)
+        rec["kind"] = kinds
+        rec["c"][:, :consts.shape[1]] = consts
+        xv = _dvec(x, 6)
+        r = np.zeros((len(kinds), 3))
+        J = np.zeros((len(kinds), 3, 6)) if want_jacobian else None
+        self._check(self._lib.velo_evaluate_functors(self._h, C.c_void_p(rec.ctypes.data), len(kinds), _ptr(xv), _ptr(r),
+                                                     _ptr(J) if want_jacobian else None))
         return r, J
 
     def solve(self, x):

@@ -163,6 +163,7 @@ struct velo_ctx {
     int asker_rows = -1;                 // tube kernel (VELO_ASKER_ROWS): phase 2 goes query by query when the asking queries' boxes have more
                                          // rows than this in total.  -1 = by target density: never on a regular scan (120k points: the tile pass
                                          // is 62 vs 105-115 us), always when the grid had to be density-shrunk (2M-point map: 244 vs 420 us)
+    DevBuf<FunctorRec> fn_in;            // velo_evaluate_functors: the records of one call
     DevBuf<int> group_perm;              // workgroup -> 64-query group, XCD-aware (see build_group_perm)
     int perm_qb = -1, perm_qe = -1, perm_nq = -1, perm_mode = -1;
     bool have_source = false;
@@ -1335,6 +1336,27 @@ int velo_evaluate_rows(velo_ctx* c, const double x[6], double* residuals, double
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipMemcpy(residuals, c->rows_r.p, sizeof(double) * rows, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(jacobian, c->rows_J.p, sizeof(double) * (size_t)rows * 6, hipMemcpyDeviceToHost));
+    return VELO_OK;
+}
+
+int velo_evaluate_functors(velo_ctx* c, const velo_functor* f, int32_t n, const double x[6], double* residuals, double* jacobians) {
+    if (!c || !x || n < 0 || (n > 0 && (!f || !residuals))) return fail(VELO_ERR_INVALID, "bad functor batch arguments");
+    static_assert(sizeof(FunctorRec) == sizeof(velo_functor), "device/host functor layout");
+    for (int i = 0; i < n; i++) if (f[i].kind < 0 || f[i].kind > VELO_FUNCTOR_3DPD) return fail(VELO_ERR_INVALID, "functor %d: kind %d", i, f[i].kind);
+    if (n == 0) return VELO_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    VELO_TRY(c->fn_in.reserve((size_t)n));
+    VELO_TRY(c->rows_r.reserve((size_t)n * 3));
+    if (jacobians) VELO_TRY(c->rows_J.reserve((size_t)n * 18));
+    std::memcpy(c->h_x, x, sizeof(double) * 6);
+    HIP_TRY(hipMemcpyAsync(c->xdev.p, c->h_x, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->fn_in.p, f, sizeof(velo_functor) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(functor_batch_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const FunctorRec*)c->fn_in.p, n, (const double*)c->xdev.p,
+                       c->rows_r.p, jacobians ? c->rows_J.p : nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));              // also: the pageable functor array has been read
+    HIP_TRY(hipMemcpy(residuals, c->rows_r.p, sizeof(double) * (size_t)n * 3, hipMemcpyDeviceToHost));
+    if (jacobians) HIP_TRY(hipMemcpy(jacobians, c->rows_J.p, sizeof(double) * (size_t)n * 18, hipMemcpyDeviceToHost));
     return VELO_OK;
 }
 

@@ -2157,4 +2157,45 @@ lm_iter_fused_kernel(EvalArgs A, LMParams Q, LMState* S, int* __restrict__ ticke
     lm_transition(Q, S, A.partials, total_rows);
 }
 
+// ---- seam 2 by value: a batch of residual functors (costfunctions.h:17-220) at one pose -----------------------------------
+// One record per functor: kind (ResidualType order 0..3, 4 = cost3DPD) and the constructor arguments widened to double in the
+// reference's order.  One thread per record writes the RAW residuals (no loss) and the 6-column Jacobian Ceres' autodiff would
+// produce -- the same device functions the LM sweeps use, so a parity check of this kernel is a parity check of theirs.
+struct FunctorRec { int kind; int reserved; double c[9]; };
+static_assert(sizeof(FunctorRec) == 80, "velo_functor layout");
+
+__global__ void __launch_bounds__(256)
+functor_batch_kernel(const FunctorRec* __restrict__ f, int n, const double* __restrict__ xd, double* __restrict__ res, double* __restrict__ jac) {
+    __shared__ PoseRot s_R, s_Rinv;
+    __shared__ double s_t[3];
+    if (threadIdx.x == 0) {
+        const double x[6] = {xd[0], xd[1], xd[2], xd[3], xd[4], xd[5]};
+        pose_rot_init(x, &s_R);
+        const double m[3] = {-x[0], -x[1], -x[2]};
+        pose_rot_init(m, &s_Rinv);
+        s_t[0] = x[3]; s_t[1] = x[4]; s_t[2] = x[5];
+    }
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const FunctorRec F = f[i];
+    const double t[3] = {s_t[0], s_t[1], s_t[2]};
+    double r[3] = {0.0, 0.0, 0.0}, J[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) J[k] = 0.0;
+    switch (F.kind) {
+        case 0: res_3d3d(s_R, t, F.c, F.c + 3, r, J); break;
+        case 1: res_3d2d(s_R, t, F.c, F.c + 3, F.c + 5, r, J); break;
+        case 2: res_2d3d(s_Rinv, t, F.c, F.c + 3, F.c + 5, r, J); break;
+        case 3: res_2d2d(s_R, t, F.c, F.c + 2, F.c + 4, r, J); break;
+        default: res_3dpd(s_R, t, F.c, F.c + 3, F.c + 6, r, J); break;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) res[(size_t)3 * i + k] = r[k];
+    if (jac) {
+#pragma unroll
+        for (int k = 0; k < 18; k++) jac[(size_t)18 * i + k] = J[k];
+    }
+}
+
 }  // namespace velo
