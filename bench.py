@@ -273,7 +273,7 @@ def main():
             line["roofline"]["valu"] = {"wave_insts_per_launch": sq["SQ_INSTS_VALU"], "salu": sq.get("SQ_INSTS_SALU"), "lds": sq.get("SQ_INSTS_LDS"),
                                         "issue_slots_per_launch_at_2p4GHz": 1024 * 2.4e9 / 4 * t_alone,
                                         "note": "from the committed PMC pass (profiles/*_traffic.json); launch time = the kernel alone"}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:             # rank 0 at N = 1 only: the other runs just report the GPU side
             cb = cpu_baseline(d, vis, a.cpu_sample_skip)
             xo = np.array(cb.pop("x"))
             cb["pose_diff_vs_gpu"] = {"dt_m": float(np.linalg.norm(xo[3:] - x_gpu[3:])),
