@@ -8,6 +8,7 @@
 // velo_frame_to_frame_batch advances several contexts in lock-step groups with shared LM launches (f2f_batch_lockstep);
 // problems whose sweep is a few workgroups run a whole solve in one launch (lm_solve_small_kernel).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -530,8 +531,13 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 c->assoc_events.emplace_back(a, b);
             }
             ev = &c->assoc_events[c->assoc_events_used++];
-            HIP_TRY(hipEventRecord(ev->first, c->stream));
         }
+        // The tube kernel is launched with hipExtLaunchKernelGGL, which stamps the two events with the KERNEL's own start and
+        // stop (what a rocprofv3 kernel trace reports); events recorded around a launch would also count the time the launch waits
+        // for the chip while other streams' kernels run.  The A/B variants keep the record-around bracket.
+        const int variant_timed = c->assoc_variant >= 0 ? c->assoc_variant : 5;
+        const bool ext_timed = variant_timed == 5 || variant_timed == 55 || variant_timed == 52 || variant_timed == 59;
+        if (ev && !ext_timed) HIP_TRY(hipEventRecord(ev->first, c->stream));
         const int aux = want_aux ? 1 : 0;
         const int groups = cdiv(qe - qb, 64);
         const double gate = gate_of_iter(c->P, iter);
@@ -590,7 +596,8 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 const int* perm = nullptr;
                 if (c->tube_map >= 0) { VELO_TRY(build_group_perm(c, qb, qe, c->tube_map)); perm = c->group_perm.p; }
 #define VELO_LAUNCH_V5(NW, MINW, DBG, PPT, ASKER)                                                                                         \
-                hipLaunchKernelGGL((assoc_search_v5_kernel<NW, MINW, DBG, PPT, ASKER>), dim3(groups), dim3(NW * 64), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe, \
+                hipExtLaunchKernelGGL((assoc_search_v5_kernel<NW, MINW, DBG, PPT, ASKER>), dim3(groups), dim3(NW * 64), 0, c->stream,                    \
+                                      ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, S, V, c->src.p, c->q_src.p, qb, qe,                      \
                                    c->tgt.p, c->tgt_off.p, c->n_tgt, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux, perm, c->debug_skip, asker_rows)
                 // default: 5 waves/SIMD (96 VGPRs, no spills, no scratch traffic), 2 candidate pairs per trip.  Measured on C2:
                 // 62 us; 6 waves + 2 pairs (5 spilled VGPRs) 65; 7 waves + 2 pairs 64; 5 waves + 4 pairs 66; 6 waves + 4 pairs 71
@@ -615,7 +622,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
 #undef VELO_LAUNCH_V2
 #undef VELO_LAUNCH_V3
         HIP_TRY(hipGetLastError());
-        if (ev) HIP_TRY(hipEventRecord(ev->second, c->stream));
+        if (ev && !ext_timed) HIP_TRY(hipEventRecord(ev->second, c->stream));
     }
     if (partial) { c->have_partials = true; c->last_partial_iter = iter; if (wait) HIP_TRY(hipStreamSynchronize(c->stream)); return VELO_OK; }
     c->have_corr = true;
@@ -625,6 +632,18 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         c->last_n_valid = c->h_int[0];
         if (n_valid) *n_valid = c->last_n_valid;
     }
+    return VELO_OK;
+}
+
+// timing on: the association launches of the call just finished, summed (HIP events)
+int read_assoc_timing(velo_ctx* c, velo_summary* S) {
+    double ms = 0.0;
+    for (int k = 0; k < c->assoc_events_used; k++) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, c->assoc_events[k].first, c->assoc_events[k].second));
+        ms += t;
+    }
+    S->assoc_kernel_ms = ms;
     return VELO_OK;
 }
 
@@ -1408,15 +1427,7 @@ int velo_frame_to_frame(velo_ctx* c, double x[6], double T[16], velo_summary* su
             S->n_solves++;
         }
     }
-    if (c->timing) {
-        double ms = 0.0;
-        for (int k = 0; k < c->assoc_events_used; k++) {
-            float t = 0.f;
-            HIP_TRY(hipEventElapsedTime(&t, c->assoc_events[k].first, c->assoc_events[k].second));
-            ms += t;
-        }
-        S->assoc_kernel_ms = ms;
-    }
+    if (c->timing) VELO_TRY(read_assoc_timing(c, S));
     for (int k = 0; k < 6; k++) x[k] = xc[k];
     if (T) velo_pose_vec_to_mat(x, T);
     return VELO_OK;
@@ -1550,13 +1561,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
     for (int i = 0; i < n; i++) {
         velo_ctx* c = ctxs[i];
         if (c->timing) {
-            double ms = 0.0;
-            for (int k = 0; k < c->assoc_events_used; k++) {
-                float t = 0.f;
-                HIP_TRY(hipEventElapsedTime(&t, c->assoc_events[k].first, c->assoc_events[k].second));
-                ms += t;
-            }
-            S[(size_t)i]->assoc_kernel_ms = ms;
+            VELO_TRY(read_assoc_timing(c, S[(size_t)i]));
         }
         for (int k = 0; k < 6; k++) x[6 * (size_t)i + k] = xc[(size_t)i][(size_t)k];
         if (T) velo_pose_vec_to_mat(x + 6 * (size_t)i, T + 16 * (size_t)i);
