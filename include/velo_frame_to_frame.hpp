@@ -92,6 +92,36 @@ private:
     std::vector<int32_t> off_;
 };
 
+// ScansLRU (lru.h:31-61) with the scans kept on the device.  `get` has the reference's meaning -- "give me frame f, reading it
+// only if it is not cached" -- with the reading supplied by the caller: load(frame) must return the ring clouds of that frame
+// (what `new ScanData(dataset, frame)` does at lru.h:49); it runs on a miss only.  The scan lands in `ctx` as target or source.
+class ScanCache {
+public:
+    explicit ScanCache(int device = 0, int capacity = 50) { check(velo_cache_create(&cache_, device, capacity), "velo_cache_create"); }
+    ~ScanCache() { velo_cache_destroy(cache_); }
+    ScanCache(const ScanCache&) = delete;
+    ScanCache& operator=(const ScanCache&) = delete;
+    velo_scan_cache* get() const { return cache_; }
+    bool contains(int frame) const { return velo_cache_contains(cache_, frame) != 0; }
+
+    // returns true on a hit.  On a miss the scan is uploaded (and, as target, indexed) once and stored for the next look-up.
+    template <typename LoadRings>
+    bool get(int frame, Context& ctx, bool as_target, LoadRings load) {
+        if (contains(frame)) {
+            check(velo_cache_load(cache_, frame, ctx.get(), as_target ? 1 : 0), "velo_cache_load");
+            return true;
+        }
+        if (as_target) ctx.set_target(load(frame)); else ctx.set_source(load(frame));
+        check(velo_cache_store(cache_, frame, ctx.get(), as_target ? 1 : 0), "velo_cache_store");
+        return false;
+    }
+    // after a registration: keep the scan `ctx` holds (e.g. the current frame, held as source) for later frames
+    void put(int frame, Context& ctx, bool of_target) { check(velo_cache_store(cache_, frame, ctx.get(), of_target ? 1 : 0), "velo_cache_store"); }
+
+private:
+    velo_scan_cache* cache_ = nullptr;
+};
+
 // The reference's globals the path reads (kitti.h:3,46-47): number of cameras and cam_trans[cam]; for the depth rows also
 // the canonical-coordinate window {min_x, max_x, min_y, max_y}[cam] (kitti.h:51,85-97) and depth_assoc_thresh (kitti.h:28).
 struct Rig {

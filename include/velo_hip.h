@@ -222,6 +222,24 @@ int velo_set_scan_velodyne(velo_ctx* ctx, int32_t as_target, const float* xyzr, 
  * buffers are swapped, nothing is uploaded or segmented again; only the target index (ring ids, grid) is built.  Afterwards the
  * context has no source until the next velo_set_source / velo_set_scan_velodyne(as_target = 0). */
 int velo_source_to_target(velo_ctx* ctx);
+/* Device-resident scan cache: the ScansLRU of the reference (lru.h:31-61, `size = 50`; look-ups main.cpp:216,349-350,544) with the
+ * scans kept in HBM instead of host memory -- the cloud as the path stores it (camera-0 frame, ring-major) and, for scans stored from
+ * a context's TARGET side, the search index built for it (the role of ScanData::trees, lru.h:9,17-20), so a frame that is matched again
+ * (frame - dframe for every dframe, main.cpp:306-350) is neither read, segmented, uploaded nor indexed a second time.
+ * store: device-to-device copy of the scan a context holds (of_target: its target incl. index / its source) under `frame`; a frame that
+ *        is already cached is replaced; the least recently used entry is dropped beyond `capacity` (lru.h:52-57).
+ * load:  device-to-device copy into a context as its target or source, and the entry becomes the most recent one (lru.h:42-47).
+ *        Loading as target reuses the cached index when it was built for the same gates, otherwise (entries stored from a source,
+ *        other params) the index is built from the cached cloud.  Any number of contexts may load the same entry.
+ * VELO_ERR_STATE when `frame` is not cached (the caller then reads the scan and stores it: what lru.h:48-58 does). */
+typedef struct velo_scan_cache velo_scan_cache;
+int velo_cache_create(velo_scan_cache** out, int32_t device, int32_t capacity);
+int velo_cache_destroy(velo_scan_cache* cache);
+int velo_cache_store(velo_scan_cache* cache, int32_t frame, velo_ctx* ctx, int32_t of_target);
+int velo_cache_load(velo_scan_cache* cache, int32_t frame, velo_ctx* ctx, int32_t as_target);
+int velo_cache_contains(const velo_scan_cache* cache, int32_t frame);                      /* 1 / 0 */
+/* frames from most to least recently used; returns the number of cached scans */
+int velo_cache_frames(const velo_scan_cache* cache, int32_t* frames_out, int32_t capacity);
 /* ring offsets / camera-frame points the context currently holds (for callers that segmented on the device) */
 int velo_get_ring_offsets(velo_ctx* ctx, int32_t of_target, int32_t* out, int32_t capacity, int32_t* n_rings);
 int velo_get_cloud(velo_ctx* ctx, int32_t of_target, float* xyz_out, int32_t capacity_points, int32_t* n_points);

@@ -153,6 +153,28 @@ int main(int argc, char** argv) {
                 else printf("h %d %zu %d %.9g %.9g %.9g\n", c, k, hd[k], kp3->at(hd[k]).x, kp3->at(hd[k]).y, kp3->at(hd[k]).z);
             }
         }
+        // ScansLRU::get with the scans on the device (lru.h:31-61): miss -> read + store, hit -> served from HBM; a LiDAR-only
+        // registration against the cached frames must equal the one against fresh uploads
+        {
+            velo_hip::ScanCache cache(0, 50);
+            int reads = 0;
+            auto read = [&](int f) -> const std::vector<PointCloud::Ptr>& { reads++; return f == frame2 ? scans_S : scans_M; };
+            velo_hip::Context fresh(0), cached(0);
+            fresh.set_params(P); cached.set_params(P);
+            fresh.set_target(scans_S); fresh.set_source(scans_M);
+            double xf[6] = {0, 0, 0, 0, 0, 1}, xc[6] = {0, 0, 0, 0, 0, 1}, Tm[16];
+            velo_summary sm;
+            velo_hip::check(velo_frame_to_frame(fresh.get(), xf, Tm, &sm), "velo_frame_to_frame");
+            const bool h0 = cache.get(frame2, cached, true, read);        // miss: read, indexed, stored
+            const bool h1 = cache.get(frame1, cached, false, read);       // miss
+            const bool h2 = cache.get(frame2, cached, true, read);        // hit: no read
+            const bool h3 = cache.get(frame1, cached, false, read);       // hit
+            velo_hip::check(velo_frame_to_frame(cached.get(), xc, Tm, &sm), "velo_frame_to_frame");
+            printf("c %d %d %d %d %d", (int)h0, (int)h1, (int)h2, (int)h3, reads);
+            for (int i = 0; i < 6; i++) printf(" %.17g", xf[i]);
+            for (int i = 0; i < 6; i++) printf(" %.17g", xc[i]);
+            printf("\n");
+        }
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 3;

@@ -68,6 +68,11 @@ def test_adaptor_matches_oracle(tmp_path, oracle):
     want = want[np.argsort(want[:, 0], kind="stable")]
     assert np.array_equal(good, want)
 
+    # the device-resident ScansLRU through the adaptor: two misses (two reads), two hits, same pose as fresh uploads
+    cl = [line.split() for line in out if line.startswith("c ")][0]
+    assert [int(v) for v in cl[1:6]] == [0, 0, 1, 1, 2]
+    assert cl[6:12] == cl[12:18]
+
     # depth rows through the adaptor: projectLidarToCamera + featureDepthAssociation on the target rings, per camera
     import oracle_lib as O
     rig_window = [-0.84466541, 0.8608222, -0.25765342, 0.25705326]          # velo_hip::Rig defaults

@@ -339,3 +339,129 @@ def test_device_memory_returns_after_destroy():
     torch.cuda.synchronize()
     drift = free0 - torch.cuda.mem_get_info(0)[0]
     assert drift < 4 << 20, f"device memory drift {drift / 1e6:.1f} MB over 25 cycles"
+
+
+@pytest.mark.gpu
+def test_scan_cache_lru_order_and_eviction(hip_lib):
+    """lru.h:31-61 on the device: most-recently-used first, a hit moves to the front, the oldest entry goes beyond `capacity`,
+    a stored frame replaces its older copy, a miss is an error the caller answers by reading the scan."""
+    d = synth.scan_pair(n_beams=8, n_azimuth=200)
+    c = api.Context(0, icp_skip=1)
+    c.set_target(d["tgt_xyz"], d["tgt_off"])
+    cache = api.ScanCache(0, capacity=3)
+    model = []                                   # python model of the std::list, front = most recent
+
+    def store(f):
+        cache.store(f, c, True)
+        if f in model: model.remove(f)
+        model.insert(0, f)
+        del model[3:]
+
+    def load(f):
+        cache.load(f, c, True)
+        model.remove(f); model.insert(0, f)
+
+    for f in (10, 11, 12):
+        store(f)
+    assert cache.frames() == model == [12, 11, 10]
+    load(10)
+    assert cache.frames() == model == [10, 12, 11]
+    store(13)                                    # evicts 11, the least recently used
+    assert cache.frames() == model == [13, 10, 12] and 11 not in cache and 10 in cache
+    store(12)                                    # replaced and moved to the front, not duplicated
+    assert cache.frames() == model == [12, 13, 10]
+    with pytest.raises(api.VeloError):
+        cache.load(11, c, True)
+    c2 = api.Context(0)
+    with pytest.raises(api.VeloError):
+        cache.store(1, c2, False)                # the context holds no source scan
+    c2.close(); cache.close(); c.close()
+
+
+@pytest.mark.gpu
+def test_scan_cache_serves_targets_and_sources_like_fresh_uploads(hip_lib):
+    """A registration against a cached scan equals the registration against a fresh upload bit for bit: entries stored from a
+    target (cloud + index reused), from a source (index built on load), loaded into several contexts, after an eviction cycle,
+    and under different gates (index rebuilt); the dframe pattern of main.cpp:306-350 (frame k against k-1 and k-2)."""
+    recs, _ = synth.velodyne_sequence(3, n_beams=16, n_azimuth=300)
+    (f0, o0), (f1, o1), (f2, o2) = [synth.segment_points(r[:, :3]) for r in recs]
+    x0 = np.array([0.0, 0.0, 0.0, 0.0, 0.0, 0.8])
+
+    def table(c):                                # the full record (indices, distances) of an explicit round at x0
+        c.associate(x0, 1)
+        return c.correspondences().tobytes()
+
+    def fresh(tgt, toff, src, soff, **params):
+        c = api.Context(0, icp_skip=1, **params)
+        c.set_target(tgt, toff); c.set_source(src, soff)
+        tab = table(c)
+        x, T, S = c.frame_to_frame(x0)
+        c.close()
+        return x, tab, [S.solves[k].lm_iterations for k in range(S.n_solves)]
+
+    cache = api.ScanCache(0, capacity=4)
+    a = api.Context(0, icp_skip=1)
+    a.set_target(f0, o0); a.set_source(f1, o1)
+    cache.store(0, a, True)                      # frame 0 with its index
+    cache.store(1, a, False)                     # frame 1 from the source side: cloud only
+    # frame 2 arrives: register it against frame 1 and frame 0 (dframe = 1, 2), both served by the cache
+    b = api.Context(0, icp_skip=1)
+    b.set_source(f2, o2)
+    for frame, tgt, toff in ((1, f1, o1), (0, f0, o0)):
+        cache.load(frame, b, True)
+        tab = table(b)
+        x, T, S = b.frame_to_frame(x0)
+        xr, tabr, itr = fresh(tgt, toff, f2, o2)
+        assert np.array_equal(x, xr) and tab == tabr
+        assert [S.solves[k].lm_iterations for k in range(S.n_solves)] == itr
+    # the same entry in two contexts at once, one of them taking its SOURCE from the cache too
+    c1, c2 = api.Context(0, icp_skip=1), api.Context(0, icp_skip=1)
+    cache.load(0, c1, True); cache.load(0, c2, True)
+    c1.set_source(f1, o1); cache.load(1, c2, False)
+    t1, t2 = table(c1), table(c2)
+    xs, Ts, Ss = api.frame_to_frame_batch([c1, c2], [x0, x0])
+    xr, tabr, _ = fresh(f0, o0, f1, o1)
+    assert np.array_equal(xs[0], xr) and np.array_equal(xs[1], xr)
+    assert t1 == tabr == t2
+    # other gates than the entry's index was built for: rebuilt from the cached cloud
+    g = api.Context(0, icp_skip=1, correspondence_thresh_icp=0.3)
+    cache.load(0, g, True); g.set_source(f1, o1)
+    tg = table(g)
+    xg, _, _ = g.frame_to_frame(x0)
+    xr, tabr, _ = fresh(f0, o0, f1, o1, correspondence_thresh_icp=0.3)
+    assert np.array_equal(xg, xr) and tg == tabr
+    # survive an eviction cycle: fill the cache, frame 0 was used last -> stays; frame 1 goes
+    for f in (5, 6, 7):
+        cache.store(f, a, True)
+    assert 0 in cache and 1 not in cache
+    cache.load(0, b, True)
+    x, _, _ = b.frame_to_frame(x0)
+    xr, _, _ = fresh(f0, o0, f2, o2)
+    assert np.array_equal(x, xr)
+    for c in (a, b, c1, c2, g):
+        c.close()
+    cache.close()
+
+
+@pytest.mark.gpu
+def test_odometry_with_diagonal_edges_from_the_scan_cache(hip_lib):
+    """ndiagonal = 3 (main.cpp:148-152,306-350): every frame is also registered against k-2 and k-3, served by the device scan
+    cache.  The chain itself is unchanged, every extra edge equals a registration against a fresh upload of that frame, and agrees
+    with the chained poses to a few centimetres."""
+    frames, truth = synth.velodyne_sequence(5, n_beams=32, n_azimuth=400)
+    plain = odometry.LidarOdometer(0, icp_skip=1)
+    diag = odometry.LidarOdometer(0, icp_skip=1, ndiagonal=3, cache_capacity=3)
+    for rec in frames:
+        plain.push(rec); diag.push(rec)
+    assert all(np.array_equal(a, b) for a, b in zip(plain.poses, diag.poses))
+    assert [(a, b) for a, b, _ in diag.edges] == [(0, 2), (1, 3), (0, 3), (2, 4), (1, 4)]
+    clouds = [synth.segment_points(r[:, :3]) for r in frames]
+    for a, b, dpose in diag.edges:
+        c = api.Context(0, icp_skip=1)
+        c.set_target(*clouds[a]); c.set_source(*clouds[b])
+        dT = np.linalg.inv(diag.poses[a]) @ diag.poses[b]
+        _, want, _ = c.frame_to_frame(api.pose_mat_to_vec(dT))
+        c.close()
+        assert np.array_equal(dpose, want)
+        assert np.linalg.norm((dpose @ np.linalg.inv(dT))[:3, 3]) < 0.05
+    plain.close(); diag.close()

@@ -152,6 +152,12 @@ SIGNATURES = {
     "velo_set_source": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int]),
     "velo_set_scan_velodyne": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int]),
     "velo_source_to_target": (C.c_int, [_ctx]),
+    "velo_cache_create": (C.c_int, [_P(C.c_void_p), C.c_int32, C.c_int32]),
+    "velo_cache_destroy": (C.c_int, [C.c_void_p]),
+    "velo_cache_store": (C.c_int, [C.c_void_p, C.c_int32, _ctx, C.c_int32]),
+    "velo_cache_load": (C.c_int, [C.c_void_p, C.c_int32, _ctx, C.c_int32]),
+    "velo_cache_contains": (C.c_int, [C.c_void_p, C.c_int32]),
+    "velo_cache_frames": (C.c_int, [C.c_void_p, _P(C.c_int32), C.c_int32]),
     "velo_get_ring_offsets": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_int32, _P(C.c_int32)]),
     "velo_get_cloud": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_int32, _P(C.c_int32)]),
     "velo_set_visual": (C.c_int, [_ctx, C.c_void_p, C.c_int32]),
@@ -487,6 +493,51 @@ class Context:
 
     def comm_destroy(self):
         self._check(self._lib.velo_comm_destroy(self._h))
+
+
+class ScanCache:
+    """Device-resident scan cache (velo_cache_*): the reference's ScansLRU (lru.h:31-61, 50 scans) with the scans and their
+    search index kept in HBM.  store() copies the scan a context holds; load() hands it to any context as target or source."""
+
+    def __init__(self, device: int = 0, capacity: int = 50):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        status = self._lib.velo_cache_create(C.byref(self._h), int(device), int(capacity))
+        if status != 0:
+            msg = self._lib.velo_last_error()
+            raise VeloError(f"velo status {status}: {msg.decode() if msg else ''}")
+
+    def _check(self, status: int):
+        if status != 0:
+            msg = self._lib.velo_last_error()
+            raise VeloError(f"velo status {status}: {msg.decode() if msg else ''}")
+
+    def close(self):
+        if self._h:
+            self._lib.velo_cache_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def store(self, frame: int, ctx: "Context", of_target: bool):
+        self._check(self._lib.velo_cache_store(self._h, int(frame), ctx.handle, int(bool(of_target))))
+
+    def load(self, frame: int, ctx: "Context", as_target: bool):
+        self._check(self._lib.velo_cache_load(self._h, int(frame), ctx.handle, int(bool(as_target))))
+
+    def __contains__(self, frame: int) -> bool:
+        return bool(self._lib.velo_cache_contains(self._h, int(frame)))
+
+    def frames(self):
+        """cached frame numbers, most recently used first"""
+        n = self._lib.velo_cache_frames(self._h, None, 0)
+        out = (C.c_int32 * max(n, 1))()
+        n = self._lib.velo_cache_frames(self._h, out, n)
+        return [int(out[i]) for i in range(n)]
 
 
 def comm_unique_id() -> bytes:

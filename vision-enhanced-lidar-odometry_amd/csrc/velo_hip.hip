@@ -19,9 +19,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <iterator>
+#include <list>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/velo_hip.h"
@@ -1088,6 +1091,150 @@ int velo_source_to_target(velo_ctx* c) {
     c->have_source = false; c->have_target = false; c->have_corr = false; c->have_partials = false;
     c->n_src = 0; c->n_src_rings = 0; c->n_q = 0; c->h_src_off.assign(1, 0); c->h_q_off.assign(1, 0);
     return target_finalize(c);
+}
+
+// ---- device-resident scan cache (lru.h:31-61) -------------------------------------------------------------------------------
+struct CachedScan {
+    int frame = 0;
+    int n = 0, n_rings = 0;
+    DevBuf<float4> cloud;
+    std::vector<int> h_off;
+    // target side only: what target_finalize builds
+    bool has_index = false;
+    DevBuf<int> ring_of;
+    float bbox[6] = {0, 0, 0, 0, 0, 0};
+    Grid grid;
+};
+struct velo_scan_cache {
+    int device = 0;
+    int capacity = 50;                                   // lru.h:33
+    std::list<CachedScan> times;                         // front = most recently used (lru.h:34)
+    std::unordered_map<int, std::list<CachedScan>::iterator> exists;   // lru.h:35
+};
+
+int velo_cache_create(velo_scan_cache** out, int32_t device, int32_t capacity) {
+    if (!out || capacity < 1) return fail(VELO_ERR_INVALID, "bad cache arguments");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return fail(VELO_ERR_NODEVICE, "no HIP device visible: the scan cache lives in device memory");
+    if (device < 0 || device >= n_dev) return fail(VELO_ERR_INVALID, "device %d out of range (%d visible)", device, n_dev);
+    velo_scan_cache* k = new velo_scan_cache();
+    k->device = device; k->capacity = capacity;
+    *out = k;
+    return VELO_OK;
+}
+
+int velo_cache_destroy(velo_scan_cache* k) {
+    if (!k) return VELO_OK;
+    (void)hipSetDevice(k->device);
+    delete k;                                            // DevBuf members release their memory
+    return VELO_OK;
+}
+
+int velo_cache_contains(const velo_scan_cache* k, int32_t frame) { return (k && k->exists.count(frame)) ? 1 : 0; }
+
+int velo_cache_frames(const velo_scan_cache* k, int32_t* frames_out, int32_t capacity) {
+    if (!k) return 0;
+    int i = 0;
+    for (const CachedScan& e : k->times) { if (frames_out && i < capacity) frames_out[i] = e.frame; i++; }
+    return i;
+}
+
+int velo_cache_store(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t of_target) {
+    if (!k || !c) return fail(VELO_ERR_INVALID, "null argument");
+    if (c->device != k->device) return fail(VELO_ERR_INVALID, "context on device %d, cache on device %d", c->device, k->device);
+    if (of_target ? !c->have_target : !c->have_source) return fail(VELO_ERR_STATE, "the context holds no %s scan", of_target ? "target" : "source");
+    if (of_target && (c->tgt_first_ring != 0 || c->tgt_first_point != 0)) return fail(VELO_ERR_STATE, "a target shard is not a whole scan");
+    HIP_TRY(hipSetDevice(k->device));
+    // The node that takes the scan: the frame's own older copy (replaced, not duplicated), else -- when the cache is full -- the
+    // least recently used one (lru.h:52-57: it would be dropped anyway), else a new one.  A recycled node keeps its device
+    // buffers, so a cache in steady state stores without allocating.
+    auto it = k->exists.find(frame);
+    if (it != k->exists.end()) {
+        k->times.splice(k->times.begin(), k->times, it->second);
+    } else if ((int)k->times.size() >= k->capacity) {
+        k->exists.erase(k->times.back().frame);
+        k->times.splice(k->times.begin(), k->times, std::prev(k->times.end()));
+    } else {
+        k->times.emplace_front();
+    }
+    CachedScan& e = k->times.front();
+    k->exists[frame] = k->times.begin();
+    e.frame = frame;
+    e.has_index = false;
+    e.n = of_target ? c->n_tgt : c->n_src;
+    e.n_rings = of_target ? c->n_tgt_rings : c->n_src_rings;
+    e.h_off = of_target ? c->h_tgt_off : c->h_src_off;
+    int st = e.cloud.reserve((size_t)std::max(e.n, 1));
+    hipError_t he = hipSuccess;
+    if (st == VELO_OK && e.n > 0) he = hipMemcpyAsync(e.cloud.p, of_target ? c->tgt.p : c->src.p, sizeof(float4) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream);
+    Grid* G = of_target ? grid_for_iter(c, 1) : nullptr;
+    if (st == VELO_OK && he == hipSuccess && G) {
+        e.has_index = true;
+        std::memcpy(e.bbox, c->bbox, sizeof(e.bbox));
+        e.grid.d = G->d; e.grid.gate = G->gate; e.grid.h = G->h; e.grid.built = true;
+        const size_t nc = (size_t)G->d.ncells + 1, ns = (size_t)e.n + kGridPad;
+        if ((st = e.ring_of.reserve((size_t)std::max(e.n, 1))) == VELO_OK && (st = e.grid.cell_start.reserve(nc)) == VELO_OK &&
+            (st = e.grid.sorted.reserve(ns)) == VELO_OK && (st = e.grid.sring.reserve(ns)) == VELO_OK) {
+            if (e.n > 0) he = hipMemcpyAsync(e.ring_of.p, c->tgt_ring_of.p, sizeof(int) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream);
+            if (he == hipSuccess) he = hipMemcpyAsync(e.grid.cell_start.p, G->cell_start.p, sizeof(int) * nc, hipMemcpyDeviceToDevice, c->stream);
+            if (he == hipSuccess) he = hipMemcpyAsync(e.grid.sorted.p, G->sorted.p, sizeof(float4) * ns, hipMemcpyDeviceToDevice, c->stream);
+            if (he == hipSuccess) he = hipMemcpyAsync(e.grid.sring.p, G->sring.p, sizeof(int) * ns, hipMemcpyDeviceToDevice, c->stream);
+        }
+    }
+    if (st == VELO_OK && he == hipSuccess) he = hipStreamSynchronize(c->stream);           // the entry is complete when the call returns
+    if (st != VELO_OK || he != hipSuccess) {
+        k->exists.erase(frame); k->times.pop_front();
+        return st != VELO_OK ? st : fail(VELO_ERR_HIP, "scan cache copy failed: %s", hipGetErrorString(he));
+    }
+    return VELO_OK;
+}
+
+int velo_cache_load(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t as_target) {
+    if (!k || !c) return fail(VELO_ERR_INVALID, "null argument");
+    if (c->device != k->device) return fail(VELO_ERR_INVALID, "context on device %d, cache on device %d", c->device, k->device);
+    auto it = k->exists.find(frame);
+    if (it == k->exists.end()) return fail(VELO_ERR_STATE, "frame %d is not in the scan cache", frame);
+    k->times.splice(k->times.begin(), k->times, it->second);                               // most recently used (lru.h:42-47)
+    const CachedScan& e = k->times.front();
+    HIP_TRY(hipSetDevice(k->device));
+    if (!as_target) {
+        VELO_TRY(c->src.reserve((size_t)std::max(e.n, 1)));
+        if (e.n > 0) HIP_TRY(hipMemcpyAsync(c->src.p, e.cloud.p, sizeof(float4) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream));
+        c->h_src_off = e.h_off;
+        c->n_src = e.n; c->n_src_rings = e.n_rings;
+        c->have_source = false;
+        return source_finalize(c);
+    }
+    for (int r = 0; r < e.n_rings; r++) if (e.h_off[(size_t)r + 1] <= e.h_off[(size_t)r]) return fail(VELO_ERR_INVALID, "target ring %d is empty", r);
+    VELO_TRY(c->tgt.reserve((size_t)std::max(e.n, 1)));
+    if (e.n > 0) HIP_TRY(hipMemcpyAsync(c->tgt.p, e.cloud.p, sizeof(float4) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream));
+    c->h_tgt_off = e.h_off;
+    c->n_tgt = e.n; c->n_tgt_rings = e.n_rings;
+    c->tgt_first_ring = 0; c->tgt_first_point = 0;
+    c->have_target = false; c->have_corr = false; c->have_partials = false;
+    // the cached index serves when it was built for the gates this context works with (same cell size rule, same cloud)
+    double gmin = gate_of_iter(c->P, 1);
+    for (int iter = 2; iter <= c->P.f2f_iterations; iter++) gmin = std::min(gmin, gate_of_iter(c->P, iter));
+    if (const char* env = getenv("VELO_GRID_GATE")) gmin = atof(env);
+    if (!e.has_index || e.grid.gate != gmin) return target_finalize(c);
+    c->prev_ready = false;
+    VELO_TRY(c->tgt_off.reserve((size_t)e.n_rings + 1));
+    VELO_TRY(c->tgt_ring_of.reserve((size_t)std::max(e.n, 1)));
+    VELO_TRY(c->tgt_cell_of.reserve((size_t)std::max(e.n, 1)));                            // scratch of a later rebuild (velo_set_params)
+    if (c->grids.empty()) c->grids.resize(1);
+    Grid& G = c->grids[0];
+    const size_t nc = (size_t)e.grid.d.ncells + 1, ns = (size_t)e.n + kGridPad;
+    VELO_TRY(G.cell_start.reserve(nc)); VELO_TRY(G.sorted.reserve(ns)); VELO_TRY(G.sring.reserve(ns));
+    HIP_TRY(hipMemcpyAsync(c->tgt_off.p, c->h_tgt_off.data(), sizeof(int) * ((size_t)e.n_rings + 1), hipMemcpyHostToDevice, c->stream));
+    if (e.n > 0) HIP_TRY(hipMemcpyAsync(c->tgt_ring_of.p, e.ring_of.p, sizeof(int) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(G.cell_start.p, e.grid.cell_start.p, sizeof(int) * nc, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(G.sorted.p, e.grid.sorted.p, sizeof(float4) * ns, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(G.sring.p, e.grid.sring.p, sizeof(int) * ns, hipMemcpyDeviceToDevice, c->stream));
+    G.d = e.grid.d; G.gate = e.grid.gate; G.h = e.grid.h; G.built = true;
+    std::memcpy(c->bbox, e.bbox, sizeof(c->bbox));
+    HIP_TRY(hipStreamSynchronize(c->stream));                                              // h_tgt_off (pageable) has been read; the entry may be evicted
+    c->have_target = true;
+    return VELO_OK;
 }
 
 int velo_get_ring_offsets(velo_ctx* c, int32_t of_target, int32_t* out, int32_t capacity, int32_t* n_rings) {

@@ -29,9 +29,14 @@ class LidarOdometer:
     registration; for the next frame it is promoted to target on the device (`velo_source_to_target`, the role the reference's
     ScansLRU cache plays for sd_prev, main.cpp:233,380) -- only its search index is built then."""
 
-    def __init__(self, device: int = 0, velo_to_cam=None, **params):
+    def __init__(self, device: int = 0, velo_to_cam=None, ndiagonal: int = 1, cache_capacity: int = 50, **params):
+        """ndiagonal > 1: every new frame is also registered against frames k-2 .. k-ndiagonal (the reference's dframes[0] with
+        ENABLE_ISAM, main.cpp:148-152,306-350); those older scans come out of a device-resident ScanCache (lru.h:31-61)."""
         from . import synth
         self.ctx = api.Context(device, **params)
+        self.ndiagonal = int(ndiagonal)
+        self.cache = api.ScanCache(device, max(cache_capacity, self.ndiagonal + 1)) if self.ndiagonal > 1 else None   # the window must fit
+        self.edges = []          # (frame_from, frame_to, 4x4 relative pose) of the extra registrations
         self.velo_to_cam = np.asarray(velo_to_cam if velo_to_cam is not None else synth.VELO_TO_CAM, dtype=np.float32)
         self.poses = []          # ceres_poses_mat (main.cpp:179), camera-0 frame
         self.prev_records = None
@@ -59,6 +64,16 @@ class LidarOdometer:
         self.agreements.append(api.pose_mat_to_vec(dpose @ np.linalg.inv(dT)))  # main.cpp:417
         self.summaries.append(s)
         self.prev_records = records
+        if self.cache is not None:
+            self.cache.store(k - 1, self.ctx, True)                            # frame k-1 with the index just built for it
+            for d in range(2, self.ndiagonal + 1):                             # main.cpp:306-307
+                if k - d < 0:
+                    break
+                dT = np.linalg.inv(self.poses[k - d]) @ self.poses[k]          # main.cpp:324-326
+                self.cache.load(k - d, self.ctx, True)                         # sd_prev = lru.get(dataset, frame - dframe), main.cpp:350
+                _, dpose_d, _ = self.ctx.frame_to_frame(api.pose_mat_to_vec(dT))
+                self.edges.append((k - d, k, dpose_d))
+            # the context still holds frame k as its source, which is all the next push needs
         return self.poses[-1]
 
     def write_kitti(self, path: str):
@@ -67,4 +82,6 @@ class LidarOdometer:
                 f.write(kitti_pose_line(T) + "\n")
 
     def close(self):
+        if self.cache is not None:
+            self.cache.close()
         self.ctx.close()
