@@ -330,6 +330,11 @@ def test_device_memory_returns_after_destroy():
         for _ in range(4):                      # a new target per frame must reuse / free the old grid
             ctxs[0].source_to_target(); ctxs[0].set_source(d["src_xyz"], d["src_off"])
         ctxs[0].frame_to_frame(d["x0"])
+        cache = api.ScanCache(0, capacity=2)        # three stores into two nodes: one eviction, one recycled node
+        for f in range(3):
+            cache.store(f, ctxs[0], True)
+        cache.load(2, ctxs[1], True)
+        cache.close()
         for c in ctxs: c.close()
 
     for _ in range(3): cycle()
