@@ -293,7 +293,10 @@ int velo_solve(velo_ctx* ctx, double x[6], velo_solve_summary* summary);
 /* frameToFrame (velo.h:598-919): f2f_iterations x [visual blocks; icp_iterations x (associate; solve)].
  * x: in = initial guess, out = solution.  T: 4x4 row-major of the solution (util::pose_mat2vec, utility.h:67-82). */
 int velo_frame_to_frame(velo_ctx* ctx, double x[6], double T[16], velo_summary* summary);
-/* Several independent scan pairs in flight (one context each), one host thread per context. */
+/* Several independent scan pairs in flight, one context each (what run.fish:2 does with one process per sequence): equivalent
+ * to n velo_frame_to_frame calls, results bit-identical.  Contexts on one device are advanced in lock-step groups (one sweep /
+ * LM-step launch serves a whole group), otherwise one host thread per context.  Every context may appear once (VELO_ERR_INVALID
+ * for duplicates or null entries); the first failing context's status is returned. */
 int velo_frame_to_frame_batch(velo_ctx** ctxs, int32_t n, double* x /* n*6 */, double* T /* n*16 */,
                               velo_summary* summaries /* n or NULL */);
 

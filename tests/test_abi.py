@@ -106,6 +106,16 @@ def test_argument_validation_without_gpu(lib):
     assert lib.velo_pose_vec_to_mat(None, None) == -1
     assert lib.velo_set_params(None, None) == -1
     assert lib.velo_version().startswith(b"velo_hip")
+    # batch entry point: a context listed twice (it would race with itself) or a null entry is refused before anything is touched
+    x = (C.c_double * 12)()
+    fake = C.c_void_p(0x1000)
+    arr = (C.c_void_p * 2)(fake, fake)
+    assert lib.velo_frame_to_frame_batch(arr, 2, x, None, None) == -1 and b"same context" in lib.velo_last_error()
+    arr = (C.c_void_p * 2)(fake, None)
+    assert lib.velo_frame_to_frame_batch(arr, 2, x, None, None) == -1 and b"null" in lib.velo_last_error()
+    assert lib.velo_frame_to_frame_batch(arr, 0, x, None, None) == 0
+    assert lib.velo_cache_create(None, 0, 50) == -1 and lib.velo_cache_destroy(None) == 0 and lib.velo_cache_contains(None, 3) == 0
+    assert lib.velo_evaluate_functors(None, None, 0, None, None, None) == -1
 
 
 def test_product_never_touches_the_oracle():
