@@ -231,7 +231,8 @@ int velo_source_to_target(velo_ctx* ctx);
  * load:  device-to-device copy into a context as its target or source, and the entry becomes the most recent one (lru.h:42-47).
  *        Loading as target reuses the cached index when it was built for the same gates, otherwise (entries stored from a source,
  *        other params) the index is built from the cached cloud.  Any number of contexts may load the same entry.
- * VELO_ERR_STATE when `frame` is not cached (the caller then reads the scan and stores it: what lru.h:48-58 does). */
+ * VELO_ERR_STATE when `frame` is not cached (the caller then reads the scan and stores it: what lru.h:48-58 does).
+ * Like a context, a cache is not internally thread-safe: one call at a time (the reference's loop is single-threaded, velo.h:900). */
 typedef struct velo_scan_cache velo_scan_cache;
 int velo_cache_create(velo_scan_cache** out, int32_t device, int32_t capacity);
 int velo_cache_destroy(velo_scan_cache* cache);
