@@ -260,9 +260,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "assoc_search_v5_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": b_launch,
-                         "note": "launch duration from HIP events on the context stream, measured in the timed region; with several "
-                                 "pairs in flight the bracket includes the time a launch shares the chip with other streams' kernels "
-                                 "(single_pair.assoc_avg_launch_us is the same kernel alone)"},
+                         "note": "launch duration from HIP events (hipExtLaunchKernelGGL start/stop) on the context stream over the timed "
+                                 "region; with several pairs in flight a launch shares the chip with other streams' kernels and its start "
+                                 "marker waits for the command processor, so this reads higher than a kernel trace of the same run "
+                                 "(profiles/*_summary.txt splits the trace by phase); single_pair.assoc_avg_launch_us is the kernel alone"},
             "solution_x": [float(v) for v in x_gpu],
         }
         if single is not None:
