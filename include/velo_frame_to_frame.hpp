@@ -153,8 +153,10 @@ Mat4 frameToFrame(Context& ctx, const Rig& rig,
     velo_params P = ctx.params();
     P.enable_icp = enable_icp ? 1 : 0;                                            // velo.h:806
     ctx.set_params(P);
-    ctx.set_target(scans_S);
-    ctx.set_source(scans_M);
+    // An EMPTY ring vector means "the scan this context already holds" -- loaded from a ScanCache, or promoted by
+    // source_to_target(); the reference never passes one (a frame has ~64 rings), so its call sites keep their meaning.
+    if (!scans_S.empty()) ctx.set_target(scans_S);
+    if (!scans_M.empty()) ctx.set_source(scans_M);
 
     // velo.h:622-654: gather, per match, what the residual-type selection needs
     std::vector<velo_match> recs;

@@ -85,6 +85,8 @@ int main(int argc, char** argv) {
     double transform[6];
     if (fread(transform, 8, 6, f) != 6) return 2;
     fclose(f);
+    double transform0[6];                              // the initial guess, for the second registration of the same pair
+    for (int i = 0; i < 6; i++) transform0[i] = transform[i];
 
     // rebuild the reference-shaped containers: frame1 = 1 (current), frame2 = 0 (previous)
     const int num_cams = 2, frame1 = 1, frame2 = 0;
@@ -170,6 +172,18 @@ int main(int argc, char** argv) {
             const bool h2 = cache.get(frame2, cached, true, read);        // hit: no read
             const bool h3 = cache.get(frame1, cached, false, read);       // hit
             velo_hip::check(velo_frame_to_frame(cached.get(), xc, Tm, &sm), "velo_frame_to_frame");
+            // seam 1 on cached scans: empty ring vectors = "what the context holds"; same call as above otherwise
+            double xs[6];
+            for (int i = 0; i < 6; i++) xs[i] = transform0[i];
+            std::vector<std::vector<std::pair<int, int>>> gm2(num_cams);
+            std::vector<std::vector<velo_hip::ResidualType>> rt2(num_cams);
+            const std::vector<PointCloud::Ptr> none;
+            velo_hip::frameToFrame<Matrix4d>(cached, rig, matches, keypoints, keypoint_ids, landmarks, kwd, has_depth, none, none, kd_trees,
+                                             frame1, frame2, xs, gm2, rt2, true);
+            bool same = true;
+            for (int i = 0; i < 6; i++) same = same && xs[i] == transform[i];
+            for (int c = 0; c < num_cams; c++) same = same && gm2[c] == good_matches[c];
+            printf("s %d\n", (int)same);
             printf("c %d %d %d %d %d", (int)h0, (int)h1, (int)h2, (int)h3, reads);
             for (int i = 0; i < 6; i++) printf(" %.17g", xf[i]);
             for (int i = 0; i < 6; i++) printf(" %.17g", xc[i]);

@@ -72,6 +72,8 @@ def test_adaptor_matches_oracle(tmp_path, oracle):
     cl = [line.split() for line in out if line.startswith("c ")][0]
     assert [int(v) for v in cl[1:6]] == [0, 0, 1, 1, 2]
     assert cl[6:12] == cl[12:18]
+    # frameToFrame with empty ring vectors registers the scans the context holds (here: loaded from the cache): same result
+    assert [line for line in out if line.startswith("s ")] == ["s 1"]
 
     # depth rows through the adaptor: projectLidarToCamera + featureDepthAssociation on the target rings, per camera
     import oracle_lib as O
