@@ -40,8 +40,8 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", choices=["replicas", "sharded", "target-sharded"], default="replicas")
     ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
                     help="c2: 120k pair; c3: + 2000 stereo blocks; c4: 120k scan vs 2M-point map")
