@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL)")
     ap.add_argument("--force-device", type=int, default=None, help="testing only: every rank uses this device (with --dist-backend gloo)")
-    ap.add_argument("--cpu-sample-skip", type=int, default=16)
+    ap.add_argument("--cpu-sample-skip", type=int, default=4)
     return ap.parse_args()
 
 
