@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="independent pairs in flight per GPU (one context + stream each)")
     ap.add_argument("--threads-per-pair", dest="batch_api", action="store_false",
                     help="drive every pair from its own host thread (frame_to_frame) instead of velo_frame_to_frame_batch")
+    ap.add_argument("--separate-loads", action="store_true",
+                    help="A/B: velo_set_target/source from B host threads, then velo_frame_to_frame_batch (instead of velo_register_batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL)")
     ap.add_argument("--force-device", type=int, default=None, help="testing only: every rank uses this device (with --dist-backend gloo)")
@@ -161,15 +163,22 @@ def main():
         results[i] = ctxs[i].frame_to_frame(d["x0"])
 
     pool = ThreadPoolExecutor(max_workers=B) if B > 1 else None
+    batch_refs = (api.scan_refs([(tgt, tgt_off)] * B), api.scan_refs([(src, d["src_off"])] * B)) if B > 1 else None
     x0s = np.tile(np.asarray(d["x0"], dtype=np.float64), (B, 1))
 
     def step():
         if pool is None:
             one_pair(0)
-        elif a.batch_api:
-            # index builds of the B pairs from B host threads, then the B registrations through the library's batch entry point
+        elif a.batch_api and a.separate_loads:
+            # A/B: index builds from B host threads (one library call each), then the registrations through the batch entry point
             list(pool.map(load_pair, range(B)))
             xs, Ts, Ss = api.frame_to_frame_batch(ctxs, x0s)
+            for i in range(B):
+                results[i] = (xs[i], Ts[i], Ss[i])
+        elif a.batch_api and a.mode == "replicas":
+            # the B pairs' scans (device pointers) and the B registrations in ONE library call: every group of contexts builds its
+            # indices and starts registering on its own thread (velo_register_batch)
+            xs, Ts, Ss = api.register_batch(ctxs, None, None, x0s, refs=batch_refs)
             for i in range(B):
                 results[i] = (xs[i], Ts[i], Ss[i])
         else:

@@ -300,6 +300,19 @@ int velo_frame_to_frame(velo_ctx* ctx, double x[6], double T[16], velo_summary* 
  * for duplicates or null entries); the first failing context's status is returned. */
 int velo_frame_to_frame_batch(velo_ctx** ctxs, int32_t n, double* x /* n*6 */, double* T /* n*16 */,
                               velo_summary* summaries /* n or NULL */);
+/* The same with the scans of every job handed over in the call (seam 1 takes scans_M / scans_S per call, velo.h:606-607): job i's
+ * target and source go into context i exactly as velo_set_target / velo_set_source would put them, on the thread that then
+ * drives that context's group -- a group starts registering as soon as ITS scans are indexed, no barrier across the batch.
+ * targets / sources may be NULL (keep what the contexts hold). */
+typedef struct velo_scan_ref {
+    const float* xyz;
+    int64_t stride_bytes;
+    const int32_t* ring_offsets;
+    int32_t n_rings;
+    int32_t on_device;
+} velo_scan_ref;   /* 32 bytes */
+int velo_register_batch(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, const velo_scan_ref* sources,
+                        double* x /* n*6 */, double* T /* n*16 */, velo_summary* summaries /* n */);
 
 /* --- pose helpers (utility.h:67-96; note the reference's swapped names) ---------------- */
 int velo_pose_vec_to_mat(const double x[6], double T[16]);  /* util::pose_mat2vec */

@@ -212,3 +212,34 @@ def test_batch_entry_point_equals_single_calls(hip_lib, monkeypatch):
                 assert Ss[i].algorithmic_bytes == s1.algorithmic_bytes
         for c in ctxs:
             c.close()
+
+
+def test_register_batch_equals_separate_uploads_and_batch(hip_lib):
+    """velo_register_batch (scans handed over with the call, indexed on the group threads) against velo_set_target + velo_set_source +
+    velo_frame_to_frame_batch: same poses, same summaries, bit for bit; host and device-resident inputs; targets only / sources only."""
+    import torch
+    d = synth.scan_pair(n_beams=32, n_azimuth=900)
+    n = 5
+    x0s = np.tile(d["x0"], (n, 1)) + 1e-3 * np.arange(n)[:, None]
+    a = [api.Context(0, icp_skip=1) for _ in range(n)]
+    b = [api.Context(0, icp_skip=1) for _ in range(n)]
+    for c in a:
+        c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])
+    xa, Ta, Sa = api.frame_to_frame_batch(a, x0s)
+    xb, Tb, Sb = api.register_batch(b, [(d["tgt_xyz"], d["tgt_off"])] * n, [(d["src_xyz"], d["src_off"])] * n, x0s)
+    assert np.array_equal(xa, xb) and np.array_equal(Ta, Tb)
+    for s1, s2 in zip(Sa, Sb):
+        assert [s1.solves[k].lm_iterations for k in range(s1.n_solves)] == [s2.solves[k].lm_iterations for k in range(s2.n_solves)]
+    # device-resident scans, and only the sources replaced (the targets stay in the contexts)
+    src_dev = torch.from_numpy(d["src_xyz"]).to("cuda:0")
+    xc, _, _ = api.register_batch(b, None, [(src_dev, d["src_off"])] * n, x0s)
+    assert np.array_equal(xc, xa)
+    tgt_dev = torch.from_numpy(d["tgt_xyz"]).to("cuda:0")
+    xd, _, _ = api.register_batch(b, [(tgt_dev, d["tgt_off"])] * n, None, x0s)
+    assert np.array_equal(xd, xa)
+    # a bad job is reported, not ignored
+    bad_off = d["tgt_off"].copy(); bad_off[3] = bad_off[2]
+    with pytest.raises(api.VeloError):
+        api.register_batch(b, [(d["tgt_xyz"], bad_off)] * n, None, x0s)
+    for c in a + b:
+        c.close()

@@ -53,6 +53,11 @@ class VeloSolveSummary(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class VeloScanRef(C.Structure):
+    _fields_ = [("xyz", C.c_void_p), ("stride_bytes", C.c_int64), ("ring_offsets", C.c_void_p), ("n_rings", C.c_int32),
+                ("on_device", C.c_int32)]
+
+
 class VeloSummary(C.Structure):
     _fields_ = [
         ("n_solves", C.c_int32), ("n_assoc_rounds", C.c_int32), ("n_queries", C.c_int32),
@@ -174,6 +179,7 @@ SIGNATURES = {
     "velo_solve": (C.c_int, [_ctx, _dp, _P(VeloSolveSummary)]),
     "velo_frame_to_frame": (C.c_int, [_ctx, _dp, _dp, _P(VeloSummary)]),
     "velo_frame_to_frame_batch": (C.c_int, [_P(_ctx), C.c_int32, _dp, _dp, _P(VeloSummary)]),
+    "velo_register_batch": (C.c_int, [_P(_ctx), C.c_int32, C.c_void_p, C.c_void_p, _dp, _dp, _P(VeloSummary)]),
     "velo_pose_vec_to_mat": (C.c_int, [_dp, _dp]),
     "velo_pose_mat_to_vec": (C.c_int, [_dp, _dp]),
     "velo_comm_unique_id": (C.c_int, [C.c_char_p]),
@@ -559,6 +565,46 @@ def frame_to_frame_batch(ctxs, x0s):
     T = np.zeros((n, 16))
     S = (VeloSummary * n)()
     st = lib.velo_frame_to_frame_batch(arr, n, _ptr(x), _ptr(T), S)
+    if st != 0:
+        msg = lib.velo_last_error()
+        raise VeloError(f"velo status {st}: {msg.decode() if msg else ''}")
+    return x, T.reshape(n, 4, 4), list(S)
+
+
+def scan_refs(scans):
+    """[(xyz, ring_offsets), ...] -> (velo_scan_ref array, objects to keep alive while it is in use).  xyz: numpy (n,3|4) float32 or a
+    torch tensor on the GPU, as for Context.set_target."""
+    n = len(scans)
+    arr = (VeloScanRef * n)()
+    keep = []
+    for i, (xyz, off) in enumerate(scans):
+        ptr, stride, off_a, dev, k = Context._cloud_args(xyz, off)
+        arr[i].xyz = ptr.value
+        arr[i].stride_bytes = stride
+        arr[i].ring_offsets = off_a.ctypes.data
+        arr[i].n_rings = len(off_a) - 1
+        arr[i].on_device = dev
+        keep.append((k, off_a))
+    return arr, keep
+
+
+def register_batch(ctxs, targets, sources, x0s, refs=None):
+    """velo_register_batch: job i's target / source scans go into context i and the batch is registered, all inside the library
+    (the index builds run on the threads that drive the groups).  targets / sources: lists of (xyz, ring_offsets) or None to keep
+    what the contexts hold; refs = (target_refs, source_refs) from scan_refs() to reuse prepared descriptors across calls."""
+    lib = load_library()
+    n = len(ctxs)
+    arr = (_ctx * n)(*[c.handle for c in ctxs])
+    if refs is None:
+        tr = scan_refs(targets) if targets is not None else (None, None)
+        sr = scan_refs(sources) if sources is not None else (None, None)
+    else:
+        tr, sr = refs
+    x = np.ascontiguousarray(np.asarray(x0s, dtype=np.float64).reshape(n, 6)).copy()
+    T = np.zeros((n, 16))
+    S = (VeloSummary * n)()
+    st = lib.velo_register_batch(arr, n, C.cast(tr[0], C.c_void_p) if tr[0] is not None else None,
+                                 C.cast(sr[0], C.c_void_p) if sr[0] is not None else None, _ptr(x), _ptr(T), S)
     if st != 0:
         msg = lib.velo_last_error()
         raise VeloError(f"velo status {st}: {msg.decode() if msg else ''}")

@@ -1586,12 +1586,12 @@ int velo_frame_to_frame(velo_ctx* c, double x[6], double T[16], velo_summary* su
 // states back per chunk.  With a host thread per context (the fallback) a step of 8 pairs is 8 x 84 small LM launches that each
 // fill half the chip and stall behind the other contexts' association kernels; here it is 84 launches that fill it.
 // Conditions: same device, same parameters, no communicator, default kernels -- anything else falls back.
-static bool batch_can_lockstep(velo_ctx** ctxs, int n) {
+static bool batch_can_lockstep(velo_ctx** ctxs, int n, bool targets_follow = false, bool sources_follow = false) {
     if (n < 2 || !ctxs[0] || !ctxs[0]->batch_lockstep) return false;
     for (int i = 0; i < n; i++) {
         const velo_ctx* c = ctxs[i];
         if (!c || c->device != ctxs[0]->device || c->comm || c->use_fused || c->use_graphs) return false;
-        if (!c->have_target || !c->have_source || c->shard_world != 1) return false;
+        if ((!c->have_target && !targets_follow) || (!c->have_source && !sources_follow) || c->shard_world != 1) return false;
         if (std::memcmp(&c->P, &ctxs[0]->P, sizeof(velo_params)) != 0) return false;
         for (int j = 0; j < i; j++) if (ctxs[j] == c) return false;
     }
@@ -1716,25 +1716,42 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
     return VELO_OK;
 }
 
-int velo_frame_to_frame_batch(velo_ctx** ctxs, int32_t n, double* x, double* T, velo_summary* summaries) {
+// upload (optional) + register: the scans of job i go into context i (velo_set_target / velo_set_source semantics), then the batch runs
+static int load_job(velo_ctx* c, const velo_scan_ref* tg, const velo_scan_ref* sr) {
+    if (tg) VELO_TRY(velo_set_target(c, tg->xyz, tg->stride_bytes, tg->ring_offsets, tg->n_rings, tg->on_device));
+    if (sr) VELO_TRY(velo_set_source(c, sr->xyz, sr->stride_bytes, sr->ring_offsets, sr->n_rings, sr->on_device));
+    return VELO_OK;
+}
+
+static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, const velo_scan_ref* sources, double* x, double* T, velo_summary* summaries) {
     if (!ctxs || n < 0 || (n > 0 && !x)) return fail(VELO_ERR_INVALID, "bad batch arguments");
     for (int i = 0; i < n; i++) {                                    // one registration per context: a context listed twice would race with itself
         if (!ctxs[i]) return fail(VELO_ERR_INVALID, "batch entry %d is null", i);
         for (int j = 0; j < i; j++) if (ctxs[j] == ctxs[i]) return fail(VELO_ERR_INVALID, "batch entries %d and %d are the same context", j, i);
     }
-    if (batch_can_lockstep(ctxs, n)) {
+    if (batch_can_lockstep(ctxs, n, targets != nullptr, sources != nullptr)) {
         // G lock-step groups, one host thread and one stream each: while one group is in its (chip-filling) association
         // launches or waits for a status copy, another group's LM launches run -- the groups hide each other's bubbles
         // Measured on C2 (pairs/s, 3 runs each): 8 contexts: 1 group 1,425, 2 groups 1,790-1,920, 4 groups 1,990-2,200, one thread per
         // context 1,600; 16 contexts: 2 groups 2,010-2,110, 4 groups 1,420-1,510 (four association kernels interleave), 8 groups 1,740-1,780.
         static const int groups_env = getenv("VELO_BATCH_GROUPS") ? std::max(atoi(getenv("VELO_BATCH_GROUPS")), 1) : 0;
         const int G = groups_env > 0 ? std::min(groups_env, n / 2) : (n >= 12 ? 2 : std::min(4, n / 2));
-        if (G <= 1) return f2f_batch_lockstep(ctxs, n, x, T, summaries);
+        if (G <= 1) {
+            for (int i = 0; i < n; i++) VELO_TRY(load_job(ctxs[i], targets ? targets + i : nullptr, sources ? sources + i : nullptr));
+            return f2f_batch_lockstep(ctxs, n, x, T, summaries);
+        }
         std::vector<int> gst((size_t)G, VELO_OK);
         std::vector<std::string> gerr((size_t)G);
         std::vector<std::thread> gth;
         auto run_group = [&](int gi) {
             const int b = (int)((int64_t)n * gi / G), e = (int)((int64_t)n * (gi + 1) / G);
+            // this group's index builds, then its registrations: no barrier across groups, so one group's association launches
+            // run under another group's index builds.  (Helper threads that load a group's contexts in parallel were measured
+            // slower, 2.32-2.34 k vs 2.42-2.47 k pairs/s: more host threads contending for the runtime's submission path.)
+            for (int i = b; i < e; i++) {
+                const int st = load_job(ctxs[i], targets ? targets + i : nullptr, sources ? sources + i : nullptr);
+                if (st != VELO_OK) { gst[(size_t)gi] = st; gerr[(size_t)gi] = g_err; return; }
+            }
             gst[(size_t)gi] = f2f_batch_lockstep(ctxs + b, e - b, x + 6 * (size_t)b, T ? T + 16 * (size_t)b : nullptr, summaries ? summaries + b : nullptr);
             if (gst[(size_t)gi] != VELO_OK) gerr[(size_t)gi] = g_err;
         };
@@ -1750,13 +1767,22 @@ int velo_frame_to_frame_batch(velo_ctx** ctxs, int32_t n, double* x, double* T, 
     th.reserve((size_t)n);
     for (int i = 0; i < n; i++) {
         th.emplace_back([&, i]() {
-            status[i] = velo_frame_to_frame(ctxs[i], x + 6 * (size_t)i, T ? T + 16 * (size_t)i : nullptr, summaries ? summaries + i : nullptr);
+            status[i] = load_job(ctxs[i], targets ? targets + i : nullptr, sources ? sources + i : nullptr);
+            if (status[i] == VELO_OK) status[i] = velo_frame_to_frame(ctxs[i], x + 6 * (size_t)i, T ? T + 16 * (size_t)i : nullptr, summaries ? summaries + i : nullptr);
             if (status[i] != VELO_OK) errs[i] = g_err;
         });
     }
     for (auto& t : th) t.join();
     for (int i = 0; i < n; i++) if (status[i] != VELO_OK) { g_err = errs[i]; return status[i]; }
     return VELO_OK;
+}
+
+int velo_frame_to_frame_batch(velo_ctx** ctxs, int32_t n, double* x, double* T, velo_summary* summaries) {
+    return batch_impl(ctxs, n, nullptr, nullptr, x, T, summaries);
+}
+
+int velo_register_batch(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, const velo_scan_ref* sources, double* x, double* T, velo_summary* summaries) {
+    return batch_impl(ctxs, n, targets, sources, x, T, summaries);
 }
 
 // util::pose_mat2vec (utility.h:67-82): 6-vector -> 4x4, row-major out.  Column j of R is R(omega) e_j, which is what
