@@ -470,3 +470,24 @@ def test_odometry_with_diagonal_edges_from_the_scan_cache(hip_lib):
         assert np.array_equal(dpose, want)
         assert np.linalg.norm((dpose @ np.linalg.inv(dT))[:3, 3]) < 0.05
     plain.close(); diag.close()
+
+
+@pytest.mark.gpu
+def test_odometry_over_a_directory_of_kitti_sweeps(hip_lib, tmp_path):
+    """KITTI layout in (velodyne/*.bin + calib.txt Tr row), KITTI pose file out: same poses as pushing the records directly."""
+    frames, _ = synth.velodyne_sequence(4, n_beams=16, n_azimuth=300)
+    vdir = tmp_path / "velodyne"
+    vdir.mkdir()
+    for k, rec in enumerate(frames):
+        synth.write_kitti_bin(str(vdir / f"{k:06d}.bin"), rec[:, :3])
+    calib = tmp_path / "calib.txt"
+    calib.write_text("P0: 1 0 0 0 0 1 0 0 0 0 1 0\nTr: " + " ".join(f"{v:.9e}" for v in synth.VELO_TO_CAM[:3, :4].reshape(-1)) + "\n")
+    assert np.array_equal(odometry.read_velo_to_cam(str(calib))[:3], synth.VELO_TO_CAM[:3].astype(np.float32))
+    odo = odometry.run_directory(str(vdir), str(tmp_path / "poses.txt"), str(calib), icp_skip=1)
+    ref = odometry.LidarOdometer(0, icp_skip=1)
+    for rec in frames:
+        ref.push(rec)
+    assert all(np.array_equal(a, b) for a, b in zip(odo.poses, ref.poses))
+    lines = (tmp_path / "poses.txt").read_text().splitlines()
+    assert len(lines) == 4 and lines[1] == odometry.kitti_pose_line(ref.poses[1]).rstrip("\n")
+    odo.close(); ref.close()

@@ -85,3 +85,48 @@ class LidarOdometer:
         if self.cache is not None:
             self.cache.close()
         self.ctx.close()
+
+
+def read_velo_to_cam(calib_path: str) -> np.ndarray:
+    """The `Tr:` row of a KITTI odometry calib.txt (3x4, row-major) as a 4x4 -- what loadCalibration keeps as velo_to_cam
+    (kitti.h:53-119)."""
+    with open(calib_path) as f:
+        for line in f:
+            if line.startswith("Tr"):
+                v = [float(t) for t in line.split()[1:13]]
+                M = np.eye(4, dtype=np.float32)
+                M[:3, :4] = np.asarray(v, dtype=np.float32).reshape(3, 4)
+                return M
+    raise ValueError(f"no Tr row in {calib_path}")
+
+
+def run_directory(velodyne_dir: str, out_path: str, calib_path: str = None, device: int = 0, max_frames: int = None, **params):
+    """LiDAR-only odometry over a directory of KITTI `.bin` sweeps (velodyne/000000.bin ...; kitti.h:121-152): poses in the
+    reference's output format (main.cpp:758-763).  Returns the odometer (poses, agreements, summaries)."""
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(velodyne_dir, "*.bin")))
+    if max_frames is not None:
+        files = files[:max_frames]
+    if not files:
+        raise FileNotFoundError(f"no .bin sweeps in {velodyne_dir}")
+    odo = LidarOdometer(device, velo_to_cam=read_velo_to_cam(calib_path) if calib_path else None, **params)
+    for path in files:
+        odo.push(np.fromfile(path, dtype=np.float32).reshape(-1, 4))
+    odo.write_kitti(out_path)
+    return odo
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser(description="LiDAR-only frame-to-frame odometry over KITTI velodyne sweeps on an MI355X")
+    ap.add_argument("velodyne_dir")
+    ap.add_argument("out", help="pose file, one 3x4 per line (KITTI odometry format)")
+    ap.add_argument("--calib", default=None, help="KITTI calib.txt (its Tr row); default: the synthetic rig's velo_to_cam")
+    ap.add_argument("--icp-skip", type=int, default=1, help="query stride per ring (the reference's constant is 200)")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--max-frames", type=int, default=None)
+    a = ap.parse_args()
+    o = run_directory(a.velodyne_dir, a.out, a.calib, a.device, a.max_frames, icp_skip=a.icp_skip)
+    print(f"{len(o.poses)} poses -> {a.out}")
+    o.close()
