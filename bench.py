@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", choices=["replicas", "sharded", "target-sharded"], default="replicas")
-    ap.add_argument("--workload", choices=["c2", "c3", "c4"], default="c2",
+    ap.add_argument("--workload", choices=["c1", "c2", "c3", "c4"], default="c2",
                     help="c2: 120k pair; c3: + 2000 stereo blocks; c4: 120k scan vs 2M-point map")
     ap.add_argument("--batch", type=int, default=8, help="independent pairs in flight per GPU (one context + stream each)")
     ap.add_argument("--threads-per-pair", dest="batch_api", action="store_false",
@@ -58,7 +58,12 @@ def parse():
 
 
 def make_workload(name):
+    """-> (scan pair, visual matches or None, label, icp_skip)"""
     from velo_amd import synth
+    if name == "c1":
+        # configs[0], the reference's own constants (kitti.h:8: icp_skip = 200 -> 640 queries per round).  KITTI seq 00 is not in
+        # this image: the synthetic pair stands in, in the same ring layout the KITTI reader produces.
+        return synth.scan_pair(), None, "configs[0] stand-in: synthetic 120k-pt pair, reference constants (icp_skip=200)", 200
     if name == "c4":
         d = synth.scan_to_map(2_000_000)
         label = "synthetic HDL-64E 120k-pt scan vs 2M-pt accumulated map (configs[3]), icp_skip=1"
@@ -69,16 +74,18 @@ def make_workload(name):
     if name == "c3":
         vis = synth.stereo_matches(1000)
         label = "configs[2]: 120k-pt pair + 2000 stereo reprojection blocks, icp_skip=1"
-    return d, vis, label
+    return d, vis, label, 1
 
 
-def cpu_baseline(d, vis, sample_skip):
+def cpu_baseline(d, vis, sample_skip, icp_skip=1):
     """The CPU restatement (oracle = 'port') timed on this host: (i) all cores on the full pair,
     (ii) one thread -- the reference's configuration (velo.h:900) -- on a 1/sample_skip query sample."""
     import oracle_lib
     cores = oracle_lib.max_threads()
     out = {}
-    o = oracle_lib.Oracle(threads=cores, icp_skip=1)
+    o = oracle_lib.Oracle(threads=cores, icp_skip=icp_skip)
+    if icp_skip > 1:
+        sample_skip = 1                      # sparse queries already: the single-thread leg runs the whole pair
     t0 = time.perf_counter()
     o.set_target(d["tgt_xyz"], d["tgt_off"])
     o.set_source(d["src_xyz"], d["src_off"])
@@ -86,7 +93,7 @@ def cpu_baseline(d, vis, sample_skip):
         o.set_visual(vis)
     x, _, s = o.frame_to_frame(d["x0"])
     t_all = time.perf_counter() - t0
-    o1 = oracle_lib.Oracle(threads=1, icp_skip=sample_skip)
+    o1 = oracle_lib.Oracle(threads=1, icp_skip=icp_skip * sample_skip)
     t0 = time.perf_counter()
     o1.set_target(d["tgt_xyz"], d["tgt_off"])
     o1.set_source(d["src_xyz"], d["src_off"])
@@ -96,7 +103,7 @@ def cpu_baseline(d, vis, sample_skip):
     t_one = (time.perf_counter() - t0) * sample_skip
     out = {
         "value": 1.0 / t_all, "unit": "scan-pairs/s", "cores": cores, "kind": "port",
-        "sample": f"1 full pair (icp_skip=1) on {cores} OpenMP threads = {t_all:.2f} s; single-thread "
+        "sample": f"1 full pair (icp_skip={icp_skip}) on {cores} OpenMP threads = {t_all:.2f} s; single-thread "
                   f"(reference configuration) extrapolated from a 1/{sample_skip} query sample = {t_one:.1f} s/pair",
         "single_thread_pairs_per_s": 1.0 / t_one,
         "x": [float(v) for v in x],
@@ -126,7 +133,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
-    d, vis, label = make_workload(a.workload)
+    d, vis, label, icp_skip = make_workload(a.workload)
     B = 1 if a.mode != "replicas" else max(1, a.batch)
     # inputs resident in HBM before the timed region (torch is only the allocator here)
     tgt_off, tgt_first_ring, tgt_first_point = d["tgt_off"], 0, 0
@@ -139,7 +146,7 @@ def main():
     tgt = torch.from_numpy(np.ascontiguousarray(tgt_np)).to(dev)
     src = torch.from_numpy(d["src_xyz"]).to(dev)
     torch.cuda.synchronize()
-    ctxs = [api.Context(local_rank, icp_skip=1) for _ in range(B)]
+    ctxs = [api.Context(local_rank, icp_skip=icp_skip) for _ in range(B)]
     for c in ctxs:
         c.set_timing(True)
         if vis is not None:
@@ -284,7 +291,7 @@ def main():
                                         "issue_slots_per_launch_at_2p4GHz": 1024 * 2.4e9 / 4 * t_alone,
                                         "note": "from the committed PMC pass (profiles/*_traffic.json); launch time = the kernel alone"}
         if not a.no_cpu_baseline and world == 1:             # rank 0 at N = 1 only: the other runs just report the GPU side
-            cb = cpu_baseline(d, vis, a.cpu_sample_skip)
+            cb = cpu_baseline(d, vis, a.cpu_sample_skip, icp_skip)
             xo = np.array(cb.pop("x"))
             cb["pose_diff_vs_gpu"] = {"dt_m": float(np.linalg.norm(xo[3:] - x_gpu[3:])),
                                       "dw_rad": float(np.linalg.norm(xo[:3] - x_gpu[:3]))}
