@@ -247,7 +247,7 @@ def main():
         n_pairs_timed = a.steps * B
         per_pair_bytes = alg_bytes / max(n_pairs_timed, 1)
         # dominant kernel: the association search.  Algorithmic bytes per launch = 12 Nq + 12 Nt + 28 Nq
-        b_launch = assoc_bytes / max(a.steps * B * max(s0.n_assoc_rounds, 1), 1)
+        b_launch = assoc_bytes / max(assoc_n, 1)            # the batch driver serves the same round of several contexts with one launch
         avg_ms = assoc_ms / max(assoc_n, 1)
         achieved = (b_launch / 1e9) / (avg_ms / 1e3) if avg_ms > 0 else 0.0
         traffic = None          # HBM-side bytes per launch from the committed PMC passes (tools/summarize_traffic.py)
@@ -276,7 +276,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "assoc_search_v5_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": b_launch,
-                         "note": "launch duration from HIP events (hipExtLaunchKernelGGL start/stop) on the context stream over the timed "
+                         "note": "with several pairs in flight one association launch serves the same round of up to 4 contexts "
+                                 "(algorithmic_bytes_per_launch says how many); "
+                                 "launch duration from HIP events (hipExtLaunchKernelGGL start/stop) on the context stream over the timed "
                                  "region; with several pairs in flight a launch shares the chip with other streams' kernels and its start "
                                  "marker waits for the command processor, so this reads higher than a kernel trace of the same run "
                                  "(profiles/*_summary.txt splits the trace by phase); single_pair.assoc_avg_launch_us is the kernel alone"},

@@ -1598,6 +1598,108 @@ static bool batch_can_lockstep(velo_ctx** ctxs, int n, bool targets_follow = fal
     return true;
 }
 
+// ---- the same association round of several contexts in ONE launch (lock-step batch driver) ---------------------------------------
+// Host-side preparation of one context's round for the tube kernel, exactly what do_associate does before its launch.
+// *groups = 0 when the context has no queries.
+static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs* A, int* groups, bool* asker) {
+    if (!c->have_target || !c->have_source) return fail(VELO_ERR_STATE, "associate needs set_target and set_source first");
+    if (c->src_skip != std::max(c->P.icp_skip, 1) || (c->n_q > 0) != (c->P.enable_icp != 0 && c->h_q_off[c->n_src_rings] > 0)) VELO_TRY(build_query_list(c));
+    Grid* G = grid_for_iter(c, iter);
+    if (!G) return VELO_ERR_HIP;
+    int qb, qe;
+    q_range(c, &qb, &qe);
+    VELO_TRY(next_valid_counter(c));
+    *groups = 0;
+    if (qe <= qb) return VELO_OK;
+    pose_scalars(x, &A->P);
+    A->G.d = G->d; A->G.cell_start = G->cell_start.p; A->G.sorted = G->sorted.p; A->G.sring = G->sring.p;
+    A->src = c->src.p; A->q_src = c->q_src.p; A->q_begin = qb; A->q_end = qe;
+    A->tgt = c->tgt.p; A->tgt_off = c->tgt_off.p; A->n_tgt_local = c->n_tgt;
+    const double gate = gate_of_iter(c->P, iter);
+    A->gate_bits = gate_bits_of(gate);
+    A->norm_cond = c->P.icp_norm_condition;
+    const int cluster_cells = std::max(1, (int)std::lround((double)c->cluster_w * 0.1785 / G->h));
+    A->cluster_w = c->cluster_w_set ? (c->cluster_w > 0 ? cluster_cells : 2000) : std::max(1, (int)std::lround(96.0 * 0.1785 / G->h));
+    A->h_safe = (float)(G->h * 0.999);
+    AssocOut& out = A->out;
+    out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p + c->nv_idx; out.dbg = c->dbg.p; out.wg_times = nullptr;
+    out.first_ring = c->tgt_first_ring; out.first_point = c->tgt_first_point; out.partial = nullptr;
+    out.prev = nullptr;
+    if (c->warm_start) {
+        if (!c->prev_ready) {
+            VELO_TRY(c->prev_pair.reserve((size_t)std::max(c->n_q, 1)));
+            HIP_TRY(hipMemsetAsync(c->prev_pair.p, 0xff, sizeof(int4) * (size_t)std::max(c->n_q, 1), c->stream));
+            c->prev_ready = true;
+        }
+        out.prev = c->prev_pair.p;
+    }
+    out.n_valid_next = c->n_valid.p + (c->nv_idx ^ 1);
+    c->nv_clean[c->nv_idx ^ 1] = true;
+    A->want_aux = 0; A->group_perm = nullptr; A->dbg = 0;
+    const int reach_cells = (int)std::ceil(std::sqrt(std::max(gate_of_iter(c->P, 1), 0.0)) / (G->h * 0.999));
+    A->asker_rows = c->asker_rows >= 0 ? c->asker_rows : (reach_cells > 5 ? 0 : (1 << 30));
+    *asker = A->asker_rows < (1 << 30);
+    *groups = cdiv(qe - qb, 64);
+    return VELO_OK;
+}
+
+// contexts whose round may share a launch: default tube kernel, no diagnostics, no placement table, whole (unsharded) query list
+static bool assoc_batchable(const velo_ctx* c) {
+    static const bool on = getenv("VELO_ASSOC_BATCH") ? atoi(getenv("VELO_ASSOC_BATCH")) != 0 : true;
+    return on && (c->assoc_variant < 0 || c->assoc_variant == 5) && !c->debug_skip && c->tube_map < 0 && !c->comm;
+}
+
+// All contexts share one stream here (the lock-step driver swapped it in).  launched[i] = 1 for the context that carries the timing
+// events of its launch, 0 for the others of the same launch.
+static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::array<double, 6>>& xs, int iter, std::vector<int>& launched) {
+    launched.assign((size_t)n, 0);
+    bool all = true;
+    for (int i = 0; i < n; i++) all = all && assoc_batchable(ctxs[i]);
+    if (!all || n < 2) {
+        for (int i = 0; i < n; i++) {
+            int nv = 0;
+            VELO_TRY(do_associate(ctxs[i], xs[(size_t)i].data(), iter, false, false, &nv));
+            int qb, qe; q_range(ctxs[i], &qb, &qe);
+            launched[(size_t)i] = qe > qb ? 1 : 0;
+        }
+        return VELO_OK;
+    }
+    for (int b = 0; b < n; b += kAssocBatchMax) {
+        const int m = std::min(kAssocBatchMax, n - b);
+        AssocBatch B;
+        std::memset(&B, 0, sizeof(B));
+        int gmax = 0, k = 0, first = -1;
+        bool any_asker = false;
+        for (int i = b; i < b + m; i++) {
+            int groups = 0; bool asker = false;
+            VELO_TRY(prepare_assoc_v5(ctxs[i], xs[(size_t)i].data(), iter, &B.item[k], &groups, &asker));
+            ctxs[i]->have_corr = true;
+            if (groups == 0) continue;                                  // no queries: nothing to launch for it
+            if (first < 0) first = i;
+            gmax = std::max(gmax, groups); any_asker = any_asker || asker; k++;
+        }
+        if (k == 0) continue;
+        velo_ctx* c = ctxs[first];
+        std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+        if (c->timing) {
+            if (c->assoc_events_used >= 256) c->assoc_events_used = 0;
+            if (c->assoc_events_used >= (int)c->assoc_events.size()) {
+                hipEvent_t e0, e1;
+                HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+                c->assoc_events.emplace_back(e0, e1);
+            }
+            ev = &c->assoc_events[c->assoc_events_used++];
+        }
+        launched[(size_t)first] = 1;
+        if (any_asker) hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, true>), dim3(gmax, k), dim3(256), 0, c->stream,
+                                             ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, B);
+        else hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, false>), dim3(gmax, k), dim3(256), 0, c->stream,
+                                   ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, B);
+        HIP_TRY(hipGetLastError());
+    }
+    return VELO_OK;
+}
+
 static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo_summary* summaries) {
     velo_ctx* c0 = ctxs[0];
     HIP_TRY(hipSetDevice(c0->device));
@@ -1633,6 +1735,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
         for (int k = 0; k < 6; k++) xc[(size_t)i][(size_t)k] = x[6 * (size_t)i + k];
     }
     const int max_iters = P.max_num_iterations + 1;
+    std::vector<int> assoc_launched;
     for (int iter = 1; iter <= P.f2f_iterations; iter++) {                              // velo.h:616
         for (int i = 0; i < n; i++) {
             VELO_TRY(do_build_visual(ctxs[i], xc[(size_t)i].data(), false, iter, nullptr));   // velo.h:622-792
@@ -1640,10 +1743,9 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
         }
         for (int icp_iter = 0; icp_iter < P.icp_iterations; icp_iter++) {               // velo.h:800
             int nb_max = 0, nbv_max = 0, first_chunk = 2;
+            VELO_TRY(do_associate_group(ctxs, n, xc, iter, assoc_launched));              // velo.h:806-894, on the shared stream
             for (int i = 0; i < n; i++) {
                 velo_ctx* c = ctxs[i];
-                int nv = 0;
-                VELO_TRY(do_associate(c, xc[(size_t)i].data(), iter, false, false, &nv));   // velo.h:806-894, on the shared stream
                 int qb, qe;
                 q_range(c, &qb, &qe);
                 velo_summary* Si = S[(size_t)i];
@@ -1651,7 +1753,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                 const uint64_t nq = (uint64_t)c->n_q;
                 const uint64_t b_assoc = 12ull * nq + 12ull * (uint64_t)c->n_tgt + 28ull * nq;
                 Si->assoc_bytes += b_assoc; Si->algorithmic_bytes += b_assoc;
-                if (qe > qb) Si->assoc_kernel_launches++;
+                Si->assoc_kernel_launches += assoc_launched[(size_t)i];
                 LMBatchItem& it = h_items[i];
                 it.A = eval_args(c, nullptr);
                 const EvalPlan E = eval_plan(it.A);

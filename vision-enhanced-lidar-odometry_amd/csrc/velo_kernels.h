@@ -854,10 +854,11 @@ __device__ __forceinline__ void top2_merge_xor(Top2& t, int mask) {
 // Tubes do not blow up with the length of the segment, so the cluster radius can be large (one cluster per group).
 //   * rounds after the first are warm-started from the previous round's winners (AssocOut::prev).
 template <int NW, int MINW, bool DBG, int PPT, bool ASKER>
-__global__ void __launch_bounds__(NW * 64, MINW)
-assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
-                       const float4* __restrict__ tgt, const int* __restrict__ tgt_off, int n_tgt_local,
-                       unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, AssocOut out, int want_aux, const int* __restrict__ group_perm, int dbg, int asker_rows) {
+__device__ __forceinline__ void
+assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
+                     const float4* __restrict__ tgt, const int* __restrict__ tgt_off, int n_tgt_local,
+                     unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, const AssocOut& out, int want_aux, const int* __restrict__ group_perm, int dbg, int asker_rows,
+                     const int block_x) {
     constexpr int NT = NW * 64;
     constexpr int NRUN = 2 * NT;
     static_assert(kTileCap % (2 * PPT) == 0, "the tile must hold whole trips (the padding of the last trip stays inside it)");
@@ -885,8 +886,8 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
     long long tlast = (DBG && (dbg & 8)) ? (long long)__builtin_readcyclecounter() : 0;
 #define VELO_STAMP(k) do { if (DBG && (dbg & 8)) { const long long now__ = (long long)__builtin_readcyclecounter(); tacc[k] += now__ - tlast; tlast = now__; } } while (0)
     // workgroup -> group through the host-built table (XCD-aware wedges, see build_group_perm); placement affects speed only
-    const int group = group_perm ? group_perm[blockIdx.x] : (int)blockIdx.x;
-    if (out.n_valid_next && blockIdx.x == 0 && tid == 0) *out.n_valid_next = 0;   // its last reader ran before this launch (same stream)
+    const int group = group_perm ? group_perm[block_x] : (int)block_x;
+    if (out.n_valid_next && block_x == 0 && tid == 0) *out.n_valid_next = 0;   // its last reader ran before this launch (same stream)
     if (DBG && out.wg_times && tid == 0) out.wg_times[2 * group] = __builtin_amdgcn_s_memrealtime();
     const int qi = q_begin + group * 64 + lane;
     const bool active = qi < q_end;
@@ -1270,6 +1271,37 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
     if (DBG && out.wg_times && tid == 0) out.wg_times[2 * group + 1] = __builtin_amdgcn_s_memrealtime();
     if (DBG && (dbg & 8) && tid == 0) { for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)&out.dbg[k], (unsigned long long)tacc[k]); }
 #undef VELO_STAMP
+}
+
+
+// one launch = one context's round
+template <int NW, int MINW, bool DBG, int PPT, bool ASKER>
+__global__ void __launch_bounds__(NW * 64, MINW)
+assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
+                       const float4* __restrict__ tgt, const int* __restrict__ tgt_off, int n_tgt_local,
+                       unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, AssocOut out, int want_aux, const int* __restrict__ group_perm, int dbg, int asker_rows) {
+    assoc_search_v5_body<NW, MINW, DBG, PPT, ASKER>(P, G, src, q_src, q_begin, q_end, tgt, tgt_off, n_tgt_local, gate_bits, norm_cond, cluster_w, h_safe, out,
+                                                    want_aux, group_perm, dbg, asker_rows, (int)blockIdx.x);
+}
+
+// one launch = the same round of SEVERAL contexts (velo_frame_to_frame_batch / velo_register_batch): blockIdx.y = context.  A round of
+// one 120k-query scan is 1,875 workgroups on 1,280 resident slots -- one and a half waves of workgroups, the second half empty;
+// four contexts in one grid fill the chip evenly (measured: 41 -> 28 us per 120k queries).  Arguments by value in the kernarg
+// segment, read with scalar loads.
+constexpr int kAssocBatchMax = 4;
+struct AssocArgs {
+    PoseScalars P; GridView G; const float4* src; const int* q_src; int q_begin, q_end;
+    const float4* tgt; const int* tgt_off; int n_tgt_local; unsigned gate_bits; double norm_cond; int cluster_w; float h_safe;
+    AssocOut out; int want_aux; const int* group_perm; int dbg; int asker_rows;
+};
+struct AssocBatch { AssocArgs item[kAssocBatchMax]; };
+template <int NW, int MINW, bool DBG, int PPT, bool ASKER>
+__global__ void __launch_bounds__(NW * 64, MINW)
+assoc_search_v5_batch_kernel(AssocBatch B) {
+    const AssocArgs& a = B.item[blockIdx.y];
+    if ((int)blockIdx.x * 64 >= a.q_end - a.q_begin) return;
+    assoc_search_v5_body<NW, MINW, DBG, PPT, ASKER>(a.P, a.G, a.src, a.q_src, a.q_begin, a.q_end, a.tgt, a.tgt_off, a.n_tgt_local, a.gate_bits, a.norm_cond,
+                                                    a.cluster_w, a.h_safe, a.out, a.want_aux, a.group_perm, a.dbg, a.asker_rows, (int)blockIdx.x);
 }
 
 // ---- association as a balanced pipeline: prepare (clusters -> work items) + persistent per-cluster search -----------------
