@@ -273,7 +273,8 @@ def main():
                        "valid_correspondences_last_round": int(s0.solves[s0.n_solves - 1].n_icp_valid),
                        "algorithmic_bytes_per_pair": per_pair_bytes},
             "achieved_hbm_GBs_whole_path": per_pair_bytes * value / 1e9,
-            "roofline": {"bound": "hbm", "kernel": "assoc_search_v5_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": "assoc_search_v5_batch_kernel" if (B > 1 and a.batch_api and a.mode == "replicas") else "assoc_search_v5_kernel",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": b_launch,
                          "note": "with several pairs in flight one association launch serves the same round of up to 4 contexts "

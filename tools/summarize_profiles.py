@@ -31,14 +31,17 @@ f = sorted(glob.glob(os.path.join(src, "trace", "*", "*kernel_trace.csv")), key=
 if f and os.path.exists(b):
     try:
         d = json.loads(open(b).read().strip().splitlines()[-1])
-        per_step = d["config"]["pairs_in_flight_per_gpu"] * 6
+        cfg = d["config"]
+        per_ctx = 12 * cfg["Nq"] + 12 * cfg["Nt"] + 28 * cfg["Nq"]                     # B_assoc of one context's round
+        k = max(1, round(d["roofline"]["algorithmic_bytes_per_launch"] / per_ctx))       # contexts served by one launch
+        per_step = cfg["pairs_in_flight_per_gpu"] * 6 // k
         rows = sorted((r for r in csv.DictReader(open(f[0])) if "assoc_search" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
         dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
         w0, t0 = d["warmup"] * per_step, (d["warmup"] + d["steps"]) * per_step
         timed, alone = sorted(dur[w0:t0]), dur[t0:]
         if timed and alone:
             pc = lambda q: timed[min(len(timed) - 1, int(q * len(timed)))]
-            lines.append(f"association launches in the kernel trace by phase: timed region ({len(timed)} launches, 8 pairs in flight) avg {sum(timed)/len(timed):.1f} us"
+            lines.append(f"association launches in the kernel trace by phase: timed region ({len(timed)} launches of {k} contexts each, 8 pairs in flight) avg {sum(timed)/len(timed):.1f} us"
                          f" (p10 {pc(.1):.1f} / p50 {pc(.5):.1f} / p90 {pc(.9):.1f}); single-pair leg ({len(alone)} launches) avg {sum(alone)/len(alone):.1f} us")
             lines.append(f"  bench line, same run: timed region {d['roofline']['avg_launch_us']:.1f} us (HIP events of hipExtLaunchKernelGGL: the start event is a marker ahead of the"
                          f" kernel, so the bracket adds the command processor's hand-over between the two packets: ~15 us with 4+ busy queues, ~11 us under the"
