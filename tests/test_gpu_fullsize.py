@@ -243,3 +243,26 @@ def test_register_batch_equals_separate_uploads_and_batch(hip_lib):
         api.register_batch(b, [(d["tgt_xyz"], bad_off)] * n, None, x0s)
     for c in a + b:
         c.close()
+
+
+def test_batch_of_unequal_scans_equals_single_calls(hip_lib):
+    """One lock-step batch over scans of different sizes (the merged association launch takes its grid from the largest, the sweeps
+    from the largest block count) and five contexts (launches of 4 + 1): every pose, table and iteration count as in single calls."""
+    shapes = [(16, 300), (64, 700), (8, 200), (32, 400), (48, 512)]
+    data = [synth.scan_pair(n_beams=b, n_azimuth=a) for b, a in shapes]
+    single, batch = [], []
+    for d in data:
+        c = api.Context(0, icp_skip=1)
+        c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])
+        x, T, S = c.frame_to_frame(d["x0"])
+        single.append((x, [S.solves[k].lm_iterations for k in range(S.n_solves)], S.solves[S.n_solves - 1].n_icp_valid))
+        c.close()
+        batch.append(api.Context(0, icp_skip=1))
+    xs, Ts, Ss = api.register_batch(batch, [(d["tgt_xyz"], d["tgt_off"]) for d in data], [(d["src_xyz"], d["src_off"]) for d in data],
+                                    [d["x0"] for d in data])
+    for i, (x, its, nv) in enumerate(single):
+        assert np.array_equal(xs[i], x), i
+        assert [Ss[i].solves[k].lm_iterations for k in range(Ss[i].n_solves)] == its
+        assert Ss[i].solves[Ss[i].n_solves - 1].n_icp_valid == nv
+    for c in batch:
+        c.close()
