@@ -399,3 +399,13 @@ def test_functor_batch_matches_oracle_autodiff(hip_lib):
     with pytest.raises(api.VeloError):
         c.evaluate_functors([5], np.zeros((1, 9)), np.zeros(6))
     c.close()
+
+
+def test_randomized_parity_sweep(hip_lib, oracle):
+    """A dozen seeds of tools/fuzz_parity.py: random clumpy geometries (tables at moving poses through warm rounds) and small street
+    pairs registered singly and in lock-step batches, everything against the oracle (the full sweep: 300 seeds, tools/README.md)."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.run(12, first_seed=500) > 150

@@ -24,41 +24,46 @@ def clumpy(rng):
     src = (centres[rng.integers(0, len(centres), soff[-1])] + rng.normal(0, 0.5, (soff[-1], 3))).astype(np.float32)
     return tgt, off, src, soff
 
-n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-checked = 0
-for seed in range(n_seeds):
-    rng = np.random.default_rng(1000 + seed)
-    tgt, off, src, soff = clumpy(rng)
-    c = api.Context(0, icp_skip=1); o = O.Oracle(icp_skip=1)
-    for obj in (c, o):
-        obj.set_target(tgt, off); obj.set_source(src, soff)
-    base = rng.normal(0, 0.05, 6)
-    for it in (1, 2, 1, 2):
-        for k in range(3):
-            x = base + rng.normal(0, 10.0 ** -rng.integers(1, 5), 6)
-            assert c.associate(x, it) == o.associate(x, it), ("n_valid", seed, it, k)
-            H.assert_corr_equal(c.correspondences(), o.correspondences())
-            checked += 1
-    c.close()
-    # whole registrations: a small street pair with random motion guess, single and lock-step batch of 3-6 contexts
-    nb, na = int(rng.choice([8, 16, 24, 32])), int(rng.integers(100, 500))
-    d = synth.scan_pair(n_beams=nb, n_azimuth=na)
-    n = int(rng.integers(3, 7))
-    x0s = np.tile(d["x0"], (n, 1)) + rng.normal(0, 2e-3, (n, 6))
-    ctxs = [api.Context(0, icp_skip=int(rng.choice([1, 1, 2, 5]))) for _ in range(1)]
-    skip = ctxs[0].get_params().icp_skip
-    ctxs += [api.Context(0, icp_skip=skip) for _ in range(n - 1)]
-    xs, Ts, Ss = api.register_batch(ctxs, [(d["tgt_xyz"], d["tgt_off"])] * n, [(d["src_xyz"], d["src_off"])] * n, x0s)
-    for i in range(n):
-        oo = O.Oracle(icp_skip=skip, threads=8)
-        oo.set_target(d["tgt_xyz"], d["tgt_off"]); oo.set_source(d["src_xyz"], d["src_off"])
-        xo, To, So = oo.frame_to_frame(x0s[i])
-        assert H.pose_close(xs[i], xo), ("pose", seed, i, xs[i], xo)
-        a = [(Ss[i].solves[k].termination, Ss[i].solves[k].lm_iterations, Ss[i].solves[k].n_icp_valid) for k in range(Ss[i].n_solves)]
-        b = [(So.solves[k].termination, So.solves[k].lm_iterations, So.solves[k].n_icp_valid) for k in range(So.n_solves)]
-        assert a == b, ("solve summaries", seed, i, a, b)
-        xsingle, _, _ = ctxs[i].frame_to_frame(x0s[i])
-        assert np.array_equal(xsingle, xs[i]), ("single vs batch", seed, i)
-        checked += 1
-    for cc in ctxs: cc.close()
-print("fuzz parity: %d seeds, %d comparisons, all equal" % (n_seeds, checked))
+def run(n_seeds, first_seed=0):
+  checked = 0
+  for seed in range(first_seed, first_seed + n_seeds):
+      rng = np.random.default_rng(1000 + seed)
+      tgt, off, src, soff = clumpy(rng)
+      c = api.Context(0, icp_skip=1); o = O.Oracle(icp_skip=1)
+      for obj in (c, o):
+          obj.set_target(tgt, off); obj.set_source(src, soff)
+      base = rng.normal(0, 0.05, 6)
+      for it in (1, 2, 1, 2):
+          for k in range(3):
+              x = base + rng.normal(0, 10.0 ** -rng.integers(1, 5), 6)
+              assert c.associate(x, it) == o.associate(x, it), ("n_valid", seed, it, k)
+              H.assert_corr_equal(c.correspondences(), o.correspondences())
+              checked += 1
+      c.close()
+      # whole registrations: a small street pair with random motion guess, single and lock-step batch of 3-6 contexts
+      nb, na = int(rng.choice([8, 16, 24, 32])), int(rng.integers(100, 500))
+      d = synth.scan_pair(n_beams=nb, n_azimuth=na)
+      n = int(rng.integers(3, 7))
+      x0s = np.tile(d["x0"], (n, 1)) + rng.normal(0, 2e-3, (n, 6))
+      ctxs = [api.Context(0, icp_skip=int(rng.choice([1, 1, 2, 5]))) for _ in range(1)]
+      skip = ctxs[0].get_params().icp_skip
+      ctxs += [api.Context(0, icp_skip=skip) for _ in range(n - 1)]
+      xs, Ts, Ss = api.register_batch(ctxs, [(d["tgt_xyz"], d["tgt_off"])] * n, [(d["src_xyz"], d["src_off"])] * n, x0s)
+      for i in range(n):
+          oo = O.Oracle(icp_skip=skip, threads=8)
+          oo.set_target(d["tgt_xyz"], d["tgt_off"]); oo.set_source(d["src_xyz"], d["src_off"])
+          xo, To, So = oo.frame_to_frame(x0s[i])
+          assert H.pose_close(xs[i], xo), ("pose", seed, i, xs[i], xo)
+          a = [(Ss[i].solves[k].termination, Ss[i].solves[k].lm_iterations, Ss[i].solves[k].n_icp_valid) for k in range(Ss[i].n_solves)]
+          b = [(So.solves[k].termination, So.solves[k].lm_iterations, So.solves[k].n_icp_valid) for k in range(So.n_solves)]
+          assert a == b, ("solve summaries", seed, i, a, b)
+          xsingle, _, _ = ctxs[i].frame_to_frame(x0s[i])
+          assert np.array_equal(xsingle, xs[i]), ("single vs batch", seed, i)
+          checked += 1
+      for cc in ctxs: cc.close()
+  return checked
+
+
+if __name__ == "__main__":
+    n_seeds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    print("fuzz parity: %d seeds, %d comparisons, all equal" % (n_seeds, run(n_seeds)))
