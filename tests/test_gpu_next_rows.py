@@ -491,3 +491,13 @@ def test_odometry_over_a_directory_of_kitti_sweeps(hip_lib, tmp_path):
     lines = (tmp_path / "poses.txt").read_text().splitlines()
     assert len(lines) == 4 and lines[1] == odometry.kitti_pose_line(ref.poses[1]).rstrip("\n")
     odo.close(); ref.close()
+
+
+@pytest.mark.gpu
+def test_randomized_next_rows_sweep(hip_lib):
+    """Eight seeds of tools/fuzz_next_rows.py: projection, keypoint depth and triangulation on random sizes, bit for bit vs the oracle."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_next_rows", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_next_rows.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.run(8, first_seed=900) == 40
