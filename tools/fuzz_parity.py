@@ -48,14 +48,19 @@ def run(n_seeds, first_seed=0):
       ctxs = [api.Context(0, icp_skip=int(rng.choice([1, 1, 2, 5]))) for _ in range(1)]
       skip = ctxs[0].get_params().icp_skip
       ctxs += [api.Context(0, icp_skip=skip) for _ in range(n - 1)]
+      vis = None
+      if rng.random() < 0.5:                                    # stereo blocks of all four kinds on half of the seeds
+          vis = api.matches_from_dict(synth.stereo_matches(int(rng.integers(5, 200)), seed=int(rng.integers(1, 10 ** 6)), mix="all"))
+          for cc in ctxs: cc.set_visual(vis)
       xs, Ts, Ss = api.register_batch(ctxs, [(d["tgt_xyz"], d["tgt_off"])] * n, [(d["src_xyz"], d["src_off"])] * n, x0s)
       for i in range(n):
           oo = O.Oracle(icp_skip=skip, threads=8)
           oo.set_target(d["tgt_xyz"], d["tgt_off"]); oo.set_source(d["src_xyz"], d["src_off"])
+          if vis is not None: oo.set_visual(vis)
           xo, To, So = oo.frame_to_frame(x0s[i])
           assert H.pose_close(xs[i], xo), ("pose", seed, i, xs[i], xo)
-          a = [(Ss[i].solves[k].termination, Ss[i].solves[k].lm_iterations, Ss[i].solves[k].n_icp_valid) for k in range(Ss[i].n_solves)]
-          b = [(So.solves[k].termination, So.solves[k].lm_iterations, So.solves[k].n_icp_valid) for k in range(So.n_solves)]
+          a = [(Ss[i].solves[k].termination, Ss[i].solves[k].lm_iterations, Ss[i].solves[k].n_icp_valid, Ss[i].solves[k].n_visual_blocks) for k in range(Ss[i].n_solves)]
+          b = [(So.solves[k].termination, So.solves[k].lm_iterations, So.solves[k].n_icp_valid, So.solves[k].n_visual_blocks) for k in range(So.n_solves)]
           assert a == b, ("solve summaries", seed, i, a, b)
           xsingle, _, _ = ctxs[i].frame_to_frame(x0s[i])
           assert np.array_equal(xsingle, xs[i]), ("single vs batch", seed, i)
