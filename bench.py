@@ -170,7 +170,7 @@ def main():
         results[i] = ctxs[i].frame_to_frame(d["x0"])
 
     pool = ThreadPoolExecutor(max_workers=B) if B > 1 else None
-    batch_refs = (api.scan_refs([(tgt, tgt_off)] * B), api.scan_refs([(src, d["src_off"])] * B)) if B > 1 else None
+    batch_refs = (api.scan_refs([(tgt, tgt_off)] * B, local_rank), api.scan_refs([(src, d["src_off"])] * B, local_rank)) if B > 1 else None
     x0s = np.tile(np.asarray(d["x0"], dtype=np.float64), (B, 1))
 
     def step():

@@ -199,7 +199,11 @@ int velo_set_timing(velo_ctx* ctx, int enable);
  * KdTreeFLANN::setInputCloud of ScanData (lru.h:17-20): the spatial index is built on the device here.
  * xyz: first float of point 0; stride_bytes between points (12 packed, 16 for pcl::PointXYZ);
  * ring_offsets[n_rings+1]: ring r = points [ring_offsets[r], ring_offsets[r+1]), each ring an ordered cyclic
- * polyline (kitti.h:158-183).  on_device != 0: xyz is already a device pointer (stays caller-owned, copied). */
+ * polyline (kitti.h:158-183).  on_device != 0: xyz is already a device pointer (stays caller-owned, copied).
+ * Device pointers (every entry point with an on_device flag, velo_scan_ref included): the memory must be on the context's
+ * device, float32, the three coordinates of a point contiguous, and COMPLETE before the call -- the library reads it on the
+ * context's own non-blocking stream, which is not ordered against the stream that produced the data: synchronise that
+ * stream (or wait for its event) first, and do not overwrite the buffer until the call has returned. */
 int velo_set_target(velo_ctx* ctx, const float* xyz, int64_t stride_bytes, const int32_t* ring_offsets,
                     int32_t n_rings, int on_device);
 /* Target-sharded variant: this context holds only `n_rings` WHOLE rings of the target (keeps the +-1 ring neighbour of

@@ -89,4 +89,11 @@ def test_shard_ranges_tile_the_query_list():
             assert max(b - a for a, b in edges) - min(b - a for a, b in edges) <= 1
     blk = shard.pack_normal_equations(2.5, np.arange(36.0).reshape(6, 6) + np.arange(36.0).reshape(6, 6).T, np.arange(6.0))
     c, Hm, g = shard.unpack_normal_equations(blk)
-    assert c == 2.5 and np.array_equal(g, np.arange(6.0)) and np.array_equal(Hm, Hm.T) and Hm[1, 3] == blk[1 * 6 - 0 + (3 - 1) - 1 + 0] or True
+    assert c == 2.5 and np.array_equal(g, np.arange(6.0)) and np.array_equal(Hm, Hm.T)
+    # wire layout = the device's: 21 upper-triangular entries row by row (tri(i, j) = 6 i - i (i - 1) / 2 + (j - i)), 6 x J^T r, cost
+    tri = lambda i, j: i * 6 - (i * (i - 1)) // 2 + (j - i)   # noqa: E731
+    Hfull = np.arange(36.0).reshape(6, 6) + np.arange(36.0).reshape(6, 6).T
+    for i in range(6):
+        for j in range(i, 6):
+            assert blk[tri(i, j)] == Hfull[i, j] == Hm[i, j] == Hm[j, i]
+    assert np.array_equal(blk[21:27], np.arange(6.0)) and blk[27] == 2.5 and len(blk) == 28

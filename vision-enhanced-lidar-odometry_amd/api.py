@@ -233,6 +233,7 @@ class Context:
     def __init__(self, device: int = 0, **params):
         self._lib = load_library()
         self._h = _ctx()
+        self._device = int(device)
         self._check(self._lib.velo_create(C.byref(self._h), int(device)))
         if params:
             self.set_params(**params)
@@ -277,24 +278,48 @@ class Context:
 
     # -- inputs ----------------------------------------------------------------------------------------
     @staticmethod
-    def _cloud_args(xyz, ring_offsets):
+    def _device_tensor_args(t, device, cols=(3, 4), what="xyz"):
+        """A torch tensor handed over as a device pointer (on_device = 1): checked here because the library only sees an address.
+        The library reads it on the context's own stream, so everything torch has queued that produces the tensor must be
+        complete first (include/velo_hip.h, "device pointers"): the producing torch stream is synchronised before the call."""
+        import torch
+        if not t.is_cuda:
+            raise ValueError(f"{what}: a torch tensor must live on the GPU (pass a numpy array for host data)")
+        if t.dtype != torch.float32:
+            raise ValueError(f"{what}: device tensor must be float32, got {t.dtype}")
+        if t.dim() != 2 or t.shape[1] not in cols:
+            raise ValueError(f"{what}: device tensor must be (n, {' or '.join(str(c) for c in cols)}), got {tuple(t.shape)}")
+        if t.shape[0] > 1 and (t.stride(1) != 1 or t.stride(0) < 3):
+            raise ValueError(f"{what}: the coordinates of a point must be contiguous (stride(1) == 1), got strides {t.stride()}")
+        if device is not None and t.device.index != int(device):
+            raise ValueError(f"{what}: tensor is on cuda:{t.device.index}, the context on device {int(device)}")
+        torch.cuda.current_stream(t.device).synchronize()
+        stride = (t.stride(0) if t.shape[0] > 1 else t.shape[1]) * t.element_size()
+        return C.c_void_p(t.data_ptr()), stride
+
+    @staticmethod
+    def _cloud_args(xyz, ring_offsets, device=None):
         off = np.ascontiguousarray(np.asarray(ring_offsets, dtype=np.int32))
         if hasattr(xyz, "data_ptr"):   # a torch tensor on the GPU: (n,3) or (n,4) float32, row stride in bytes
-            stride = xyz.stride(0) * xyz.element_size()
-            return C.c_void_p(xyz.data_ptr()), stride, off, 1, xyz
+            ptr, stride = Context._device_tensor_args(xyz, device)
+            if len(off) and int(off[-1]) > xyz.shape[0]:
+                raise ValueError(f"ring_offsets end at {int(off[-1])} but the tensor holds {xyz.shape[0]} points")
+            return ptr, stride, off, 1, xyz
         a = np.asarray(xyz, dtype=np.float32)
         if a.ndim != 2 or a.shape[1] not in (3, 4):
             raise ValueError("xyz must be (n,3) or (n,4) float32")
         a = np.ascontiguousarray(a)
+        if len(off) and int(off[-1]) > a.shape[0]:
+            raise ValueError(f"ring_offsets end at {int(off[-1])} but the array holds {a.shape[0]} points")
         return C.c_void_p(a.ctypes.data), a.strides[0], off, 0, a
 
     def set_target(self, xyz, ring_offsets):
-        ptr, stride, off, dev, keep = self._cloud_args(xyz, ring_offsets)
+        ptr, stride, off, dev, keep = self._cloud_args(xyz, ring_offsets, self._device)
         self._check(self._lib.velo_set_target(self._h, ptr, stride, C.c_void_p(off.ctypes.data), len(off) - 1, dev))
 
     def set_target_part(self, xyz, ring_offsets, first_ring: int, first_point: int):
         """Target-sharded mode: this context holds only a block of whole rings (local offsets, [0] == 0)."""
-        ptr, stride, off, dev, keep = self._cloud_args(xyz, ring_offsets)
+        ptr, stride, off, dev, keep = self._cloud_args(xyz, ring_offsets, self._device)
         self._check(self._lib.velo_set_target_part(self._h, ptr, stride, C.c_void_p(off.ctypes.data), len(off) - 1,
                                                    int(first_ring), int(first_point), dev))
 
@@ -321,14 +346,14 @@ class Context:
         self._check(self._lib.velo_comm_set_target_sharded(self._h, int(bool(enable))))
 
     def set_source(self, xyz, ring_offsets):
-        ptr, stride, off, dev, keep = self._cloud_args(xyz, ring_offsets)
+        ptr, stride, off, dev, keep = self._cloud_args(xyz, ring_offsets, self._device)
         self._check(self._lib.velo_set_source(self._h, ptr, stride, C.c_void_p(off.ctypes.data), len(off) - 1, dev))
 
     def set_scan_velodyne(self, as_target: bool, records, velo_to_cam):
         """Raw Velodyne records (n,4) float32 in file order (or a torch tensor on the GPU) -> rings on the device."""
         M = np.ascontiguousarray(np.asarray(velo_to_cam, dtype=np.float32).reshape(4, 4))
         if hasattr(records, "data_ptr"):
-            ptr, stride, n, dev = C.c_void_p(records.data_ptr()), records.stride(0) * records.element_size(), records.shape[0], 1
+            (ptr, stride), n, dev = self._device_tensor_args(records, self._device, cols=(3, 4), what="records"), records.shape[0], 1
         else:
             a = np.ascontiguousarray(np.asarray(records, dtype=np.float32))
             ptr, stride, n, dev = C.c_void_p(a.ctypes.data), a.strides[0], a.shape[0], 0
@@ -571,14 +596,15 @@ def frame_to_frame_batch(ctxs, x0s):
     return x, T.reshape(n, 4, 4), list(S)
 
 
-def scan_refs(scans):
+def scan_refs(scans, device=None):
     """[(xyz, ring_offsets), ...] -> (velo_scan_ref array, objects to keep alive while it is in use).  xyz: numpy (n,3|4) float32 or a
-    torch tensor on the GPU, as for Context.set_target."""
+    torch tensor on the GPU, as for Context.set_target (device: the contexts' device, checked against the tensors').  Device tensors
+    must not be written by torch between this call and the registration that uses the descriptors."""
     n = len(scans)
     arr = (VeloScanRef * n)()
     keep = []
     for i, (xyz, off) in enumerate(scans):
-        ptr, stride, off_a, dev, k = Context._cloud_args(xyz, off)
+        ptr, stride, off_a, dev, k = Context._cloud_args(xyz, off, device)
         arr[i].xyz = ptr.value
         arr[i].stride_bytes = stride
         arr[i].ring_offsets = off_a.ctypes.data
@@ -596,8 +622,9 @@ def register_batch(ctxs, targets, sources, x0s, refs=None):
     n = len(ctxs)
     arr = (_ctx * n)(*[c.handle for c in ctxs])
     if refs is None:
-        tr = scan_refs(targets) if targets is not None else (None, None)
-        sr = scan_refs(sources) if sources is not None else (None, None)
+        dev = ctxs[0]._device if n else None
+        tr = scan_refs(targets, dev) if targets is not None else (None, None)
+        sr = scan_refs(sources, dev) if sources is not None else (None, None)
     else:
         tr, sr = refs
     x = np.ascontiguousarray(np.asarray(x0s, dtype=np.float64).reshape(n, 6)).copy()
