@@ -13,33 +13,33 @@ XS = [[0.0, 0.0, 0.0, 0.0, 0.0, 1.0],
       [-0.0020959990910373962, -0.019976930496238523, 0.0021406826256700853, -0.025498945008825564, -0.010253558573431909, 0.9985500856943826]]
 ITER = [1, 1, 1, 2, 2, 2]
 
+
 if len(sys.argv) > 1 and sys.argv[1] == "child":
-    n = int(sys.argv[2])
     import velo_amd
     from velo_amd import api, synth
     d = synth.scan_pair()
     c = api.Context(0, icp_skip=1)
     c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])
-    for k in range(n):
-        c.associate(XS[k], ITER[k])
+    for rep in range(2):                       # second pass = steady state (buffers allocated); seeds reset by the new source
+        if rep: c.set_source(d["src_xyz"], d["src_off"])
+        for k in range(6):
+            c.associate(XS[k], ITER[k])
+            if os.environ.get("VELO_DEBUG_SKIP") == "32":
+                c.close(); c = api.Context(0, icp_skip=1)      # the per-workgroup times are printed when the context goes
+                c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])
+                for j in range(k + 1):
+                    c.associate(XS[j], ITER[j])
     c.close()
     sys.exit(0)
 
+from velo_amd import build
+lib = build.build_hip(diagnostics=True)
 names = ["setup", "cluster", "runlist", "stage", "sweep", "sweepbar", "merge", "finish"]
-for dbg in (8, 32):
-    prev = [0] * 8
-    for n in range(1, 7):
-        env = dict(os.environ, VELO_DEBUG_SKIP=str(dbg), VELO_ASSOC_VARIANT="5")
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "child", str(n)], env=env, capture_output=True, text=True).stderr
-        if dbg == 8:
-            m = re.search(r"wave-0 cycles: (.*)", out)
-            vals = [int(v) for v in re.findall(r"\d+", m.group(1))] if m else [0] * 8
-            # the stamp list starts with "wave-0"'s zero: drop it
-            vals = vals[-8:]
-            diff = [a - b for a, b in zip(vals, prev)]
-            prev = vals
-            groups = 1875
-            print(f"round {n} (iter {ITER[n-1]}): cycles per group: " + " ".join(f"{nm} {v / groups:.0f}" for nm, v in zip(names, diff)) + f" | total {sum(diff) / groups:.0f}", flush=True)
-        else:
-            m = re.search(r"last assoc launch: (.*)", out)
-            print(f"round {n}: {m.group(1) if m else out[-300:]}", flush=True)
+env = dict(os.environ, VELO_DEBUG_SKIP="8", VELO_DEBUG_EACH="1", VELO_ASSOC_VARIANT="5", VELO_LIB_PATH=lib)
+out = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=env, capture_output=True, text=True).stderr
+rows = re.findall(r"\[velo dbg launch\] groups (\d+) iter (\d+): (.*)", out)
+for k, (g, it, vals) in enumerate(rows[6:]):
+    v = [int(x) for x in vals.split()]
+    print(f"round {k + 1} (iter {it}): wave-0 cycles per group: " + " ".join(f"{nm} {x / int(g):.0f}" for nm, x in zip(names, v)) + f" | total {sum(v) / int(g):.0f}", flush=True)
+if not rows:
+    print(out[-2000:])

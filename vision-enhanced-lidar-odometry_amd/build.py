@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libvelo_hip.so")
+LIB_DIAG = os.path.join(CSRC, "libvelo_hip_diag.so")     # the tools' build: -DVELO_DIAGNOSTICS (stamps, counters, VELO_DEBUG_SKIP)
 SOURCES = ["velo_hip.hip"]
 HEADERS = ["velo_kernels.h", "velo_depth_kernels.h", "velo_tri_kernels.h", "velo_device_math.h", os.path.join(ROOT, "include", "velo_hip.h")]
 
@@ -24,6 +25,8 @@ HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
     # the association compares float distances bit-for-bit with the CPU restatement: no FMA contraction anywhere
     "-ffp-contract=off", "-fno-fast-math",
+    # the SLP vectoriser re-packs the plain f32 candidate sweep into v_pk_* instructions and costs 7 more VGPRs (measured: slower)
+    "-fno-slp-vectorize",
     "-Wall", "-Wno-unused-function", "-Wno-unused-result",
 ]
 
@@ -39,19 +42,24 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_hip(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+def build_hip(force: bool = False, verbose: bool = False, extra_flags=(), diagnostics: bool = False) -> str:
+    """The product library; diagnostics=True builds the tools' variant next to it (same source, -DVELO_DIAGNOSTICS: the
+    VELO_DEBUG_SKIP hooks exist only there, so a leaked environment variable cannot corrupt a product registration)."""
     hipcc = shutil.which("hipcc") or os.path.join(_rocm(), "bin", "hipcc")
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    if not force and not _stale(LIB, deps):
-        return LIB
+    out = LIB_DIAG if diagnostics else LIB
+    if diagnostics:
+        extra_flags = (*extra_flags, "-DVELO_DIAGNOSTICS")
+    if not force and not _stale(out, deps):
+        return out
     cmd = [hipcc, *HIPCC_FLAGS, *extra_flags, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(_rocm(), "include"),
-           *srcs, "-o", LIB, "-L", os.path.join(_rocm(), "lib"), "-lrccl", "-lpthread",
+           *srcs, "-o", out, "-L", os.path.join(_rocm(), "lib"), "-lrccl", "-lpthread",
            f"-Wl,-rpath,{os.path.join(_rocm(), 'lib')}"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
-    return LIB
+    return out
 
 
 def build_all(force: bool = False, verbose: bool = False):
@@ -59,4 +67,4 @@ def build_all(force: bool = False, verbose: bool = False):
 
 
 if __name__ == "__main__":
-    print(build_all(force="--force" in sys.argv, verbose=True))
+    print(build_hip(force="--force" in sys.argv, verbose=True, diagnostics="--diag" in sys.argv))

@@ -144,6 +144,7 @@ struct velo_ctx {
     int n_tgt = 0, n_tgt_rings = 0;
     int tgt_first_ring = 0, tgt_first_point = 0;   // target-sharded mode: global ids of the first local ring / point
     DevBuf<float4> tgt;
+    DevBuf<float4> tgt_pad;              // ring-major copy with a wrap-around sentinel on either side of every ring (pad_rings_kernel)
     DevBuf<int> tgt_off, tgt_ring_of, tgt_cell_of;
     std::vector<int> h_tgt_off;
     std::vector<Grid> grids;             // one per distinct gate among iter = 1..f2f_iterations
@@ -160,8 +161,11 @@ struct velo_ctx {
     DevBuf<int> src_off, q_off, q_src;
     std::vector<int> h_src_off, h_q_off;
     int src_skip = 0;                    // icp_skip the query list was built with
-    DevBuf<int4> prev_pair;              // tube kernel warm start: last round's winners per query (-1 = none); reset with every new source / target
-    bool prev_ready = false;             // prev_pair holds n_q initialised entries for the current source and target
+    DevBuf<float4> qpts_buf;             // query points by query index when icp_skip > 1 (with icp_skip == 1 the source cloud is the list)
+    const float4* qpts = nullptr;
+    DevBuf<float4> prev_a, prev_b;       // tube kernel warm start: last round's winners per query with their coordinates (index -1 = none),
+    DevBuf<int2> prev_r;                 // and their rings; reset with every new source / target
+    bool prev_ready = false;             // the seed arrays hold n_q initialised entries for the current source and target
     int warm_start = 1;                  // VELO_WARM_START=0 turns the seeds off (A/B; results are identical either way)
     int small_solve = 1;                 // VELO_SMALL_SOLVE=0: small problems go through the launch-per-iteration path too (A/B, identical results)
     int asker_rows = -1;                 // tube kernel (VELO_ASKER_ROWS): phase 2 goes query by query when the asking queries' boxes have more
@@ -205,6 +209,8 @@ struct velo_ctx {
     DevBuf<LMState> state;
     DevBuf<double> partials, reduced, xdev;
     DevBuf<int> ticket;
+    DevBuf<unsigned long long> lm_trace;  // diagnostics build, VELO_LM_TRACE=1: stage stamps of the LM chain (tools/lm_trace.py)
+    bool lm_trace_on = false;
     // captured LM chunks (single GPU): key = iterations per chunk; rebuilt when anything baked into the nodes changes
     hipGraphExec_t chunk_graph[2] = {nullptr, nullptr};
     int chunk_graph_iters[2] = {0, 0};
@@ -381,6 +387,13 @@ int build_query_list(velo_ctx* c) {
         HIP_TRY(hipGetLastError());
     }
     const size_t nq = (size_t)std::max(c->n_q, 1);
+    if (skip == 1) c->qpts = c->src.p;                                    // q_src[i] == i
+    else {
+        VELO_TRY(c->qpts_buf.reserve(nq));
+        if (c->n_q > 0) hipLaunchKernelGGL(gather_queries_kernel, dim3(cdiv(c->n_q, 256)), dim3(256), 0, c->stream, (const float4*)c->src.p, (const int*)c->q_src.p, c->n_q, c->qpts_buf.p);
+        HIP_TRY(hipGetLastError());
+        c->qpts = c->qpts_buf.p;
+    }
     VELO_TRY(c->cp.reserve(nq)); VELO_TRY(c->cn.reserve(nq)); VELO_TRY(c->cv0.reserve(nq));
     VELO_TRY(c->aux0.reserve(nq)); VELO_TRY(c->aux1.reserve(nq));
     c->have_corr = false;
@@ -476,6 +489,7 @@ EvalArgs eval_args(velo_ctx* c, const double* x_override) {
     A.loss_a_3dpd = c->P.loss_thresh_3DPD; A.w_3dpd = c->P.weight_3DPD;
     A.V = visual_params(c->P);
     A.partials = c->partials.p;
+    A.trace = c->lm_trace_on ? c->lm_trace.p : nullptr;
     return A;
 }
 
@@ -497,12 +511,27 @@ void launch_eval(velo_ctx* c, EvalArgs A, const EvalPlan& E) {
     }
 }
 
+// warm-start seeds of the tube kernel: cleared (index -1) on the first round after a new source or target
+int attach_seeds(velo_ctx* c, AssocOut* out) {
+    out->prev_a = nullptr; out->prev_b = nullptr; out->prev_r = nullptr;
+    if (!c->warm_start) return VELO_OK;
+    const size_t nq = (size_t)std::max(c->n_q, 1);
+    if (!c->prev_ready) {
+        VELO_TRY(c->prev_a.reserve(nq)); VELO_TRY(c->prev_b.reserve(nq)); VELO_TRY(c->prev_r.reserve(nq));
+        HIP_TRY(hipMemsetAsync(c->prev_a.p, 0xff, sizeof(float4) * nq, c->stream));
+        HIP_TRY(hipMemsetAsync(c->prev_b.p, 0xff, sizeof(float4) * nq, c->stream));
+        c->prev_ready = true;
+    }
+    out->prev_a = c->prev_a.p; out->prev_b = c->prev_b.p; out->prev_r = c->prev_r.p;
+    return VELO_OK;
+}
+
 int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool wait, int* n_valid, bool partial = false) {
     if (!c->have_target || !c->have_source) return fail(VELO_ERR_STATE, "associate needs set_target and set_source first");
     if (iter < 1) return fail(VELO_ERR_INVALID, "iter must be >= 1");
     if (c->src_skip != std::max(c->P.icp_skip, 1) || (c->n_q > 0) != (c->P.enable_icp != 0 && c->h_q_off[c->n_src_rings] > 0)) VELO_TRY(build_query_list(c));
     Grid* G = grid_for_iter(c, iter);
-    if (!G) return VELO_ERR_HIP;
+    if (!G) return fail(VELO_ERR_STATE, "the target's search index has not been built");
     int qb, qe;
     q_range(c, &qb, &qe);
     if (partial) { qb = 0; qe = c->n_q; VELO_TRY(c->partials_rec.reserve((size_t)std::max(c->n_q, 1))); }   // every query against the local rings
@@ -515,15 +544,8 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         AssocOut out;
         out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p + c->nv_idx; out.dbg = c->dbg.p; out.wg_times = nullptr;
         out.first_ring = c->tgt_first_ring; out.first_point = c->tgt_first_point; out.partial = partial ? c->partials_rec.p : nullptr;
-        out.prev = nullptr; out.n_valid_next = nullptr;
-        if (c->warm_start) {
-            if (!c->prev_ready) {                                     // first round after a new source or target: no seeds yet
-                VELO_TRY(c->prev_pair.reserve((size_t)std::max(c->n_q, 1)));
-                HIP_TRY(hipMemsetAsync(c->prev_pair.p, 0xff, sizeof(int4) * (size_t)std::max(c->n_q, 1), c->stream));
-                c->prev_ready = true;
-            }
-            out.prev = c->prev_pair.p;
-        }
+        out.n_valid_next = nullptr;
+        VELO_TRY(attach_seeds(c, &out));
         if (c->debug_skip & 32) { VELO_TRY(c->wg_times.reserve((size_t)2 * cdiv(qe - qb, 64) + 2)); out.wg_times = c->wg_times.p; c->wg_times_n = cdiv(qe - qb, 64); }
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
         if (c->timing) {
@@ -552,7 +574,11 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         hipLaunchKernelGGL((assoc_search_v3_kernel<NW, MINW, DBG>), dim3(c->xcd_map ? ((groups + 7) / 8) * 8 : groups), dim3(NW * 64), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe, \
                            c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, cluster_cells, h_safe, out, aux, c->debug_skip, c->xcd_map)
         // the diagnostic hooks (VELO_DEBUG_SKIP != 0) live in a separate instantiation: compiled in, they spill registers
+#ifdef VELO_DIAGNOSTICS
 #define VELO_LAUNCH_V2(NW, MINW) do { if (c->debug_skip) VELO_LAUNCH_V3(NW, MINW, true); else VELO_LAUNCH_V3(NW, MINW, false); } while (0)
+#else
+#define VELO_LAUNCH_V2(NW, MINW) VELO_LAUNCH_V3(NW, MINW, false)
+#endif
         // Default = tube kernel (5) with warm start.  120k-pt scans: 69 us per launch averaged over the 6 rounds of a call (box
         // kernel 4: 121 us); 2M-pt map: 535 us vs 1.49 ms -- its cold first round is slower there (density-shrunk grid, gate radius
         // = 15 cells, every query asks for a (2e+1)^2-row box: 1.59 vs 1.45 ms) but the five warm rounds need tiny boxes.
@@ -600,12 +626,15 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 if (c->tube_map >= 0) { VELO_TRY(build_group_perm(c, qb, qe, c->tube_map)); perm = c->group_perm.p; }
 #define VELO_LAUNCH_V5(NW, MINW, DBG, PPT, ASKER)                                                                                         \
                 hipExtLaunchKernelGGL((assoc_search_v5_kernel<NW, MINW, DBG, PPT, ASKER>), dim3(groups), dim3(NW * 64), 0, c->stream,                    \
-                                      ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, S, V, c->src.p, c->q_src.p, qb, qe,                      \
-                                   c->tgt.p, c->tgt_off.p, c->n_tgt, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux, perm, c->debug_skip, asker_rows)
+                                      ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, S, V, c->qpts, qb, qe,                      \
+                                   (const float4*)c->tgt_pad.p, (const int*)c->tgt_off.p, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux, perm, c->debug_skip, asker_rows)
                 // default: 5 waves/SIMD (96 VGPRs, no spills, no scratch traffic), 2 candidate pairs per trip.  Measured on C2:
                 // 62 us; 6 waves + 2 pairs (5 spilled VGPRs) 65; 7 waves + 2 pairs 64; 5 waves + 4 pairs 66; 6 waves + 4 pairs 71
+#ifdef VELO_DIAGNOSTICS
                 if (c->debug_skip) VELO_LAUNCH_V5(4, 5, true, 2, true);
-                else if (variant == 55) VELO_LAUNCH_V5(4, 5, false, 4, true);
+                else
+#endif
+                if (variant == 55) VELO_LAUNCH_V5(4, 5, false, 4, true);
                 else if (variant == 52) VELO_LAUNCH_V5(4, 6, false, 2, true);
                 else if (variant == 59) VELO_LAUNCH_V5(4, 5, false, 2, false);   // phase 2 through the row/tile machinery (A/B)
                 else if (asker_rows >= (1 << 30)) VELO_LAUNCH_V5(4, 5, false, 2, false);   // regular grid: instantiation without the query-by-query code (no spills)
@@ -626,6 +655,15 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
 #undef VELO_LAUNCH_V3
         HIP_TRY(hipGetLastError());
         if (ev && !ext_timed) HIP_TRY(hipEventRecord(ev->second, c->stream));
+#ifdef VELO_DIAGNOSTICS
+        if ((c->debug_skip & 24) && getenv("VELO_DEBUG_EACH")) {       // per-launch read-out (default: totals when the context goes)
+            unsigned long long h[8];
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipMemcpy(h, c->dbg.p, sizeof(h), hipMemcpyDeviceToHost));
+            fprintf(stderr, "[velo dbg launch] groups %d iter %d: %llu %llu %llu %llu %llu %llu %llu %llu\n", groups, iter, h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+            HIP_TRY(hipMemset(c->dbg.p, 0, sizeof(h)));
+        }
+#endif
     }
     if (partial) { c->have_partials = true; c->last_partial_iter = iter; if (wait) HIP_TRY(hipStreamSynchronize(c->stream)); return VELO_OK; }
     c->have_corr = true;
@@ -705,9 +743,9 @@ int enqueue_lm_iteration(velo_ctx* c, const EvalArgs& A, const EvalPlan& E, cons
         // every rank reaches this call the same number of times: `done` is identical on all ranks, and when it is
         // set the kernels above exit early and the buffer keeps its previous (identical) content
         NCCL_TRY(ncclAllReduce(c->reduced.p, c->reduced.p + kNumAcc, kNumAcc, ncclDouble, ncclSum, c->comm, c->stream));
-        hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, (const double*)(c->reduced.p + kNumAcc), 1);
+        hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, (const double*)(c->reduced.p + kNumAcc), 1, A.trace);
     } else {
-        hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, (const double*)c->partials.p, nblocks);
+        hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, (const double*)c->partials.p, nblocks, A.trace);
     }
     HIP_TRY(hipGetLastError());
     return VELO_OK;
@@ -768,6 +806,13 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
         xd = c->xdev.p;
     }
     const int max_iters_all = c->P.max_num_iterations + 1;
+#ifdef VELO_DIAGNOSTICS
+    if (c->lm_trace_on) {
+        std::vector<unsigned long long> init((size_t)kTraceMaxEvals * 16);
+        for (size_t k = 0; k < init.size(); k += 2) { init[k] = ~0ull; init[k + 1] = 0ull; }
+        HIP_TRY(hipMemcpy(c->lm_trace.p, init.data(), init.size() * 8, hipMemcpyHostToDevice));
+    }
+#endif
     if (!c->comm && !c->use_fused && !c->use_graphs && c->small_solve && E.total() >= 1 && E.total() <= kSmallRows) {
         // small problem (the reference's icp_skip = 200): the whole solve in one single-workgroup launch, one status copy
         hipLaunchKernelGGL(lm_solve_small_kernel, dim3(1), dim3(kEvalThreads), 0, c->stream, A, Q, c->state.p, xd,
@@ -791,6 +836,21 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
     }
     }
     const LMState& s = c->h_status->s;
+#ifdef VELO_DIAGNOSTICS
+    if (c->lm_trace_on) {
+        std::vector<unsigned long long> tr((size_t)kTraceMaxEvals * 16);
+        HIP_TRY(hipMemcpy(tr.data(), c->lm_trace.p, tr.size() * 8, hipMemcpyDeviceToHost));
+        const unsigned long long t0 = tr[0];
+        for (int e = 0; e < s.evals && e < kTraceMaxEvals; e++) {
+            fprintf(stderr, "[velo lm trace] eval %2d:", e);
+            for (int st = 0; st < 8; st++) {
+                const unsigned long long a = tr[((size_t)e * 8 + st) * 2], b = tr[((size_t)e * 8 + st) * 2 + 1];
+                if (a == ~0ull) fprintf(stderr, " -"); else fprintf(stderr, " %.2f/%.2f", (double)(a - t0) * 0.01, (double)(b - t0) * 0.01);
+            }
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     for (int k = 0; k < 6; k++) x_out[k] = s.x[k];
     if (S) {
         std::memset(S, 0, sizeof(*S));
@@ -813,6 +873,7 @@ int target_finalize(velo_ctx* c) {
     VELO_TRY(c->tgt_off.reserve((size_t)n_rings + 1));
     VELO_TRY(c->tgt_ring_of.reserve((size_t)std::max(n, 1)));
     VELO_TRY(c->tgt_cell_of.reserve((size_t)std::max(n, 1)));
+    VELO_TRY(c->tgt_pad.reserve((size_t)n + 2 * (size_t)n_rings + 2));
     HIP_TRY(hipMemcpyAsync(c->tgt_off.p, c->h_tgt_off.data(), sizeof(int) * ((size_t)n_rings + 1), hipMemcpyHostToDevice, c->stream));
     // bbox of the finite points -> host (the only sync of set_target; the grid dimensions are sized from it)
     unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
@@ -820,6 +881,8 @@ int target_finalize(velo_ctx* c) {
     HIP_TRY(hipMemcpyAsync(c->bbox_keys.p, c->h_int, sizeof(init), hipMemcpyHostToDevice, c->stream));
     if (n > 0) {
         hipLaunchKernelGGL(ring_of_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->tgt_off.p, n_rings, n, c->tgt_first_ring, c->tgt_ring_of.p);
+        hipLaunchKernelGGL(pad_rings_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const float4*)c->tgt.p, (const int*)c->tgt_off.p, (const int*)c->tgt_ring_of.p, n,
+                           c->tgt_first_ring, c->tgt_pad.p);
         hipLaunchKernelGGL(bbox_kernel, dim3(std::min(cdiv(n, 256 * 8), 256)), dim3(256), 0, c->stream, c->tgt.p, n, c->bbox_keys.p);
         HIP_TRY(hipGetLastError());
     }
@@ -882,39 +945,54 @@ int velo_create(velo_ctx** out, int device) {
         return fail(VELO_ERR_NODEVICE, "device %d is %s; this library carries gfx950 code objects only", device, prop.gcnArchName);
     velo_ctx* c = new velo_ctx();
     c->device = device;
-    default_params(&c->P);
-    for (int k = 0; k < VELO_MAX_SOLVES; k++) c->pred_evals[k] = (k == 0) ? 12 : 5;
-    if (const char* e = getenv("VELO_ASSOC_VARIANT")) c->assoc_variant = atoi(e);
-    if (const char* e = getenv("VELO_CLUSTER_W")) { c->cluster_w = std::max(atoi(e), 0); c->cluster_w_set = true; }
-    if (const char* e = getenv("VELO_TRI_VARIANT")) c->tri_variant = atoi(e);
-    if (const char* e = getenv("VELO_DEBUG_SKIP")) c->debug_skip = atoi(e);
-    if (const char* e = getenv("VELO_GRAPHS")) c->use_graphs = atoi(e) != 0;
-    if (const char* e = getenv("VELO_XCD_MAP")) c->xcd_map = atoi(e);
-    if (const char* e = getenv("VELO_TUBE_MAP")) c->tube_map = atoi(e);
-    if (const char* e = getenv("VELO_WARM_START")) c->warm_start = atoi(e);
-    if (const char* e = getenv("VELO_SMALL_SOLVE")) c->small_solve = atoi(e);
-    if (const char* e = getenv("VELO_ASKER_ROWS")) c->asker_rows = atoi(e);
-    if (const char* e = getenv("VELO_PERSISTENT_WGS")) c->persistent_wgs = std::max(atoi(e), 1);
-    if (const char* e = getenv("VELO_FUSED")) c->use_fused = atoi(e) != 0;
-    if (const char* e = getenv("VELO_BATCH_LOCKSTEP")) c->batch_lockstep = atoi(e);
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipHostMalloc((void**)&c->h_status, sizeof(HostStatus), hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void**)&c->h_x, sizeof(double) * 64, hipHostMallocDefault));
-    HIP_TRY(hipHostMalloc((void**)&c->h_int, sizeof(int) * 16, hipHostMallocDefault));
-    VELO_TRY(c->state.reserve(1));
-    VELO_TRY(c->partials.reserve((size_t)(kMaxEvalBlocks + kMaxVisBlocks) * kNumAcc));
-    VELO_TRY(c->reduced.reserve(2 * kNumAcc));
-    VELO_TRY(c->xdev.reserve(8));
-    VELO_TRY(c->ticket.reserve(1));
-    HIP_TRY(hipMemsetAsync(c->ticket.p, 0, sizeof(int), c->stream));
-    VELO_TRY(c->bbox_keys.reserve(6));
-    VELO_TRY(c->n_valid.reserve(2));
-    VELO_TRY(c->dbg.reserve(8));
-    HIP_TRY(hipMemsetAsync(c->dbg.p, 0, 64, c->stream));
-    HIP_TRY(hipMemsetAsync(c->state.p, 0, sizeof(LMState), c->stream));
-    HIP_TRY(hipEventCreate(&c->ev0));
-    HIP_TRY(hipEventCreate(&c->ev1));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // everything that can fail after the allocation runs inside init, so that a failure releases what was already created
+    // (stream, pinned buffers, events, device buffers) instead of leaking it behind a NULL *out
+    auto init = [&]() -> int {
+        default_params(&c->P);
+        for (int k = 0; k < VELO_MAX_SOLVES; k++) c->pred_evals[k] = (k == 0) ? 12 : 5;
+        if (const char* e = getenv("VELO_ASSOC_VARIANT")) c->assoc_variant = atoi(e);
+        if (const char* e = getenv("VELO_CLUSTER_W")) { c->cluster_w = std::max(atoi(e), 0); c->cluster_w_set = true; }
+        if (const char* e = getenv("VELO_TRI_VARIANT")) c->tri_variant = atoi(e);
+#ifdef VELO_DIAGNOSTICS
+        if (getenv("VELO_LM_TRACE") && atoi(getenv("VELO_LM_TRACE"))) {
+            c->lm_trace_on = true;
+            VELO_TRY(c->lm_trace.reserve((size_t)kTraceMaxEvals * 16));
+        }
+        // the diagnostic instantiations (cycle stamps, counters, sections switched off -- some bits give WRONG results on purpose) exist
+        // only in the tools' build of this file (build.py: libvelo_hip_diag.so); the product library ignores the variable
+        if (const char* e = getenv("VELO_DEBUG_SKIP")) c->debug_skip = atoi(e);
+#endif
+        if (const char* e = getenv("VELO_GRAPHS")) c->use_graphs = atoi(e) != 0;
+        if (const char* e = getenv("VELO_XCD_MAP")) c->xcd_map = atoi(e);
+        if (const char* e = getenv("VELO_TUBE_MAP")) c->tube_map = atoi(e);
+        if (const char* e = getenv("VELO_WARM_START")) c->warm_start = atoi(e);
+        if (const char* e = getenv("VELO_SMALL_SOLVE")) c->small_solve = atoi(e);
+        if (const char* e = getenv("VELO_ASKER_ROWS")) c->asker_rows = atoi(e);
+        if (const char* e = getenv("VELO_PERSISTENT_WGS")) c->persistent_wgs = std::max(atoi(e), 1);
+        if (const char* e = getenv("VELO_FUSED")) c->use_fused = atoi(e) != 0;
+        if (const char* e = getenv("VELO_BATCH_LOCKSTEP")) c->batch_lockstep = atoi(e);
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIP_TRY(hipHostMalloc((void**)&c->h_status, sizeof(HostStatus), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&c->h_x, sizeof(double) * 64, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&c->h_int, sizeof(int) * 16, hipHostMallocDefault));
+        VELO_TRY(c->state.reserve(1));
+        VELO_TRY(c->partials.reserve((size_t)(kMaxEvalBlocks + kMaxVisBlocks) * kNumAcc));
+        VELO_TRY(c->reduced.reserve(2 * kNumAcc));
+        VELO_TRY(c->xdev.reserve(8));
+        VELO_TRY(c->ticket.reserve(1));
+        HIP_TRY(hipMemsetAsync(c->ticket.p, 0, sizeof(int), c->stream));
+        VELO_TRY(c->bbox_keys.reserve(6));
+        VELO_TRY(c->n_valid.reserve(2));
+        VELO_TRY(c->dbg.reserve(8));
+        HIP_TRY(hipMemsetAsync(c->dbg.p, 0, 64, c->stream));
+        HIP_TRY(hipMemsetAsync(c->state.p, 0, sizeof(LMState), c->stream));
+        HIP_TRY(hipEventCreate(&c->ev0));
+        HIP_TRY(hipEventCreate(&c->ev1));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return VELO_OK;
+    };
+    const int st = init();
+    if (st != VELO_OK) { const std::string keep = g_err; velo_destroy(c); g_err = keep; return st; }
     *out = c;
     return VELO_OK;
 }
@@ -1227,6 +1305,11 @@ int velo_cache_load(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t as_t
     VELO_TRY(G.cell_start.reserve(nc)); VELO_TRY(G.sorted.reserve(ns)); VELO_TRY(G.sring.reserve(ns));
     HIP_TRY(hipMemcpyAsync(c->tgt_off.p, c->h_tgt_off.data(), sizeof(int) * ((size_t)e.n_rings + 1), hipMemcpyHostToDevice, c->stream));
     if (e.n > 0) HIP_TRY(hipMemcpyAsync(c->tgt_ring_of.p, e.ring_of.p, sizeof(int) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream));
+    VELO_TRY(c->tgt_pad.reserve((size_t)e.n + 2 * (size_t)e.n_rings + 2));
+    if (e.n > 0) {
+        hipLaunchKernelGGL(pad_rings_kernel, dim3(cdiv(e.n, 256)), dim3(256), 0, c->stream, (const float4*)c->tgt.p, (const int*)c->tgt_off.p, (const int*)c->tgt_ring_of.p, e.n, 0, c->tgt_pad.p);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipMemcpyAsync(G.cell_start.p, e.grid.cell_start.p, sizeof(int) * nc, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(G.sorted.p, e.grid.sorted.p, sizeof(float4) * ns, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(G.sring.p, e.grid.sring.p, sizeof(int) * ns, hipMemcpyDeviceToDevice, c->stream));
@@ -1300,7 +1383,7 @@ static int launch_merge(velo_ctx* c, const PartialRec* tables, int world, int st
     if (qe > qb) {
         AssocOut out;
         out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p + c->nv_idx;
-        out.dbg = c->dbg.p; out.wg_times = nullptr; out.first_ring = c->tgt_first_ring; out.first_point = c->tgt_first_point; out.partial = nullptr; out.prev = nullptr; out.n_valid_next = nullptr;
+        out.dbg = c->dbg.p; out.wg_times = nullptr; out.first_ring = c->tgt_first_ring; out.first_point = c->tgt_first_point; out.partial = nullptr; out.prev_a = nullptr; out.prev_b = nullptr; out.prev_r = nullptr; out.n_valid_next = nullptr;
         const unsigned long long key_inf = ((unsigned long long)gate_bits_of(gate_of_iter(c->P, iter)) + 1ull) << 32;
         hipLaunchKernelGGL(merge_partials_kernel, dim3(cdiv(qe - qb, 256)), dim3(256), 0, c->stream, tables, world, stride, qb, qe,
                            (const float4*)c->src.p, (const int*)c->q_src.p, key_inf, c->P.icp_norm_condition, out, want_aux ? 1 : 0);
@@ -1605,7 +1688,7 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
     if (!c->have_target || !c->have_source) return fail(VELO_ERR_STATE, "associate needs set_target and set_source first");
     if (c->src_skip != std::max(c->P.icp_skip, 1) || (c->n_q > 0) != (c->P.enable_icp != 0 && c->h_q_off[c->n_src_rings] > 0)) VELO_TRY(build_query_list(c));
     Grid* G = grid_for_iter(c, iter);
-    if (!G) return VELO_ERR_HIP;
+    if (!G) return fail(VELO_ERR_STATE, "the target's search index has not been built");
     int qb, qe;
     q_range(c, &qb, &qe);
     VELO_TRY(next_valid_counter(c));
@@ -1613,8 +1696,8 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
     if (qe <= qb) return VELO_OK;
     pose_scalars(x, &A->P);
     A->G.d = G->d; A->G.cell_start = G->cell_start.p; A->G.sorted = G->sorted.p; A->G.sring = G->sring.p;
-    A->src = c->src.p; A->q_src = c->q_src.p; A->q_begin = qb; A->q_end = qe;
-    A->tgt = c->tgt.p; A->tgt_off = c->tgt_off.p; A->n_tgt_local = c->n_tgt;
+    A->qpts = c->qpts; A->q_begin = qb; A->q_end = qe;
+    A->tgt_pad = c->tgt_pad.p; A->tgt_off = c->tgt_off.p;
     const double gate = gate_of_iter(c->P, iter);
     A->gate_bits = gate_bits_of(gate);
     A->norm_cond = c->P.icp_norm_condition;
@@ -1624,15 +1707,7 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
     AssocOut& out = A->out;
     out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p + c->nv_idx; out.dbg = c->dbg.p; out.wg_times = nullptr;
     out.first_ring = c->tgt_first_ring; out.first_point = c->tgt_first_point; out.partial = nullptr;
-    out.prev = nullptr;
-    if (c->warm_start) {
-        if (!c->prev_ready) {
-            VELO_TRY(c->prev_pair.reserve((size_t)std::max(c->n_q, 1)));
-            HIP_TRY(hipMemsetAsync(c->prev_pair.p, 0xff, sizeof(int4) * (size_t)std::max(c->n_q, 1), c->stream));
-            c->prev_ready = true;
-        }
-        out.prev = c->prev_pair.p;
-    }
+    VELO_TRY(attach_seeds(c, &out));
     out.n_valid_next = c->n_valid.p + (c->nv_idx ^ 1);
     c->nv_clean[c->nv_idx ^ 1] = true;
     A->want_aux = 0; A->group_perm = nullptr; A->dbg = 0;

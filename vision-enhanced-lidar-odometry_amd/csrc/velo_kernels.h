@@ -79,6 +79,27 @@ __global__ void ring_of_kernel(const int* __restrict__ off, int n_rings, int n, 
     ring_of[i] = lo + first_ring;
 }
 
+// Ring-major copy of the target with one wrap-around sentinel on either side of every ring:
+//     ring r (n_r points at [off[r], off[r+1])) -> pad[off[r] + 2 r] = its LAST point, then its points, then its FIRST point,
+// so the cyclic ring neighbours (velo.h:852-854) of point i of local ring r are pad[i + 2 r] and pad[i + 2 r + 2], whatever i:
+// the finish of the association reads three adjacent records and needs neither the ring bounds nor a second trip for the wrap.
+__global__ void pad_rings_kernel(const float4* __restrict__ tgt, const int* __restrict__ off, const int* __restrict__ ring_of, int n, int first_ring,
+                                 float4* __restrict__ pad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int r = ring_of[i] - first_ring, base = off[r], end = off[r + 1];
+    const float4 p = tgt[i];
+    pad[i + 2 * r + 1] = p;
+    if (i == base) pad[end + 2 * r + 1] = p;          // trailing sentinel = first point
+    if (i == end - 1) pad[base + 2 * r] = p;          // leading sentinel = last point
+}
+
+// compact query points: qpts[i] = src[q_src[i]] (icp_skip > 1; with icp_skip == 1 the source cloud itself is the list)
+__global__ void gather_queries_kernel(const float4* __restrict__ src, const int* __restrict__ q_src, int nq, float4* __restrict__ qpts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nq) qpts[i] = src[q_src[i]];
+}
+
 // query list: query i -> global source index.  Ring r contributes ceil(n_r / skip) queries (velo.h:806-807).
 __global__ void query_list_kernel(const int* __restrict__ src_off, const int* __restrict__ q_off, int n_rings,
                                   int skip, int nq, int* __restrict__ q_src) {
@@ -281,8 +302,12 @@ struct AssocOut {
     unsigned long long* __restrict__ wg_times;   // [2 * groups] start/end s_memrealtime per workgroup (VELO_DEBUG_SKIP & 32)
     int first_ring, first_point;                  // global ids of this context's first target ring / point
     struct PartialRec* __restrict__ partial;      // target-sharded mode: per-query top-2 record instead of the table
-    int4* __restrict__ prev;                      // tube kernel: {local index of best1, of best2, ring1, ring2} of the last round (-1: none);
-                                                  // read as warm-start seeds, rewritten at the end (same entry, same workgroup), or null
+    // tube kernel, warm start: the two winners of the last round WITH their coordinates -- {x, y, z, bits(local index)} of best1 /
+    // best2 (index -1: none) and their rings -- read as seeds with one coalesced load each (no gather behind an index), rewritten
+    // at the end (same entry, same workgroup); prev_a == null: no warm start
+    float4* __restrict__ prev_a;
+    float4* __restrict__ prev_b;
+    int2* __restrict__ prev_r;
 };
 
 // Target-sharded mode (BASELINE config 5): what one rank knows about a query after searching ITS rings.
@@ -400,48 +425,54 @@ __device__ __forceinline__ void finish_correspondence(
     write_correspondence(qi, psrc, valid, n, v0, ring_i, idx_i, ring_j, idx_j, idx_k, di, dj, out, want_aux);
 }
 
-// The same rows with both ring ids already known (the tube kernel tracks them): no ring_of look-up, and the two ring neighbours
-// of the winner are fetched speculatively at gi +- 1 together with the ring bounds -- one memory round trip instead of three
-// dependent ones; only a winner at the end of its ring (2 of ~1,875 points) pays a second load for the wrap-around.
-__device__ __forceinline__ void finish_correspondence_rings(
-    int qi, const float4& psrc, float qx, float qy, float qz, unsigned long long b1, unsigned long long b2, int ring_i_in, int ring_j_in,
-    unsigned long long key_inf, const float4* __restrict__ tgt, const int* __restrict__ tgt_off, int n_tgt_local, double norm_cond,
+// The same rows for the tube kernel, which tracks both ring ids: no ring_of look-up, and the winner with its two cyclic ring
+// neighbours is three adjacent records of the padded target copy (pad_rings_kernel) -- ONE memory round trip, issued together with
+// the reload of the source point; ring bounds are fetched only for the index outputs of tests / the target-sharded record.
+__device__ __forceinline__ void finish_correspondence_pad(
+    int qi, const float4* __restrict__ qpts, float qx, float qy, float qz, unsigned long long b1, unsigned long long b2, int ring_i_in, int ring_j_in,
+    unsigned long long key_inf, const float4* __restrict__ pad, const int* __restrict__ tgt_off, double norm_cond,
     const AssocOut& out, bool want_aux) {
-    int ring_i = -1, idx_i = 0, ring_j = -1, idx_j = 0, idx_k = 0;
-    float di = 1e18f, dj = 1e18f;
-    float v0[3] = {0.f, 0.f, 0.f}, v1[3] = {0.f, 0.f, 0.f}, v2[3] = {0.f, 0.f, 0.f};
     const bool has1 = b1 < key_inf, has2 = b2 < key_inf;
     const int gi = has1 ? (int)(unsigned)(b1 & 0xffffffffull) - out.first_point : 0;
     const int gj = has2 ? (int)(unsigned)(b2 & 0xffffffffull) - out.first_point : 0;
-    // everything that needs no other load first: the two winners, the speculative neighbours, the ring bounds
+    const int li = has1 ? ring_i_in - out.first_ring : 0, lj = has2 ? ring_j_in - out.first_ring : 0;
+    const int pi = gi + 2 * li + 1, pj = gj + 2 * lj + 1;
+    const float4 psrc = qpts[qi];
     float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, a1 = p0, a2 = p0;
-    int base = 0, end = 1, base_j = 0;
-    if (has1) {
-        p0 = tgt[gi]; a1 = tgt[min(gi + 1, n_tgt_local - 1)]; a2 = tgt[max(gi - 1, 0)];
-        base = tgt_off[ring_i_in - out.first_ring]; end = tgt_off[ring_i_in - out.first_ring + 1];
-    }
-    if (has2) { p1 = tgt[gj]; base_j = tgt_off[ring_j_in - out.first_ring]; }
+    if (has1) { p0 = pad[pi]; a1 = pad[pi + 1]; a2 = pad[pi - 1]; }        // a1 = (np_i + 1) mod n, a2 = (np_i - 1 + n) mod n  (velo.h:852-854)
+    if (has2) p1 = pad[pj];
+    int ring_i = -1, idx_i = 0, ring_j = -1, idx_j = 0, idx_k = 0;
+    float di = 1e18f, dj = 1e18f;
+    float v0[3] = {0.f, 0.f, 0.f}, v1[3] = {0.f, 0.f, 0.f}, v2[3] = {0.f, 0.f, 0.f};
+    bool next_closer = false;
     if (has1) {
         ring_i = ring_i_in;
-        const int n = end - base;
-        idx_i = gi - base;
         di = __uint_as_float((unsigned)(b1 >> 32));
-        const int k1 = (idx_i + 1 == n) ? 0 : idx_i + 1, k2 = (idx_i == 0) ? n - 1 : idx_i - 1;       // velo.h:852-854
-        if (k1 != idx_i + 1) a1 = tgt[base + k1];                       // wrap-around: the speculative neighbour was the next ring's
-        if (k2 != idx_i - 1) a2 = tgt[base + k2];
         const float d1 = dist2_f(a1.x, a1.y, a1.z, qx, qy, qz);
         const float d2 = dist2_f(a2.x, a2.y, a2.z, qx, qy, qz);
-        idx_k = (d1 < d2) ? k1 : k2;                                    // velo.h:859-863
-        const float4 p2 = (idx_k == k1) ? a1 : a2;
+        next_closer = d1 < d2;                                          // velo.h:859-863 (tie -> the -1 neighbour)
+        const float4 p2 = next_closer ? a1 : a2;
         v0[0] = p0.x; v0[1] = p0.y; v0[2] = p0.z; v2[0] = p2.x; v2[1] = p2.y; v2[2] = p2.z;
     }
     if (has2) {
         ring_j = ring_j_in;
-        idx_j = gj - base_j;
         dj = __uint_as_float((unsigned)(b2 >> 32));
         v1[0] = p1.x; v1[1] = p1.y; v1[2] = p1.z;
     }
-    if (out.prev) out.prev[qi] = make_int4(has1 ? gi : -1, has2 ? gj : -1, ring_i, ring_j);   // seeds of the next round
+    if (out.prev_a) {                                                   // seeds of the next round
+        out.prev_a[qi] = make_float4(p0.x, p0.y, p0.z, __int_as_float(has1 ? gi : -1));
+        out.prev_b[qi] = make_float4(p1.x, p1.y, p1.z, __int_as_float(has2 ? gj : -1));
+        out.prev_r[qi] = make_int2(ring_i, ring_j);
+    }
+    if (want_aux || out.partial) {                                      // in-ring indices: tests and the target-sharded record only
+        if (has1) {
+            const int base = tgt_off[li], n = tgt_off[li + 1] - base;
+            idx_i = gi - base;
+            const int k1 = (idx_i + 1 == n) ? 0 : idx_i + 1, k2 = (idx_i == 0) ? n - 1 : idx_i - 1;
+            idx_k = next_closer ? k1 : k2;
+        }
+        if (has2) idx_j = gj - tgt_off[lj];
+    }
     if (out.partial) {
         PartialRec r;
         r.key1 = b1; r.key2 = b2; r.ring1 = ring_i; r.ring2 = ring_j; r.idx1 = idx_i; r.idx_k = idx_k; r.idx2 = idx_j; r.pad = 0;
@@ -586,6 +617,9 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // so the walk stops once (e * cell)^2 > max over member lanes of b2d (second-best squared distance, or the gate when a
 // lane has no second ring yet): no unvisited point can enter any lane's result.  In the dense part of a scan this ends
 // after the first phase; the answer is still the exact exhaustive one.
+#ifndef VELO_SWEEP_PACKED
+#define VELO_SWEEP_PACKED 0       // 1: the candidate sweep of the tube kernel with packed-f32 instructions (A/B builds)
+#endif
 constexpr int kTileCap = 512;      // candidates per LDS tile (keeps the workgroup under 20 KB of LDS: 8 workgroups per CU)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -855,8 +889,8 @@ __device__ __forceinline__ void top2_merge_xor(Top2& t, int mask) {
 //   * rounds after the first are warm-started from the previous round's winners (AssocOut::prev).
 template <int NW, int MINW, bool DBG, int PPT, bool ASKER>
 __device__ __forceinline__ void
-assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
-                     const float4* __restrict__ tgt, const int* __restrict__ tgt_off, int n_tgt_local,
+assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __restrict__ qpts, int q_begin, int q_end,
+                     const float4* __restrict__ tgt_pad, const int* __restrict__ tgt_off,
                      unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, const AssocOut& out, int want_aux, const int* __restrict__ group_perm, int dbg, int asker_rows,
                      const int block_x) {
     constexpr int NT = NW * 64;
@@ -904,24 +938,24 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
         int* sr = s_ring;                                                        // [2][64] their rings
         if (wid == 0) {
             if (active) {
-                const float4 psrc = src[q_src[qi]];
+                // everything the set-up needs is requested at once (coalesced, no load behind another load's result)
+                const float4 psrc = qpts[qi];
+                const bool seeded = out.prev_a && !(DBG && (dbg & 512));
+                float4 sa = make_float4(0.f, 0.f, 0.f, __int_as_float(-1)), sb = sa;
+                int2 sr = make_int2(-1, -1);
+                if (seeded) { sa = out.prev_a[qi]; sb = out.prev_b[qi]; sr = out.prev_r[qi]; }
                 transform_query(P, psrc, &qx, &qy, &qz);
                 // Warm start: the two winners of the previous round (same source, same target, slightly different pose) are real
                 // candidates of this round, so entering them first changes nothing in the result (top-2 is idempotent) but starts the
                 // search with a tight second-best bound: almost every later candidate fails the cheap trip test and the per-query
                 // second phase is rarely needed.  Seeds beyond the current gate are dropped like any other candidate.
-                if (out.prev && !(DBG && (dbg & 512))) {
-                    const int4 pv = out.prev[qi];
-                    if (pv.x >= 0) {
-                        const float4 c = tgt[pv.x];
-                        const float d = dist2_f(c.x, c.y, c.z, qx, qy, qz);
-                        if (__float_as_uint(d) <= gate_bits) top2_update(t, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(pv.x + out.first_point), pv.z);
-                    }
-                    if (pv.y >= 0) {
-                        const float4 c = tgt[pv.y];
-                        const float d = dist2_f(c.x, c.y, c.z, qx, qy, qz);
-                        if (__float_as_uint(d) <= gate_bits) top2_update(t, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(pv.y + out.first_point), pv.w);
-                    }
+                if (__float_as_int(sa.w) >= 0) {
+                    const float d = dist2_f(sa.x, sa.y, sa.z, qx, qy, qz);
+                    if (__float_as_uint(d) <= gate_bits) top2_update(t, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(__float_as_int(sa.w) + out.first_point), sr.x);
+                }
+                if (__float_as_int(sb.w) >= 0) {
+                    const float d = dist2_f(sb.x, sb.y, sb.z, qx, qy, qz);
+                    if (__float_as_uint(d) <= gate_bits) top2_update(t, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(__float_as_int(sb.w) + out.first_point), sr.y);
                 }
             }
             sq[lane] = qx; sq[64 + lane] = qy; sq[128 + lane] = qz;
@@ -938,7 +972,9 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
     int cx = 0, cy = 0, cz = 0;
     if (active) { cx = cell_coord(qx, g.ox, g.inv_h, g.nx); cy = cell_coord(qy, g.oy, g.inv_h, g.ny); cz = cell_coord(qz, g.oz, g.inv_h, g.nz); }
     VELO_STAMP(0);
+#if VELO_SWEEP_PACKED
     const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
+#endif
     float* s_xy_f = reinterpret_cast<float*>(s_xy);
     float* s_zg_f = reinterpret_cast<float*>(s_zg);
     const int big = 1 << 28;
@@ -1109,7 +1145,8 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
                             int2 rg[PPT];
 #pragma unroll
                             for (int u = 0; u < PPT; u++) { a[u] = s_xy[pi + u]; bq[u] = s_zg[pi + u]; rg[u] = s_ring2[pi + u]; }
-                            f32x2 d2[PPT];
+                            float d2x[PPT], d2y[PPT];
+#if VELO_SWEEP_PACKED
 #pragma unroll
                             for (int u = 0; u < PPT; u++) {
                                 const f32x2 cxp = {a[u].x, a[u].y}, cyp = {a[u].z, a[u].w}, czp = {bq[u].x, bq[u].y};
@@ -1117,20 +1154,29 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
                                 f32x2 d = dx * dx;                     // x -> y -> z accumulation, no FMA (-ffp-contract=off)
                                 d = d + dy * dy;
                                 d = d + dz * dz;
-                                d2[u] = d;
+                                d2x[u] = d.x; d2y[u] = d.y;
                             }
-                            float dmin = fminf(d2[0].x, d2[0].y);
+#else
+                            // plain f32 operations: on gfx950 a packed-f32 instruction costs the issue slots of several plain ones
+                            // (MI355X_MICROARCH.md, price of a v_pk_add_f32 against a v_fma_f32), so two plain sequences are cheaper
 #pragma unroll
-                            for (int u = 1; u < PPT; u++) dmin = fminf(dmin, fminf(d2[u].x, d2[u].y));
+                            for (int u = 0; u < PPT; u++) {
+                                d2x[u] = dist2_f(qx, qy, qz, a[u].x, a[u].z, bq[u].x);
+                                d2y[u] = dist2_f(qx, qy, qz, a[u].y, a[u].w, bq[u].y);
+                            }
+#endif
+                            float dmin = fminf(d2x[0], d2y[0]);
+#pragma unroll
+                            for (int u = 1; u < PPT; u++) dmin = fminf(dmin, fminf(d2x[u], d2y[u]));
                             if (dmin <= t.b2d) {                       // some candidate of the trip may matter for this lane
 #pragma unroll
                                 for (int u = 0; u < PPT; u++) {
-                                    if (d2[u].x <= t.b2d) {
-                                        const unsigned long long key = ((unsigned long long)__float_as_uint(d2[u].x) << 32) | (unsigned)__float_as_int(bq[u].z);
+                                    if (d2x[u] <= t.b2d) {
+                                        const unsigned long long key = ((unsigned long long)__float_as_uint(d2x[u]) << 32) | (unsigned)__float_as_int(bq[u].z);
                                         top2_update(t, key, rg[u].x);
                                     }
-                                    if (d2[u].y <= t.b2d) {
-                                        const unsigned long long key = ((unsigned long long)__float_as_uint(d2[u].y) << 32) | (unsigned)__float_as_int(bq[u].w);
+                                    if (d2y[u] <= t.b2d) {
+                                        const unsigned long long key = ((unsigned long long)__float_as_uint(d2y[u]) << 32) | (unsigned)__float_as_int(bq[u].w);
                                         top2_update(t, key, rg[u].y);
                                     }
                                 }
@@ -1258,15 +1304,8 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
     if (NW > 1 && wid != 0) return;
     if (DBG && (dbg & 128)) {                                          // diagnostic: finish without the gathers (wrong results)
         if (active) { out.p[qi] = make_float4(qx, qy, qz, 0.f); out.n[qi] = make_float4((float)(t.b1 >> 32), (float)(t.b2 >> 32), 0.f, 0.f); out.v0[qi] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    } else if (DBG && (dbg & 256)) {                                   // diagnostic: gathers but a trivial write and no counter
-        if (active) {
-            const float4 ps = src[q_src[qi]];
-            const int gi = (int)(unsigned)(t.b1 & 0xffffffffull) % max(n_tgt_local, 1), gj = (int)(unsigned)(t.b2 & 0xffffffffull) % max(n_tgt_local, 1);
-            const float4 p0 = tgt[gi], p1 = tgt[gj], a1 = tgt[min(gi + 1, n_tgt_local - 1)], a2 = tgt[max(gi - 1, 0)];
-            out.p[qi] = make_float4(ps.x + p0.x + p1.x, a1.y + a2.y, qz, 0.f);
-        }
     } else
-    if (active) finish_correspondence_rings(qi, src[q_src[qi]], qx, qy, qz, t.b1, t.b2, t.b1ring, t.b2ring, key_inf, tgt, tgt_off, n_tgt_local, norm_cond, out, want_aux != 0);
+    if (active) finish_correspondence_pad(qi, qpts, qx, qy, qz, t.b1, t.b2, t.b1ring, t.b2ring, key_inf, tgt_pad, tgt_off, norm_cond, out, want_aux != 0);
     VELO_STAMP(7);
     if (DBG && out.wg_times && tid == 0) out.wg_times[2 * group + 1] = __builtin_amdgcn_s_memrealtime();
     if (DBG && (dbg & 8) && tid == 0) { for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)&out.dbg[k], (unsigned long long)tacc[k]); }
@@ -1277,10 +1316,10 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
 // one launch = one context's round
 template <int NW, int MINW, bool DBG, int PPT, bool ASKER>
 __global__ void __launch_bounds__(NW * 64, MINW)
-assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
-                       const float4* __restrict__ tgt, const int* __restrict__ tgt_off, int n_tgt_local,
+assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ qpts, int q_begin, int q_end,
+                       const float4* __restrict__ tgt_pad, const int* __restrict__ tgt_off,
                        unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, AssocOut out, int want_aux, const int* __restrict__ group_perm, int dbg, int asker_rows) {
-    assoc_search_v5_body<NW, MINW, DBG, PPT, ASKER>(P, G, src, q_src, q_begin, q_end, tgt, tgt_off, n_tgt_local, gate_bits, norm_cond, cluster_w, h_safe, out,
+    assoc_search_v5_body<NW, MINW, DBG, PPT, ASKER>(P, G, qpts, q_begin, q_end, tgt_pad, tgt_off, gate_bits, norm_cond, cluster_w, h_safe, out,
                                                     want_aux, group_perm, dbg, asker_rows, (int)blockIdx.x);
 }
 
@@ -1290,8 +1329,8 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
 // segment, read with scalar loads.
 constexpr int kAssocBatchMax = 4;
 struct AssocArgs {
-    PoseScalars P; GridView G; const float4* src; const int* q_src; int q_begin, q_end;
-    const float4* tgt; const int* tgt_off; int n_tgt_local; unsigned gate_bits; double norm_cond; int cluster_w; float h_safe;
+    PoseScalars P; GridView G; const float4* qpts; int q_begin, q_end;
+    const float4* tgt_pad; const int* tgt_off; unsigned gate_bits; double norm_cond; int cluster_w; float h_safe;
     AssocOut out; int want_aux; const int* group_perm; int dbg; int asker_rows;
 };
 struct AssocBatch { AssocArgs item[kAssocBatchMax]; };
@@ -1300,7 +1339,7 @@ __global__ void __launch_bounds__(NW * 64, MINW)
 assoc_search_v5_batch_kernel(AssocBatch B) {
     const AssocArgs& a = B.item[blockIdx.y];
     if ((int)blockIdx.x * 64 >= a.q_end - a.q_begin) return;
-    assoc_search_v5_body<NW, MINW, DBG, PPT, ASKER>(a.P, a.G, a.src, a.q_src, a.q_begin, a.q_end, a.tgt, a.tgt_off, a.n_tgt_local, a.gate_bits, a.norm_cond,
+    assoc_search_v5_body<NW, MINW, DBG, PPT, ASKER>(a.P, a.G, a.qpts, a.q_begin, a.q_end, a.tgt_pad, a.tgt_off, a.gate_bits, a.norm_cond,
                                                     a.cluster_w, a.h_safe, a.out, a.want_aux, a.group_perm, a.dbg, a.asker_rows, (int)blockIdx.x);
 }
 
@@ -1701,7 +1740,24 @@ struct EvalArgs {
     double* __restrict__ rows_J;
     const int* __restrict__ row_offset_vis; // [3*n_matches] row index of each visual slot (exclusive scan of dims)
     const int* __restrict__ row_offset_icp; // [nq] row index of each query's block (or -1)
+    unsigned long long* __restrict__ trace; // diagnostics build only (VELO_LM_TRACE): [evaluation][8 stages][first, last] s_memrealtime stamps
 };
+
+// Time line of the LM chain (tools/lm_trace.py): every workgroup's thread 0 stamps the stages it passes with the 100 MHz real-time
+// counter; per evaluation and stage the buffer keeps the first and the last stamp.  Compiled only into the tools' build.
+#ifdef VELO_DIAGNOSTICS
+constexpr int kTraceMaxEvals = 64;
+__device__ __forceinline__ void lm_trace(unsigned long long* trace, int eval, int stage) {
+    if (trace && threadIdx.x == 0 && eval < kTraceMaxEvals) {
+        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
+        atomicMin(&trace[(eval * 8 + stage) * 2], t);
+        atomicMax(&trace[(eval * 8 + stage) * 2 + 1], t);
+    }
+}
+#define VELO_LM_TRACE(trace, eval, stage) lm_trace(trace, eval, stage)
+#else
+#define VELO_LM_TRACE(trace, eval, stage) do { } while (0)
+#endif
 
 // acc += (sr J)^T (sr J), (sr J)^T (sr r): one robustified residual row
 __device__ __forceinline__ void accumulate_row(double acc[kNumAcc], double r, const double Jr[6], double sr) {
@@ -1778,13 +1834,16 @@ __device__ __forceinline__ void eval_icp_body(const EvalArgs& A, const int bx, c
         const int i = min(A.q_begin + tid + k * nthreads, A.q_end - 1);
         pp[k] = A.cp[i]; pn[k] = A.cn[i]; pv[k] = A.cv0[i];
     }
+    VELO_LM_TRACE(A.trace, A.x_override ? 0 : A.state->evals, 0);
     double x[6];
     if (!eval_load_x(A, x)) return;
+    VELO_LM_TRACE(A.trace, A.x_override ? 0 : A.state->evals, 1);
     // the point-independent part of the rotation (sqrt, sin, cos and their partials) once per workgroup, not per thread
     __shared__ PoseRot s_R;
     if (threadIdx.x == 0) pose_rot_init(x, &s_R);
     __syncthreads();
     const PoseRot R = s_R;
+    VELO_LM_TRACE(A.trace, A.x_override ? 0 : A.state->evals, 2);
     const double t[3] = {x[3], x[4], x[5]};
     double acc[kNumAcc];
 #pragma unroll
@@ -1813,7 +1872,9 @@ __device__ __forceinline__ void eval_icp_body(const EvalArgs& A, const int bx, c
             for (int k = 0; k < 6; k++) A.rows_J[(size_t)row * 6 + k] = J[k] * sr;
         }
     }
+    VELO_LM_TRACE(A.trace, A.x_override ? 0 : A.state->evals, 3);
     block_reduce_store(acc, A.partials + (size_t)bx * kNumAcc);
+    VELO_LM_TRACE(A.trace, A.x_override ? 0 : A.state->evals, 4);
 }
 
 __global__ void __launch_bounds__(kEvalThreads)
@@ -1993,10 +2054,15 @@ __global__ void lm_begin_kernel(LMState* S, const double* __restrict__ x_in, con
 // sums: either the per-workgroup partials [n_blocks][28] (single GPU) or an already reduced [1][28] block (after all-reduce);
 // then ONE LM state transition.  Called by a whole 256-thread workgroup.
 __device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* S, const double* E);
-__device__ __forceinline__ void lm_transition(const LMParams& Q, LMState* Sg, const double* __restrict__ partials, int n_blocks) {
+__device__ __forceinline__ void lm_transition(const LMParams& Q, LMState* Sg, const double* __restrict__ partials, int n_blocks,
+                                              unsigned long long* trace = nullptr) {
     __shared__ double part[8][kNumAcc];
     __shared__ double E[kNumAcc];
     const int t = threadIdx.x;
+#ifdef VELO_DIAGNOSTICS
+    const int trace_eval = trace ? Sg->evals : 0;
+#endif
+    VELO_LM_TRACE(trace, trace_eval, 5);
     if (t < 8 * kNumAcc) {
         const int k = t % kNumAcc, p = t / kNumAcc;
         double v = 0.0;
@@ -2007,11 +2073,13 @@ __device__ __forceinline__ void lm_transition(const LMParams& Q, LMState* Sg, co
     if (t < kNumAcc) { double v = 0.0; for (int p = 0; p < 8; p++) v += part[p][t]; E[t] = v; }
     __syncthreads();
     if (t != 0) return;
+    VELO_LM_TRACE(trace, trace_eval, 6);
     // the transition is ~300 dependent double operations on the state: run it on a private copy (one batch of loads, one batch
     // of stores) instead of walking the global struct field by field with a wait after every access
     LMState L = *Sg;
     lm_transition_local(Q, &L, E);
     *Sg = L;
+    VELO_LM_TRACE(trace, trace_eval, 7);
 }
 
 __device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* S, const double* E) {
@@ -2052,9 +2120,9 @@ __device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* 
 }
 
 __global__ void __launch_bounds__(256)
-lm_step_kernel(LMParams Q, LMState* S, const double* __restrict__ partials, int n_blocks) {
+lm_step_kernel(LMParams Q, LMState* S, const double* __restrict__ partials, int n_blocks, unsigned long long* trace) {
     if (S->done) return;
-    lm_transition(Q, S, partials, n_blocks);
+    lm_transition(Q, S, partials, n_blocks, trace);
 }
 __global__ void lm_begin_batch_kernel(const LMBatchItem* __restrict__ items) {
     const LMBatchItem& it = items[blockIdx.x];
