@@ -96,7 +96,8 @@ __device__ __forceinline__ void pose_rot_init(const double w[3], PoseRot* R) {
     R->small = !(theta2.a > 2.220446049250313e-16);
     if (!R->small) {
         const D3 theta = dsqrt(theta2);
-        const double sv = sin(theta.a), cv = cos(theta.a);
+        double sv, cv;
+        sincos(theta.a, &sv, &cv);                       // one argument reduction for both
         R->s.a = sv; R->c.a = cv;
 #pragma unroll
         for (int i = 0; i < 3; i++) { R->s.v[i] = cv * theta.v[i]; R->c.v[i] = -sv * theta.v[i]; }

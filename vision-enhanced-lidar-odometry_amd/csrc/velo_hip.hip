@@ -167,6 +167,7 @@ struct velo_ctx {
     DevBuf<int2> prev_r;                 // and their rings; reset with every new source / target
     bool prev_ready = false;             // the seed arrays hold n_q initialised entries for the current source and target
     int warm_start = 1;                  // VELO_WARM_START=0 turns the seeds off (A/B; results are identical either way)
+    int lm_merged = 1;                   // VELO_LM_MERGED=0: sweep and LM step as two launches per iteration also where one would do (A/B, identical results)
     int small_solve = 1;                 // VELO_SMALL_SOLVE=0: small problems go through the launch-per-iteration path too (A/B, identical results)
     int asker_rows = -1;                 // tube kernel (VELO_ASKER_ROWS): phase 2 goes query by query when the asking queries' boxes have more
                                          // rows than this in total.  -1 = by target density: never on a regular scan (120k points: the tile pass
@@ -207,17 +208,17 @@ struct velo_ctx {
 
     // LM
     DevBuf<LMState> state;
+    DevBuf<LMEvalPoint> eval_pt;         // where the next sweep evaluates: written by lm_begin / the LM step, read by the sweep workgroups
     DevBuf<double> partials, reduced, xdev;
     DevBuf<int> ticket;
     DevBuf<unsigned long long> lm_trace;  // diagnostics build, VELO_LM_TRACE=1: stage stamps of the LM chain (tools/lm_trace.py)
     bool lm_trace_on = false;
+    int lm_trace_idx = 0;                 // launches of the current solve so far
     // captured LM chunks (single GPU): key = iterations per chunk; rebuilt when anything baked into the nodes changes
     hipGraphExec_t chunk_graph[2] = {nullptr, nullptr};
     int chunk_graph_iters[2] = {0, 0};
     std::vector<unsigned char> chunk_graph_sig[2];   // bytes of everything baked into the nodes
     bool use_graphs = false;             // LM chunks as hipGraphs (VELO_GRAPHS=1): measured no gain, replay overhead ~ launches saved
-    bool use_fused = false;              // one-launch LM iteration (last workgroup reduces + steps), VELO_FUSED=1: measured equal or
-                                         // slightly slower than sweep + lm_step as two launches (release/acquire cost ~ the boundary saved)
     int pred_evals[VELO_MAX_SOLVES];     // evaluations each solve of the previous frame_to_frame needed (chunk sizing)
     HostStatus* h_status = nullptr;      // pinned
     double* h_x = nullptr;               // pinned, 8 doubles
@@ -474,13 +475,14 @@ LMParams lm_params(const velo_params& P) {
 }
 
 constexpr int kMaxVisBlocks = 64;
-constexpr int kEvalPerThread = 4;      // nominal residuals per thread of the ICP sweep
+constexpr int kEvalPerThread = 4;      // nominal residuals per thread of the ICP sweep (alone: 4 -> 3.4 us of rows per sweep, 2 -> 2.0 us but twice the partial rows for the step: same 15.2 us per iteration; 8 pairs in flight: 2,553 vs 2,348 pairs/s)
 struct EvalPlan { int nb_icp, nb_vis; int total() const { return nb_icp + nb_vis; } };
 
 EvalArgs eval_args(velo_ctx* c, const double* x_override) {
     EvalArgs A;
     std::memset(&A, 0, sizeof(A));
     A.state = c->state.p;
+    A.pt = c->eval_pt.p;
     A.x_override = x_override;
     A.cp = c->cp.p; A.cn = c->cn.p; A.cv0 = c->cv0.p;
     if (c->have_corr) q_range(c, &A.q_begin, &A.q_end);
@@ -490,6 +492,7 @@ EvalArgs eval_args(velo_ctx* c, const double* x_override) {
     A.V = visual_params(c->P);
     A.partials = c->partials.p;
     A.trace = c->lm_trace_on ? c->lm_trace.p : nullptr;
+    A.trace_eval = 0;
     return A;
 }
 
@@ -723,19 +726,9 @@ void visual_counts(const velo_ctx* c, int* blocks, int* residuals) {
 }
 
 // enqueue: eval sweep at the state's current point, (all-reduce), LM transition
-int enqueue_lm_iteration(velo_ctx* c, const EvalArgs& A, const EvalPlan& E, const LMParams& Q) {
-    if (!c->comm && c->use_fused) {
-        // fused: [visual sweep] + one launch whose last workgroup reduces and steps
-        EvalArgs B = A;
-        const int nb = std::max(E.nb_icp, 1);
-        if (E.nb_vis > 0) {
-            B.vis_row0 = nb;
-            hipLaunchKernelGGL(eval_visual_kernel, dim3(E.nb_vis), dim3(kEvalThreads), 0, c->stream, B);
-        }
-        hipLaunchKernelGGL(lm_iter_fused_kernel, dim3(nb), dim3(kEvalThreads), 0, c->stream, B, Q, c->state.p, c->ticket.p, nb + E.nb_vis);
-        HIP_TRY(hipGetLastError());
-        return VELO_OK;
-    }
+int enqueue_lm_iteration(velo_ctx* c, const EvalArgs& A_in, const EvalPlan& E, const LMParams& Q) {
+    EvalArgs A = A_in;
+    A.trace_eval = c->lm_trace_idx++;
     launch_eval(c, A, E);
     const int nblocks = E.total();
     if (c->comm) {
@@ -743,9 +736,9 @@ int enqueue_lm_iteration(velo_ctx* c, const EvalArgs& A, const EvalPlan& E, cons
         // every rank reaches this call the same number of times: `done` is identical on all ranks, and when it is
         // set the kernels above exit early and the buffer keeps its previous (identical) content
         NCCL_TRY(ncclAllReduce(c->reduced.p, c->reduced.p + kNumAcc, kNumAcc, ncclDouble, ncclSum, c->comm, c->stream));
-        hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, (const double*)(c->reduced.p + kNumAcc), 1, A.trace);
+        hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, c->eval_pt.p, (const double*)(c->reduced.p + kNumAcc), 1, A.trace, A.trace_eval);
     } else {
-        hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, (const double*)c->partials.p, nblocks, A.trace);
+        hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, c->eval_pt.p, (const double*)c->partials.p, nblocks, A.trace, A.trace_eval);
     }
     HIP_TRY(hipGetLastError());
     return VELO_OK;
@@ -766,10 +759,10 @@ int launch_chunk(velo_ctx* c, const EvalArgs& A, const EvalPlan& E, const LMPara
         std::memcpy(w, &A, sizeof(EvalArgs)); w += sizeof(EvalArgs);
         std::memcpy(w, &Q, sizeof(LMParams)); w += sizeof(LMParams);
         std::memcpy(w, &E, sizeof(EvalPlan)); w += sizeof(EvalPlan);
-        const void* ptrs[3] = {c->state.p, c->ticket.p, c->h_status};
+        const void* ptrs[3] = {c->state.p, c->eval_pt.p, c->h_status};
         std::memcpy(w, ptrs, sizeof(ptrs)); w += sizeof(ptrs);
-        const int fused = c->use_fused ? 1 : 0;
-        std::memcpy(w, &fused, sizeof(int));
+        const int zero = 0;
+        std::memcpy(w, &zero, sizeof(int));
     }
     int slot = -1;
     for (int k = 0; k < 2; k++) if (c->chunk_graph[k] && c->chunk_graph_iters[k] == iters && c->chunk_graph_sig[k] == sig) slot = k;
@@ -806,14 +799,13 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
         xd = c->xdev.p;
     }
     const int max_iters_all = c->P.max_num_iterations + 1;
+    c->lm_trace_idx = 0;
 #ifdef VELO_DIAGNOSTICS
     if (c->lm_trace_on) {
-        std::vector<unsigned long long> init((size_t)kTraceMaxEvals * 16);
-        for (size_t k = 0; k < init.size(); k += 2) { init[k] = ~0ull; init[k + 1] = 0ull; }
-        HIP_TRY(hipMemcpy(c->lm_trace.p, init.data(), init.size() * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(c->lm_trace.p, 0, (size_t)kTraceMaxEvals * kTraceStages * kTraceWgs * 8));
     }
 #endif
-    if (!c->comm && !c->use_fused && !c->use_graphs && c->small_solve && E.total() >= 1 && E.total() <= kSmallRows) {
+    if (!c->comm && !c->use_graphs && c->small_solve && E.total() >= 1 && E.total() <= kSmallRows) {
         // small problem (the reference's icp_skip = 200): the whole solve in one single-workgroup launch, one status copy
         hipLaunchKernelGGL(lm_solve_small_kernel, dim3(1), dim3(kEvalThreads), 0, c->stream, A, Q, c->state.p, xd,
                            (const int*)(c->have_corr ? c->n_valid.p + c->nv_idx : nullptr), E.nb_icp, E.nb_vis, max_iters_all + 2);
@@ -821,8 +813,30 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
         HIP_TRY(hipMemcpyAsync(&c->h_status->s, c->state.p, sizeof(LMState), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (!c->h_status->s.done) return fail(VELO_ERR_STATE, "LM did not terminate after %d sweeps", max_iters_all + 2);
+    } else if (!c->comm && !c->use_graphs && c->lm_merged && x_in && E.nb_icp > 0 && E.nb_vis == 0) {
+        // one launch per LM iteration: every sweep workgroup consumes the previous sweep's partial rows itself (lm_iter_kernel).
+        // Launch k reads state / partial rows [k & 1] and writes [(k + 1) & 1]; launch 0 starts the solve.  A solve of n
+        // evaluations needs n + 1 launches (the last one only finds the solve done); launches behind that copy the state through.
+        const size_t half = (size_t)(kMaxEvalBlocks + kMaxVisBlocks) * kNumAcc;
+        const int* nvp = c->have_corr ? c->n_valid.p + c->nv_idx : nullptr;
+        int k = 0, chunk = first_chunk + 1;
+        const int max_launches = c->P.max_num_iterations + 2;
+        for (;;) {
+            for (int j = 0; j < chunk; j++, k++) {
+                EvalArgs Ak = A;
+                Ak.trace_eval = k;
+                hipLaunchKernelGGL(lm_iter_kernel, dim3(E.nb_icp), dim3(kEvalThreads), 0, c->stream, Ak, Q, (const LMState*)(c->state.p + (k & 1)), c->state.p + ((k + 1) & 1),
+                                   (const double*)(c->partials.p + (size_t)(k & 1) * half), E.nb_icp, c->partials.p + (size_t)((k + 1) & 1) * half, k == 0 ? 1 : 0, xd, nvp);
+            }
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(&c->h_status->s, c->state.p + (k & 1), sizeof(LMState), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->h_status->s.done) break;
+            if (k > max_launches + 16) return fail(VELO_ERR_STATE, "LM did not terminate after %d launches", k);
+            chunk = 3;
+        }
     } else {
-    hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->state.p, xd, (const int*)(c->have_corr ? c->n_valid.p + c->nv_idx : nullptr));
+    hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->state.p, c->eval_pt.p, xd, (const int*)(c->have_corr ? c->n_valid.p + c->nv_idx : nullptr));
     int launched = 0;
     int chunk = first_chunk;                // LM iterations per host round trip
     const int max_iters = c->P.max_num_iterations + 1;
@@ -838,13 +852,18 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
     const LMState& s = c->h_status->s;
 #ifdef VELO_DIAGNOSTICS
     if (c->lm_trace_on) {
-        std::vector<unsigned long long> tr((size_t)kTraceMaxEvals * 16);
+        std::vector<unsigned long long> tr((size_t)kTraceMaxEvals * kTraceStages * kTraceWgs);
         HIP_TRY(hipMemcpy(tr.data(), c->lm_trace.p, tr.size() * 8, hipMemcpyDeviceToHost));
-        const unsigned long long t0 = tr[0];
+        unsigned long long t0 = ~0ull;
+        for (int w = 0; w < kTraceWgs; w++) if (tr[(size_t)w]) t0 = std::min(t0, tr[(size_t)w]);
         for (int e = 0; e < s.evals && e < kTraceMaxEvals; e++) {
             fprintf(stderr, "[velo lm trace] eval %2d:", e);
-            for (int st = 0; st < 8; st++) {
-                const unsigned long long a = tr[((size_t)e * 8 + st) * 2], b = tr[((size_t)e * 8 + st) * 2 + 1];
+            for (int st = 0; st < 10; st++) {
+                unsigned long long a = ~0ull, b = 0ull;
+                for (int w = 0; w < kTraceWgs; w++) {
+                    const unsigned long long v = tr[((size_t)e * kTraceStages + st) * kTraceWgs + w];
+                    if (v) { a = std::min(a, v); b = std::max(b, v); }
+                }
                 if (a == ~0ull) fprintf(stderr, " -"); else fprintf(stderr, " %.2f/%.2f", (double)(a - t0) * 0.01, (double)(b - t0) * 0.01);
             }
             fprintf(stderr, "\n");
@@ -956,7 +975,7 @@ int velo_create(velo_ctx** out, int device) {
 #ifdef VELO_DIAGNOSTICS
         if (getenv("VELO_LM_TRACE") && atoi(getenv("VELO_LM_TRACE"))) {
             c->lm_trace_on = true;
-            VELO_TRY(c->lm_trace.reserve((size_t)kTraceMaxEvals * 16));
+            VELO_TRY(c->lm_trace.reserve((size_t)kTraceMaxEvals * kTraceStages * kTraceWgs));
         }
         // the diagnostic instantiations (cycle stamps, counters, sections switched off -- some bits give WRONG results on purpose) exist
         // only in the tools' build of this file (build.py: libvelo_hip_diag.so); the product library ignores the variable
@@ -967,16 +986,17 @@ int velo_create(velo_ctx** out, int device) {
         if (const char* e = getenv("VELO_TUBE_MAP")) c->tube_map = atoi(e);
         if (const char* e = getenv("VELO_WARM_START")) c->warm_start = atoi(e);
         if (const char* e = getenv("VELO_SMALL_SOLVE")) c->small_solve = atoi(e);
+        if (const char* e = getenv("VELO_LM_MERGED")) c->lm_merged = atoi(e);
         if (const char* e = getenv("VELO_ASKER_ROWS")) c->asker_rows = atoi(e);
         if (const char* e = getenv("VELO_PERSISTENT_WGS")) c->persistent_wgs = std::max(atoi(e), 1);
-        if (const char* e = getenv("VELO_FUSED")) c->use_fused = atoi(e) != 0;
         if (const char* e = getenv("VELO_BATCH_LOCKSTEP")) c->batch_lockstep = atoi(e);
         HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_TRY(hipHostMalloc((void**)&c->h_status, sizeof(HostStatus), hipHostMallocDefault));
         HIP_TRY(hipHostMalloc((void**)&c->h_x, sizeof(double) * 64, hipHostMallocDefault));
         HIP_TRY(hipHostMalloc((void**)&c->h_int, sizeof(int) * 16, hipHostMallocDefault));
-        VELO_TRY(c->state.reserve(1));
-        VELO_TRY(c->partials.reserve((size_t)(kMaxEvalBlocks + kMaxVisBlocks) * kNumAcc));
+        VELO_TRY(c->state.reserve(2));                       // [1]: the other half of the one-launch iteration's double buffer
+        VELO_TRY(c->eval_pt.reserve(1));
+        VELO_TRY(c->partials.reserve((size_t)2 * (kMaxEvalBlocks + kMaxVisBlocks) * kNumAcc));   // two halves, same reason
         VELO_TRY(c->reduced.reserve(2 * kNumAcc));
         VELO_TRY(c->xdev.reserve(8));
         VELO_TRY(c->ticket.reserve(1));
@@ -985,7 +1005,7 @@ int velo_create(velo_ctx** out, int device) {
         VELO_TRY(c->n_valid.reserve(2));
         VELO_TRY(c->dbg.reserve(8));
         HIP_TRY(hipMemsetAsync(c->dbg.p, 0, 64, c->stream));
-        HIP_TRY(hipMemsetAsync(c->state.p, 0, sizeof(LMState), c->stream));
+        HIP_TRY(hipMemsetAsync(c->state.p, 0, 2 * sizeof(LMState), c->stream));
         HIP_TRY(hipEventCreate(&c->ev0));
         HIP_TRY(hipEventCreate(&c->ev1));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1673,7 +1693,7 @@ static bool batch_can_lockstep(velo_ctx** ctxs, int n, bool targets_follow = fal
     if (n < 2 || !ctxs[0] || !ctxs[0]->batch_lockstep) return false;
     for (int i = 0; i < n; i++) {
         const velo_ctx* c = ctxs[i];
-        if (!c || c->device != ctxs[0]->device || c->comm || c->use_fused || c->use_graphs) return false;
+        if (!c || c->device != ctxs[0]->device || c->comm || c->use_graphs) return false;
         if ((!c->have_target && !targets_follow) || (!c->have_source && !sources_follow) || c->shard_world != 1) return false;
         if (std::memcmp(&c->P, &ctxs[0]->P, sizeof(velo_params)) != 0) return false;
         for (int j = 0; j < i; j++) if (ctxs[j] == c) return false;
@@ -1843,18 +1863,28 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
             }
             HIP_TRY(hipMemcpyAsync(c0->batch_items.p, h_items, sizeof(LMBatchItem) * (size_t)n, hipMemcpyHostToDevice, bs));
             HIP_TRY(hipMemcpyAsync(c0->batch_x.p, h_x, sizeof(double) * 8 * (size_t)n, hipMemcpyHostToDevice, bs));
-            hipLaunchKernelGGL(lm_begin_batch_kernel, dim3(n), dim3(64), 0, bs, (const LMBatchItem*)c0->batch_items.p);
-            int launched = 0, chunk = first_chunk;
+            // one launch per LM iteration for the whole group (lm_iter_batch_kernel) when every context has point-to-plane rows only
+            // (measured with 8 pairs in flight: 2,040-2,120 pairs/s against 2,410-2,450 with sweep + step as two launches -- the redundant
+            //  transitions keep 118 workgroups per context resident for 5 us longer, and at one wave per SIMD; hence VELO_LM_MERGED=2 only)
+            bool merged = c0->lm_merged >= 2 && nbv_max == 0;
+            for (int i = 0; i < n; i++) merged = merged && h_items[i].nb_icp > 0;
+            const size_t half = (size_t)(kMaxEvalBlocks + kMaxVisBlocks) * kNumAcc;
+            int launched = 0, chunk = first_chunk + (merged ? 1 : 0);
+            if (!merged) hipLaunchKernelGGL(lm_begin_batch_kernel, dim3(n), dim3(64), 0, bs, (const LMBatchItem*)c0->batch_items.p);
             for (;;) {                                                                  // one ceres::Solve per context, velo.h:897-902
                 for (int k = 0; k < chunk; k++) {
+                    if (merged) {
+                        hipLaunchKernelGGL(lm_iter_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p, launched + k, half);
+                        continue;
+                    }
                     if (nb_max > 0) hipLaunchKernelGGL(eval_icp_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, (const LMBatchItem*)c0->batch_items.p);
                     if (nbv_max > 0) hipLaunchKernelGGL(eval_visual_batch_kernel, dim3(nbv_max, n), dim3(kEvalThreads), 0, bs, (const LMBatchItem*)c0->batch_items.p);
                     hipLaunchKernelGGL(lm_step_batch_kernel, dim3(n), dim3(256), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p);
                 }
-                hipLaunchKernelGGL(lm_gather_states_kernel, dim3(n), dim3(128), 0, bs, (const LMBatchItem*)c0->batch_items.p, c0->batch_states.p);
+                launched += chunk;
+                hipLaunchKernelGGL(lm_gather_states_kernel, dim3(n), dim3(128), 0, bs, (const LMBatchItem*)c0->batch_items.p, c0->batch_states.p, merged ? (launched & 1) : 0);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(h_states, c0->batch_states.p, sizeof(LMState) * (size_t)n, hipMemcpyDeviceToHost, bs));
-                launched += chunk;
                 HIP_TRY(hipStreamSynchronize(bs));
                 bool all_done = true;
                 for (int i = 0; i < n; i++) all_done = all_done && h_states[i].done != 0;

@@ -1718,13 +1718,70 @@ struct LMState {
     double initial_cost;
     int reuse_diag, invalid, iter, evals, done, termination, phase, n_valid;   // n_valid: copy of the association's counter
 };
+static_assert(sizeof(LMState) % 8 == 0 && sizeof(LMState) / 8 <= 64, "the state is copied by one wave, one 8-byte word per lane");
 
 __device__ __forceinline__ int tri(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }   // i <= j
 
 // ---- evaluation sweeps ---------------------------------------------------------------------------------------------------------
+// The point a sweep evaluates at, as ONE block the LM step (or lm_begin) leaves behind for the sweep workgroups: the pose, the
+// rotation R(omega) and its three partials dR/d omega_j as plain 3x3 matrices (R p and its derivative are linear in the point p, so a
+// residual row is four matrix-vector products instead of a dual-number pass through Rodrigues' formula per row), and the done
+// flag.  A sweep workgroup fetches it with one cooperative load -- no chain of dependent reads through the LM state, no
+// sqrt / sin / cos per workgroup.  The matrices are built by pushing the unit vectors through the SAME dual-number rotation
+// (eval_point_column), so they are the autodiff values, not a re-derivation.
+struct LMEvalPoint {
+    double M[4][9];     // row-major 3x3: R, dR/dw0, dR/dw1, dR/dw2
+    double t[3];
+    double x[6];
+    int done;           // LMState::done at the time the block was written
+    int pad;
+};
+static_assert(sizeof(LMEvalPoint) % 8 == 0 && sizeof(LMEvalPoint) / 8 <= 64, "the eval point is copied by one wave, one 8-byte word per lane");
+
+// lane `col` (0..2) fills column `col` of the four matrices; lane 3 the rest
+__device__ __forceinline__ void eval_point_column(const double x[6], int done, int col, LMEvalPoint* P) {
+    if (col < 3) {
+        PoseRot R;
+        pose_rot_init(x, &R);
+        const double e[3] = {col == 0 ? 1.0 : 0.0, col == 1 ? 1.0 : 0.0, col == 2 ? 1.0 : 0.0};
+        D3 m[3];
+        rotate_point(R, e, m);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            P->M[0][3 * k + col] = m[k].a;
+#pragma unroll
+            for (int j = 0; j < 3; j++) P->M[1 + j][3 * k + col] = m[k].v[j];
+        }
+    } else if (col == 3) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) P->t[k] = x[3 + k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) P->x[k] = x[k];
+        P->done = done; P->pad = 0;
+    }
+}
+
+// R1 cost3DPD (costfunctions.h:39-54) through the matrices of the eval point: r = N . (R p + t - v0), dr/dw_j = N . (dR/dw_j p)
+__device__ __forceinline__ void res_3dpd_mat(const double (*M)[9], const double t[3], const double p[3], const double n[3], const double v0[3],
+                                             double* r, double J[6]) {
+    double m[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) m[k] = (M[0][3 * k] * p[0] + M[0][3 * k + 1] * p[1] + M[0][3 * k + 2] * p[2]) + (t[k] - v0[k]);
+    *r = m[0] * n[0] + m[1] * n[1] + m[2] * n[2];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        double d[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) d[k] = M[1 + j][3 * k] * p[0] + M[1 + j][3 * k + 1] * p[1] + M[1 + j][3 * k + 2] * p[2];
+        J[j] = d[0] * n[0] + d[1] * n[1] + d[2] * n[2];
+    }
+    J[3] = n[0]; J[4] = n[1]; J[5] = n[2];
+}
+
 struct EvalArgs {
-    const LMState* __restrict__ state;      // x / xc and the done flag live here
-    const double* __restrict__ x_override;  // when non-null: evaluate at this device x, ignore state (velo_evaluate)
+    const LMState* __restrict__ state;      // the LM state (trace index only; the sweeps read the eval point)
+    const LMEvalPoint* __restrict__ pt;     // where to evaluate (written by lm_begin / the LM step)
+    const double* __restrict__ x_override;  // when non-null: evaluate at this x instead (velo_evaluate; LDS x of the one-launch solve)
     const float4* __restrict__ cp;          // correspondences
     const float4* __restrict__ cn;
     const float4* __restrict__ cv0;
@@ -1740,19 +1797,17 @@ struct EvalArgs {
     double* __restrict__ rows_J;
     const int* __restrict__ row_offset_vis; // [3*n_matches] row index of each visual slot (exclusive scan of dims)
     const int* __restrict__ row_offset_icp; // [nq] row index of each query's block (or -1)
-    unsigned long long* __restrict__ trace; // diagnostics build only (VELO_LM_TRACE): [evaluation][8 stages][first, last] s_memrealtime stamps
+    unsigned long long* __restrict__ trace; // diagnostics build only (VELO_LM_TRACE): [evaluation][16 stages][first, last] s_memrealtime stamps
+    int trace_eval;                         // index of this evaluation within the solve (from the host: the stamps add no loads)
 };
 
 // Time line of the LM chain (tools/lm_trace.py): every workgroup's thread 0 stamps the stages it passes with the 100 MHz real-time
 // counter; per evaluation and stage the buffer keeps the first and the last stamp.  Compiled only into the tools' build.
 #ifdef VELO_DIAGNOSTICS
-constexpr int kTraceMaxEvals = 64;
+constexpr int kTraceMaxEvals = 64, kTraceStages = 16, kTraceWgs = 512;    // a slot per (evaluation, stage, workgroup): plain stores, no atomics
 __device__ __forceinline__ void lm_trace(unsigned long long* trace, int eval, int stage) {
-    if (trace && threadIdx.x == 0 && eval < kTraceMaxEvals) {
-        const unsigned long long t = __builtin_amdgcn_s_memrealtime();
-        atomicMin(&trace[(eval * 8 + stage) * 2], t);
-        atomicMax(&trace[(eval * 8 + stage) * 2 + 1], t);
-    }
+    if (trace && threadIdx.x == 0 && eval < kTraceMaxEvals && (int)blockIdx.x < kTraceWgs)
+        trace[((size_t)eval * kTraceStages + stage) * kTraceWgs + blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 }
 #define VELO_LM_TRACE(trace, eval, stage) lm_trace(trace, eval, stage)
 #else
@@ -1775,13 +1830,17 @@ __device__ __forceinline__ void accumulate_row(double acc[kNumAcc], double r, co
     for (int i = 0; i < 6; i++) acc[21 + i] += J[i] * rk;
 }
 
-// Workgroup reduction of the 28 accumulators with (almost) no LDS, so that sweep workgroups can share a CU with the
-// LDS-heavy association workgroups of other scan pairs in flight.  Wave level: a halving butterfly -- at mask 32 every
-// lane keeps one half of the (padded to 32) accumulators and ships the other half to its partner, at mask 16 a quarter,
-// ... -- 32 double exchanges instead of 28 x 6; after mask 2 lane L holds accumulator
-//   idx(L) = 16 b5 + 8 b4 + 4 b3 + 2 b2 + b1      (bk = bit k of L), summed over its wave after the mask-1 exchange.
-// Workgroup level: 1 KB of LDS.  Fixed order -> deterministic.
-__device__ __forceinline__ void block_reduce_store(double acc[kNumAcc], double* __restrict__ dst /* [28] */) {
+// Workgroup reduction of the 28 accumulators, laid out for latency (the LM chain waits for it): one exchange with the lane 32
+// away (28 independent shuffles), the 32 x 4 partial sums of every accumulator through LDS ([accumulator][128], conflict-free
+// 8-byte stores), eight threads per accumulator add 16 values each, one thread per accumulator adds those eight and stores.
+// Two barriers, ~0.4 us; 28 KB of LDS.  Fixed order -> deterministic.
+constexpr int kScratchDoubles = 128 * kNumAcc;                    // 28,672 bytes: the sweep's reduction and the step's chunk of partial rows share it
+#ifndef VELO_REDUCE_LDS
+#define VELO_REDUCE_LDS 1
+#endif
+#if !VELO_REDUCE_LDS
+// A/B: the halving butterfly (1 KB of LDS)
+__device__ __forceinline__ void block_reduce_store(double acc[kNumAcc], double* __restrict__ dst /* [28] */, double* __restrict__) {
     __shared__ double red[kEvalThreads / kWave][32];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     double v[32];
@@ -1808,73 +1867,138 @@ __device__ __forceinline__ void block_reduce_store(double acc[kNumAcc], double* 
         dst[threadIdx.x] = t;
     }
 }
-
-__device__ __forceinline__ bool eval_load_x(const EvalArgs& A, double x[6]) {
-    if (A.x_override) {
+#else
+__device__ __forceinline__ void block_reduce_store(double acc[kNumAcc], double* __restrict__ dst /* [28] */, double* __restrict__ scratch) {
+    constexpr int kCols = kEvalThreads / 2;                       // 128 partial sums per accumulator
+    static_assert(kNumAcc * kCols <= kScratchDoubles, "scratch size");
+    double (*red)[kCols] = reinterpret_cast<double (*)[kCols]>(scratch);
+    __shared__ double red2[kNumAcc][8];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
 #pragma unroll
-        for (int k = 0; k < 6; k++) x[k] = A.x_override[k];
-        return true;
+    for (int k = 0; k < kNumAcc; k++) acc[k] += __shfl_xor(acc[k], 32);
+    if (lane < 32) {
+#pragma unroll
+        for (int k = 0; k < kNumAcc; k++) red[k][wid * 32 + lane] = acc[k];
     }
-    if (A.state->done) return false;
-    const bool cand = A.state->phase == PHASE_CAND;
+    __syncthreads();
+    if (t < kNumAcc * 8) {
+        const int k = t >> 3, part = t & 7;
+        double v = 0.0;
 #pragma unroll
-    for (int k = 0; k < 6; k++) x[k] = cand ? A.state->xc[k] : A.state->x[k];
-    return true;
+        for (int i = 0; i < kCols / 8; i++) v += red[k][part * (kCols / 8) + i];
+        red2[k][part] = v;
+    }
+    __syncthreads();
+    if (t < kNumAcc) {
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v += red2[t][i];
+        dst[t] = v;
+    }
+}
+#endif
+
+// The eval point into LDS: one cooperative copy of the block the LM step left (or, for an explicit x, built here by four
+// lanes).  Returns false when the solve is already done (every thread of the workgroup gets the same answer).
+__device__ __forceinline__ bool eval_point_load(const EvalArgs& A, LMEvalPoint* s_pt) {
+    if (A.x_override) {
+        if (threadIdx.x < 4) {
+            double x[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) x[k] = A.x_override[k];
+            eval_point_column(x, 0, threadIdx.x, s_pt);
+        }
+    } else if (threadIdx.x < sizeof(LMEvalPoint) / 8) {
+        reinterpret_cast<unsigned long long*>(s_pt)[threadIdx.x] = reinterpret_cast<const unsigned long long*>(A.pt)[threadIdx.x];
+    }
+    __syncthreads();
+    return A.x_override || !s_pt->done;
 }
 
 // point-to-plane blocks (row R1 + Scaled(Cauchy(loss_thresh_3DPD), weight_3DPD), velo.h:875-892)
-__device__ __forceinline__ void eval_icp_body(const EvalArgs& A, const int bx, const int nbx) {
-    // The correspondences do not depend on the pose: the first kPre strided rows of this thread are requested BEFORE the LM
-    // state (written by the previous launch) is read and the rotation constants are set up, so both latencies overlap.
-    constexpr int kPre = 4;
+// The correspondences do not depend on the pose: the first kPre strided rows of a thread are requested at the very start of the
+// kernel, BEFORE the eval point (or, in the one-launch iteration, the whole LM step) is dealt with, so the latencies overlap.
+constexpr int kPre = 4;
+struct RowPrefetch { float4 p[kPre], n[kPre], v[kPre]; };
+__device__ __forceinline__ RowPrefetch prefetch_rows(const EvalArgs& A, const int bx, const int nbx) {
+    RowPrefetch f;
     const int tid = bx * blockDim.x + threadIdx.x, nthreads = nbx * blockDim.x;
-    float4 pp[kPre], pn[kPre], pv[kPre];
 #pragma unroll
     for (int k = 0; k < kPre; k++) {
         const int i = min(A.q_begin + tid + k * nthreads, A.q_end - 1);
-        pp[k] = A.cp[i]; pn[k] = A.cn[i]; pv[k] = A.cv0[i];
+        f.p[k] = A.cp[i]; f.n[k] = A.cn[i]; f.v[k] = A.cv0[i];
     }
-    VELO_LM_TRACE(A.trace, A.x_override ? 0 : A.state->evals, 0);
-    double x[6];
-    if (!eval_load_x(A, x)) return;
-    VELO_LM_TRACE(A.trace, A.x_override ? 0 : A.state->evals, 1);
-    // the point-independent part of the rotation (sqrt, sin, cos and their partials) once per workgroup, not per thread
-    __shared__ PoseRot s_R;
-    if (threadIdx.x == 0) pose_rot_init(x, &s_R);
-    __syncthreads();
-    const PoseRot R = s_R;
-    VELO_LM_TRACE(A.trace, A.x_override ? 0 : A.state->evals, 2);
-    const double t[3] = {x[3], x[4], x[5]};
-    double acc[kNumAcc];
+    return f;
+}
+// one point-to-plane row into the accumulators
+template <bool M_FROM_LDS>
+__device__ __forceinline__ void sweep_row(const EvalArgs& A, const LMEvalPoint& s_pt, const double (*Mreg)[9], const double t[3], const float4& p, const float4& n,
+                                          const float4& v, const int i, double acc[kNumAcc]) {
+    if (__float_as_int(p.w) == 0) return;
+    // M_FROM_LDS (the sweep kernels that must run two waves per SIMD next to other pairs' kernels): the four matrices are read
+    // from LDS for every row (uniform addresses: broadcast reads) instead of living in 72 registers across the loop -- with them,
+    // the 56 accumulator registers and the prefetched rows the kernel would need scratch memory, and a kernel that touches scratch
+    // at all costs ~11 us more per launch on this system.  The pointer is made opaque so that the loads are not hoisted out of the
+    // loop again.  The one-launch iteration (one wave per SIMD, registers to spare) keeps them in registers: 3.2 vs 4.7 us of rows.
+    const double (*M)[9] = M_FROM_LDS ? s_pt.M : Mreg;
+    if (M_FROM_LDS) asm volatile("" : "+v"(M));
+    const double pd[3] = {p.x, p.y, p.z}, nd[3] = {n.x, n.y, n.z}, vd[3] = {v.x, v.y, v.z};
+    double r, J[6];
+    res_3dpd_mat(M, t, pd, nd, vd, &r, J);
+    double rho0, rho1;
+    loss_cauchy(A.loss_a_3dpd, A.w_3dpd, r * r, &rho0, &rho1);
+    acc[27] += 0.5 * rho0;
+    const double sr = sqrt(rho1);
+    accumulate_row(acc, r, J, sr);
+    if (A.rows_r) {
+        const int row = A.row_offset_icp[i];
+        A.rows_r[row] = r * sr;
 #pragma unroll
-    for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
-    int it = 0;
-    for (int i = A.q_begin + tid; i < A.q_end; i += nthreads, it++) {
-        float4 p, n, v;
-        if (it < kPre) {                                     // (compile-time indices after unrolling the first kPre trips)
-            p = pp[0]; n = pn[0]; v = pv[0];
+        for (int k = 0; k < 6; k++) A.rows_J[(size_t)row * 6 + k] = J[k] * sr;
+    }
+}
+// this workgroup's rows at the eval point in LDS -> the 28 accumulators of every thread (the prefetched rows first, with
+// compile-time indices, then whatever is left)
+template <bool M_FROM_LDS>
+__device__ __forceinline__ void sweep_rows(const EvalArgs& A, const RowPrefetch& f, const LMEvalPoint& s_pt, const int bx, const int nbx, double acc[kNumAcc]) {
+    const int tid = bx * blockDim.x + threadIdx.x, nthreads = nbx * blockDim.x;
+    double Mreg[4][9];
+    if (!M_FROM_LDS) {
 #pragma unroll
-            for (int k = 1; k < kPre; k++) if (it == k) { p = pp[k]; n = pn[k]; v = pv[k]; }
-        } else { p = A.cp[i]; n = A.cn[i]; v = A.cv0[i]; }
-        if (__float_as_int(p.w) == 0) continue;
-        const double pd[3] = {p.x, p.y, p.z}, nd[3] = {n.x, n.y, n.z}, vd[3] = {v.x, v.y, v.z};
-        double r, J[6];
-        res_3dpd(R, t, pd, nd, vd, &r, J);
-        double rho0, rho1;
-        loss_cauchy(A.loss_a_3dpd, A.w_3dpd, r * r, &rho0, &rho1);
-        acc[27] += 0.5 * rho0;
-        const double sr = sqrt(rho1);
-        accumulate_row(acc, r, J, sr);
-        if (A.rows_r) {
-            const int row = A.row_offset_icp[i];
-            A.rows_r[row] = r * sr;
+        for (int a = 0; a < 4; a++) {
 #pragma unroll
-            for (int k = 0; k < 6; k++) A.rows_J[(size_t)row * 6 + k] = J[k] * sr;
+            for (int k = 0; k < 9; k++) Mreg[a][k] = s_pt.M[a][k];
         }
     }
-    VELO_LM_TRACE(A.trace, A.x_override ? 0 : A.state->evals, 3);
-    block_reduce_store(acc, A.partials + (size_t)bx * kNumAcc);
-    VELO_LM_TRACE(A.trace, A.x_override ? 0 : A.state->evals, 4);
+    double t[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) t[k] = s_pt.t[k];
+#pragma unroll
+    for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < kPre; k++) {
+        const int i = A.q_begin + tid + k * nthreads;
+        if (i < A.q_end) sweep_row<M_FROM_LDS>(A, s_pt, Mreg, t, f.p[k], f.n[k], f.v[k], i, acc);
+    }
+    for (int i = A.q_begin + tid + kPre * nthreads; i < A.q_end; i += nthreads) sweep_row<M_FROM_LDS>(A, s_pt, Mreg, t, A.cp[i], A.cn[i], A.cv0[i], i, acc);
+}
+
+__device__ __forceinline__ void eval_icp_body(const EvalArgs& A, const int bx, const int nbx) {
+    const RowPrefetch f = prefetch_rows(A, bx, nbx);
+    VELO_LM_TRACE(A.trace, A.trace_eval, 0);
+    __shared__ LMEvalPoint s_pt;
+    if (!eval_point_load(A, &s_pt)) return;
+    VELO_LM_TRACE(A.trace, A.trace_eval, 1);
+    double acc[kNumAcc];
+    sweep_rows<true>(A, f, s_pt, bx, nbx, acc);
+    VELO_LM_TRACE(A.trace, A.trace_eval, 2);
+#if VELO_REDUCE_LDS
+    __shared__ double s_scratch[kScratchDoubles];
+#else
+    double* s_scratch = nullptr;
+#endif
+    block_reduce_store(acc, A.partials + (size_t)bx * kNumAcc, s_scratch);
+    VELO_LM_TRACE(A.trace, A.trace_eval, 3);
 }
 
 __global__ void __launch_bounds__(kEvalThreads)
@@ -1900,8 +2024,11 @@ eval_icp_batch_kernel(const LMBatchItem* __restrict__ items) {
 }
 // visual blocks (rows R2-R5; losses velo.h:688,714-717,748-751,781-784)
 __device__ __forceinline__ void eval_visual_body(const EvalArgs& A, const int bx, const int nbx) {
+    __shared__ LMEvalPoint s_pt;
+    if (!eval_point_load(A, &s_pt)) return;
     double x[6];
-    if (!eval_load_x(A, x)) return;
+#pragma unroll
+    for (int k = 0; k < 6; k++) x[k] = s_pt.x[k];
     PoseEval P;
     pose_eval_init(x, &P, true);
     double acc[kNumAcc];
@@ -1933,7 +2060,12 @@ __device__ __forceinline__ void eval_visual_body(const EvalArgs& A, const int bx
             }
         }
     }
-    block_reduce_store(acc, A.partials + (size_t)(A.vis_row0 + bx) * kNumAcc);
+#if VELO_REDUCE_LDS
+    __shared__ double s_scratch[kScratchDoubles];
+#else
+    double* s_scratch = nullptr;
+#endif
+    block_reduce_store(acc, A.partials + (size_t)(A.vis_row0 + bx) * kNumAcc, s_scratch);
 }
 
 __global__ void __launch_bounds__(kEvalThreads)
@@ -2043,43 +2175,150 @@ __device__ inline void lm_compute_step(const LMParams& Q, LMState* S) {
     }
 }
 
-__global__ void lm_begin_kernel(LMState* S, const double* __restrict__ x_in, const int* __restrict__ n_valid) {
-    if (threadIdx.x == 0) {
-        if (x_in) for (int i = 0; i < 6; i++) S->x[i] = x_in[i];
+// Start of a solve: the state's bookkeeping and the eval point of the first sweep (four lanes build it).
+__device__ __forceinline__ void lm_begin_body(LMState* S, LMEvalPoint* pt, const double* __restrict__ x_in, const int* __restrict__ n_valid) {
+    const int t = threadIdx.x;
+    double x[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] = x_in ? x_in[i] : S->x[i];
+    if (t == 0) {
+        if (x_in) for (int i = 0; i < 6; i++) S->x[i] = x[i];
         S->n_valid = n_valid ? *n_valid : 0;
         S->phase = PHASE_INIT; S->done = 0; S->termination = 1; S->iter = 0; S->evals = 0; S->invalid = 0; S->reuse_diag = 0;
     }
+    if (t < 4) eval_point_column(x, 0, t, pt);
+}
+__global__ void lm_begin_kernel(LMState* S, LMEvalPoint* pt, const double* __restrict__ x_in, const int* __restrict__ n_valid) {
+    lm_begin_body(S, pt, x_in, n_valid);
 }
 
-// sums: either the per-workgroup partials [n_blocks][28] (single GPU) or an already reduced [1][28] block (after all-reduce);
-// then ONE LM state transition.  Called by a whole 256-thread workgroup.
+// The LM step of one solve, by one 256-thread workgroup: fixed-order sum of the per-workgroup partial rows [n_blocks][28] (or of
+// the already reduced [1][28] block behind an all-reduce), ONE trust-region state transition, and the eval point of the next
+// sweep -- all into LDS (sL, s_pt); the caller stores what it needs.  Laid out for latency: the partial rows and the 496-byte
+// state are requested together at the very start (a thread's share of a 128-row chunk is 14 independent coalesced loads, all
+// issued before the first is used), the transition runs on a register copy, four lanes build the eval point.
+// first != 0: start of a solve (what lm_begin_kernel does) -- no partial rows yet, the state's bookkeeping is reset and the eval
+// point is x_in (or the state's x).  Returns with the workgroup synchronised.
 __device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* S, const double* E);
-__device__ __forceinline__ void lm_transition(const LMParams& Q, LMState* Sg, const double* __restrict__ partials, int n_blocks,
-                                              unsigned long long* trace = nullptr) {
+constexpr int kStepChunk = 128;
+static_assert(kStepChunk * kNumAcc == kScratchDoubles && kStepChunk * kNumAcc % 256 == 0 && kStepChunk % 8 == 0, "chunk geometry");
+__device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __restrict__ Sin, const double* __restrict__ partials, int n_blocks, int first,
+                                           const double* __restrict__ x_in, const int* __restrict__ n_valid,
+                                           double* __restrict__ s_rows, LMState* sL, LMEvalPoint* s_pt, unsigned long long* trace, int trace_eval) {
     __shared__ double part[8][kNumAcc];
     __shared__ double E[kNumAcc];
+    constexpr int kPerThread = kStepChunk * kNumAcc / 256;
     const int t = threadIdx.x;
-#ifdef VELO_DIAGNOSTICS
-    const int trace_eval = trace ? Sg->evals : 0;
-#endif
-    VELO_LM_TRACE(trace, trace_eval, 5);
-    if (t < 8 * kNumAcc) {
-        const int k = t % kNumAcc, p = t / kNumAcc;
-        double v = 0.0;
-        for (int b = p; b < n_blocks; b += 8) v += partials[(size_t)b * kNumAcc + k];
-        part[p][k] = v;
+    if (t < (int)(sizeof(LMState) / 8)) reinterpret_cast<unsigned long long*>(sL)[t] = reinterpret_cast<const unsigned long long*>(Sin)[t];
+    double xin[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int nv = 0;
+    if (first && t == 0) {
+        if (x_in) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) xin[i] = x_in[i];
+        }
+        nv = n_valid ? *n_valid : 0;
+    }
+    const int k_acc = t % kNumAcc, p_acc = t / kNumAcc;
+    double v_acc = 0.0;
+    if (!first) {
+        for (int c0 = 0; c0 < n_blocks; c0 += kStepChunk) {
+            const int nrows = min(kStepChunk, n_blocks - c0), total = nrows * kNumAcc;
+            const double* __restrict__ src = partials + (size_t)c0 * kNumAcc;
+            double a[kPerThread];
+#pragma unroll
+            for (int u = 0; u < kPerThread; u++) { const int i = t + 256 * u; a[u] = (i < total) ? src[i] : 0.0; }
+            if (c0 > 0) __syncthreads();                        // the previous chunk has been summed
+#pragma unroll
+            for (int u = 0; u < kPerThread; u++) { const int i = t + 256 * u; if (i < total) s_rows[i] = a[u]; }
+            __syncthreads();
+            if (t < 8 * kNumAcc) for (int b = p_acc; b < nrows; b += 8) v_acc += s_rows[b * kNumAcc + k_acc];
+        }
+        if (t < 8 * kNumAcc) part[p_acc][k_acc] = v_acc;
     }
     __syncthreads();
-    if (t < kNumAcc) { double v = 0.0; for (int p = 0; p < 8; p++) v += part[p][t]; E[t] = v; }
+    VELO_LM_TRACE(trace, trace_eval, 5);
+    if (first) {
+        if (t == 0) {                                        // lm_begin
+            if (x_in) for (int i = 0; i < 6; i++) sL->x[i] = xin[i];
+            sL->n_valid = nv;
+            sL->phase = PHASE_INIT; sL->done = 0; sL->termination = 1; sL->iter = 0; sL->evals = 0; sL->invalid = 0; sL->reuse_diag = 0;
+        }
+    } else if (!sL->done) {                                  // uniform: a step behind a finished solve changes nothing
+        if (t < kNumAcc) { double v = 0.0; for (int p = 0; p < 8; p++) v += part[p][t]; E[t] = v; }
+        __syncthreads();
+        VELO_LM_TRACE(trace, trace_eval, 6);
+        if (t == 0) {
+            LMState L = *sL;
+            lm_transition_local(Q, &L, E);
+            *sL = L;
+        }
+    }
     __syncthreads();
-    if (t != 0) return;
-    VELO_LM_TRACE(trace, trace_eval, 6);
-    // the transition is ~300 dependent double operations on the state: run it on a private copy (one batch of loads, one batch
-    // of stores) instead of walking the global struct field by field with a wait after every access
-    LMState L = *Sg;
-    lm_transition_local(Q, &L, E);
-    *Sg = L;
     VELO_LM_TRACE(trace, trace_eval, 7);
+    if (t < 4) {
+        double x[6];
+        const bool cand = sL->phase == PHASE_CAND;
+#pragma unroll
+        for (int k = 0; k < 6; k++) x[k] = cand ? sL->xc[k] : sL->x[k];
+        eval_point_column(x, sL->done, t, s_pt);
+    }
+    __syncthreads();
+    VELO_LM_TRACE(trace, trace_eval, 8);
+}
+
+// two launches per iteration (sweep kernels, then this): used behind an all-reduce, with visual blocks, and by the lock-step batch driver
+__device__ __forceinline__ void lm_transition(const LMParams& Q, LMState* Sg, LMEvalPoint* pt, const double* __restrict__ partials, int n_blocks,
+                                              unsigned long long* trace = nullptr, int trace_eval = 0) {
+    __shared__ LMState sL;
+    __shared__ LMEvalPoint s_pt;
+    __shared__ double s_rows[kScratchDoubles];
+    const int t = threadIdx.x;
+    VELO_LM_TRACE(trace, trace_eval, 4);
+    lm_advance(Q, Sg, partials, n_blocks, 0, nullptr, nullptr, s_rows, &sL, &s_pt, trace, trace_eval);
+    if (t < (int)(sizeof(LMState) / 8)) reinterpret_cast<unsigned long long*>(Sg)[t] = reinterpret_cast<const unsigned long long*>(&sL)[t];
+    else if (t >= 64 && t < 64 + (int)(sizeof(LMEvalPoint) / 8)) reinterpret_cast<unsigned long long*>(pt)[t - 64] = reinterpret_cast<const unsigned long long*>(&s_pt)[t - 64];
+    VELO_LM_TRACE(trace, trace_eval, 9);
+}
+
+// ONE launch per LM iteration (single GPU, point-to-plane rows only): every sweep workgroup first consumes the PREVIOUS sweep's
+// partial rows itself -- the same lm_advance, redundantly in all of them: identical inputs, identical arithmetic, identical
+// state and eval point in every workgroup's LDS, no grid barrier and no hand-off between workgroups -- and then sweeps its rows
+// at the new point.  State and partial rows are double-buffered (launch k reads buffer k & 1 and writes the other one; workgroup 0
+// stores the state), because a fast workgroup must not overwrite what a slow one has yet to read.  Per iteration this is one
+// kernel boundary and one cold-load latency (partial rows, state and this workgroup's correspondences are all requested at the
+// start) instead of two each; launch 0 also does what lm_begin_kernel did.  Bit-identical to the two-launch path.
+__device__ __forceinline__ void lm_iter_body(const EvalArgs& A, const LMParams& Q, const LMState* __restrict__ Sin, LMState* __restrict__ Sout,
+                                             const double* __restrict__ pin, int n_in, double* __restrict__ pout, int first,
+                                             const double* __restrict__ x_in, const int* __restrict__ n_valid, const int bx, const int nbx) {
+    __shared__ LMState sL;
+    __shared__ LMEvalPoint s_pt;
+    __shared__ double s_scratch[kScratchDoubles];
+    const RowPrefetch f = prefetch_rows(A, bx, nbx);
+    VELO_LM_TRACE(A.trace, A.trace_eval, 0);
+    lm_advance(Q, Sin, pin, n_in, first, x_in, n_valid, s_scratch, &sL, &s_pt, A.trace, A.trace_eval);
+    const int t = threadIdx.x;
+    if (bx == 0 && t < (int)(sizeof(LMState) / 8)) reinterpret_cast<unsigned long long*>(Sout)[t] = reinterpret_cast<const unsigned long long*>(&sL)[t];
+    if (sL.done) return;
+    double acc[kNumAcc];
+    sweep_rows<false>(A, f, s_pt, bx, nbx, acc);
+    VELO_LM_TRACE(A.trace, A.trace_eval, 2);
+    block_reduce_store(acc, pout + (size_t)bx * kNumAcc, s_scratch);
+    VELO_LM_TRACE(A.trace, A.trace_eval, 3);
+}
+__global__ void __launch_bounds__(kEvalThreads)
+lm_iter_kernel(EvalArgs A, LMParams Q, const LMState* __restrict__ Sin, LMState* __restrict__ Sout, const double* __restrict__ pin, int n_in,
+               double* __restrict__ pout, int first, const double* __restrict__ x_in, const int* __restrict__ n_valid) {
+    lm_iter_body(A, Q, Sin, Sout, pin, n_in, pout, first, x_in, n_valid, blockIdx.x, gridDim.x);
+}
+// the same for the contexts of a lock-step group: blockIdx.y = context, k = index of the launch within the solve (its parity
+// selects the halves of every context's state / partial-row double buffer; `half` = doubles per half)
+__global__ void __launch_bounds__(kEvalThreads)
+lm_iter_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int k, size_t half) {
+    const LMBatchItem& it = items[blockIdx.y];
+    if ((int)blockIdx.x >= it.nb_icp) return;
+    lm_iter_body(it.A, Q, it.S + (k & 1), it.S + ((k + 1) & 1), it.A.partials + (size_t)(k & 1) * half, it.nb_icp,
+                 it.A.partials + (size_t)((k + 1) & 1) * half, k == 0 ? 1 : 0, it.xd, it.n_valid, blockIdx.x, it.nb_icp);
 }
 
 __device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* S, const double* E) {
@@ -2120,28 +2359,21 @@ __device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* 
 }
 
 __global__ void __launch_bounds__(256)
-lm_step_kernel(LMParams Q, LMState* S, const double* __restrict__ partials, int n_blocks, unsigned long long* trace) {
-    if (S->done) return;
-    lm_transition(Q, S, partials, n_blocks, trace);
+lm_step_kernel(LMParams Q, LMState* S, LMEvalPoint* pt, const double* __restrict__ partials, int n_blocks, unsigned long long* trace, int trace_eval) {
+    lm_transition(Q, S, pt, partials, n_blocks, trace, trace_eval);
 }
 __global__ void lm_begin_batch_kernel(const LMBatchItem* __restrict__ items) {
     const LMBatchItem& it = items[blockIdx.x];
-    LMState* S = it.S;
-    if (threadIdx.x == 0) {
-        if (it.xd) for (int i = 0; i < 6; i++) S->x[i] = it.xd[i];
-        S->n_valid = it.n_valid ? *it.n_valid : 0;
-        S->phase = PHASE_INIT; S->done = 0; S->termination = 1; S->iter = 0; S->evals = 0; S->invalid = 0; S->reuse_diag = 0;
-    }
+    lm_begin_body(it.S, const_cast<LMEvalPoint*>(it.A.pt), it.xd, it.n_valid);
 }
 __global__ void __launch_bounds__(256)
 lm_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items) {
     const LMBatchItem& it = items[blockIdx.x];
-    if (it.S->done) return;
-    lm_transition(Q, it.S, it.A.partials, it.n_rows);
+    lm_transition(Q, it.S, const_cast<LMEvalPoint*>(it.A.pt), it.A.partials, it.n_rows);
 }
 // all states of the batch into one contiguous block (one D2H copy per chunk instead of one per context)
-__global__ void lm_gather_states_kernel(const LMBatchItem* __restrict__ items, LMState* __restrict__ out) {
-    const unsigned* src = reinterpret_cast<const unsigned*>(items[blockIdx.x].S);
+__global__ void lm_gather_states_kernel(const LMBatchItem* __restrict__ items, LMState* __restrict__ out, int which) {
+    const unsigned* src = reinterpret_cast<const unsigned*>(items[blockIdx.x].S + which);
     unsigned* dst = reinterpret_cast<unsigned*>(out + blockIdx.x);
     for (int k = threadIdx.x; k < (int)(sizeof(LMState) / 4); k += blockDim.x) dst[k] = src[k];
 }
@@ -2203,58 +2435,6 @@ lm_solve_small_kernel(EvalArgs A, LMParams Q, LMState* Sg, const double* __restr
         __syncthreads();
     }
     if (t == 0) *Sg = sL;
-}
-
-// Fused LM iteration (single GPU): the point-to-plane sweep, and the LAST workgroup to arrive performs the final
-// reduction and the LM transition -- one launch per LM iteration instead of two.  Inter-workgroup hand-off by the
-// placement-independent protocol of the CDNA guide (Guideline 16, counter form): every storing wave drains its
-// stores, workgroup barrier, one lane does an agent-scope release then a relaxed agent-scope ticket add; the last
-// arriver does an agent-scope acquire before any thread of its workgroup reads the other workgroups' partial rows.
-// `total_rows` also covers the rows the visual sweep (an earlier launch on the same stream) wrote.
-__global__ void __launch_bounds__(kEvalThreads)
-lm_iter_fused_kernel(EvalArgs A, LMParams Q, LMState* S, int* __restrict__ ticket, int total_rows) {
-    double x[6];
-    if (!eval_load_x(A, x)) return;                      // `done`: nobody touches the ticket
-    __shared__ PoseRot s_R;                              // rotation constants once per workgroup
-    if (threadIdx.x == 0) pose_rot_init(x, &s_R);
-    __syncthreads();
-    const PoseRot R = s_R;
-    const double t[3] = {x[3], x[4], x[5]};
-    double acc[kNumAcc];
-#pragma unroll
-    for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
-    for (int i = A.q_begin + tid; i < A.q_end; i += nthreads) {
-        const float4 p = A.cp[i];
-        if (__float_as_int(p.w) == 0) continue;
-        const float4 n = A.cn[i], v = A.cv0[i];
-        const double pd[3] = {p.x, p.y, p.z}, nd[3] = {n.x, n.y, n.z}, vd[3] = {v.x, v.y, v.z};
-        double r, J[6];
-        res_3dpd(R, t, pd, nd, vd, &r, J);
-        double rho0, rho1;
-        loss_cauchy(A.loss_a_3dpd, A.w_3dpd, r * r, &rho0, &rho1);
-        acc[27] += 0.5 * rho0;
-        accumulate_row(acc, r, J, sqrt(rho1));
-    }
-    block_reduce_store(acc, A.partials + (size_t)blockIdx.x * kNumAcc);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every storing wave drains its stores
-    __syncthreads();
-    __shared__ int s_last;
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int prev = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = (prev == (int)gridDim.x - 1) ? 1 : 0;
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-armed for the next launch
-        }
-        s_last = last;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    lm_transition(Q, S, A.partials, total_rows);
 }
 
 // ---- seam 2 by value: a batch of residual functors (costfunctions.h:17-220) at one pose -----------------------------------
