@@ -564,7 +564,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         // stop (what a rocprofv3 kernel trace reports); events recorded around a launch would also count the time the launch waits
         // for the chip while other streams' kernels run.  The A/B variants keep the record-around bracket.
         const int variant_timed = c->assoc_variant >= 0 ? c->assoc_variant : 5;
-        const bool ext_timed = variant_timed == 5 || variant_timed == 55 || variant_timed == 52 || variant_timed == 59;
+        const bool ext_timed = variant_timed == 5 || (variant_timed >= 52 && variant_timed <= 59);
         if (ev && !ext_timed) HIP_TRY(hipEventRecord(ev->first, c->stream));
         const int aux = want_aux ? 1 : 0;
         const int groups = cdiv(qe - qb, 64);
@@ -617,7 +617,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                                        c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, h_safe, out, aux);
                 break;
             }
-            case 5: case 55: case 52: case 59: {   // tube variant: per-row intervals, per-query phase 2 (cluster radius only when VELO_CLUSTER_W is given)
+            case 5: case 55: case 52: case 56: case 57: case 58: case 59: {   // tube variant: per-row intervals, per-query phase 2 (cluster radius only when VELO_CLUSTER_W is given)
                 // tubes do not grow with the segment, so the cluster radius only has to bound the row box of pathological groups
                 // (a 64-query group straddling a gap in its ring): 96 default cells = 17 m unless VELO_CLUSTER_W says otherwise
                 const int cw = c->cluster_w_set ? (c->cluster_w > 0 ? cluster_cells : 2000)
@@ -639,6 +639,9 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
 #endif
                 if (variant == 55) VELO_LAUNCH_V5(4, 5, false, 4, true);
                 else if (variant == 52) VELO_LAUNCH_V5(4, 6, false, 2, true);
+                else if (variant == 56) VELO_LAUNCH_V5(4, 6, false, 2, false);   // occupancy A/B: 6 / 7 / 8 waves per SIMD
+                else if (variant == 57) VELO_LAUNCH_V5(4, 7, false, 2, false);
+                else if (variant == 58) VELO_LAUNCH_V5(4, 8, false, 2, false);
                 else if (variant == 59) VELO_LAUNCH_V5(4, 5, false, 2, false);   // phase 2 through the row/tile machinery (A/B)
                 else if (asker_rows >= (1 << 30)) VELO_LAUNCH_V5(4, 5, false, 2, false);   // regular grid: instantiation without the query-by-query code (no spills)
                 else VELO_LAUNCH_V5(4, 5, false, 2, true);

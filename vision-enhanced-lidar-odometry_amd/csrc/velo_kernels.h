@@ -617,9 +617,6 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // so the walk stops once (e * cell)^2 > max over member lanes of b2d (second-best squared distance, or the gate when a
 // lane has no second ring yet): no unvisited point can enter any lane's result.  In the dense part of a scan this ends
 // after the first phase; the answer is still the exact exhaustive one.
-#ifndef VELO_SWEEP_PACKED
-#define VELO_SWEEP_PACKED 0       // 1: the candidate sweep of the tube kernel with packed-f32 instructions (A/B builds)
-#endif
 constexpr int kTileCap = 512;      // candidates per LDS tile (keeps the workgroup under 20 KB of LDS: 8 workgroups per CU)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -905,6 +902,11 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
     __shared__ int s_lo[NT], s_hi[NT], s_plo[NT], s_phi[NT];   // per-row x-interval of this phase / of what phase 1 visited
     __shared__ int s_box[2][6][64];                            // per-query cell box of phase 1 / phase 2 (x0, x1, y0, y1, z0, z1)
     __shared__ int s_phase[8];                                 // Y0, Y1, Z0, Z1, asking-lane mask (lo, hi), total rows asked for
+    // The transformed queries live HERE, not in registers: lane i of every wave re-reads query i where it needs it (cell boxes, the
+    // rare exact-distance path of the sweep, the finish).  Three registers less across the sweep is what keeps the kernel at
+    // 96 VGPRs -- five waves per SIMD -- without a single spilled register (a kernel that touches scratch pays ~11 us per launch).
+    __shared__ float s_q[3][64];
+#define VELO_Q(x, y, z) const float x = s_q[0][lane], y = s_q[1][lane], z = s_q[2][lane]
     // merge scratch aliases the tile: the barrier that closes the last sweep separates the two uses (NW <= 4)
     static_assert(NW * 64 * 16 <= (int)sizeof(float4) * (kTileCap / 2) && NW * 64 * 8 <= (int)sizeof(int) * kTileCap, "merge scratch must fit the tile");
     unsigned long long (*m1)[64] = reinterpret_cast<unsigned long long (*)[64]>(s_xy);
@@ -926,17 +928,16 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
     const int qi = q_begin + group * 64 + lane;
     const bool active = qi < q_end;
     const unsigned long long key_inf = ((unsigned long long)gate_bits + 1ull) << 32;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
     Top2 t;
     t.b1 = key_inf; t.b2 = key_inf; t.b1ring = -1; t.b2ring = -1; t.b2d = __uint_as_float(gate_bits + 1u);
     const GridDesc g = G.d;
     // Set-up once per GROUP, not once per wave: wave 0 transforms the 64 queries (double precision) and enters the warm-start
     // seeds, the other waves pick the result up from LDS (scratch aliases the tile, which is not in use yet).
     {
-        float* sq = reinterpret_cast<float*>(s_xy);                              // [3][64] transformed query
         unsigned long long* sb = reinterpret_cast<unsigned long long*>(s_zg);   // [2][64] best1 / best2 keys
         int* sr = s_ring;                                                        // [2][64] their rings
         if (wid == 0) {
+            float qx = 0.f, qy = 0.f, qz = 0.f;
             if (active) {
                 // everything the set-up needs is requested at once (coalesced, no load behind another load's result)
                 const float4 psrc = qpts[qi];
@@ -958,23 +959,17 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
                     if (__float_as_uint(d) <= gate_bits) top2_update(t, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(__float_as_int(sb.w) + out.first_point), sr.y);
                 }
             }
-            sq[lane] = qx; sq[64 + lane] = qy; sq[128 + lane] = qz;
+            s_q[0][lane] = qx; s_q[1][lane] = qy; s_q[2][lane] = qz;
             sb[lane] = t.b1; sb[64 + lane] = t.b2; sr[lane] = t.b1ring; sr[64 + lane] = t.b2ring;
         }
         __syncthreads();
         if (wid != 0) {
-            qx = sq[lane]; qy = sq[64 + lane]; qz = sq[128 + lane];
             t.b1 = sb[lane]; t.b2 = sb[64 + lane]; t.b1ring = sr[lane]; t.b2ring = sr[64 + lane];
             t.b2d = __uint_as_float((unsigned)(t.b2 >> 32));
         }
         __syncthreads();                                                         // the tile may be overwritten from here on
     }
-    int cx = 0, cy = 0, cz = 0;
-    if (active) { cx = cell_coord(qx, g.ox, g.inv_h, g.nx); cy = cell_coord(qy, g.oy, g.inv_h, g.ny); cz = cell_coord(qz, g.oz, g.inv_h, g.nz); }
     VELO_STAMP(0);
-#if VELO_SWEEP_PACKED
-    const f32x2 qx2 = {qx, qx}, qy2 = {qy, qy}, qz2 = {qz, qz};
-#endif
     float* s_xy_f = reinterpret_cast<float*>(s_xy);
     float* s_zg_f = reinterpret_cast<float*>(s_zg);
     const int big = 1 << 28;
@@ -983,8 +978,14 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
         const unsigned long long pm = __ballot(pending);
         if (pm == 0ull) break;
         const int leader = (int)__ffsll((long long)pm) - 1;
-        const int scx = __builtin_amdgcn_readlane(cx, leader), scy = __builtin_amdgcn_readlane(cy, leader), scz = __builtin_amdgcn_readlane(cz, leader);
-        const bool member = pending && abs(cx - scx) <= cluster_w && abs(cy - scy) <= cluster_w && abs(cz - scz) <= cluster_w;
+        bool member;
+        {
+            VELO_Q(qx, qy, qz);
+            int cx = 0, cy = 0, cz = 0;
+            if (active) { cx = cell_coord(qx, g.ox, g.inv_h, g.nx); cy = cell_coord(qy, g.oy, g.inv_h, g.ny); cz = cell_coord(qz, g.oz, g.inv_h, g.nz); }
+            const int scx = __builtin_amdgcn_readlane(cx, leader), scy = __builtin_amdgcn_readlane(cy, leader), scz = __builtin_amdgcn_readlane(cz, leader);
+            member = pending && abs(cx - scx) <= cluster_w && abs(cy - scy) <= cluster_w && abs(cz - scz) <= cluster_w;
+        }
         if (DBG && (dbg & 16) && tid == 0) atomicAdd(&out.dbg[0], 1ull);
         // Per-query cell boxes.  Everything closer to the query than r = sqrt(b2d) lies in the cells [cell(q - r), cell(q + r)] per
         // axis (the cell function is monotone; r is padded against rounding).  Phase 1 visits that box clipped to the query's
@@ -1001,6 +1002,8 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
                 bool asks0 = member;
                 CellBox bb;
                 int rows_all = 0;
+                VELO_Q(qx, qy, qz);
+                const int cx = cell_coord(qx, g.ox, g.inv_h, g.nx), cy = cell_coord(qy, g.oy, g.inv_h, g.ny), cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
                 if (ph == 0) bb = query_box(g, qx, qy, qz, cx, cy, cz, r1, true);
                 else {
                     const float rq = sqrtf(t.b2d) * 1.0001f + 1e-6f;
@@ -1146,25 +1149,14 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
 #pragma unroll
                             for (int u = 0; u < PPT; u++) { a[u] = s_xy[pi + u]; bq[u] = s_zg[pi + u]; rg[u] = s_ring2[pi + u]; }
                             float d2x[PPT], d2y[PPT];
-#if VELO_SWEEP_PACKED
+                            {
+                                VELO_Q(qx, qy, qz);                    // plain f32 operations (a packed-f32 instruction takes two issue slots: measured equal)
 #pragma unroll
-                            for (int u = 0; u < PPT; u++) {
-                                const f32x2 cxp = {a[u].x, a[u].y}, cyp = {a[u].z, a[u].w}, czp = {bq[u].x, bq[u].y};
-                                const f32x2 dx = qx2 - cxp, dy = qy2 - cyp, dz = qz2 - czp;
-                                f32x2 d = dx * dx;                     // x -> y -> z accumulation, no FMA (-ffp-contract=off)
-                                d = d + dy * dy;
-                                d = d + dz * dz;
-                                d2x[u] = d.x; d2y[u] = d.y;
+                                for (int u = 0; u < PPT; u++) {
+                                    d2x[u] = dist2_f(qx, qy, qz, a[u].x, a[u].z, bq[u].x);
+                                    d2y[u] = dist2_f(qx, qy, qz, a[u].y, a[u].w, bq[u].y);
+                                }
                             }
-#else
-                            // plain f32 operations: on gfx950 a packed-f32 instruction costs the issue slots of several plain ones
-                            // (MI355X_MICROARCH.md, price of a v_pk_add_f32 against a v_fma_f32), so two plain sequences are cheaper
-#pragma unroll
-                            for (int u = 0; u < PPT; u++) {
-                                d2x[u] = dist2_f(qx, qy, qz, a[u].x, a[u].z, bq[u].x);
-                                d2y[u] = dist2_f(qx, qy, qz, a[u].y, a[u].w, bq[u].y);
-                            }
-#endif
                             float dmin = fminf(d2x[0], d2y[0]);
 #pragma unroll
                             for (int u = 1; u < PPT; u++) dmin = fminf(dmin, fminf(d2x[u], d2y[u]));
@@ -1217,6 +1209,8 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
             // still reaches beyond those 4 cells search their full sphere.
             const float cap = 4.0f * h_safe;
             bool asks;
+            VELO_Q(qx, qy, qz);
+            const int cx = cell_coord(qx, g.ox, g.inv_h, g.nx), cy = cell_coord(qy, g.oy, g.inv_h, g.ny), cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
             {
                 const float rq0 = sqrtf(t.b2d) * 1.0001f + 1e-6f;
                 const CellBox b2 = query_box(g, qx, qy, qz, cx, cy, cz, rq0, false), b1 = query_box(g, qx, qy, qz, cx, cy, cz, r1, true);
@@ -1302,6 +1296,14 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
         pending = pending && !member;
     }
     if (NW > 1 && wid != 0) return;
+    VELO_Q(qx, qy, qz);
+    // the query index is recomputed here (opaque to the compiler) instead of living, sign-extended to 64 bits, across the whole search
+    int lane_fin = lane;
+    asm volatile("" : "+v"(lane_fin));
+    const int qi_fin = q_begin + group * 64 + lane_fin;
+    const bool active_fin = qi_fin < q_end;
+#define qi qi_fin
+#define active active_fin
     if (DBG && (dbg & 128)) {                                          // diagnostic: finish without the gathers (wrong results)
         if (active) { out.p[qi] = make_float4(qx, qy, qz, 0.f); out.n[qi] = make_float4((float)(t.b1 >> 32), (float)(t.b2 >> 32), 0.f, 0.f); out.v0[qi] = make_float4(0.f, 0.f, 0.f, 0.f); }
     } else
@@ -1310,6 +1312,9 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
     if (DBG && out.wg_times && tid == 0) out.wg_times[2 * group + 1] = __builtin_amdgcn_s_memrealtime();
     if (DBG && (dbg & 8) && tid == 0) { for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)&out.dbg[k], (unsigned long long)tacc[k]); }
 #undef VELO_STAMP
+#undef VELO_Q
+#undef qi
+#undef active
 }
 
 
