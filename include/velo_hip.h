@@ -329,6 +329,17 @@ int velo_pose_mat_to_vec(const double T[16], double x[6]);  /* util::pose_vec2ma
 int velo_comm_unique_id(char id[128]);
 int velo_comm_init(velo_ctx* ctx, const char id[128], int32_t rank, int32_t world);
 int velo_comm_destroy(velo_ctx* ctx);
+/* The same mode without a collective library call per evaluation ("peer-mapped one-shot all-reduce"): every
+ * rank owns a small slab in device memory; velo_comm_peer_export creates it and returns its 64-byte IPC handle
+ * (hipIpcMemHandle_t); the host program gathers the handles of all ranks (rank order) and hands them to velo_comm_peer_attach,
+ * which maps the peers' slabs.  Each LM step then writes its 28 doubles straight into every peer's slab and adds the world's
+ * blocks in rank order inside the step kernel: deterministic, identical on all ranks, a few microseconds over xGMI instead of a
+ * collective launch.  world <= 8.  Ranks may be processes on different GPUs of one node or -- for tests -- on the same GPU.
+ * A peer that never arrives makes the wait time out (5 s): the call in flight returns VELO_ERR_COMM. */
+int velo_comm_peer_export(velo_ctx* ctx, char handle[64]);
+int velo_comm_peer_attach(velo_ctx* ctx, const char* handles /* world * 64 bytes, rank order */, int32_t rank, int32_t world);
+/* What is attached: kind 0 = nothing, 1 = RCCL communicator (world read back with ncclCommCount), 2 = peer slabs. */
+int velo_comm_info(const velo_ctx* ctx, int32_t* kind, int32_t* rank, int32_t* world);
 /* enable != 0: the communicator's ranks hold disjoint ring blocks of the target (velo_set_target_part) instead of
  * replicas; association then exchanges per-query top-2 records (all-to-all) before the query-sharded evaluation. */
 int velo_comm_set_target_sharded(velo_ctx* ctx, int enable);

@@ -266,3 +266,58 @@ def test_batch_of_unequal_scans_equals_single_calls(hip_lib):
         assert Ss[i].solves[Ss[i].n_solves - 1].n_icp_valid == nv
     for c in batch:
         c.close()
+
+
+# ---- BASELINE configs at full size against the oracle (the oracle needs ~1.5-3 s per pair on the GPU box's host cores) ----------
+def _solve_counts(s):
+    return [(s.solves[k].termination, s.solves[k].lm_iterations, s.solves[k].evaluations, s.solves[k].n_icp_valid,
+             s.solves[k].n_visual_blocks, s.solves[k].n_visual_residuals) for k in range(s.n_solves)]
+
+
+def test_config2_full_pair_pose_and_solves_match_oracle(full_ctx, oracle, pair):
+    """configs[1]: the whole 120k x 120k registration (6 association rounds + 6 LM solves) against the CPU restatement: pose
+    within the north_star tolerance (1e-4 m / 1e-5 rad), every solve with the same termination, iteration, evaluation and
+    valid-correspondence counts, the same algorithmic byte count."""
+    orc = oracle.Oracle(threads=oracle.max_threads(), icp_skip=1)
+    orc.set_target(pair["tgt_xyz"], pair["tgt_off"])
+    orc.set_source(pair["src_xyz"], pair["src_off"])
+    xo, To, so = orc.frame_to_frame(pair["x0"])
+    full_ctx.set_source(pair["src_xyz"], pair["src_off"])          # fresh seeds, like a new frame
+    x, T, s = full_ctx.frame_to_frame(pair["x0"])
+    assert H.pose_close(x, xo, 1e-4, 1e-5), (x, xo)
+    assert s.n_solves == so.n_solves == 6 and _solve_counts(s) == _solve_counts(so)
+    assert s.algorithmic_bytes == so.algorithmic_bytes and s.n_queries == 120000
+    np.testing.assert_allclose(T, To, atol=1e-6)
+    # the simulated motion is recovered too (not a parity statement: a sanity bound on the workload itself)
+    assert np.linalg.norm(x[3:] - pair["x_true"][3:]) < 0.02 and np.linalg.norm(x[:3] - pair["x_true"][:3]) < 2e-3
+
+
+def test_config3_full_pair_with_2000_stereo_blocks_matches_oracle(hip_lib, oracle, pair):
+    """configs[2]: the 120k pair + 1,000 matches x 2 cameras (2,000 reprojection blocks, 10 % gross outliers): pose, the outlier
+    gate's good_matches list after the call (iter 2) and every solve's counts equal the oracle's; single call and lock-step
+    batch entry agree bit for bit."""
+    vis = synth.stereo_matches(1000)
+    orc = oracle.Oracle(threads=oracle.max_threads(), icp_skip=1)
+    orc.set_target(pair["tgt_xyz"], pair["tgt_off"])
+    orc.set_source(pair["src_xyz"], pair["src_off"])
+    orc.set_visual(vis)
+    xo, To, so = orc.frame_to_frame(pair["x0"])
+    go = orc.good_matches()
+    ctxs = [api.Context(0, icp_skip=1) for _ in range(2)]
+    try:
+        for c in ctxs:
+            c.set_target(pair["tgt_xyz"], pair["tgt_off"]); c.set_source(pair["src_xyz"], pair["src_off"]); c.set_visual(vis)
+        x, T, s = ctxs[0].frame_to_frame(pair["x0"])
+        assert H.pose_close(x, xo, 1e-4, 1e-5), (x, xo)
+        assert _solve_counts(s) == _solve_counts(so)
+        assert s.solves[0].n_visual_blocks == 2000 and s.solves[3].n_visual_blocks < 2000      # iter 2 gates the outliers out
+        assert np.array_equal(ctxs[0].good_matches(), go)
+        assert s.algorithmic_bytes == so.algorithmic_bytes
+        for c in ctxs:
+            c.set_source(pair["src_xyz"], pair["src_off"])
+        xs, Ts, Ss = api.frame_to_frame_batch(ctxs, [pair["x0"], pair["x0"]])
+        for i in range(2):
+            assert np.array_equal(xs[i], x) and _solve_counts(Ss[i]) == _solve_counts(s)
+    finally:
+        for c in ctxs:
+            c.close()

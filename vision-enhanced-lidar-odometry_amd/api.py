@@ -185,6 +185,9 @@ SIGNATURES = {
     "velo_comm_unique_id": (C.c_int, [C.c_char_p]),
     "velo_comm_init": (C.c_int, [_ctx, C.c_char_p, C.c_int32, C.c_int32]),
     "velo_comm_destroy": (C.c_int, [_ctx]),
+    "velo_comm_peer_export": (C.c_int, [_ctx, C.c_char_p]),
+    "velo_comm_peer_attach": (C.c_int, [_ctx, C.c_char_p, C.c_int32, C.c_int32]),
+    "velo_comm_info": (C.c_int, [_ctx, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
     "velo_comm_set_target_sharded": (C.c_int, [_ctx, C.c_int]),
     "velo_set_query_shard": (C.c_int, [_ctx, C.c_int32, C.c_int32]),
     "velo_synchronize": (C.c_int, [_ctx]),
@@ -524,6 +527,24 @@ class Context:
 
     def comm_destroy(self):
         self._check(self._lib.velo_comm_destroy(self._h))
+
+    def comm_peer_export(self) -> bytes:
+        """IPC handle (64 bytes) of this context's all-reduce slab; gather the handles of all ranks, then comm_peer_attach."""
+        buf = C.create_string_buffer(64)
+        self._check(self._lib.velo_comm_peer_export(self._h, buf))
+        return buf.raw
+
+    def comm_peer_attach(self, handles, rank: int, world: int):
+        blob = b"".join(bytes(h) for h in handles)
+        if len(blob) != 64 * world:
+            raise ValueError("one 64-byte handle per rank, in rank order")
+        self._check(self._lib.velo_comm_peer_attach(self._h, C.create_string_buffer(blob, len(blob)), int(rank), int(world)))
+
+    def comm_info(self):
+        """(kind, rank, world): kind 0 = none, 1 = RCCL (world read back from the communicator), 2 = peer slabs."""
+        k, r, w = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.velo_comm_info(self._h, C.byref(k), C.byref(r), C.byref(w)))
+        return k.value, r.value, w.value
 
 
 class ScanCache:

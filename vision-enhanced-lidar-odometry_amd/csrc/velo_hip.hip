@@ -255,6 +255,13 @@ struct velo_ctx {
     // sharding / comm
     int shard_rank = 0, shard_world = 1;
     ncclComm_t comm = nullptr;
+    // peer-slab all-reduce (velo_comm_peer_export / _attach): my slab, the peers' mappings, my sequence counter and error word
+    PeerSlab* peer_slab = nullptr;
+    bool peer_on = false;
+    PeerComm peer{};
+    void* peer_mapped[kMaxPeers] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    DevBuf<unsigned long long> peer_seq;
+    DevBuf<int> peer_err;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> assoc_events;   // reused pool
@@ -734,7 +741,9 @@ int enqueue_lm_iteration(velo_ctx* c, const EvalArgs& A_in, const EvalPlan& E, c
     A.trace_eval = c->lm_trace_idx++;
     launch_eval(c, A, E);
     const int nblocks = E.total();
-    if (c->comm) {
+    if (c->peer_on) {
+        hipLaunchKernelGGL(lm_step_peer_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, c->eval_pt.p, (const double*)c->partials.p, nblocks, c->peer);
+    } else if (c->comm) {
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, c->stream, (const LMState*)c->state.p, (const double*)c->partials.p, nblocks, c->reduced.p);
         // every rank reaches this call the same number of times: `done` is identical on all ranks, and when it is
         // set the kernels above exit early and the buffer keeps its previous (identical) content
@@ -749,7 +758,7 @@ int enqueue_lm_iteration(velo_ctx* c, const EvalArgs& A_in, const EvalPlan& E, c
 
 // K LM iterations + the status read-back as ONE graph launch (the launch-bound inner loop of the solve).
 int launch_chunk(velo_ctx* c, const EvalArgs& A, const EvalPlan& E, const LMParams& Q, int iters) {
-    const bool graphable = c->use_graphs && !c->comm;
+    const bool graphable = c->use_graphs && !c->comm && !c->peer_on;
     if (!graphable) {
         for (int k = 0; k < iters; k++) VELO_TRY(enqueue_lm_iteration(c, A, E, Q));
         HIP_TRY(hipMemcpyAsync(&c->h_status->s, c->state.p, sizeof(LMState), hipMemcpyDeviceToHost, c->stream));
@@ -808,7 +817,7 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
         HIP_TRY(hipMemset(c->lm_trace.p, 0, (size_t)kTraceMaxEvals * kTraceStages * kTraceWgs * 8));
     }
 #endif
-    if (!c->comm && !c->use_graphs && c->small_solve && E.total() >= 1 && E.total() <= kSmallRows) {
+    if (!c->comm && !c->peer_on && !c->use_graphs && c->small_solve && E.total() >= 1 && E.total() <= kSmallRows) {
         // small problem (the reference's icp_skip = 200): the whole solve in one single-workgroup launch, one status copy
         hipLaunchKernelGGL(lm_solve_small_kernel, dim3(1), dim3(kEvalThreads), 0, c->stream, A, Q, c->state.p, xd,
                            (const int*)(c->have_corr ? c->n_valid.p + c->nv_idx : nullptr), E.nb_icp, E.nb_vis, max_iters_all + 2);
@@ -816,7 +825,7 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
         HIP_TRY(hipMemcpyAsync(&c->h_status->s, c->state.p, sizeof(LMState), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (!c->h_status->s.done) return fail(VELO_ERR_STATE, "LM did not terminate after %d sweeps", max_iters_all + 2);
-    } else if (!c->comm && !c->use_graphs && c->lm_merged && x_in && E.nb_icp > 0 && E.nb_vis == 0) {
+    } else if (!c->comm && !c->peer_on && !c->use_graphs && c->lm_merged && x_in && E.nb_icp > 0 && E.nb_vis == 0) {
         // one launch per LM iteration: every sweep workgroup consumes the previous sweep's partial rows itself (lm_iter_kernel).
         // Launch k reads state / partial rows [k & 1] and writes [(k + 1) & 1]; launch 0 starts the solve.  A solve of n
         // evaluations needs n + 1 launches (the last one only finds the solve done); launches behind that copy the state through.
@@ -851,6 +860,10 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
         if (launched > max_iters + 16) return fail(VELO_ERR_STATE, "LM did not terminate after %d sweeps", launched);
         chunk = 3;
     }
+    }
+    if (c->peer_on) {
+        HIP_TRY(hipMemcpy(c->h_int, c->peer_err.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (c->h_int[0]) return fail(VELO_ERR_COMM, "peer all-reduce timed out: a rank of the communicator did not arrive");
     }
     const LMState& s = c->h_status->s;
 #ifdef VELO_DIAGNOSTICS
@@ -1044,6 +1057,8 @@ int velo_destroy(velo_ctx* c) {
         }
     }
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
+    for (int r = 0; r < kMaxPeers; r++) if (c->peer_mapped[r]) { (void)hipIpcCloseMemHandle(c->peer_mapped[r]); c->peer_mapped[r] = nullptr; }
+    if (c->peer_slab) { (void)hipFree(c->peer_slab); c->peer_slab = nullptr; }
     c->tgt.release(); c->tgt_off.release(); c->tgt_ring_of.release(); c->tgt_cell_of.release();
     for (Grid& G : c->grids) { G.cell_start.release(); G.sorted.release(); G.sring.release(); }
     c->scan_tiles.release(); c->cursor.release(); c->scan_total.release(); c->bbox_keys.release();
@@ -1428,12 +1443,15 @@ static int associate_target_sharded(velo_ctx* c, const double x[6], int iter, bo
     for (int r = 0; r < W; r++) max_share = std::max(max_share, (int)((int64_t)c->n_q * (r + 1) / W - (int64_t)c->n_q * r / W));
     VELO_TRY(c->partials_all.reserve((size_t)W * std::max(max_share, 1)));
     NCCL_TRY(ncclGroupStart());
-    for (int r = 0; r < W; r++) {
+    ncclResult_t gr = ncclSuccess;                                      // an error inside the group must still close it
+    for (int r = 0; r < W && gr == ncclSuccess; r++) {
         const int rb = (int)((int64_t)c->n_q * r / W), re = (int)((int64_t)c->n_q * (r + 1) / W);
-        if (re > rb) NCCL_TRY(ncclSend(c->partials_rec.p + rb, (size_t)(re - rb) * sizeof(PartialRec), ncclChar, r, c->comm, c->stream));
-        if (qe > qb) NCCL_TRY(ncclRecv(c->partials_all.p + (size_t)r * max_share, (size_t)(qe - qb) * sizeof(PartialRec), ncclChar, r, c->comm, c->stream));
+        if (re > rb) gr = ncclSend(c->partials_rec.p + rb, (size_t)(re - rb) * sizeof(PartialRec), ncclChar, r, c->comm, c->stream);
+        if (gr == ncclSuccess && qe > qb) gr = ncclRecv(c->partials_all.p + (size_t)r * max_share, (size_t)(qe - qb) * sizeof(PartialRec), ncclChar, r, c->comm, c->stream);
     }
-    NCCL_TRY(ncclGroupEnd());
+    const ncclResult_t ge = ncclGroupEnd();
+    if (gr != ncclSuccess) return fail(VELO_ERR_COMM, "record exchange failed: %s", ncclGetErrorString(gr));
+    if (ge != ncclSuccess) return fail(VELO_ERR_COMM, "ncclGroupEnd failed: %s", ncclGetErrorString(ge));
     return launch_merge(c, c->partials_all.p, W, max_share, iter, want_aux);
 }
 
@@ -1548,7 +1566,11 @@ int velo_evaluate(velo_ctx* c, const double x[6], double* cost, double JtJ[36], 
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, c->stream, (const LMState*)nullptr, (const double*)c->partials.p, nblocks, c->reduced.p);
     HIP_TRY(hipGetLastError());
     double* res = c->reduced.p;
-    if (c->comm) {
+    if (c->peer_on) {
+        hipLaunchKernelGGL(peer_reduce_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)c->partials.p, nblocks, c->peer, c->reduced.p + kNumAcc);
+        HIP_TRY(hipGetLastError());
+        res = c->reduced.p + kNumAcc;
+    } else if (c->comm) {
         NCCL_TRY(ncclAllReduce(c->reduced.p, c->reduced.p + kNumAcc, kNumAcc, ncclDouble, ncclSum, c->comm, c->stream));
         res = c->reduced.p + kNumAcc;
     }
@@ -1696,7 +1718,7 @@ static bool batch_can_lockstep(velo_ctx** ctxs, int n, bool targets_follow = fal
     if (n < 2 || !ctxs[0] || !ctxs[0]->batch_lockstep) return false;
     for (int i = 0; i < n; i++) {
         const velo_ctx* c = ctxs[i];
-        if (!c || c->device != ctxs[0]->device || c->comm || c->use_graphs) return false;
+        if (!c || c->device != ctxs[0]->device || c->comm || c->peer_on || c->use_graphs) return false;
         if ((!c->have_target && !targets_follow) || (!c->have_source && !sources_follow) || c->shard_world != 1) return false;
         if (std::memcmp(&c->P, &ctxs[0]->P, sizeof(velo_params)) != 0) return false;
         for (int j = 0; j < i; j++) if (ctxs[j] == c) return false;
@@ -1744,7 +1766,7 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
 // contexts whose round may share a launch: default tube kernel, no diagnostics, no placement table, whole (unsharded) query list
 static bool assoc_batchable(const velo_ctx* c) {
     static const bool on = getenv("VELO_ASSOC_BATCH") ? atoi(getenv("VELO_ASSOC_BATCH")) != 0 : true;
-    return on && (c->assoc_variant < 0 || c->assoc_variant == 5) && !c->debug_skip && c->tube_map < 0 && !c->comm;
+    return on && (c->assoc_variant < 0 || c->assoc_variant == 5) && !c->debug_skip && c->tube_map < 0 && !c->comm && !c->peer_on;
 }
 
 // All contexts share one stream here (the lock-step driver swapped it in).  launched[i] = 1 for the context that carries the timing
@@ -2071,8 +2093,84 @@ int velo_comm_init(velo_ctx* c, const char id[128], int32_t rank, int32_t world)
     return VELO_OK;
 }
 
+static void peer_release(velo_ctx* c) {
+    for (int r = 0; r < kMaxPeers; r++) {
+        if (c->peer_mapped[r]) { (void)hipIpcCloseMemHandle(c->peer_mapped[r]); c->peer_mapped[r] = nullptr; }
+    }
+    c->peer_on = false;
+    std::memset(&c->peer, 0, sizeof(c->peer));
+}
+
+int velo_comm_peer_export(velo_ctx* c, char handle[64]) {
+    if (!c || !handle) return fail(VELO_ERR_INVALID, "null argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes in the ABI");
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->peer_slab) {
+        // fine-grained device memory: stores of a peer on another GPU become visible while the kernels run
+        void* p = nullptr;
+        if (hipExtMallocWithFlags(&p, sizeof(PeerSlab), hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(hipMalloc(&p, sizeof(PeerSlab)));
+        }
+        c->peer_slab = (PeerSlab*)p;
+        HIP_TRY(hipMemset(c->peer_slab, 0, sizeof(PeerSlab)));
+    }
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, c->peer_slab));
+    std::memcpy(handle, &h, 64);
+    return VELO_OK;
+}
+
+int velo_comm_peer_attach(velo_ctx* c, const char* handles, int32_t rank, int32_t world) {
+    if (!c || !handles || world < 1 || world > kMaxPeers || rank < 0 || rank >= world) return fail(VELO_ERR_INVALID, "bad peer arguments (world <= %d)", kMaxPeers);
+    if (!c->peer_slab) return fail(VELO_ERR_STATE, "velo_comm_peer_export must be called first");
+    if (c->comm) return fail(VELO_ERR_STATE, "an RCCL communicator is attached; destroy it first");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    peer_release(c);
+    VELO_TRY(c->peer_seq.reserve(1)); VELO_TRY(c->peer_err.reserve(1));
+    HIP_TRY(hipMemset(c->peer_seq.p, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->peer_err.p, 0, sizeof(int)));
+    HIP_TRY(hipMemset(c->peer_slab, 0, sizeof(PeerSlab)));
+    for (int r = 0; r < world; r++) {
+        if (r == rank) { c->peer.slab[r] = c->peer_slab; continue; }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, handles + (size_t)r * 64, 64);
+        void* p = nullptr;
+        HIP_TRY(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        c->peer_mapped[r] = p;
+        c->peer.slab[r] = (PeerSlab*)p;
+    }
+    c->peer.seq = c->peer_seq.p; c->peer.error = c->peer_err.p; c->peer.rank = rank; c->peer.world = world;
+    c->peer_on = true;
+    c->shard_rank = rank; c->shard_world = world;
+    c->have_corr = false;
+    return VELO_OK;
+}
+
+int velo_comm_info(const velo_ctx* c, int32_t* kind, int32_t* rank, int32_t* world) {
+    if (!c) return fail(VELO_ERR_INVALID, "null ctx");
+    int k = 0, w = c->shard_world;
+    if (c->peer_on) k = 2;
+    else if (c->comm) {
+        k = 1;
+        int n = 0;
+        NCCL_TRY(ncclCommCount(c->comm, &n));                   // read back from the communicator, not from what the caller said
+        w = n;
+    }
+    if (kind) *kind = k;
+    if (rank) *rank = c->shard_rank;
+    if (world) *world = w;
+    return VELO_OK;
+}
+
 int velo_comm_destroy(velo_ctx* c) {
     if (!c) return fail(VELO_ERR_INVALID, "null ctx");
+    if (c->peer_on) {
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        peer_release(c);
+    }
     if (c->comm) {
         HIP_TRY(hipSetDevice(c->device));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2093,7 +2191,7 @@ int velo_comm_set_target_sharded(velo_ctx* c, int enable) {
 
 int velo_set_query_shard(velo_ctx* c, int32_t rank, int32_t world) {
     if (!c || world < 1 || rank < 0 || rank >= world) return fail(VELO_ERR_INVALID, "bad shard arguments");
-    if (c->comm) return fail(VELO_ERR_STATE, "a communicator is attached; its rank/world define the shard");
+    if (c->comm || c->peer_on) return fail(VELO_ERR_STATE, "a communicator is attached; its rank/world define the shard");
     c->shard_rank = rank; c->shard_world = world;
     c->have_corr = false;
     return VELO_OK;

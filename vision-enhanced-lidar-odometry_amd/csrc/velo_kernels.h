@@ -2082,6 +2082,76 @@ eval_visual_batch_kernel(const LMBatchItem* __restrict__ items) {
     eval_visual_body(it.A, blockIdx.x, it.nb_vis);
 }
 
+// ---- one-shot all-reduce of the 28-double block through peer-mapped slabs (SURVEY.md sections 5 and 8(e)) -------------------------
+// Query-sharded registration all-reduces 224 bytes per LM evaluation: pure latency.  Every rank owns a small slab in fine-grained
+// device memory that all its peers have mapped (hipIpc handles, exchanged once by the host program); an all-reduce is: write my
+// 28 doubles into MY slot of EVERY rank's slab (one store per value and peer, over xGMI for the remote ones), then my sequence
+// number into the flag of that slot, wait until the flags of all slots of my own slab carry the sequence number, and add the
+// slots in rank order -- every rank adds the same values in the same order, so all ranks hold bit-identical sums and take
+// identical LM decisions.  No collective library call, no extra kernel: it runs inside the LM step.  The slab is double-buffered
+// by the parity of the sequence number (a rank can be at most one all-reduce ahead of a peer that is still reading).
+// All slab traffic is system-scope (sc0 sc1: bypasses the caches of the issuing device); waits are bounded.
+constexpr int kMaxPeers = 8;
+struct PeerSlab {
+    double data[2][kMaxPeers][32];             // [parity][writer rank][value]
+    unsigned long long flag[2][kMaxPeers];     // sequence number the writer's block belongs to
+};
+struct PeerComm {
+    PeerSlab* slab[kMaxPeers];                 // slab[r]: rank r's slab as mapped into this process (slab[rank]: my own)
+    unsigned long long* seq;                   // my all-reduce counter (device memory, starts at 0)
+    int* error;                                // set to 1 when a wait ran into its time limit
+    int rank, world;
+};
+__device__ __forceinline__ void sys_store(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double sys_load(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+// in/out: 28 doubles in LDS; called by all 256 threads of a workgroup (uniformly); returns with the workgroup synchronised
+__device__ __forceinline__ void peer_allreduce28(const PeerComm& C, double* __restrict__ v28) {
+    __shared__ double s_peer[kMaxPeers][32];
+    const int t = threadIdx.x, p = t >> 5, k = t & 31;
+    const unsigned long long seq = *C.seq + 1ull;
+    const int par = (int)(seq & 1ull);
+    if (p < C.world && k < kNumAcc) sys_store(&C.slab[p]->data[par][C.rank][k], v28[k]);
+    __threadfence_system();                                  // every storing thread: its values are out before the barrier is passed
+    __syncthreads();
+    if (t < C.world) {
+        __hip_atomic_store(&C.slab[t]->flag[par][C.rank], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(&C.slab[C.rank]->flag[par][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { *C.error = 1; break; }   // 5 s at 100 MHz: a peer is gone
+        }
+    }
+    __syncthreads();
+    __threadfence_system();
+    if (p < C.world && k < kNumAcc) s_peer[p][k] = sys_load(&C.slab[C.rank]->data[par][p][k]);
+    __syncthreads();
+    if (t < kNumAcc) {
+        double v = 0.0;
+        for (int r = 0; r < C.world; r++) v += s_peer[r][t];   // rank order: identical on every rank
+        v28[t] = v;
+    }
+    if (t == 0) *C.seq = seq;
+    __syncthreads();
+}
+
+// velo_evaluate behind a peer communicator: fixed-order sum of my partial rows, all-reduce, out[28]
+__global__ void __launch_bounds__(256)
+peer_reduce_kernel(const double* __restrict__ partials, int n_blocks, PeerComm C, double* __restrict__ out) {
+    __shared__ double E[32];
+    if (threadIdx.x < kNumAcc) {
+        double v = 0.0;
+        for (int b = 0; b < n_blocks; b++) v += partials[(size_t)b * kNumAcc + threadIdx.x];
+        E[threadIdx.x] = v;
+    }
+    __syncthreads();
+    peer_allreduce28(C, E);
+    if (threadIdx.x < kNumAcc) out[threadIdx.x] = E[threadIdx.x];
+}
+
 // sums the per-workgroup partials in a fixed order into out[28] (used before the RCCL all-reduce and by velo_evaluate)
 __global__ void reduce_partials_kernel(const LMState* __restrict__ state, const double* __restrict__ partials, int n_blocks, double* __restrict__ out) {
     if (state && state->done) return;
@@ -2209,7 +2279,8 @@ constexpr int kStepChunk = 128;
 static_assert(kStepChunk * kNumAcc == kScratchDoubles && kStepChunk * kNumAcc % 256 == 0 && kStepChunk % 8 == 0, "chunk geometry");
 __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __restrict__ Sin, const double* __restrict__ partials, int n_blocks, int first,
                                            const double* __restrict__ x_in, const int* __restrict__ n_valid,
-                                           double* __restrict__ s_rows, LMState* sL, LMEvalPoint* s_pt, unsigned long long* trace, int trace_eval) {
+                                           double* __restrict__ s_rows, LMState* sL, LMEvalPoint* s_pt, unsigned long long* trace, int trace_eval,
+                                           const PeerComm* comm = nullptr) {
     __shared__ double part[8][kNumAcc];
     __shared__ double E[kNumAcc];
     constexpr int kPerThread = kStepChunk * kNumAcc / 256;
@@ -2252,6 +2323,7 @@ __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __r
     } else if (!sL->done) {                                  // uniform: a step behind a finished solve changes nothing
         if (t < kNumAcc) { double v = 0.0; for (int p = 0; p < 8; p++) v += part[p][t]; E[t] = v; }
         __syncthreads();
+        if (comm) peer_allreduce28(*comm, E);                // query-sharded: every rank continues with the same 28 sums
         VELO_LM_TRACE(trace, trace_eval, 6);
         if (t == 0) {
             LMState L = *sL;
@@ -2274,13 +2346,13 @@ __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __r
 
 // two launches per iteration (sweep kernels, then this): used behind an all-reduce, with visual blocks, and by the lock-step batch driver
 __device__ __forceinline__ void lm_transition(const LMParams& Q, LMState* Sg, LMEvalPoint* pt, const double* __restrict__ partials, int n_blocks,
-                                              unsigned long long* trace = nullptr, int trace_eval = 0) {
+                                              unsigned long long* trace = nullptr, int trace_eval = 0, const PeerComm* comm = nullptr) {
     __shared__ LMState sL;
     __shared__ LMEvalPoint s_pt;
     __shared__ double s_rows[kScratchDoubles];
     const int t = threadIdx.x;
     VELO_LM_TRACE(trace, trace_eval, 4);
-    lm_advance(Q, Sg, partials, n_blocks, 0, nullptr, nullptr, s_rows, &sL, &s_pt, trace, trace_eval);
+    lm_advance(Q, Sg, partials, n_blocks, 0, nullptr, nullptr, s_rows, &sL, &s_pt, trace, trace_eval, comm);
     if (t < (int)(sizeof(LMState) / 8)) reinterpret_cast<unsigned long long*>(Sg)[t] = reinterpret_cast<const unsigned long long*>(&sL)[t];
     else if (t >= 64 && t < 64 + (int)(sizeof(LMEvalPoint) / 8)) reinterpret_cast<unsigned long long*>(pt)[t - 64] = reinterpret_cast<const unsigned long long*>(&s_pt)[t - 64];
     VELO_LM_TRACE(trace, trace_eval, 9);
@@ -2366,6 +2438,11 @@ __device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* 
 __global__ void __launch_bounds__(256)
 lm_step_kernel(LMParams Q, LMState* S, LMEvalPoint* pt, const double* __restrict__ partials, int n_blocks, unsigned long long* trace, int trace_eval) {
     lm_transition(Q, S, pt, partials, n_blocks, trace, trace_eval);
+}
+// the LM step of a query-sharded solve: my partial rows, the peer all-reduce, the transition -- one launch
+__global__ void __launch_bounds__(256)
+lm_step_peer_kernel(LMParams Q, LMState* S, LMEvalPoint* pt, const double* __restrict__ partials, int n_blocks, PeerComm C) {
+    lm_transition(Q, S, pt, partials, n_blocks, nullptr, 0, &C);
 }
 __global__ void lm_begin_batch_kernel(const LMBatchItem* __restrict__ items) {
     const LMBatchItem& it = items[blockIdx.x];
