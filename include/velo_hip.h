@@ -338,6 +338,11 @@ int velo_comm_destroy(velo_ctx* ctx);
  * A peer that never arrives makes the wait time out (5 s): the call in flight returns VELO_ERR_COMM. */
 int velo_comm_peer_export(velo_ctx* ctx, char handle[64]);
 int velo_comm_peer_attach(velo_ctx* ctx, const char* handles /* world * 64 bytes, rank order */, int32_t rank, int32_t world);
+/* Target-sharded mode over the same peers (instead of RCCL send/recv): the receive area for the per-query records of up to
+ * max_queries queries (2 x (max_queries + 8 world) x 80 bytes), exported and attached like the slab, after velo_comm_peer_attach.
+ * With it, velo_comm_set_target_sharded(ctx, 1) exchanges the records by direct stores into the owners' areas. */
+int velo_comm_peer_export_records(velo_ctx* ctx, int32_t max_queries, char handle[64]);
+int velo_comm_peer_attach_records(velo_ctx* ctx, const char* handles /* world * 64 bytes, rank order */, int32_t max_queries);
 /* What is attached: kind 0 = nothing, 1 = RCCL communicator (world read back with ncclCommCount), 2 = peer slabs. */
 int velo_comm_info(const velo_ctx* ctx, int32_t* kind, int32_t* rank, int32_t* world);
 /* enable != 0: the communicator's ranks hold disjoint ring blocks of the target (velo_set_target_part) instead of

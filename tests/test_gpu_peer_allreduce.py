@@ -110,3 +110,66 @@ def test_peer_communicator_of_one_rank_changes_nothing(hip_lib):
     b.comm_destroy()
     assert b.comm_info()[0] == 0
     a.close(); b.close()
+
+
+# ---- BASELINE config 5 with more than one rank: every rank holds a block of whole target rings -------------------------------------
+def _target_sharded_main(rank, world, port, out_dir, n_scans):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import velo_amd  # noqa: F401
+    from velo_amd import api, shard, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = synth.scan_to_map(n_scans * 32 * 300, n_beams=32, n_azimuth=300)           # a small accumulated map: n_scans x 32 rings
+    nq = 32 * 300
+    ctx = api.Context(0, icp_skip=1)
+    handles = [None] * world
+    dist.all_gather_object(handles, ctx.comm_peer_export())
+    ctx.comm_peer_attach(handles, rank, world)
+    dist.all_gather_object(handles, ctx.comm_peer_export_records(nq))
+    ctx.comm_peer_attach_records(handles, nq)
+    ctx.comm_set_target_sharded(True)
+    r0, r1, p0, local = shard.target_ring_block(d["tgt_off"], rank, world)
+    ctx.set_target_part(d["tgt_xyz"][p0:p0 + int(local[-1])], local, r0, p0)
+    ctx.set_source(d["src_xyz"], d["src_off"])
+    n = ctx.associate(d["x0"], 1)                           # partial search, record exchange, merge of my query share
+    corr = ctx.correspondences()
+    for rep in range(2):
+        x, T, s = ctx.frame_to_frame(d["x0"])
+    np.savez(os.path.join(out_dir, f"ts_{rank}.npz"), n_valid=n, corr=corr, x=x,
+             counts=np.array([[s.solves[k].termination, s.solves[k].lm_iterations, s.solves[k].evaluations, s.solves[k].n_icp_valid] for k in range(s.n_solves)]))
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_target_sharded_ranks_on_one_gpu_match_the_oracle(hip_lib, oracle, tmp_path, world):
+    """Scan-to-map with the map's rings dealt over the ranks (processes on the one GPU): per-query top-2 records exchanged by
+    direct stores into the owners' peer-mapped areas every association round, merged by the owner, then the query-sharded
+    solve with the peer all-reduce.  Merged tables = the oracle's association against the WHOLE map; pose = the oracle's."""
+    import torch.multiprocessing as mp
+    import helpers as H
+    from velo_amd import synth
+    n_scans = 5
+    mp.spawn(_target_sharded_main, args=(world, _free_port(), str(tmp_path), n_scans), nprocs=world, join=True)
+    ranks = [np.load(tmp_path / f"ts_{r}.npz") for r in range(world)]
+    d = synth.scan_to_map(n_scans * 32 * 300, n_beams=32, n_azimuth=300)
+    orc = oracle.Oracle(threads=8, icp_skip=1)
+    orc.set_target(d["tgt_xyz"], d["tgt_off"])
+    orc.set_source(d["src_xyz"], d["src_off"])
+    n_cpu = orc.associate(d["x0"], 1)
+    assert sum(int(r["n_valid"]) for r in ranks) == n_cpu
+    H.assert_corr_equal(np.concatenate([r["corr"] for r in ranks]), orc.correspondences())
+    xo, To, so = orc.frame_to_frame(d["x0"])
+    for r in ranks:
+        assert np.array_equal(r["x"], ranks[0]["x"])                              # every rank took the same LM decisions
+        assert np.array_equal(r["counts"][:, :3], ranks[0]["counts"][:, :3])
+    assert H.pose_close(ranks[0]["x"], xo, 1e-9, 1e-10)
+    want = np.array([[so.solves[k].termination, so.solves[k].lm_iterations, so.solves[k].evaluations] for k in range(so.n_solves)])
+    assert np.array_equal(ranks[0]["counts"][:, :3], want)
+    assert sum(int(r["counts"][-1, 3]) for r in ranks) == so.solves[so.n_solves - 1].n_icp_valid

@@ -12,7 +12,7 @@ for r in range(rounds):
     for lib in (a, b) if r % 2 == 0 else (b, a):
         for mode in ("1", "8"):
             env = dict(os.environ, VELO_LIB_PATH=lib)
-            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", mode, "--no-cpu-baseline", *extra],
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", mode, "--no-cpu-baseline", "--no-legs", *extra],
                                  env=env, capture_output=True, text=True).stdout.strip().splitlines()[-1]
             res[(lib, mode)].append(json.loads(out)["value"])
 for mode in ("1", "8"):

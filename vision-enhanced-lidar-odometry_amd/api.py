@@ -188,6 +188,8 @@ SIGNATURES = {
     "velo_comm_peer_export": (C.c_int, [_ctx, C.c_char_p]),
     "velo_comm_peer_attach": (C.c_int, [_ctx, C.c_char_p, C.c_int32, C.c_int32]),
     "velo_comm_info": (C.c_int, [_ctx, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
+    "velo_comm_peer_export_records": (C.c_int, [_ctx, C.c_int32, C.c_char_p]),
+    "velo_comm_peer_attach_records": (C.c_int, [_ctx, C.c_char_p, C.c_int32]),
     "velo_comm_set_target_sharded": (C.c_int, [_ctx, C.c_int]),
     "velo_set_query_shard": (C.c_int, [_ctx, C.c_int32, C.c_int32]),
     "velo_synchronize": (C.c_int, [_ctx]),
@@ -539,6 +541,15 @@ class Context:
         if len(blob) != 64 * world:
             raise ValueError("one 64-byte handle per rank, in rank order")
         self._check(self._lib.velo_comm_peer_attach(self._h, C.create_string_buffer(blob, len(blob)), int(rank), int(world)))
+
+    def comm_peer_export_records(self, max_queries: int) -> bytes:
+        buf = C.create_string_buffer(64)
+        self._check(self._lib.velo_comm_peer_export_records(self._h, int(max_queries), buf))
+        return buf.raw
+
+    def comm_peer_attach_records(self, handles, max_queries: int):
+        blob = b"".join(bytes(h) for h in handles)
+        self._check(self._lib.velo_comm_peer_attach_records(self._h, C.create_string_buffer(blob, len(blob)), int(max_queries)))
 
     def comm_info(self):
         """(kind, rank, world): kind 0 = none, 1 = RCCL (world read back from the communicator), 2 = peer slabs."""

@@ -262,6 +262,12 @@ struct velo_ctx {
     void* peer_mapped[kMaxPeers] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     DevBuf<unsigned long long> peer_seq;
     DevBuf<int> peer_err;
+    PartialRec* peer_area = nullptr;     // my receive area of the record exchange (fine-grained, exported)
+    int peer_area_queries = 0;           // max_queries it was sized for
+    void* peer_area_mapped[kMaxPeers] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    PeerRecs peer_recs{};
+    bool peer_recs_on = false;
+    unsigned long long peer_xseq = 0;    // exchanges so far (all ranks count alike)
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> assoc_events;   // reused pool
@@ -1058,7 +1064,9 @@ int velo_destroy(velo_ctx* c) {
     }
     if (c->comm) { (void)ncclCommDestroy(c->comm); c->comm = nullptr; }
     for (int r = 0; r < kMaxPeers; r++) if (c->peer_mapped[r]) { (void)hipIpcCloseMemHandle(c->peer_mapped[r]); c->peer_mapped[r] = nullptr; }
+    for (int r = 0; r < kMaxPeers; r++) if (c->peer_area_mapped[r]) { (void)hipIpcCloseMemHandle(c->peer_area_mapped[r]); c->peer_area_mapped[r] = nullptr; }
     if (c->peer_slab) { (void)hipFree(c->peer_slab); c->peer_slab = nullptr; }
+    if (c->peer_area) { (void)hipFree(c->peer_area); c->peer_area = nullptr; }
     c->tgt.release(); c->tgt_off.release(); c->tgt_ring_of.release(); c->tgt_cell_of.release();
     for (Grid& G : c->grids) { G.cell_start.release(); G.sorted.release(); G.sring.release(); }
     c->scan_tiles.release(); c->cursor.release(); c->scan_total.release(); c->bbox_keys.release();
@@ -1402,7 +1410,7 @@ int velo_set_visual(velo_ctx* c, const velo_match* m, int32_t n) {
 int velo_associate(velo_ctx* c, const double x[6], int32_t iter, int32_t* n_valid) {
     if (!c || !x) return fail(VELO_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
-    if (c->comm && c->target_sharded) {
+    if ((c->comm || c->peer_on) && c->target_sharded) {
         VELO_TRY(associate_target_sharded(c, x, iter, true));
         HIP_TRY(hipMemcpyAsync(c->h_int, c->n_valid.p + c->nv_idx, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1441,6 +1449,18 @@ static int associate_target_sharded(velo_ctx* c, const double x[6], int iter, bo
     q_range(c, &qb, &qe);
     int max_share = 0;
     for (int r = 0; r < W; r++) max_share = std::max(max_share, (int)((int64_t)c->n_q * (r + 1) / W - (int64_t)c->n_q * r / W));
+    if (c->peer_on) {
+        if (!c->peer_recs_on) return fail(VELO_ERR_STATE, "target-sharded mode over peers needs velo_comm_peer_attach_records");
+        if (c->n_q > c->peer_area_queries) return fail(VELO_ERR_INVALID, "%d queries, the peers' record areas were sized for %d", c->n_q, c->peer_area_queries);
+        const unsigned long long seq = ++c->peer_xseq;
+        PeerRecs R = c->peer_recs;
+        R.max_share = max_share;
+        if ((size_t)W * max_share > R.parity_stride) return fail(VELO_ERR_STATE, "record area too small");
+        if (c->n_q > 0) hipLaunchKernelGGL(peer_scatter_records_kernel, dim3(cdiv(c->n_q, 256)), dim3(256), 0, c->stream, (const PartialRec*)c->partials_rec.p, c->n_q, R, (int)(seq & 1ull));
+        hipLaunchKernelGGL(peer_exchange_sync_kernel, dim3(1), dim3(64), 0, c->stream, c->peer, seq);
+        HIP_TRY(hipGetLastError());
+        return launch_merge(c, c->peer_area + (size_t)(seq & 1ull) * R.parity_stride, W, max_share, iter, want_aux);
+    }
     VELO_TRY(c->partials_all.reserve((size_t)W * std::max(max_share, 1)));
     NCCL_TRY(ncclGroupStart());
     ncclResult_t gr = ncclSuccess;                                      // an error inside the group must still close it
@@ -1680,7 +1700,7 @@ int velo_frame_to_frame(velo_ctx* c, double x[6], double T[16], velo_summary* su
         c->last_n_valid = 0;
         for (int icp_iter = 0; icp_iter < c->P.icp_iterations; icp_iter++) {        // velo.h:800
             int nv = 0;
-            if (c->comm && c->target_sharded) VELO_TRY(associate_target_sharded(c, xc, iter, false));
+            if ((c->comm || c->peer_on) && c->target_sharded) VELO_TRY(associate_target_sharded(c, xc, iter, false));
             else VELO_TRY(do_associate(c, xc, iter, false, false, &nv));             // velo.h:806-894 (no host sync: the count rides on the LM status)
             int qb, qe;
             q_range(c, &qb, &qe);
@@ -2097,8 +2117,12 @@ static void peer_release(velo_ctx* c) {
     for (int r = 0; r < kMaxPeers; r++) {
         if (c->peer_mapped[r]) { (void)hipIpcCloseMemHandle(c->peer_mapped[r]); c->peer_mapped[r] = nullptr; }
     }
-    c->peer_on = false;
+    for (int r = 0; r < kMaxPeers; r++) {
+        if (c->peer_area_mapped[r]) { (void)hipIpcCloseMemHandle(c->peer_area_mapped[r]); c->peer_area_mapped[r] = nullptr; }
+    }
+    c->peer_on = false; c->peer_recs_on = false;
     std::memset(&c->peer, 0, sizeof(c->peer));
+    std::memset(&c->peer_recs, 0, sizeof(c->peer_recs));
 }
 
 int velo_comm_peer_export(velo_ctx* c, char handle[64]) {
@@ -2145,6 +2169,49 @@ int velo_comm_peer_attach(velo_ctx* c, const char* handles, int32_t rank, int32_
     c->peer_on = true;
     c->shard_rank = rank; c->shard_world = world;
     c->have_corr = false;
+    return VELO_OK;
+}
+
+int velo_comm_peer_export_records(velo_ctx* c, int32_t max_queries, char handle[64]) {
+    if (!c || !handle || max_queries < 1) return fail(VELO_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->peer_area && c->peer_area_queries != max_queries) return fail(VELO_ERR_STATE, "the record area exists already, sized for %d queries", c->peer_area_queries);
+    if (!c->peer_area) {
+        const size_t recs = 2 * ((size_t)max_queries + 8 * kMaxPeers);
+        void* p = nullptr;
+        if (hipExtMallocWithFlags(&p, recs * sizeof(PartialRec), hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(hipMalloc(&p, recs * sizeof(PartialRec)));
+        }
+        c->peer_area = (PartialRec*)p;
+        c->peer_area_queries = max_queries;
+    }
+    hipIpcMemHandle_t h;
+    HIP_TRY(hipIpcGetMemHandle(&h, c->peer_area));
+    std::memcpy(handle, &h, 64);
+    return VELO_OK;
+}
+
+int velo_comm_peer_attach_records(velo_ctx* c, const char* handles, int32_t max_queries) {
+    if (!c || !handles) return fail(VELO_ERR_INVALID, "null argument");
+    if (!c->peer_on) return fail(VELO_ERR_STATE, "velo_comm_peer_attach comes first");
+    if (!c->peer_area || c->peer_area_queries != max_queries) return fail(VELO_ERR_STATE, "velo_comm_peer_export_records(%d) comes first", max_queries);
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int W = c->peer.world, rank = c->peer.rank;
+    for (int r = 0; r < W; r++) {
+        if (r == rank) { c->peer_recs.area[r] = c->peer_area; continue; }
+        hipIpcMemHandle_t h;
+        std::memcpy(&h, handles + (size_t)r * 64, 64);
+        void* p = nullptr;
+        HIP_TRY(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+        c->peer_area_mapped[r] = p;
+        c->peer_recs.area[r] = (PartialRec*)p;
+    }
+    c->peer_recs.rank = rank; c->peer_recs.world = W; c->peer_recs.max_share = 0;
+    c->peer_recs.parity_stride = (size_t)max_queries + 8 * kMaxPeers;
+    c->peer_recs_on = true;
+    c->peer_xseq = 0;
     return VELO_OK;
 }
 

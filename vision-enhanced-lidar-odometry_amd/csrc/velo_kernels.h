@@ -2095,6 +2095,7 @@ constexpr int kMaxPeers = 8;
 struct PeerSlab {
     double data[2][kMaxPeers][32];             // [parity][writer rank][value]
     unsigned long long flag[2][kMaxPeers];     // sequence number the writer's block belongs to
+    unsigned long long xflag[2][kMaxPeers];    // the same for the record exchange of the target-sharded mode
 };
 struct PeerComm {
     PeerSlab* slab[kMaxPeers];                 // slab[r]: rank r's slab as mapped into this process (slab[rank]: my own)
@@ -2136,6 +2137,48 @@ __device__ __forceinline__ void peer_allreduce28(const PeerComm& C, double* __re
     }
     if (t == 0) *C.seq = seq;
     __syncthreads();
+}
+
+// ---- target-sharded mode over the same peers (BASELINE config 5): the per-round exchange of the per-query top-2 records -------------
+// Every rank has searched ITS rings for ALL queries (PartialRec per query).  Rank r must end up with everybody's records of ITS
+// query share: each rank stores the slices straight into the owners' receive areas (peer-mapped, fine-grained memory; area of
+// rank p: [parity][writer rank][max_share] records), then a one-workgroup kernel publishes "my slices of exchange `seq` are out"
+// in every peer's slab and waits for the same word from every peer.  The receive area is double-buffered by the parity of seq:
+// a fast rank may scatter round n + 1 while a slow one still merges round n.
+struct PeerRecs {
+    PartialRec* area[kMaxPeers];               // receive area of rank p as mapped into this process
+    int rank, world, max_share;                // max_share = largest query share: slot stride inside an area
+    size_t parity_stride;                      // records per parity half (= world * max_share, rounded up by the host)
+};
+__global__ void __launch_bounds__(256)
+peer_scatter_records_kernel(const PartialRec* __restrict__ mine, int n_q, PeerRecs R, int parity) {
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= n_q) return;
+    int owner = 0, qb = 0;
+    for (int p = 0; p < R.world; p++) {                      // same rule as q_range(): share p = [n_q p / W, n_q (p + 1) / W)
+        const int b = (int)((long long)n_q * p / R.world), e = (int)((long long)n_q * (p + 1) / R.world);
+        if (qi >= b && qi < e) { owner = p; qb = b; }
+    }
+    const uint4* src = reinterpret_cast<const uint4*>(mine + qi);
+    uint4* dst = reinterpret_cast<uint4*>(R.area[owner] + (size_t)parity * R.parity_stride + (size_t)R.rank * R.max_share + (qi - qb));
+    static_assert(sizeof(PartialRec) == 80, "five 16-byte words per record");
+#pragma unroll
+    for (int k = 0; k < 5; k++) dst[k] = src[k];
+    __threadfence_system();
+}
+__global__ void __launch_bounds__(64)
+peer_exchange_sync_kernel(PeerComm C, unsigned long long seq) {
+    const int t = threadIdx.x, par = (int)(seq & 1ull);
+    if (t < C.world) {
+        // the scatter kernel ahead of this one on the stream has completed: its stores are out
+        __hip_atomic_store(&C.slab[t]->xflag[par][C.rank], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(&C.slab[C.rank]->xflag[par][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { *C.error = 1; break; }
+        }
+    }
+    __threadfence_system();
 }
 
 // velo_evaluate behind a peer communicator: fixed-order sum of my partial rows, all-reduce, out[28]
