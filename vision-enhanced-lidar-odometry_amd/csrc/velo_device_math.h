@@ -202,13 +202,16 @@ __device__ __forceinline__ void res_2d3d(const PoseRot& Rinv, const double t[3],
         J[j] = d0 - s[0] * d2;
         J[6 + j] = d1 - s[1] * d2;
     }
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const double e[3] = {k == 0 ? -1.0 : 0.0, k == 1 ? -1.0 : 0.0, k == 2 ? -1.0 : 0.0};
-        double c[3];
-        rotate_point_value(Rinv, e, c);
-        J[3 + k] = c[0] - s[0] * c[2];
-        J[9 + k] = c[1] - s[1] * c[2];
+    // d/dt_k = R(-omega)(-e_k): minus the k-th column of R(-omega), each from the value-only rotation of a unit vector
+    {
+        const double e0[3] = {-1.0, 0.0, 0.0}, e1[3] = {0.0, -1.0, 0.0}, e2[3] = {0.0, 0.0, -1.0};
+        double c0[3], c1[3], c2[3];
+        rotate_point_value(Rinv, e0, c0);
+        rotate_point_value(Rinv, e1, c1);
+        rotate_point_value(Rinv, e2, c2);
+        J[3] = c0[0] - s[0] * c0[2]; J[9] = c0[1] - s[1] * c0[2];
+        J[4] = c1[0] - s[0] * c1[2]; J[10] = c1[1] - s[1] * c1[2];
+        J[5] = c2[0] - s[0] * c2[2]; J[11] = c2[1] - s[1] * c2[2];
     }
 }
 // R5 cost2D2D (costfunctions.h:192-216): epipolar residual, 6-wide duals after the two rotations

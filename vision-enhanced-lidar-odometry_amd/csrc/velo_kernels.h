@@ -1644,26 +1644,41 @@ __device__ __forceinline__ void pose_eval_init(const double x[6], PoseEval* P, b
 }
 
 // residuals r[<=3] and row-major Jacobian J[<=3][6] of one visual block; returns the residual dimension
-__device__ __forceinline__ int visual_block_eval(const PoseEval& P, const VisualMatch& m, int slot, double r[3], double J[18]) {
+__device__ __forceinline__ int visual_block_eval3(const PoseEval& P, const VisualMatch& m, int slot, double& r0, double& r1, double& r2, double J[18]) {
+    // one exit, residuals carried as scalars: written as an array on several branches they end up on the stack
+    r0 = 0.0; r1 = 0.0; r2 = 0.0;
+    int d;
     if (slot == 0) {
         if (m.d1 && m.d2) {
             const double a[3] = {m.p3_1[0], m.p3_1[1], m.p3_1[2]}, s[3] = {m.p3_2[0], m.p3_2[1], m.p3_2[2]};
-            res_3d3d(P.fwd, P.t, a, s, r, J);
-            return 3;
+            double rl[3];
+            res_3d3d(P.fwd, P.t, a, s, rl, J);
+            r0 = rl[0]; r1 = rl[1]; r2 = rl[2]; d = 3;
+        } else {
+            const double a[2] = {m.p2_1[0], m.p2_1[1]}, s[2] = {m.p2_2[0], m.p2_2[1]}, tc[3] = {m.t_cam[0], m.t_cam[1], m.t_cam[2]};
+            double rl[1];
+            res_2d2d(P.fwd, P.t, a, s, tc, rl, J);
+            r0 = rl[0]; d = 1;
         }
-        const double a[2] = {m.p2_1[0], m.p2_1[1]}, s[2] = {m.p2_2[0], m.p2_2[1]}, tc[3] = {m.t_cam[0], m.t_cam[1], m.t_cam[2]};
-        res_2d2d(P.fwd, P.t, a, s, tc, r, J);
-        return 1;
-    }
-    const double tc[3] = {m.t_cam[0], m.t_cam[1], m.t_cam[2]};
-    if (slot == 1) {
-        const double a[3] = {m.p3_1[0], m.p3_1[1], m.p3_1[2]}, s[2] = {m.p2_2[0], m.p2_2[1]};
-        res_3d2d(P.fwd, P.t, a, s, tc, r, J);
     } else {
-        const double a[3] = {m.p3_2[0], m.p3_2[1], m.p3_2[2]}, s[2] = {m.p2_1[0], m.p2_1[1]};
-        res_2d3d(P.inv, P.t, a, s, tc, r, J);
+        const double tc[3] = {m.t_cam[0], m.t_cam[1], m.t_cam[2]};
+        double rl[2];
+        if (slot == 1) {
+            const double a[3] = {m.p3_1[0], m.p3_1[1], m.p3_1[2]}, s[2] = {m.p2_2[0], m.p2_2[1]};
+            res_3d2d(P.fwd, P.t, a, s, tc, rl, J);
+        } else {
+            const double a[3] = {m.p3_2[0], m.p3_2[1], m.p3_2[2]}, s[2] = {m.p2_1[0], m.p2_1[1]};
+            res_2d3d(P.inv, P.t, a, s, tc, rl, J);
+        }
+        r0 = rl[0]; r1 = rl[1]; d = 2;
     }
-    return 2;
+    return d;
+}
+__device__ __forceinline__ int visual_block_eval(const PoseEval& P, const VisualMatch& m, int slot, double r[3], double J[18]) {
+    double r0, r1, r2;
+    const int d = visual_block_eval3(P, m, slot, r0, r1, r2, J);
+    r[0] = r0; r[1] = r1; r[2] = r2;
+    return d;
 }
 
 // flags[3*m + slot]: 0 = no block, 1 + residual_type = block present
@@ -2031,11 +2046,17 @@ eval_icp_batch_kernel(const LMBatchItem* __restrict__ items) {
 __device__ __forceinline__ void eval_visual_body(const EvalArgs& A, const int bx, const int nbx) {
     __shared__ LMEvalPoint s_pt;
     if (!eval_point_load(A, &s_pt)) return;
-    double x[6];
+    // the rotation constants of R(omega) and R(-omega) once per workgroup, read from LDS where a block needs them (in registers
+    // they, the 56 accumulator registers and the 6-wide duals of the epipolar block push the kernel into scratch memory)
+    __shared__ PoseEval s_P;
+    if (threadIdx.x == 0) {
+        double x[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) x[k] = s_pt.x[k];
-    PoseEval P;
-    pose_eval_init(x, &P, true);
+        for (int k = 0; k < 6; k++) x[k] = s_pt.x[k];
+        pose_eval_init(x, &s_P, true);
+    }
+    __syncthreads();
+    const PoseEval& P = s_P;
     double acc[kNumAcc];
 #pragma unroll
     for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
@@ -2045,10 +2066,11 @@ __device__ __forceinline__ void eval_visual_body(const EvalArgs& A, const int bx
         if (!f) continue;
         const int mi = s / 3, slot = s - 3 * mi;
         const VisualMatch m = A.vm[mi];
-        double r[3], J[18];
-        const int d = visual_block_eval(P, m, slot, r, J);
-        double sq = 0.0;
-        for (int k = 0; k < d; k++) sq += r[k] * r[k];
+        // residuals as three scalars and every use with compile-time indices: an array written by the four block types on
+        // different branches ends up on the stack, and a kernel with any stack at all pays ~11 us per launch
+        double r0, r1, r2, J[18];
+        const int d = visual_block_eval3(P, m, slot, r0, r1, r2, J);
+        const double sq = r0 * r0 + (d > 1 ? r1 * r1 : 0.0) + (d > 2 ? r2 * r2 : 0.0);
         double rho0, rho1;
         const int type = f - 1;
         if (type == 0) loss_arctan(A.V.th_3d3d, 1.0, sq, &rho0, &rho1);
@@ -2056,13 +2078,16 @@ __device__ __forceinline__ void eval_visual_body(const EvalArgs& A, const int bx
         else loss_arctan(A.V.th_3d2d, A.V.w_3d2d, sq, &rho0, &rho1);
         acc[27] += 0.5 * rho0;
         const double sr = sqrt(rho1);
-        for (int k = 0; k < d; k++) {
-            accumulate_row(acc, r[k], J + 6 * k, sr);
-            if (A.rows_r) {
-                const int row = A.row_offset_vis[s] + k;
-                A.rows_r[row] = r[k] * sr;
-                for (int c = 0; c < 6; c++) A.rows_J[(size_t)row * 6 + c] = J[6 * k + c] * sr;
-            }
+        accumulate_row(acc, r0, J, sr);
+        if (d > 1) accumulate_row(acc, r1, J + 6, sr);
+        if (d > 2) accumulate_row(acc, r2, J + 12, sr);
+        if (A.rows_r) {
+            const int row = A.row_offset_vis[s];
+            A.rows_r[row] = r0 * sr;
+            if (d > 1) A.rows_r[row + 1] = r1 * sr;
+            if (d > 2) A.rows_r[row + 2] = r2 * sr;
+#pragma unroll
+            for (int c = 0; c < 18; c++) if (c < 6 * d) A.rows_J[(size_t)row * 6 + c] = J[c] * sr;
         }
     }
 #if VELO_REDUCE_LDS
