@@ -284,6 +284,24 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
             lat = (time.perf_counter() - t1) / n1
             single = {"pairs_in_flight": 1, "ms_per_pair": 1e3 * lat, "pairs_per_s": 1.0 / lat, "assoc_avg_launch_us": 1e3 * a_ms / max(a_n, 1)}
 
+        shared = None
+        if workload == "c4" and mode == "replicas" and B > 1 and a.batch_api:
+            # scan-to-map as it is used: B scans against ONE map -- the jobs name the same target with VELO_SCAN_SHARED, the library
+            # indexes it once per step and the B contexts hold it by reference (one 110 MB map in HBM instead of B)
+            refs_sh = (api.scan_refs([(tgt, tgt_off)] * B, rig.local_rank, shared=True), batch_refs[1])
+            for _ in range(2):
+                api.register_batch(ctxs, None, None, x0s, refs=refs_sh)
+            rig.barrier(ctxs)
+            t1 = time.perf_counter()
+            n_sh = max(4, steps // 2)
+            for _ in range(n_sh):
+                xs_sh, _, _ = api.register_batch(ctxs, None, None, x0s, refs=refs_sh)
+            rig.barrier(ctxs)
+            dt_sh = rig.max_over_ranks(time.perf_counter() - t1)
+            shared = {"pairs_per_s": n_sh * B * world / dt_sh, "ms_per_step": 1e3 * dt_sh / n_sh, "steps": n_sh,
+                      "pose_equal_to_unshared": bool(np.array_equal(xs_sh[0], results[0][0])),
+                      "note": "the B jobs share one target (VELO_SCAN_SHARED): one upload + index build per step instead of B"}
+
         n_pairs_rank = steps * B
         total_pairs = n_pairs_rank * (world if mode == "replicas" else 1)
         s0 = results[0][2]
@@ -308,6 +326,8 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
         }
         if single is not None:
             leg["single_pair"] = single
+        if shared is not None:
+            leg["shared_target"] = shared
         if comm_info is not None:
             leg["communicator"] = comm_info
         return leg
@@ -380,6 +400,8 @@ def main():
             line["config"]["communicator"] = main_leg["communicator"]
         if single is not None:
             line["single_pair"] = single
+        if "shared_target" in main_leg:
+            line["shared_target"] = main_leg["shared_target"]
         if legs:
             line["configs"] = {k: {kk: vv for kk, vv in v.items() if kk not in ("solution_x",)} for k, v in legs.items()}
         if modes:

@@ -226,6 +226,11 @@ int velo_set_scan_velodyne(velo_ctx* ctx, int32_t as_target, const float* xyzr, 
  * buffers are swapped, nothing is uploaded or segmented again; only the target index (ring ids, grid) is built.  Afterwards the
  * context has no source until the next velo_set_source / velo_set_scan_velodyne(as_target = 0). */
 int velo_source_to_target(velo_ctx* ctx);
+/* Scan-to-map batches (BASELINE configs 4-5: many scans against ONE accumulated map): `dst` takes the target `src` holds -- cloud
+ * and search index -- BY REFERENCE: no copy, no second index build, one 110 MB map in HBM instead of one per context.  The shared
+ * target is read-only; it lives as long as any context holds it, and a context that loads a new target simply lets go of it.
+ * Both contexts must be on the same device and work with the same gates. */
+int velo_share_target(velo_ctx* dst, velo_ctx* src);
 /* Device-resident scan cache: the ScansLRU of the reference (lru.h:31-61, `size = 50`; look-ups main.cpp:216,349-350,544) with the
  * scans kept in HBM instead of host memory -- the cloud as the path stores it (camera-0 frame, ring-major) and, for scans stored from
  * a context's TARGET side, the search index built for it (the role of ScanData::trees, lru.h:9,17-20), so a frame that is matched again
@@ -308,12 +313,15 @@ int velo_frame_to_frame_batch(velo_ctx** ctxs, int32_t n, double* x /* n*6 */, d
  * target and source go into context i exactly as velo_set_target / velo_set_source would put them, on the thread that then
  * drives that context's group -- a group starts registering as soon as ITS scans are indexed, no barrier across the batch.
  * targets / sources may be NULL (keep what the contexts hold). */
+#define VELO_SCAN_ON_DEVICE 1   /* xyz is a device pointer */
+#define VELO_SCAN_SHARED 2      /* targets only: jobs with IDENTICAL descriptors carrying this flag share one device copy and one
+                                 * index (scan-to-map: many scans against one map) -- built once, held by reference */
 typedef struct velo_scan_ref {
     const float* xyz;
     int64_t stride_bytes;
     const int32_t* ring_offsets;
     int32_t n_rings;
-    int32_t on_device;
+    int32_t on_device;          /* VELO_SCAN_* flags */
 } velo_scan_ref;   /* 32 bytes */
 int velo_register_batch(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, const velo_scan_ref* sources,
                         double* x /* n*6 */, double* T /* n*16 */, velo_summary* summaries /* n */);

@@ -409,3 +409,41 @@ def test_randomized_parity_sweep(hip_lib, oracle):
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     assert m.run(12, first_seed=500) > 150
+
+
+def test_shared_target_equals_own_copy_and_outlives_its_owner(hip_lib, oracle):
+    """velo_share_target: contexts that register different scans against ONE target hold it by reference.  Same tables and poses as
+    with a copy of their own; the shared target stays valid when the context that built it loads something else or is destroyed."""
+    d = H.small_pair(24, 200)
+    d2 = H.small_pair(24, 200, scene_seed=5)
+    owner, own_copy, borrower = api.Context(0, icp_skip=1), api.Context(0, icp_skip=1), api.Context(0, icp_skip=1)
+    owner.set_target(d["tgt_xyz"], d["tgt_off"])
+    own_copy.set_target(d["tgt_xyz"], d["tgt_off"])
+    borrower.share_target(owner)
+    for c in (own_copy, borrower):
+        c.set_source(d2["src_xyz"], d2["src_off"])                      # a different scan than the owner's
+    assert borrower.associate(d["x0"], 1) == own_copy.associate(d["x0"], 1)
+    H.assert_corr_equal(borrower.correspondences(), own_copy.correspondences())
+    owner.set_target(d2["tgt_xyz"], d2["tgt_off"])                      # the owner moves on: the borrower keeps the old target
+    xa, Ta, sa = own_copy.frame_to_frame(d["x0"])
+    xb, Tb, sb = borrower.frame_to_frame(d["x0"])
+    assert np.array_equal(xa, xb) and sa.n_solves == sb.n_solves
+    owner.close()                                                       # ... and goes away
+    xb2, _, _ = borrower.frame_to_frame(d["x0"])
+    assert np.array_equal(xb2, xa)
+    # batch entry: jobs flagged SCAN_SHARED with the same target descriptor are indexed once
+    ctxs = [api.Context(0, icp_skip=1) for _ in range(4)]
+    srcs = [(d["src_xyz"], d["src_off"]), (d2["src_xyz"], d2["src_off"])] * 2
+    x0s = np.tile(d["x0"], (4, 1))
+    tgt = (d["tgt_xyz"], d["tgt_off"])
+    refs_sh = (api.scan_refs([tgt] * 4, 0, shared=True), api.scan_refs(srcs, 0))
+    refs_own = (api.scan_refs([tgt] * 4, 0), api.scan_refs(srcs, 0))
+    xs1, _, S1 = api.register_batch(ctxs, None, None, x0s, refs=refs_sh)
+    xs2, _, S2 = api.register_batch(ctxs, None, None, x0s, refs=refs_own)
+    assert np.array_equal(xs1, xs2) and np.array_equal(xs1[0], xs1[2]) and not np.array_equal(xs1[0], xs1[1])
+    orc = oracle.Oracle(threads=4, icp_skip=1)
+    orc.set_target(d["tgt_xyz"], d["tgt_off"]); orc.set_source(d2["src_xyz"], d2["src_off"])
+    xo, _, _ = orc.frame_to_frame(d["x0"])
+    assert H.pose_close(xs1[1], xo, 1e-9, 1e-10)
+    for c in ctxs + [own_copy, borrower]:
+        c.close()

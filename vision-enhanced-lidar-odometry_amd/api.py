@@ -157,6 +157,7 @@ SIGNATURES = {
     "velo_set_source": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int]),
     "velo_set_scan_velodyne": (C.c_int, [_ctx, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int]),
     "velo_source_to_target": (C.c_int, [_ctx]),
+    "velo_share_target": (C.c_int, [_ctx, _ctx]),
     "velo_cache_create": (C.c_int, [_P(C.c_void_p), C.c_int32, C.c_int32]),
     "velo_cache_destroy": (C.c_int, [C.c_void_p]),
     "velo_cache_store": (C.c_int, [C.c_void_p, C.c_int32, _ctx, C.c_int32]),
@@ -374,6 +375,10 @@ class Context:
     def source_to_target(self):
         """The device-resident source scan becomes the target of the next registration (no upload, no second segmentation)."""
         self._check(self._lib.velo_source_to_target(self._h))
+
+    def share_target(self, src: "Context"):
+        """Take the target `src` holds (cloud + index) by reference: scan-to-map batches keep ONE map for all their contexts."""
+        self._check(self._lib.velo_share_target(self._h, src.handle))
 
     def cloud(self, of_target: bool) -> np.ndarray:
         n = C.c_int32(0)
@@ -628,20 +633,27 @@ def frame_to_frame_batch(ctxs, x0s):
     return x, T.reshape(n, 4, 4), list(S)
 
 
-def scan_refs(scans, device=None):
+SCAN_ON_DEVICE, SCAN_SHARED = 1, 2
+
+
+def scan_refs(scans, device=None, shared=False):
     """[(xyz, ring_offsets), ...] -> (velo_scan_ref array, objects to keep alive while it is in use).  xyz: numpy (n,3|4) float32 or a
     torch tensor on the GPU, as for Context.set_target (device: the contexts' device, checked against the tensors').  Device tensors
     must not be written by torch between this call and the registration that uses the descriptors."""
     n = len(scans)
     arr = (VeloScanRef * n)()
     keep = []
+    seen = {}                       # the same (cloud, offsets) objects give the same descriptor (what SCAN_SHARED keys on)
     for i, (xyz, off) in enumerate(scans):
-        ptr, stride, off_a, dev, k = Context._cloud_args(xyz, off, device)
+        key = (id(xyz), id(off))
+        if key not in seen:
+            seen[key] = Context._cloud_args(xyz, off, device)
+        ptr, stride, off_a, dev, k = seen[key]
         arr[i].xyz = ptr.value
         arr[i].stride_bytes = stride
         arr[i].ring_offsets = off_a.ctypes.data
         arr[i].n_rings = len(off_a) - 1
-        arr[i].on_device = dev
+        arr[i].on_device = dev | (SCAN_SHARED if shared else 0)
         keep.append((k, off_a))
     return arr, keep
 

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <iterator>
 #include <list>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -123,6 +124,21 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 }  // namespace
 
+// What set_target builds: the target cloud and its search index.  Held through a shared_ptr: contexts that register different
+// scans against the same map (scan-to-map batches) share ONE copy -- 110 MB for a 2M-point map instead of one per context, one index
+// build instead of one per context.  Read-only once built; a context that loads a new target while others still hold this one
+// starts a fresh TargetData instead of overwriting it.
+struct TargetData {
+    int n_tgt = 0, n_tgt_rings = 0;
+    int tgt_first_ring = 0, tgt_first_point = 0;   // target-sharded mode: global ids of the first local ring / point
+    DevBuf<float4> tgt;
+    DevBuf<float4> tgt_pad;              // ring-major copy with a wrap-around sentinel on either side of every ring (pad_rings_kernel)
+    DevBuf<int> tgt_off, tgt_ring_of, tgt_cell_of;
+    std::vector<int> h_tgt_off;
+    std::vector<Grid> grids;             // one per distinct gate among iter = 1..f2f_iterations
+    float bbox[6] = {0, 0, 0, 0, 0, 0};
+};
+
 struct velo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -140,19 +156,10 @@ struct velo_ctx {
                                          // (dense bottom rings all land on one XCD); round-robin placement balances better
     int debug_skip = 0;                  // timing experiments only (VELO_DEBUG_SKIP): results are wrong when non-zero
 
-    // target (frame2)
-    int n_tgt = 0, n_tgt_rings = 0;
-    int tgt_first_ring = 0, tgt_first_point = 0;   // target-sharded mode: global ids of the first local ring / point
-    DevBuf<float4> tgt;
-    DevBuf<float4> tgt_pad;              // ring-major copy with a wrap-around sentinel on either side of every ring (pad_rings_kernel)
-    DevBuf<int> tgt_off, tgt_ring_of, tgt_cell_of;
-    std::vector<int> h_tgt_off;
-    std::vector<Grid> grids;             // one per distinct gate among iter = 1..f2f_iterations
-    std::vector<int> grid_of_iter;       // iter (1-based) -> grid index
-    DevBuf<int> scan_tiles, cursor, scan_total;
+    // target (frame2): cloud + search index, shareable between contexts (velo_share_target: many scans against one map)
+    std::shared_ptr<TargetData> T = std::make_shared<TargetData>();
+    DevBuf<int> scan_tiles, cursor, scan_total;   // scratch of an index build
     DevBuf<unsigned> bbox_keys;
-    float bbox[6] = {0, 0, 0, 0, 0, 0};
-    bool bbox_valid = false;
     bool have_target = false;
 
     // source (frame1)
@@ -276,6 +283,11 @@ struct velo_ctx {
 
 namespace {
 
+// a context about to load a NEW target: a TargetData other contexts still hold is left to them
+void own_target(velo_ctx* c) {
+    if (!c->T || c->T.use_count() > 1) c->T = std::make_shared<TargetData>();
+}
+
 int q_range(const velo_ctx* c, int* b, int* e) {
     const int64_t nq = c->n_q;
     *b = (int)(nq * c->shard_rank / c->shard_world);
@@ -331,9 +343,9 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
     // maps, BASELINE config 4) shrink the cell like N^-1/2 to keep the per-cell population -- and with it the candidates
     // per query -- at the level the kernel is tuned for.  Any cell size is exact (the box walk handles every gate).
     const double dense_ref = getenv("VELO_DENSE_REF") ? atof(getenv("VELO_DENSE_REF")) : 150000.0;
-    if (dense_ref > 0.0 && (double)c->n_tgt > dense_ref) h *= std::sqrt(dense_ref / (double)c->n_tgt);
+    if (dense_ref > 0.0 && (double)c->T->n_tgt > dense_ref) h *= std::sqrt(dense_ref / (double)c->T->n_tgt);
     h = std::max(h, 1e-6);
-    const double ext[3] = {(double)c->bbox[3] - c->bbox[0], (double)c->bbox[4] - c->bbox[1], (double)c->bbox[5] - c->bbox[2]};
+    const double ext[3] = {(double)c->T->bbox[3] - c->T->bbox[0], (double)c->T->bbox[4] - c->T->bbox[1], (double)c->T->bbox[5] - c->T->bbox[2]};
     int dims[3];
     for (;;) {   // per-axis <= 8192 cells and <= 2^25 cells in all, else coarsen (still exhaustive: cell >= radius)
         bool ok = true;
@@ -347,12 +359,12 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
         if (ok && total <= 33554432.0) break;
         h *= 1.26;
     }
-    G.d.ox = c->bbox[0]; G.d.oy = c->bbox[1]; G.d.oz = c->bbox[2];
+    G.d.ox = c->T->bbox[0]; G.d.oy = c->T->bbox[1]; G.d.oz = c->T->bbox[2];
     G.d.inv_h = (float)(1.0 / h);
     G.h = h;
     G.d.nx = dims[0]; G.d.ny = dims[1]; G.d.nz = dims[2];
     G.d.ncells = dims[0] * dims[1] * dims[2];
-    const int nc = G.d.ncells, n = c->n_tgt;
+    const int nc = G.d.ncells, n = c->T->n_tgt;
     VELO_TRY(G.cell_start.reserve((size_t)nc + 1));
     const size_t ns = (size_t)n + kGridPad;
     VELO_TRY(G.sorted.reserve(ns)); VELO_TRY(G.sring.reserve(ns));
@@ -361,12 +373,12 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
     VELO_TRY(c->scan_tiles.reserve((size_t)n_tiles + 1));
     VELO_TRY(c->scan_total.reserve(1));
     HIP_TRY(hipMemsetAsync(G.cell_start.p, 0, sizeof(int) * ((size_t)nc + 1), c->stream));
-    if (n > 0) hipLaunchKernelGGL(grid_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, G.d, c->tgt.p, n, c->tgt_cell_of.p, G.cell_start.p);
+    if (n > 0) hipLaunchKernelGGL(grid_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, G.d, c->T->tgt.p, n, c->T->tgt_cell_of.p, G.cell_start.p);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(n_tiles), dim3(kScanThreads), 0, c->stream, G.cell_start.p, nc, c->scan_tiles.p);
     hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kScanThreads), 0, c->stream, c->scan_tiles.p, n_tiles, c->scan_total.p);
     hipLaunchKernelGGL(scan_add_kernel, dim3(cdiv(nc + 1, 256)), dim3(256), 0, c->stream, G.cell_start.p, nc, c->scan_tiles.p, c->scan_total.p, c->cursor.p);
-    hipLaunchKernelGGL(grid_scatter_kernel, dim3(cdiv(std::max(n, kGridPad), 256)), dim3(256), 0, c->stream, c->tgt.p, c->tgt_cell_of.p, c->tgt_ring_of.p, n, c->cursor.p,
-                       (const int*)(G.cell_start.p + nc), c->tgt_first_point, G.sorted.p, G.sring.p);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(cdiv(std::max(n, kGridPad), 256)), dim3(256), 0, c->stream, c->T->tgt.p, c->T->tgt_cell_of.p, c->T->tgt_ring_of.p, n, c->cursor.p,
+                       (const int*)(G.cell_start.p + nc), c->T->tgt_first_point, G.sorted.p, G.sring.p);
     HIP_TRY(hipGetLastError());
     G.built = true;
     return VELO_OK;
@@ -377,11 +389,11 @@ int build_grids(velo_ctx* c) {
     double gmin = gate_of_iter(c->P, 1);
     for (int it = 2; it <= c->P.f2f_iterations; it++) gmin = std::min(gmin, gate_of_iter(c->P, it));
     if (const char* e = getenv("VELO_GRID_GATE")) gmin = atof(e);
-    if (c->grids.empty()) c->grids.resize(1);
-    return build_grid(c, c->grids[0], gmin);
+    if (c->T->grids.empty()) c->T->grids.resize(1);
+    return build_grid(c, c->T->grids[0], gmin);
 }
 
-Grid* grid_for_iter(velo_ctx* c, int) { return (!c->grids.empty() && c->grids[0].built) ? &c->grids[0] : nullptr; }
+Grid* grid_for_iter(velo_ctx* c, int) { return (!c->T->grids.empty() && c->T->grids[0].built) ? &c->T->grids[0] : nullptr; }
 
 int build_query_list(velo_ctx* c) {
     const int skip = std::max(c->P.icp_skip, 1);
@@ -559,7 +571,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         V.d = G->d; V.cell_start = G->cell_start.p; V.sorted = G->sorted.p; V.sring = G->sring.p;
         AssocOut out;
         out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p + c->nv_idx; out.dbg = c->dbg.p; out.wg_times = nullptr;
-        out.first_ring = c->tgt_first_ring; out.first_point = c->tgt_first_point; out.partial = partial ? c->partials_rec.p : nullptr;
+        out.first_ring = c->T->tgt_first_ring; out.first_point = c->T->tgt_first_point; out.partial = partial ? c->partials_rec.p : nullptr;
         out.n_valid_next = nullptr;
         VELO_TRY(attach_seeds(c, &out));
         if (c->debug_skip & 32) { VELO_TRY(c->wg_times.reserve((size_t)2 * cdiv(qe - qb, 64) + 2)); out.wg_times = c->wg_times.p; c->wg_times_n = cdiv(qe - qb, 64); }
@@ -588,7 +600,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         const int cluster_cells = std::max(1, (int)std::lround((double)c->cluster_w * 0.1785 / G->h));
 #define VELO_LAUNCH_V3(NW, MINW, DBG)                                                                                              \
         hipLaunchKernelGGL((assoc_search_v3_kernel<NW, MINW, DBG>), dim3(c->xcd_map ? ((groups + 7) / 8) * 8 : groups), dim3(NW * 64), 0, c->stream, S, V, c->src.p, c->q_src.p, qb, qe, \
-                           c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, cluster_cells, h_safe, out, aux, c->debug_skip, c->xcd_map)
+                           c->T->tgt.p, c->T->tgt_off.p, c->T->tgt_ring_of.p, gbits, c->P.icp_norm_condition, cluster_cells, h_safe, out, aux, c->debug_skip, c->xcd_map)
         // the diagnostic hooks (VELO_DEBUG_SKIP != 0) live in a separate instantiation: compiled in, they spill registers
 #ifdef VELO_DIAGNOSTICS
 #define VELO_LAUNCH_V2(NW, MINW) do { if (c->debug_skip) VELO_LAUNCH_V3(NW, MINW, true); else VELO_LAUNCH_V3(NW, MINW, false); } while (0)
@@ -604,7 +616,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
             case 0: {
                 const int reach = (int)std::ceil(std::sqrt(std::max(gate, 0.0)) / (G->h * 0.999)) ;
                 hipLaunchKernelGGL(assoc_search_kernel, dim3(cdiv(qe - qb, kAssocThreads)), dim3(kAssocThreads), 0, c->stream,
-                                   S, V, c->src.p, c->q_src.p, qb, qe, c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, std::max(reach, 1), out, aux);
+                                   S, V, c->src.p, c->q_src.p, qb, qe, c->T->tgt.p, c->T->tgt_off.p, c->T->tgt_ring_of.p, gbits, c->P.icp_norm_condition, std::max(reach, 1), out, aux);
                 break;
             }
             case 104: case 102: case 108: {   // pipelined: prepare (one item per cluster) + persistent per-cluster search
@@ -621,13 +633,13 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 const int wgs = std::min(groups * 4, c->persistent_wgs);
                 if (variant == 102)
                     hipLaunchKernelGGL((assoc_cluster_kernel<2, 1>), dim3(wgs), dim3(128), 0, c->stream, V, Q, c->src.p, c->q_src.p, qb, qe,
-                                       c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, h_safe, out, aux);
+                                       c->T->tgt.p, c->T->tgt_off.p, c->T->tgt_ring_of.p, gbits, c->P.icp_norm_condition, h_safe, out, aux);
                 else if (variant == 108)
                     hipLaunchKernelGGL((assoc_cluster_kernel<8, 6>), dim3(wgs), dim3(512), 0, c->stream, V, Q, c->src.p, c->q_src.p, qb, qe,
-                                       c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, h_safe, out, aux);
+                                       c->T->tgt.p, c->T->tgt_off.p, c->T->tgt_ring_of.p, gbits, c->P.icp_norm_condition, h_safe, out, aux);
                 else
                     hipLaunchKernelGGL((assoc_cluster_kernel<4, 6>), dim3(wgs), dim3(256), 0, c->stream, V, Q, c->src.p, c->q_src.p, qb, qe,
-                                       c->tgt.p, c->tgt_off.p, c->tgt_ring_of.p, gbits, c->P.icp_norm_condition, h_safe, out, aux);
+                                       c->T->tgt.p, c->T->tgt_off.p, c->T->tgt_ring_of.p, gbits, c->P.icp_norm_condition, h_safe, out, aux);
                 break;
             }
             case 5: case 55: case 52: case 56: case 57: case 58: case 59: {   // tube variant: per-row intervals, per-query phase 2 (cluster radius only when VELO_CLUSTER_W is given)
@@ -643,7 +655,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
 #define VELO_LAUNCH_V5(NW, MINW, DBG, PPT, ASKER)                                                                                         \
                 hipExtLaunchKernelGGL((assoc_search_v5_kernel<NW, MINW, DBG, PPT, ASKER>), dim3(groups), dim3(NW * 64), 0, c->stream,                    \
                                       ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, S, V, c->qpts, qb, qe,                      \
-                                   (const float4*)c->tgt_pad.p, (const int*)c->tgt_off.p, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux, perm, c->debug_skip, asker_rows)
+                                   (const float4*)c->T->tgt_pad.p, (const int*)c->T->tgt_off.p, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux, perm, c->debug_skip, asker_rows)
                 // default: 5 waves/SIMD (96 VGPRs, no spills, no scratch traffic), 2 candidate pairs per trip.  Measured on C2:
                 // 62 us; 6 waves + 2 pairs (5 spilled VGPRs) 65; 7 waves + 2 pairs 64; 5 waves + 4 pairs 66; 6 waves + 4 pairs 71
 #ifdef VELO_DIAGNOSTICS
@@ -908,23 +920,23 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
 
 // common tail of every way a target enters the context: ring table, ring ids, bounding box, grid
 int target_finalize(velo_ctx* c) {
-    const int n = c->n_tgt, n_rings = c->n_tgt_rings;
+    const int n = c->T->n_tgt, n_rings = c->T->n_tgt_rings;
     c->prev_ready = false;                                            // seeds refer to points of the old target
-    for (int r = 0; r < n_rings; r++) if (c->h_tgt_off[r + 1] <= c->h_tgt_off[r]) return fail(VELO_ERR_INVALID, "target ring %d is empty", r);
-    VELO_TRY(c->tgt_off.reserve((size_t)n_rings + 1));
-    VELO_TRY(c->tgt_ring_of.reserve((size_t)std::max(n, 1)));
-    VELO_TRY(c->tgt_cell_of.reserve((size_t)std::max(n, 1)));
-    VELO_TRY(c->tgt_pad.reserve((size_t)n + 2 * (size_t)n_rings + 2));
-    HIP_TRY(hipMemcpyAsync(c->tgt_off.p, c->h_tgt_off.data(), sizeof(int) * ((size_t)n_rings + 1), hipMemcpyHostToDevice, c->stream));
+    for (int r = 0; r < n_rings; r++) if (c->T->h_tgt_off[r + 1] <= c->T->h_tgt_off[r]) return fail(VELO_ERR_INVALID, "target ring %d is empty", r);
+    VELO_TRY(c->T->tgt_off.reserve((size_t)n_rings + 1));
+    VELO_TRY(c->T->tgt_ring_of.reserve((size_t)std::max(n, 1)));
+    VELO_TRY(c->T->tgt_cell_of.reserve((size_t)std::max(n, 1)));
+    VELO_TRY(c->T->tgt_pad.reserve((size_t)n + 2 * (size_t)n_rings + 2));
+    HIP_TRY(hipMemcpyAsync(c->T->tgt_off.p, c->T->h_tgt_off.data(), sizeof(int) * ((size_t)n_rings + 1), hipMemcpyHostToDevice, c->stream));
     // bbox of the finite points -> host (the only sync of set_target; the grid dimensions are sized from it)
     unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
     std::memcpy(c->h_int, init, sizeof(init));
     HIP_TRY(hipMemcpyAsync(c->bbox_keys.p, c->h_int, sizeof(init), hipMemcpyHostToDevice, c->stream));
     if (n > 0) {
-        hipLaunchKernelGGL(ring_of_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->tgt_off.p, n_rings, n, c->tgt_first_ring, c->tgt_ring_of.p);
-        hipLaunchKernelGGL(pad_rings_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const float4*)c->tgt.p, (const int*)c->tgt_off.p, (const int*)c->tgt_ring_of.p, n,
-                           c->tgt_first_ring, c->tgt_pad.p);
-        hipLaunchKernelGGL(bbox_kernel, dim3(std::min(cdiv(n, 256 * 8), 256)), dim3(256), 0, c->stream, c->tgt.p, n, c->bbox_keys.p);
+        hipLaunchKernelGGL(ring_of_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->T->tgt_off.p, n_rings, n, c->T->tgt_first_ring, c->T->tgt_ring_of.p);
+        hipLaunchKernelGGL(pad_rings_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const float4*)c->T->tgt.p, (const int*)c->T->tgt_off.p, (const int*)c->T->tgt_ring_of.p, n,
+                           c->T->tgt_first_ring, c->T->tgt_pad.p);
+        hipLaunchKernelGGL(bbox_kernel, dim3(std::min(cdiv(n, 256 * 8), 256)), dim3(256), 0, c->stream, c->T->tgt.p, n, c->bbox_keys.p);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(c->h_int + 8, c->bbox_keys.p, sizeof(init), hipMemcpyDeviceToHost, c->stream));
@@ -932,11 +944,11 @@ int target_finalize(velo_ctx* c) {
     unsigned keys[6];
     std::memcpy(keys, c->h_int + 8, sizeof(keys));
     if (keys[0] == 0xffffffffu) {   // no finite point at all
-        for (int k = 0; k < 6; k++) c->bbox[k] = 0.f;
+        for (int k = 0; k < 6; k++) c->T->bbox[k] = 0.f;
     } else {
-        for (int k = 0; k < 6; k++) c->bbox[k] = key2f(keys[k]);
+        for (int k = 0; k < 6; k++) c->T->bbox[k] = key2f(keys[k]);
     }
-    for (Grid& G : c->grids) G.built = false;                         // keep the buffers: a new target of the same size rebuilds in place
+    for (Grid& G : c->T->grids) G.built = false;                         // keep the buffers: a new target of the same size rebuilds in place
     VELO_TRY(build_grids(c));
     c->have_target = true;
     return VELO_OK;
@@ -1067,8 +1079,7 @@ int velo_destroy(velo_ctx* c) {
     for (int r = 0; r < kMaxPeers; r++) if (c->peer_area_mapped[r]) { (void)hipIpcCloseMemHandle(c->peer_area_mapped[r]); c->peer_area_mapped[r] = nullptr; }
     if (c->peer_slab) { (void)hipFree(c->peer_slab); c->peer_slab = nullptr; }
     if (c->peer_area) { (void)hipFree(c->peer_area); c->peer_area = nullptr; }
-    c->tgt.release(); c->tgt_off.release(); c->tgt_ring_of.release(); c->tgt_cell_of.release();
-    for (Grid& G : c->grids) { G.cell_start.release(); G.sorted.release(); G.sring.release(); }
+    c->T.reset();                                            // the target goes with its last holder
     c->scan_tiles.release(); c->cursor.release(); c->scan_total.release(); c->bbox_keys.release();
     c->src.release(); c->src_off.release(); c->q_off.release(); c->q_src.release(); c->staging.release();
     c->seg_flag.release(); c->seg_excl.release(); c->seg_ring.release(); c->seg_off.release();
@@ -1099,6 +1110,8 @@ int velo_set_params(velo_ctx* c, const velo_params* p) {
     HIP_TRY(hipSetDevice(c->device));
     const bool gates_changed = p->correspondence_thresh_icp != c->P.correspondence_thresh_icp || p->f2f_iterations != c->P.f2f_iterations;
     const bool queries_changed = p->icp_skip != c->P.icp_skip || p->enable_icp != c->P.enable_icp;
+    if (gates_changed && c->have_target && c->T.use_count() > 1)
+        return fail(VELO_ERR_STATE, "the target is shared with other contexts: its index cannot be rebuilt for new gates here; load the target again");
     c->P = *p;
     if (gates_changed && c->have_target) VELO_TRY(build_grids(c));
     if (queries_changed && c->have_source) VELO_TRY(build_query_list(c));
@@ -1132,11 +1145,12 @@ int velo_set_target_part(velo_ctx* c, const float* xyz, int64_t stride, const in
     const int n = n_rings > 0 ? off[n_rings] : 0;
     if (n > 0 && !xyz) return fail(VELO_ERR_INVALID, "null xyz");
     HIP_TRY(hipSetDevice(c->device));
+    own_target(c);
     c->have_target = false; c->have_corr = false; c->have_partials = false;
-    c->n_tgt = n; c->n_tgt_rings = n_rings;
-    c->tgt_first_ring = first_ring; c->tgt_first_point = first_point;
-    c->h_tgt_off.assign(off, off + n_rings + 1);
-    VELO_TRY(upload_cloud(c, xyz, stride, n, on_device, c->tgt));
+    c->T->n_tgt = n; c->T->n_tgt_rings = n_rings;
+    c->T->tgt_first_ring = first_ring; c->T->tgt_first_point = first_point;
+    c->T->h_tgt_off.assign(off, off + n_rings + 1);
+    VELO_TRY(upload_cloud(c, xyz, stride, n, on_device, c->T->tgt));
     return target_finalize(c);
 }
 
@@ -1161,9 +1175,10 @@ int velo_set_scan_velodyne(velo_ctx* c, int32_t as_target, const float* xyzr, in
     if (!c || n < 0 || (n > 0 && !xyzr) || !velo_to_cam) return fail(VELO_ERR_INVALID, "null/negative argument");
     if (stride < 12) return fail(VELO_ERR_INVALID, "stride_bytes must be >= 12");
     HIP_TRY(hipSetDevice(c->device));
-    DevBuf<float4>& dst = as_target ? c->tgt : c->src;
-    std::vector<int>& h_off = as_target ? c->h_tgt_off : c->h_src_off;
-    if (as_target) { c->have_target = false; c->have_partials = false; c->tgt_first_ring = 0; c->tgt_first_point = 0; } else c->have_source = false;
+    if (as_target) own_target(c);
+    DevBuf<float4>& dst = as_target ? c->T->tgt : c->src;
+    std::vector<int>& h_off = as_target ? c->T->h_tgt_off : c->h_src_off;
+    if (as_target) { c->have_target = false; c->have_partials = false; c->T->tgt_first_ring = 0; c->T->tgt_first_point = 0; } else c->have_source = false;
     c->have_corr = false;
     VELO_TRY(dst.reserve((size_t)std::max(n, 1)));
     int n_rings = 0;
@@ -1199,19 +1214,38 @@ int velo_set_scan_velodyne(velo_ctx* c, int32_t as_target, const float* xyzr, in
         h_off.resize((size_t)n_rings + 1);
         HIP_TRY(hipMemcpy(h_off.data(), c->seg_off.p, sizeof(int) * ((size_t)n_rings + 1), hipMemcpyDeviceToHost));
     }
-    if (as_target) { c->n_tgt = n; c->n_tgt_rings = n_rings; return target_finalize(c); }
+    if (as_target) { c->T->n_tgt = n; c->T->n_tgt_rings = n_rings; return target_finalize(c); }
     c->n_src = n; c->n_src_rings = n_rings;
     return source_finalize(c);
+}
+
+int velo_share_target(velo_ctx* dst, velo_ctx* src) {
+    if (!dst || !src) return fail(VELO_ERR_INVALID, "null ctx");
+    if (dst == src) return VELO_OK;
+    if (dst->device != src->device) return fail(VELO_ERR_INVALID, "contexts on different devices (%d, %d)", dst->device, src->device);
+    if (!src->have_target) return fail(VELO_ERR_STATE, "the source context holds no target");
+    double g1 = gate_of_iter(dst->P, 1), g2 = gate_of_iter(src->P, 1);
+    for (int it = 2; it <= dst->P.f2f_iterations; it++) g1 = std::min(g1, gate_of_iter(dst->P, it));
+    for (int it = 2; it <= src->P.f2f_iterations; it++) g2 = std::min(g2, gate_of_iter(src->P, it));
+    if (g1 != g2) return fail(VELO_ERR_INVALID, "the contexts work with different gates: the index of one does not serve the other");
+    HIP_TRY(hipSetDevice(src->device));
+    HIP_TRY(hipStreamSynchronize(src->stream));                // the index is complete before another stream reads it
+    HIP_TRY(hipStreamSynchronize(dst->stream));                // nothing of dst still reads what it is about to drop
+    dst->T = src->T;
+    dst->have_target = true; dst->have_corr = false; dst->have_partials = false;
+    dst->prev_ready = false;
+    return VELO_OK;
 }
 
 int velo_source_to_target(velo_ctx* c) {
     if (!c) return fail(VELO_ERR_INVALID, "null ctx");
     if (!c->have_source) return fail(VELO_ERR_STATE, "no source cloud to promote");
     HIP_TRY(hipSetDevice(c->device));
-    std::swap(c->tgt.p, c->src.p); std::swap(c->tgt.cap, c->src.cap);
-    c->h_tgt_off = c->h_src_off;
-    c->n_tgt = c->n_src; c->n_tgt_rings = c->n_src_rings;
-    c->tgt_first_ring = 0; c->tgt_first_point = 0;
+    own_target(c);
+    std::swap(c->T->tgt.p, c->src.p); std::swap(c->T->tgt.cap, c->src.cap);
+    c->T->h_tgt_off = c->h_src_off;
+    c->T->n_tgt = c->n_src; c->T->n_tgt_rings = c->n_src_rings;
+    c->T->tgt_first_ring = 0; c->T->tgt_first_point = 0;
     c->have_source = false; c->have_target = false; c->have_corr = false; c->have_partials = false;
     c->n_src = 0; c->n_src_rings = 0; c->n_q = 0; c->h_src_off.assign(1, 0); c->h_q_off.assign(1, 0);
     return target_finalize(c);
@@ -1267,7 +1301,7 @@ int velo_cache_store(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t of_
     if (!k || !c) return fail(VELO_ERR_INVALID, "null argument");
     if (c->device != k->device) return fail(VELO_ERR_INVALID, "context on device %d, cache on device %d", c->device, k->device);
     if (of_target ? !c->have_target : !c->have_source) return fail(VELO_ERR_STATE, "the context holds no %s scan", of_target ? "target" : "source");
-    if (of_target && (c->tgt_first_ring != 0 || c->tgt_first_point != 0)) return fail(VELO_ERR_STATE, "a target shard is not a whole scan");
+    if (of_target && (c->T->tgt_first_ring != 0 || c->T->tgt_first_point != 0)) return fail(VELO_ERR_STATE, "a target shard is not a whole scan");
     HIP_TRY(hipSetDevice(k->device));
     // The node that takes the scan: the frame's own older copy (replaced, not duplicated), else -- when the cache is full -- the
     // least recently used one (lru.h:52-57: it would be dropped anyway), else a new one.  A recycled node keeps its device
@@ -1285,21 +1319,21 @@ int velo_cache_store(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t of_
     k->exists[frame] = k->times.begin();
     e.frame = frame;
     e.has_index = false;
-    e.n = of_target ? c->n_tgt : c->n_src;
-    e.n_rings = of_target ? c->n_tgt_rings : c->n_src_rings;
-    e.h_off = of_target ? c->h_tgt_off : c->h_src_off;
+    e.n = of_target ? c->T->n_tgt : c->n_src;
+    e.n_rings = of_target ? c->T->n_tgt_rings : c->n_src_rings;
+    e.h_off = of_target ? c->T->h_tgt_off : c->h_src_off;
     int st = e.cloud.reserve((size_t)std::max(e.n, 1));
     hipError_t he = hipSuccess;
-    if (st == VELO_OK && e.n > 0) he = hipMemcpyAsync(e.cloud.p, of_target ? c->tgt.p : c->src.p, sizeof(float4) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream);
+    if (st == VELO_OK && e.n > 0) he = hipMemcpyAsync(e.cloud.p, of_target ? c->T->tgt.p : c->src.p, sizeof(float4) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream);
     Grid* G = of_target ? grid_for_iter(c, 1) : nullptr;
     if (st == VELO_OK && he == hipSuccess && G) {
         e.has_index = true;
-        std::memcpy(e.bbox, c->bbox, sizeof(e.bbox));
+        std::memcpy(e.bbox, c->T->bbox, sizeof(e.bbox));
         e.grid.d = G->d; e.grid.gate = G->gate; e.grid.h = G->h; e.grid.built = true;
         const size_t nc = (size_t)G->d.ncells + 1, ns = (size_t)e.n + kGridPad;
         if ((st = e.ring_of.reserve((size_t)std::max(e.n, 1))) == VELO_OK && (st = e.grid.cell_start.reserve(nc)) == VELO_OK &&
             (st = e.grid.sorted.reserve(ns)) == VELO_OK && (st = e.grid.sring.reserve(ns)) == VELO_OK) {
-            if (e.n > 0) he = hipMemcpyAsync(e.ring_of.p, c->tgt_ring_of.p, sizeof(int) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream);
+            if (e.n > 0) he = hipMemcpyAsync(e.ring_of.p, c->T->tgt_ring_of.p, sizeof(int) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream);
             if (he == hipSuccess) he = hipMemcpyAsync(e.grid.cell_start.p, G->cell_start.p, sizeof(int) * nc, hipMemcpyDeviceToDevice, c->stream);
             if (he == hipSuccess) he = hipMemcpyAsync(e.grid.sorted.p, G->sorted.p, sizeof(float4) * ns, hipMemcpyDeviceToDevice, c->stream);
             if (he == hipSuccess) he = hipMemcpyAsync(e.grid.sring.p, G->sring.p, sizeof(int) * ns, hipMemcpyDeviceToDevice, c->stream);
@@ -1330,11 +1364,12 @@ int velo_cache_load(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t as_t
         return source_finalize(c);
     }
     for (int r = 0; r < e.n_rings; r++) if (e.h_off[(size_t)r + 1] <= e.h_off[(size_t)r]) return fail(VELO_ERR_INVALID, "target ring %d is empty", r);
-    VELO_TRY(c->tgt.reserve((size_t)std::max(e.n, 1)));
-    if (e.n > 0) HIP_TRY(hipMemcpyAsync(c->tgt.p, e.cloud.p, sizeof(float4) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream));
-    c->h_tgt_off = e.h_off;
-    c->n_tgt = e.n; c->n_tgt_rings = e.n_rings;
-    c->tgt_first_ring = 0; c->tgt_first_point = 0;
+    own_target(c);
+    VELO_TRY(c->T->tgt.reserve((size_t)std::max(e.n, 1)));
+    if (e.n > 0) HIP_TRY(hipMemcpyAsync(c->T->tgt.p, e.cloud.p, sizeof(float4) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream));
+    c->T->h_tgt_off = e.h_off;
+    c->T->n_tgt = e.n; c->T->n_tgt_rings = e.n_rings;
+    c->T->tgt_first_ring = 0; c->T->tgt_first_point = 0;
     c->have_target = false; c->have_corr = false; c->have_partials = false;
     // the cached index serves when it was built for the gates this context works with (same cell size rule, same cloud)
     double gmin = gate_of_iter(c->P, 1);
@@ -1342,25 +1377,25 @@ int velo_cache_load(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t as_t
     if (const char* env = getenv("VELO_GRID_GATE")) gmin = atof(env);
     if (!e.has_index || e.grid.gate != gmin) return target_finalize(c);
     c->prev_ready = false;
-    VELO_TRY(c->tgt_off.reserve((size_t)e.n_rings + 1));
-    VELO_TRY(c->tgt_ring_of.reserve((size_t)std::max(e.n, 1)));
-    VELO_TRY(c->tgt_cell_of.reserve((size_t)std::max(e.n, 1)));                            // scratch of a later rebuild (velo_set_params)
-    if (c->grids.empty()) c->grids.resize(1);
-    Grid& G = c->grids[0];
+    VELO_TRY(c->T->tgt_off.reserve((size_t)e.n_rings + 1));
+    VELO_TRY(c->T->tgt_ring_of.reserve((size_t)std::max(e.n, 1)));
+    VELO_TRY(c->T->tgt_cell_of.reserve((size_t)std::max(e.n, 1)));                            // scratch of a later rebuild (velo_set_params)
+    if (c->T->grids.empty()) c->T->grids.resize(1);
+    Grid& G = c->T->grids[0];
     const size_t nc = (size_t)e.grid.d.ncells + 1, ns = (size_t)e.n + kGridPad;
     VELO_TRY(G.cell_start.reserve(nc)); VELO_TRY(G.sorted.reserve(ns)); VELO_TRY(G.sring.reserve(ns));
-    HIP_TRY(hipMemcpyAsync(c->tgt_off.p, c->h_tgt_off.data(), sizeof(int) * ((size_t)e.n_rings + 1), hipMemcpyHostToDevice, c->stream));
-    if (e.n > 0) HIP_TRY(hipMemcpyAsync(c->tgt_ring_of.p, e.ring_of.p, sizeof(int) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream));
-    VELO_TRY(c->tgt_pad.reserve((size_t)e.n + 2 * (size_t)e.n_rings + 2));
+    HIP_TRY(hipMemcpyAsync(c->T->tgt_off.p, c->T->h_tgt_off.data(), sizeof(int) * ((size_t)e.n_rings + 1), hipMemcpyHostToDevice, c->stream));
+    if (e.n > 0) HIP_TRY(hipMemcpyAsync(c->T->tgt_ring_of.p, e.ring_of.p, sizeof(int) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream));
+    VELO_TRY(c->T->tgt_pad.reserve((size_t)e.n + 2 * (size_t)e.n_rings + 2));
     if (e.n > 0) {
-        hipLaunchKernelGGL(pad_rings_kernel, dim3(cdiv(e.n, 256)), dim3(256), 0, c->stream, (const float4*)c->tgt.p, (const int*)c->tgt_off.p, (const int*)c->tgt_ring_of.p, e.n, 0, c->tgt_pad.p);
+        hipLaunchKernelGGL(pad_rings_kernel, dim3(cdiv(e.n, 256)), dim3(256), 0, c->stream, (const float4*)c->T->tgt.p, (const int*)c->T->tgt_off.p, (const int*)c->T->tgt_ring_of.p, e.n, 0, c->T->tgt_pad.p);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(G.cell_start.p, e.grid.cell_start.p, sizeof(int) * nc, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(G.sorted.p, e.grid.sorted.p, sizeof(float4) * ns, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(G.sring.p, e.grid.sring.p, sizeof(int) * ns, hipMemcpyDeviceToDevice, c->stream));
     G.d = e.grid.d; G.gate = e.grid.gate; G.h = e.grid.h; G.built = true;
-    std::memcpy(c->bbox, e.bbox, sizeof(c->bbox));
+    std::memcpy(c->T->bbox, e.bbox, sizeof(c->T->bbox));
     HIP_TRY(hipStreamSynchronize(c->stream));                                              // h_tgt_off (pageable) has been read; the entry may be evicted
     c->have_target = true;
     return VELO_OK;
@@ -1368,7 +1403,7 @@ int velo_cache_load(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t as_t
 
 int velo_get_ring_offsets(velo_ctx* c, int32_t of_target, int32_t* out, int32_t capacity, int32_t* n_rings) {
     if (!c) return fail(VELO_ERR_INVALID, "null ctx");
-    const std::vector<int>& h = of_target ? c->h_tgt_off : c->h_src_off;
+    const std::vector<int>& h = of_target ? c->T->h_tgt_off : c->h_src_off;
     const int nr = h.empty() ? 0 : (int)h.size() - 1;
     if (n_rings) *n_rings = nr;
     if (out) for (int i = 0; i <= nr && i < capacity; i++) out[i] = h[i];
@@ -1378,13 +1413,13 @@ int velo_get_ring_offsets(velo_ctx* c, int32_t of_target, int32_t* out, int32_t 
 // copies the context's camera-frame cloud back (tests): n points, 3 floats each
 int velo_get_cloud(velo_ctx* c, int32_t of_target, float* xyz_out, int32_t capacity_points, int32_t* n_points) {
     if (!c) return fail(VELO_ERR_INVALID, "null ctx");
-    const int n = of_target ? c->n_tgt : c->n_src;
+    const int n = of_target ? c->T->n_tgt : c->n_src;
     if (n_points) *n_points = n;
     if (!xyz_out || capacity_points <= 0 || n == 0) return VELO_OK;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     std::vector<float4> h((size_t)n);
-    HIP_TRY(hipMemcpy(h.data(), of_target ? c->tgt.p : c->src.p, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(h.data(), of_target ? c->T->tgt.p : c->src.p, sizeof(float4) * (size_t)n, hipMemcpyDeviceToHost));
     for (int i = 0; i < n && i < capacity_points; i++) { xyz_out[3 * i] = h[i].x; xyz_out[3 * i + 1] = h[i].y; xyz_out[3 * i + 2] = h[i].z; }
     return VELO_OK;
 }
@@ -1429,7 +1464,7 @@ static int launch_merge(velo_ctx* c, const PartialRec* tables, int world, int st
     if (qe > qb) {
         AssocOut out;
         out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p + c->nv_idx;
-        out.dbg = c->dbg.p; out.wg_times = nullptr; out.first_ring = c->tgt_first_ring; out.first_point = c->tgt_first_point; out.partial = nullptr; out.prev_a = nullptr; out.prev_b = nullptr; out.prev_r = nullptr; out.n_valid_next = nullptr;
+        out.dbg = c->dbg.p; out.wg_times = nullptr; out.first_ring = c->T->tgt_first_ring; out.first_point = c->T->tgt_first_point; out.partial = nullptr; out.prev_a = nullptr; out.prev_b = nullptr; out.prev_r = nullptr; out.n_valid_next = nullptr;
         const unsigned long long key_inf = ((unsigned long long)gate_bits_of(gate_of_iter(c->P, iter)) + 1ull) << 32;
         hipLaunchKernelGGL(merge_partials_kernel, dim3(cdiv(qe - qb, 256)), dim3(256), 0, c->stream, tables, world, stride, qb, qe,
                            (const float4*)c->src.p, (const int*)c->q_src.p, key_inf, c->P.icp_norm_condition, out, want_aux ? 1 : 0);
@@ -1690,7 +1725,7 @@ int velo_frame_to_frame(velo_ctx* c, double x[6], double T[16], velo_summary* su
     velo_summary local;
     velo_summary* S = summary ? summary : &local;
     std::memset(S, 0, sizeof(*S));
-    S->n_target = c->n_tgt;
+    S->n_target = c->T->n_tgt;
     c->assoc_events_used = 0;
     double xc[6];
     for (int k = 0; k < 6; k++) xc[k] = x[k];
@@ -1707,7 +1742,7 @@ int velo_frame_to_frame(velo_ctx* c, double x[6], double T[16], velo_summary* su
             S->n_assoc_rounds++;
             S->n_queries = c->n_q;
             const uint64_t nq = (uint64_t)c->n_q;
-            const uint64_t b_assoc = 12ull * nq + 12ull * (uint64_t)c->n_tgt + 28ull * nq;
+            const uint64_t b_assoc = 12ull * nq + 12ull * (uint64_t)c->T->n_tgt + 28ull * nq;
             S->assoc_bytes += b_assoc; S->algorithmic_bytes += b_assoc;
             if (qe > qb) S->assoc_kernel_launches++;
             velo_solve_summary ss;
@@ -1762,7 +1797,7 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
     pose_scalars(x, &A->P);
     A->G.d = G->d; A->G.cell_start = G->cell_start.p; A->G.sorted = G->sorted.p; A->G.sring = G->sring.p;
     A->qpts = c->qpts; A->q_begin = qb; A->q_end = qe;
-    A->tgt_pad = c->tgt_pad.p; A->tgt_off = c->tgt_off.p;
+    A->tgt_pad = c->T->tgt_pad.p; A->tgt_off = c->T->tgt_off.p;
     const double gate = gate_of_iter(c->P, iter);
     A->gate_bits = gate_bits_of(gate);
     A->norm_cond = c->P.icp_norm_condition;
@@ -1771,7 +1806,7 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
     A->h_safe = (float)(G->h * 0.999);
     AssocOut& out = A->out;
     out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p + c->nv_idx; out.dbg = c->dbg.p; out.wg_times = nullptr;
-    out.first_ring = c->tgt_first_ring; out.first_point = c->tgt_first_point; out.partial = nullptr;
+    out.first_ring = c->T->tgt_first_ring; out.first_point = c->T->tgt_first_point; out.partial = nullptr;
     VELO_TRY(attach_seeds(c, &out));
     out.n_valid_next = c->n_valid.p + (c->nv_idx ^ 1);
     c->nv_clean[c->nv_idx ^ 1] = true;
@@ -1870,7 +1905,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
     for (int i = 0; i < n; i++) {
         S[(size_t)i] = summaries ? summaries + i : &local[(size_t)i];
         std::memset(S[(size_t)i], 0, sizeof(velo_summary));
-        S[(size_t)i]->n_target = ctxs[i]->n_tgt;
+        S[(size_t)i]->n_target = ctxs[i]->T->n_tgt;
         ctxs[i]->assoc_events_used = 0;
         for (int k = 0; k < 6; k++) xc[(size_t)i][(size_t)k] = x[6 * (size_t)i + k];
     }
@@ -1891,7 +1926,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                 velo_summary* Si = S[(size_t)i];
                 Si->n_assoc_rounds++; Si->n_queries = c->n_q;
                 const uint64_t nq = (uint64_t)c->n_q;
-                const uint64_t b_assoc = 12ull * nq + 12ull * (uint64_t)c->n_tgt + 28ull * nq;
+                const uint64_t b_assoc = 12ull * nq + 12ull * (uint64_t)c->T->n_tgt + 28ull * nq;
                 Si->assoc_bytes += b_assoc; Si->algorithmic_bytes += b_assoc;
                 Si->assoc_kernel_launches += assoc_launched[(size_t)i];
                 LMBatchItem& it = h_items[i];
@@ -1970,8 +2005,8 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
 
 // upload (optional) + register: the scans of job i go into context i (velo_set_target / velo_set_source semantics), then the batch runs
 static int load_job(velo_ctx* c, const velo_scan_ref* tg, const velo_scan_ref* sr) {
-    if (tg) VELO_TRY(velo_set_target(c, tg->xyz, tg->stride_bytes, tg->ring_offsets, tg->n_rings, tg->on_device));
-    if (sr) VELO_TRY(velo_set_source(c, sr->xyz, sr->stride_bytes, sr->ring_offsets, sr->n_rings, sr->on_device));
+    if (tg) VELO_TRY(velo_set_target(c, tg->xyz, tg->stride_bytes, tg->ring_offsets, tg->n_rings, tg->on_device & 1));
+    if (sr) VELO_TRY(velo_set_source(c, sr->xyz, sr->stride_bytes, sr->ring_offsets, sr->n_rings, sr->on_device & 1));
     return VELO_OK;
 }
 
@@ -1981,6 +2016,33 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
         if (!ctxs[i]) return fail(VELO_ERR_INVALID, "batch entry %d is null", i);
         for (int j = 0; j < i; j++) if (ctxs[j] == ctxs[i]) return fail(VELO_ERR_INVALID, "batch entries %d and %d are the same context", j, i);
     }
+    // Targets flagged VELO_SCAN_SHARED with identical descriptors (scan-to-map: many scans against one map) are loaded and indexed
+    // ONCE, by the first job that names them; the other jobs' contexts take that target by reference (velo_share_target).
+    std::vector<velo_scan_ref> tgt_local;
+    if (targets) {
+        bool any = false;
+        for (int i = 0; i < n; i++) any = any || (targets[i].on_device & VELO_SCAN_SHARED) != 0;
+        if (any) {
+            tgt_local.assign(targets, targets + n);
+            for (int i = 0; i < n; i++) {
+                if (!(targets[i].on_device & VELO_SCAN_SHARED)) continue;
+                int owner = -1;
+                for (int j = 0; j < i && owner < 0; j++) {
+                    const velo_scan_ref &a = targets[i], &b = targets[j];
+                    if ((b.on_device & VELO_SCAN_SHARED) && a.xyz == b.xyz && a.stride_bytes == b.stride_bytes && a.ring_offsets == b.ring_offsets &&
+                        a.n_rings == b.n_rings && a.on_device == b.on_device && ctxs[i]->device == ctxs[j]->device) owner = j;
+                }
+                if (owner < 0) VELO_TRY(load_job(ctxs[i], &targets[i], nullptr));
+                else VELO_TRY(velo_share_target(ctxs[i], ctxs[owner]));
+                tgt_local[(size_t)i].xyz = nullptr; tgt_local[(size_t)i].n_rings = -1;      // marks "already loaded"
+            }
+        }
+    }
+    auto target_of = [&](int i) -> const velo_scan_ref* {
+        if (!targets) return nullptr;
+        if (!tgt_local.empty()) return tgt_local[(size_t)i].n_rings < 0 ? nullptr : &tgt_local[(size_t)i];
+        return targets + i;
+    };
     if (batch_can_lockstep(ctxs, n, targets != nullptr, sources != nullptr)) {
         // G lock-step groups, one host thread and one stream each: while one group is in its (chip-filling) association
         // launches or waits for a status copy, another group's LM launches run -- the groups hide each other's bubbles
@@ -1989,7 +2051,7 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
         static const int groups_env = getenv("VELO_BATCH_GROUPS") ? std::max(atoi(getenv("VELO_BATCH_GROUPS")), 1) : 0;
         const int G = groups_env > 0 ? std::min(groups_env, n / 2) : (n >= 12 ? 2 : std::min(4, n / 2));
         if (G <= 1) {
-            for (int i = 0; i < n; i++) VELO_TRY(load_job(ctxs[i], targets ? targets + i : nullptr, sources ? sources + i : nullptr));
+            for (int i = 0; i < n; i++) VELO_TRY(load_job(ctxs[i], target_of(i), sources ? sources + i : nullptr));
             return f2f_batch_lockstep(ctxs, n, x, T, summaries);
         }
         std::vector<int> gst((size_t)G, VELO_OK);
@@ -2001,7 +2063,7 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
             // run under another group's index builds.  (Helper threads that load a group's contexts in parallel were measured
             // slower, 2.32-2.34 k vs 2.42-2.47 k pairs/s: more host threads contending for the runtime's submission path.)
             for (int i = b; i < e; i++) {
-                const int st = load_job(ctxs[i], targets ? targets + i : nullptr, sources ? sources + i : nullptr);
+                const int st = load_job(ctxs[i], target_of(i), sources ? sources + i : nullptr);
                 if (st != VELO_OK) { gst[(size_t)gi] = st; gerr[(size_t)gi] = g_err; return; }
             }
             gst[(size_t)gi] = f2f_batch_lockstep(ctxs + b, e - b, x + 6 * (size_t)b, T ? T + 16 * (size_t)b : nullptr, summaries ? summaries + b : nullptr);
@@ -2019,7 +2081,7 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
     th.reserve((size_t)n);
     for (int i = 0; i < n; i++) {
         th.emplace_back([&, i]() {
-            status[i] = load_job(ctxs[i], targets ? targets + i : nullptr, sources ? sources + i : nullptr);
+            status[i] = load_job(ctxs[i], target_of(i), sources ? sources + i : nullptr);
             if (status[i] == VELO_OK) status[i] = velo_frame_to_frame(ctxs[i], x + 6 * (size_t)i, T ? T + 16 * (size_t)i : nullptr, summaries ? summaries + i : nullptr);
             if (status[i] != VELO_OK) errs[i] = g_err;
         });
@@ -2276,8 +2338,8 @@ int velo_project_lidar(velo_ctx* c, int32_t of_target, const float cam_t[3], con
     if (!c || !cam_t || !bounds) return fail(VELO_ERR_INVALID, "null argument");
     if (of_target ? !c->have_target : !c->have_source) return fail(VELO_ERR_STATE, "no %s cloud loaded", of_target ? "target" : "source");
     HIP_TRY(hipSetDevice(c->device));
-    const int n = of_target ? c->n_tgt : c->n_src;
-    const std::vector<int>& h_off = of_target ? c->h_tgt_off : c->h_src_off;
+    const int n = of_target ? c->T->n_tgt : c->n_src;
+    const std::vector<int>& h_off = of_target ? c->T->h_tgt_off : c->h_src_off;
     const int nr = (int)h_off.size() - 1;
     c->have_projection = false;
     c->h_proj_off = h_off;
@@ -2292,7 +2354,7 @@ int velo_project_lidar(velo_ctx* c, int32_t of_target, const float cam_t[3], con
         CamWindow W;
         W.tx = cam_t[0]; W.ty = cam_t[1]; W.tz = cam_t[2];
         W.min_x = bounds[0]; W.max_x = bounds[1]; W.min_y = bounds[2]; W.max_y = bounds[3];
-        hipLaunchKernelGGL(project_ring_kernel, dim3(nr), dim3(256), 0, c->stream, (const float4*)(of_target ? c->tgt.p : c->src.p),
+        hipLaunchKernelGGL(project_ring_kernel, dim3(nr), dim3(256), 0, c->stream, (const float4*)(of_target ? c->T->tgt.p : c->src.p),
                            (const int*)c->proj_off.p, nr, W, c->pstack.p, c->vstack.p, c->ring_cnt.p);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(c->h_ring_cnt.data(), c->ring_cnt.p, sizeof(int) * (size_t)nr, hipMemcpyDeviceToHost, c->stream));
