@@ -303,6 +303,13 @@ int velo_solve(velo_ctx* ctx, double x[6], velo_solve_summary* summary);
 /* frameToFrame (velo.h:598-919): f2f_iterations x [visual blocks; icp_iterations x (associate; solve)].
  * x: in = initial guess, out = solution.  T: 4x4 row-major of the solution (util::pose_mat2vec, utility.h:67-82). */
 int velo_frame_to_frame(velo_ctx* ctx, double x[6], double T[16], velo_summary* summary);
+/* How the calls above ran.  A single-GPU, LiDAR-only call is enqueued as ONE chain of launches with one host synchronisation at its
+ * end: the pose of round r+1's association and every solve's summary stay on the device, and the number of LM launches per solve is
+ * the previous call's count plus a margin.  A solve that needs more is detected on the device (the next association finds its pose
+ * record not ready); the call is then repeated with a host round trip per solve -- same kernels, bit-identical results.
+ * calls = calls that went down the chain, misses = calls that had to be repeated.  VELO_CHAIN=0 (read by velo_create) switches the
+ * chain off, VELO_CHAIN_MARGIN=n sets the margin (default 2). */
+int velo_chain_stats(const velo_ctx* ctx, int32_t* calls, int32_t* misses);
 /* Several independent scan pairs in flight, one context each (what run.fish:2 does with one process per sequence): equivalent
  * to n velo_frame_to_frame calls, results bit-identical.  Contexts on one device are advanced in lock-step groups (one sweep /
  * LM-step launch serves a whole group), otherwise one host thread per context.  Every context may appear once (VELO_ERR_INVALID

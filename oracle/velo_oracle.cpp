@@ -69,13 +69,45 @@ template <int N> inline bool operator>(const Jet<N>& f, const Jet<N>& g) { retur
 template <int N> inline Jet<N> sqrt(const Jet<N>& f) {
     Jet<N> h; h.a = std::sqrt(f.a); const double d = 1.0 / (2.0 * h.a);
     for (int i = 0; i < N; i++) h.v[i] = f.v[i] * d; return h; }
-template <int N> inline Jet<N> sin(const Jet<N>& f) {
-    Jet<N> h; h.a = std::sin(f.a); const double c = std::cos(f.a);
+// sin / cos [3P libm, unpinned by the reference: ceres::AngleAxisRotatePoint calls sin() and cos() of whatever libm is linked].  The
+// float coordinates of the transformed queries (utility.h:97-103) depend on the last bit of these two values, so the restatement
+// PINS them: the fdlibm kernels (__kernel_sin / __kernel_cos polynomials, Cody-Waite reduction by pi/2 in three parts) in plain IEEE
+// double operations, fixed order, no FMA (-ffp-contract=off).  The HIP library carries the same definition (velo_device_math.h),
+// which lets it compute a round's pose scalars on the device and still produce bit-identical tables.  ~1 ulp for |x| < 1e5.
+inline void pinned_sincos(double x, double* s, double* c) {
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00, pio2_2 = 6.07710050630396597660e-11,
+                 pio2_3 = 2.02226624871116645580e-21;
+    if (!(x == x) || x - x != 0.0) { *s = x - x; *c = x - x; return; }
+    double r = x;
+    long long n = 0;
+    if (x > 0.78539816339744830962 || x < -0.78539816339744830962) {
+        const double fn = std::floor(x * invpio2 + 0.5);
+        n = (long long)fn;
+        r = ((x - fn * pio2_1) - fn * pio2_2) - fn * pio2_3;
+    }
+    const double z = r * r;
+    const double ks = r + (z * r) * (S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)))));
+    const double kc = 1.0 - (0.5 * z - z * (z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))))));
+    switch ((int)(n & 3)) {
+        case 0: *s = ks; *c = kc; break;
+        case 1: *s = kc; *c = -ks; break;
+        case 2: *s = -ks; *c = -kc; break;
+        default: *s = -kc; *c = ks; break;
+    }
+}
+inline double psin(double x) { double s, c; pinned_sincos(x, &s, &c); return s; }
+inline double pcos(double x) { double s, c; pinned_sincos(x, &s, &c); return c; }
+template <int N> inline Jet<N> psin(const Jet<N>& f) {
+    Jet<N> h; double sv, c; pinned_sincos(f.a, &sv, &c); h.a = sv;
     for (int i = 0; i < N; i++) h.v[i] = c * f.v[i]; return h; }
-template <int N> inline Jet<N> cos(const Jet<N>& f) {
-    Jet<N> h; h.a = std::cos(f.a); const double s = -std::sin(f.a);
+template <int N> inline Jet<N> pcos(const Jet<N>& f) {
+    Jet<N> h; double sv, cv; pinned_sincos(f.a, &sv, &cv); h.a = cv; const double s = -sv;
     for (int i = 0; i < N; i++) h.v[i] = s * f.v[i]; return h; }
-using std::sqrt; using std::sin; using std::cos;
+using std::sqrt;
 
 // ------------------------------------------------------------------------------------------------
 // ceres::AngleAxisRotatePoint [3P rotation.h]: Rodrigues when theta^2 > DBL_EPSILON,
@@ -86,8 +118,8 @@ inline void angle_axis_rotate_point(const T w[3], const T p[3], T out[3]) {
     const T theta2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
     if (theta2 > T(std::numeric_limits<double>::epsilon())) {
         const T theta = sqrt(theta2);
-        const T c = cos(theta);
-        const T s = sin(theta);
+        const T c = pcos(theta);
+        const T s = psin(theta);
         const T ti = T(1.0) / theta;
         const T u[3] = {w[0] * ti, w[1] * ti, w[2] * ti};
         const T uxp[3] = {u[1] * p[2] - u[2] * p[1], u[2] * p[0] - u[0] * p[2], u[0] * p[1] - u[1] * p[0]};

@@ -447,3 +447,69 @@ def test_shared_target_equals_own_copy_and_outlives_its_owner(hip_lib, oracle):
     assert H.pose_close(xs1[1], xo, 1e-9, 1e-10)
     for c in ctxs + [own_copy, borrower]:
         c.close()
+
+
+def _summary_tuple(s):
+    return [(s.solves[k].termination, s.solves[k].lm_iterations, s.solves[k].evaluations, s.solves[k].n_icp_valid,
+             s.solves[k].initial_cost, s.solves[k].final_cost) for k in range(s.n_solves)]
+
+
+def test_chain_mode_is_bit_identical_and_survives_mispredictions(hip_lib, oracle, monkeypatch):
+    """A LiDAR-only call is ONE chain of launches (pose scalars of the next round and the solve summaries stay on the device,
+    velo_chain_stats).  Its results must equal the host-driven path's bit for bit -- pose, every solve's costs and counts -- also
+    when the launch prediction is too short (margin 0, first call: the call is repeated host-driven) and for a pair the context
+    has not seen before (different evaluation counts than predicted)."""
+    a = synth.scan_pair(n_beams=32, n_azimuth=400, scene_seed=3)
+    b = synth.scan_pair(n_beams=32, n_azimuth=400, scene_seed=4, sigma=0.05)
+    b["x0"] = np.array([0.01, -0.02, 0.0, 0.3, 0.0, 0.4])        # a poor guess: other evaluation counts than the previous call's
+    res = {}
+    for name, env in (("host", {"VELO_CHAIN": "0"}), ("chain", {"VELO_CHAIN": "1"}), ("tight", {"VELO_CHAIN": "1", "VELO_CHAIN_MARGIN": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        c = api.Context(0, icp_skip=1)
+        monkeypatch.delenv("VELO_CHAIN_MARGIN", raising=False)
+        out = []
+        for d in (a, a, b, a):
+            c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])
+            x, T, s = c.frame_to_frame(d["x0"])
+            out.append((x.copy(), T.copy(), _summary_tuple(s), s.n_assoc_rounds, s.assoc_kernel_launches, s.eval_kernel_launches, s.algorithmic_bytes))
+        res[name] = (out, c.chain_stats())
+        c.close()
+    assert res["host"][1] == (0, 0)
+    assert res["chain"][1][0] == 4 and res["tight"][1][0] == 4
+    assert res["tight"][1][1] >= 1                              # margin 0: at least one call outran its prediction and was repeated
+    for name in ("chain", "tight"):
+        for (x0, T0, s0, *r0), (x1, T1, s1, *r1) in zip(res["host"][0], res[name][0]):
+            assert np.array_equal(x0, x1) and np.array_equal(T0, T1) and s0 == s1 and r0 == r1
+    # and the pose is the oracle's
+    orc = oracle.Oracle(threads=8, icp_skip=1)
+    orc.set_target(a["tgt_xyz"], a["tgt_off"]); orc.set_source(a["src_xyz"], a["src_off"])
+    xo = orc.frame_to_frame(a["x0"])[0]
+    assert np.abs(res["chain"][0][0][0] - xo).max() <= 1e-9
+
+
+def test_chain_mode_lockstep_batch_is_bit_identical(hip_lib, monkeypatch):
+    pairs = [synth.scan_pair(n_beams=32, n_azimuth=400, scene_seed=10 + k, sigma=0.02 * (k + 1)) for k in range(3)]
+    pairs[2]["x0"] = np.array([0.01, -0.02, 0.0, 0.3, 0.0, 0.4])
+    res = {}
+    for name, env in (("host", {"VELO_CHAIN": "0"}), ("chain", {"VELO_CHAIN": "1"}), ("tight", {"VELO_CHAIN": "1", "VELO_CHAIN_MARGIN": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctxs = [api.Context(0, icp_skip=1) for _ in pairs]
+        monkeypatch.delenv("VELO_CHAIN_MARGIN", raising=False)
+        out = []
+        for rep in range(3):
+            order = pairs if rep != 1 else pairs[::-1]           # the second call gives every context another pair than predicted
+            for c, d in zip(ctxs, order):
+                c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])
+            x, T, S = api.frame_to_frame_batch(ctxs, [d["x0"] for d in order])
+            out.append((x.copy(), T.copy(), [_summary_tuple(s) for s in S], [(s.n_assoc_rounds, s.eval_kernel_launches, s.algorithmic_bytes) for s in S]))
+        res[name] = (out, [c.chain_stats() for c in ctxs])
+        for c in ctxs:
+            c.close()
+    assert all(st == (0, 0) for st in res["host"][1])
+    assert all(st[0] == 3 for st in res["chain"][1])
+    assert any(st[1] >= 1 for st in res["tight"][1])
+    for name in ("chain", "tight"):
+        for (x0, T0, s0, r0), (x1, T1, s1, r1) in zip(res["host"][0], res[name][0]):
+            assert np.array_equal(x0, x1) and np.array_equal(T0, T1) and s0 == s1 and r0 == r1

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Dev tool: what the chip does during the timed region of the default bench, from a rocprofv3 kernel trace
+(gpurun_out/<tag>/trace): wall time covered by association kernels / by any kernel / by nothing, how many kernels overlap, and the
+kernel-time sums by kernel -- the numbers behind DESIGN.md's step budget.  Usage: python tools/trace_timeline.py <tag>"""
+import collections, csv, glob, os, sys
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+f = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag, "trace", "*", "*kernel_trace.csv")), key=os.path.getmtime, reverse=True)
+rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", ""), r.get("Queue_Id", "")) for r in csv.DictReader(open(f[0]))]
+rows.sort()
+# the timed region = the densest stretch: take the launches of the batched association kernel and drop warm-up (first 3/13) and the tail
+ab = [r for r in rows if "assoc_search_v5_batch" in r[2]]
+if not ab:
+    sys.exit("no batched association launches in the trace")
+n = len(ab)
+t0, t1 = ab[int(n * 3 / 13)][0], ab[-1][1]
+sel = [r for r in rows if r[0] >= t0 and r[1] <= t1]
+
+
+def union(iv):
+    iv = sorted(iv)
+    tot, cur_s, cur_e = 0, None, None
+    for s, e in iv:
+        if cur_e is None or s > cur_e:
+            if cur_e is not None:
+                tot += cur_e - cur_s
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    if cur_e is not None:
+        tot += cur_e - cur_s
+    return tot
+
+
+wall = t1 - t0
+any_busy = union([(s, e) for s, e, _, _ in sel])
+assoc_busy = union([(s, e) for s, e, k, _ in sel if "assoc_search" in k])
+lm_busy = union([(s, e) for s, e, k, _ in sel if k.startswith("velo::eval_") or k.startswith("velo::lm_")])
+ksum = collections.defaultdict(lambda: [0, 0])
+for s, e, k, _ in sel:
+    ksum[k][0] += e - s
+    ksum[k][1] += 1
+print(f"timed stretch {wall / 1e6:.2f} ms: some kernel running {100 * any_busy / wall:.1f} %, an association kernel running {100 * assoc_busy / wall:.1f} %, "
+      f"an LM kernel running {100 * lm_busy / wall:.1f} %, nothing running {100 * (wall - any_busy) / wall:.1f} %")
+print(f"sum of kernel durations / wall = {sum(v[0] for v in ksum.values()) / wall:.2f} kernels in flight on average")
+for k, (d, c) in sorted(ksum.items(), key=lambda kv: -kv[1][0])[:14]:
+    print(f"  {k[:64]:64s} {c:6d} launches  {d / 1e6:8.2f} ms  avg {d / c / 1e3:7.1f} us  ({100 * d / wall:5.1f} % of wall)")
+q = collections.defaultdict(list)
+for s, e, k, qid in sel:
+    q[qid].append((s, e))
+print("per hardware queue: busy share of the stretch: " + ", ".join(f"q{qid}: {100 * union(v) / wall:.0f} %" for qid, v in sorted(q.items())))

@@ -189,6 +189,7 @@ SIGNATURES = {
     "velo_comm_peer_export": (C.c_int, [_ctx, C.c_char_p]),
     "velo_comm_peer_attach": (C.c_int, [_ctx, C.c_char_p, C.c_int32, C.c_int32]),
     "velo_comm_info": (C.c_int, [_ctx, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
+    "velo_chain_stats": (C.c_int, [_ctx, _P(C.c_int32), _P(C.c_int32)]),
     "velo_comm_peer_export_records": (C.c_int, [_ctx, C.c_int32, C.c_char_p]),
     "velo_comm_peer_attach_records": (C.c_int, [_ctx, C.c_char_p, C.c_int32]),
     "velo_comm_set_target_sharded": (C.c_int, [_ctx, C.c_int]),
@@ -555,6 +556,12 @@ class Context:
     def comm_peer_attach_records(self, handles, max_queries: int):
         blob = b"".join(bytes(h) for h in handles)
         self._check(self._lib.velo_comm_peer_attach_records(self._h, C.create_string_buffer(blob, len(blob)), int(max_queries)))
+
+    def chain_stats(self):
+        """(calls, misses) of the one-chain-per-call mode (velo_chain_stats): misses were repeated host-driven, same results."""
+        a, b = C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.velo_chain_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def comm_info(self):
         """(kind, rank, world): kind 0 = none, 1 = RCCL (world read back from the communicator), 2 = peer slabs."""

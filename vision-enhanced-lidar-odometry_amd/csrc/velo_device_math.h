@@ -13,6 +13,40 @@
 
 namespace velo {
 
+// ---- sin / cos of the rotation angle, PINNED -------------------------------------------------------------------------------------
+// The reference takes sin and cos of theta = |omega| from whatever libm it is linked against ([3P], unpinned: ceres::AngleAxisRotatePoint
+// calls sin() / cos()), and the float coordinates of the transformed queries (utility.h:97-103) depend on their last
+// bit.  To let the DEVICE compute the pose scalars of an association round -- so that a whole frame_to_frame runs without a
+// host round trip per round -- while the tables stay bit-identical to the CPU restatement, both sides use THIS function: the
+// fdlibm kernels (__kernel_sin / __kernel_cos polynomials, Cody-Waite reduction by pi/2 in three parts), written with plain IEEE
+// double operations in a fixed order (no FMA: the file is built with -ffp-contract=off, the oracle too), so host, device and
+// oracle produce the same bits.  Accuracy ~1 ulp for |x| < 1e5 -- the accuracy class of the libm calls it replaces.
+__host__ __device__ inline void velo_sincos(double x, double* s, double* c) {
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00, pio2_2 = 6.07710050630396597660e-11,
+                 pio2_3 = 2.02226624871116645580e-21;
+    if (!(x == x) || x - x != 0.0) { *s = x - x; *c = x - x; return; }     // NaN / infinity -> NaN
+    double r = x;
+    long long n = 0;
+    if (x > 0.78539816339744830962 || x < -0.78539816339744830962) {
+        const double fn = floor(x * invpio2 + 0.5);
+        n = (long long)fn;
+        r = ((x - fn * pio2_1) - fn * pio2_2) - fn * pio2_3;
+    }
+    const double z = r * r;
+    const double ks = r + (z * r) * (S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)))));
+    const double kc = 1.0 - (0.5 * z - z * (z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))))));
+    switch ((int)(n & 3)) {
+        case 0: *s = ks; *c = kc; break;
+        case 1: *s = kc; *c = -ks; break;
+        case 2: *s = -ks; *c = -kc; break;
+        default: *s = -kc; *c = ks; break;
+    }
+}
+
 template <int N>
 struct Dual {
     double a;
@@ -97,7 +131,7 @@ __device__ __forceinline__ void pose_rot_init(const double w[3], PoseRot* R) {
     if (!R->small) {
         const D3 theta = dsqrt(theta2);
         double sv, cv;
-        sincos(theta.a, &sv, &cv);                       // one argument reduction for both
+        velo_sincos(theta.a, &sv, &cv);
         R->s.a = sv; R->c.a = cv;
 #pragma unroll
         for (int i = 0; i < 3; i++) { R->s.v[i] = cv * theta.v[i]; R->c.v[i] = -sv * theta.v[i]; }

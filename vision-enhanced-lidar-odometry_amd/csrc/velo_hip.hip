@@ -174,6 +174,17 @@ struct velo_ctx {
     DevBuf<int2> prev_r;                 // and their rings; reset with every new source / target
     bool prev_ready = false;             // the seed arrays hold n_q initialised entries for the current source and target
     int warm_start = 1;                  // VELO_WARM_START=0 turns the seeds off (A/B; results are identical either way)
+    int assoc_lds_pad = 0;               // VELO_ASSOC_LDS_PAD: bytes of unused dynamic LDS per association workgroup -- caps the association
+                                         // kernel's workgroups per CU so that LM workgroups of other pairs in flight find room at once
+    // chain mode: a whole frame_to_frame as ONE chain of launches (pose scalars of the next round and the solve summaries stay on the device)
+    int chain_calls = 0;                 // calls that went down the chain
+    int chain_margin = 2;                // LM launches enqueued per solve beyond the previous call's count (VELO_CHAIN_MARGIN)
+    int chain_misses = 0;                // calls whose chain was too short and were repeated by the host-driven path
+    int chain = 1;                       // VELO_CHAIN=0: host round trip after every solve (A/B; identical results)
+    DevBuf<PoseRecord> pose_rec;
+    DevBuf<SolveLog> solve_log;
+    DevBuf<int> chain_fail;
+    SolveLog* h_log = nullptr;           // pinned: VELO_MAX_SOLVES logs + the failure flag behind them
     int lm_merged = 1;                   // VELO_LM_MERGED=0: sweep and LM step as two launches per iteration also where one would do (A/B, identical results)
     int small_solve = 1;                 // VELO_SMALL_SOLVE=0: small problems go through the launch-per-iteration path too (A/B, identical results)
     int asker_rows = -1;                 // tube kernel (VELO_ASKER_ROWS): phase 2 goes query by query when the asking queries' boxes have more
@@ -253,6 +264,9 @@ struct velo_ctx {
 
     // lock-step batch driver (velo_frame_to_frame_batch): scratch owned by the FIRST context of a batch
     DevBuf<LMBatchItem> batch_items;
+    DevBuf<PoseRecord> batch_pose;       // chain mode of the lock-step driver: per-context records, logs, failure flags
+    DevBuf<SolveLog> batch_logs;
+    DevBuf<int> batch_fail;
     DevBuf<LMState> batch_states;
     DevBuf<double> batch_x;
     void* h_batch = nullptr;             // pinned: items, x, states
@@ -473,7 +487,7 @@ void pose_scalars(const double x[6], PoseScalars* S) {
     const double theta2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
     if (theta2 > std::numeric_limits<double>::epsilon()) {
         const double theta = std::sqrt(theta2);
-        S->c = std::cos(theta); S->s = std::sin(theta);
+        velo_sincos(theta, &S->s, &S->c);              // the pinned sin / cos (velo_device_math.h): same bits on host, device and in the oracle
         const double ti = 1.0 / theta;
         S->u[0] = x[0] * ti; S->u[1] = x[1] * ti; S->u[2] = x[2] * ti;
         S->omc = 1.0 - S->c;
@@ -554,7 +568,7 @@ int attach_seeds(velo_ctx* c, AssocOut* out) {
     return VELO_OK;
 }
 
-int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool wait, int* n_valid, bool partial = false) {
+int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool wait, int* n_valid, bool partial = false, const PoseRecord* P_dev = nullptr) {
     if (!c->have_target || !c->have_source) return fail(VELO_ERR_STATE, "associate needs set_target and set_source first");
     if (iter < 1) return fail(VELO_ERR_INVALID, "iter must be >= 1");
     if (c->src_skip != std::max(c->P.icp_skip, 1) || (c->n_q > 0) != (c->P.enable_icp != 0 && c->h_q_off[c->n_src_rings] > 0)) VELO_TRY(build_query_list(c));
@@ -653,8 +667,8 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 const int* perm = nullptr;
                 if (c->tube_map >= 0) { VELO_TRY(build_group_perm(c, qb, qe, c->tube_map)); perm = c->group_perm.p; }
 #define VELO_LAUNCH_V5(NW, MINW, DBG, PPT, ASKER)                                                                                         \
-                hipExtLaunchKernelGGL((assoc_search_v5_kernel<NW, MINW, DBG, PPT, ASKER>), dim3(groups), dim3(NW * 64), 0, c->stream,                    \
-                                      ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, S, V, c->qpts, qb, qe,                      \
+                hipExtLaunchKernelGGL((assoc_search_v5_kernel<NW, MINW, DBG, PPT, ASKER>), dim3(groups), dim3(NW * 64), c->assoc_lds_pad, c->stream,                    \
+                                      ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, S, P_dev, P_dev ? c->chain_fail.p : (int*)nullptr, V, c->qpts, qb, qe,                      \
                                    (const float4*)c->T->tgt_pad.p, (const int*)c->T->tgt_off.p, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux, perm, c->debug_skip, asker_rows)
                 // default: 5 waves/SIMD (96 VGPRs, no spills, no scratch traffic), 2 candidate pairs per trip.  Measured on C2:
                 // 62 us; 6 waves + 2 pairs (5 spilled VGPRs) 65; 7 waves + 2 pairs 64; 5 waves + 4 pairs 66; 6 waves + 4 pairs 71
@@ -856,7 +870,7 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
                 EvalArgs Ak = A;
                 Ak.trace_eval = k;
                 hipLaunchKernelGGL(lm_iter_kernel, dim3(E.nb_icp), dim3(kEvalThreads), 0, c->stream, Ak, Q, (const LMState*)(c->state.p + (k & 1)), c->state.p + ((k + 1) & 1),
-                                   (const double*)(c->partials.p + (size_t)(k & 1) * half), E.nb_icp, c->partials.p + (size_t)((k + 1) & 1) * half, k == 0 ? 1 : 0, xd, nvp);
+                                   (const double*)(c->partials.p + (size_t)(k & 1) * half), E.nb_icp, c->partials.p + (size_t)((k + 1) & 1) * half, k == 0 ? 1 : 0, xd, nvp, (PoseRecord*)nullptr, (SolveLog*)nullptr);
             }
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipMemcpyAsync(&c->h_status->s, c->state.p + (k & 1), sizeof(LMState), hipMemcpyDeviceToHost, c->stream));
@@ -1021,6 +1035,9 @@ int velo_create(velo_ctx** out, int device) {
         if (const char* e = getenv("VELO_WARM_START")) c->warm_start = atoi(e);
         if (const char* e = getenv("VELO_SMALL_SOLVE")) c->small_solve = atoi(e);
         if (const char* e = getenv("VELO_LM_MERGED")) c->lm_merged = atoi(e);
+        if (const char* e = getenv("VELO_CHAIN")) c->chain = atoi(e);
+        if (const char* e = getenv("VELO_CHAIN_MARGIN")) c->chain_margin = std::max(atoi(e), 0);
+        if (const char* e = getenv("VELO_ASSOC_LDS_PAD")) c->assoc_lds_pad = std::max(atoi(e), 0);
         if (const char* e = getenv("VELO_ASKER_ROWS")) c->asker_rows = atoi(e);
         if (const char* e = getenv("VELO_PERSISTENT_WGS")) c->persistent_wgs = std::max(atoi(e), 1);
         if (const char* e = getenv("VELO_BATCH_LOCKSTEP")) c->batch_lockstep = atoi(e);
@@ -1030,6 +1047,10 @@ int velo_create(velo_ctx** out, int device) {
         HIP_TRY(hipHostMalloc((void**)&c->h_int, sizeof(int) * 16, hipHostMallocDefault));
         VELO_TRY(c->state.reserve(2));                       // [1]: the other half of the one-launch iteration's double buffer
         VELO_TRY(c->eval_pt.reserve(1));
+        VELO_TRY(c->pose_rec.reserve(1)); VELO_TRY(c->solve_log.reserve(VELO_MAX_SOLVES)); VELO_TRY(c->chain_fail.reserve(1));
+        HIP_TRY(hipMemsetAsync(c->chain_fail.p, 0, sizeof(int), c->stream));
+        HIP_TRY(hipMemsetAsync(c->pose_rec.p, 0, sizeof(PoseRecord), c->stream));
+        HIP_TRY(hipHostMalloc((void**)&c->h_log, sizeof(SolveLog) * VELO_MAX_SOLVES + 64, hipHostMallocDefault));
         VELO_TRY(c->partials.reserve((size_t)2 * (kMaxEvalBlocks + kMaxVisBlocks) * kNumAcc));   // two halves, same reason
         VELO_TRY(c->reduced.reserve(2 * kNumAcc));
         VELO_TRY(c->xdev.reserve(8));
@@ -1090,6 +1111,8 @@ int velo_destroy(velo_ctx* c) {
     c->row_off_vis.release(); c->row_off_icp.release(); c->rows_r.release(); c->rows_J.release();
     if (c->h_batch) (void)hipHostFree(c->h_batch);
     c->batch_items.release(); c->batch_states.release(); c->batch_x.release();
+    c->batch_pose.release(); c->batch_logs.release(); c->batch_fail.release(); c->pose_rec.release(); c->solve_log.release(); c->chain_fail.release();
+    if (c->h_log) (void)hipHostFree(c->h_log);
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->h_x) (void)hipHostFree(c->h_x);
     if (c->h_int) (void)hipHostFree(c->h_int);
@@ -1718,6 +1741,111 @@ int velo_solve(velo_ctx* c, double x[6], velo_solve_summary* summary) {
     return VELO_OK;
 }
 
+}  // extern "C"
+
+// ---- chain mode ---------------------------------------------------------------------------------------------------------------------
+// The whole call as ONE chain of launches with ONE host synchronisation at its end.  What the host needed between rounds -- the pose
+// scalars of the next association, the solve summary -- stays on the device: the LM launch that finishes a solve writes a
+// PoseRecord (pose_scalars_compute: the pinned sin/cos, bit-identical to the host's) and a SolveLog; the next round's tube kernel
+// reads the record.  The host cannot see when a solve ends, so it enqueues as many LM launches per solve as the same solve of the
+// previous call needed plus a margin (launches behind the end of a solve copy the state through, ~3 us each); a solve that needs
+// more raises the chain's failure flag in the next association (its record is not ready), everything behind it drains, and the
+// call is repeated by the host-driven path below -- same kernels, same arithmetic, so the result does not depend on which path ran.
+static bool chain_eligible(velo_ctx* c) {
+    if (!c->chain || c->comm || c->peer_on || c->use_graphs || !c->lm_merged || c->n_matches > 0 || !c->P.enable_icp) return false;
+    if (c->assoc_variant >= 0 && c->assoc_variant != 5) return false;
+    if (c->debug_skip || c->lm_trace_on || c->tube_map >= 0 || c->shard_world != 1) return false;
+    if (c->P.f2f_iterations * c->P.icp_iterations < 1) return false;
+    return true;
+}
+
+static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool* completed) {
+    *completed = false;
+    if (c->src_skip != std::max(c->P.icp_skip, 1) || (c->n_q > 0) != (c->P.enable_icp != 0 && c->h_q_off[c->n_src_rings] > 0)) VELO_TRY(build_query_list(c));
+    int qb, qe;
+    q_range(c, &qb, &qe);
+    if (qe <= qb) return VELO_OK;
+    {   // problems of a few workgroups run their whole solve in one launch (lm_solve_small_kernel): not a chain problem
+        EvalArgs A0;
+        std::memset(&A0, 0, sizeof(A0));
+        A0.q_begin = qb; A0.q_end = qe;
+        const EvalPlan E0 = eval_plan(A0);
+        if (E0.nb_icp <= 0 || (c->small_solve && E0.total() <= kSmallRows)) return VELO_OK;
+    }
+    const LMParams Q = lm_params(c->P);
+    const int margin = c->chain_margin;
+    const size_t half = (size_t)(kMaxEvalBlocks + kMaxVisBlocks) * kNumAcc;
+    const int max_launches = c->P.max_num_iterations + 2;
+    std::memcpy(c->h_x, xc, sizeof(double) * 6);
+    HIP_TRY(hipMemcpyAsync(c->xdev.p, c->h_x, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
+    VELO_TRY(do_build_visual(c, xc, false, 1, nullptr));             // no measurements: only clears the host flags
+    c->have_corr = false;
+    c->chain_calls++;
+    int j = 0, r = 0;                                                // launch counter (its parity selects the double-buffer halves), round
+    const int rounds = c->P.f2f_iterations * c->P.icp_iterations;
+    for (int iter = 1; iter <= c->P.f2f_iterations; iter++) {
+        for (int icp_iter = 0; icp_iter < c->P.icp_iterations; icp_iter++, r++) {
+            int nv = 0;
+            VELO_TRY(do_associate(c, xc, iter, false, false, &nv, false, r == 0 ? nullptr : c->pose_rec.p));
+            const EvalArgs A = eval_args(c, nullptr);
+            const EvalPlan E = eval_plan(A);
+            if (E.nb_icp <= 0 || E.nb_vis > 0) return fail(VELO_ERR_STATE, "chain mode: unexpected evaluation plan");
+            const int* nvp = c->n_valid.p + c->nv_idx;
+            const int K = std::min(std::max(c->pred_evals[std::min(r, VELO_MAX_SOLVES - 1)], 1) + 1 + margin, max_launches);
+            for (int k = 0; k < K; k++, j++) {
+                hipLaunchKernelGGL(lm_iter_kernel, dim3(E.nb_icp), dim3(kEvalThreads), 0, c->stream, A, Q, (const LMState*)(c->state.p + (j & 1)), c->state.p + ((j + 1) & 1),
+                                   (const double*)(c->partials.p + (size_t)(j & 1) * half), E.nb_icp, c->partials.p + (size_t)((j + 1) & 1) * half, k == 0 ? 1 : 0,
+                                   (const double*)((r == 0 && k == 0) ? c->xdev.p : nullptr), nvp, c->pose_rec.p, c->solve_log.p + std::min(r, VELO_MAX_SOLVES - 1));
+            }
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    // the last solve has no association behind it that would notice an unfinished solve: the final state says so itself
+    int* h_fail = reinterpret_cast<int*>(c->h_log + VELO_MAX_SOLVES);
+    HIP_TRY(hipMemcpyAsync(c->h_log, c->solve_log.p, sizeof(SolveLog) * (size_t)std::min(rounds, VELO_MAX_SOLVES), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(h_fail, c->chain_fail.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&c->h_status->s, c->state.p + (j & 1), sizeof(LMState), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (*h_fail || !c->h_status->s.done) {
+        HIP_TRY(hipMemsetAsync(c->chain_fail.p, 0, sizeof(int), c->stream));
+        for (int k = 0; k < VELO_MAX_SOLVES; k++) c->pred_evals[k] += 2;    // the host-driven repeat below records the real counts
+        c->nv_clean[0] = c->nv_clean[1] = false;                            // drained association launches did not clear the next round's counter
+        c->chain_misses++;
+        return VELO_OK;
+    }
+    const uint64_t nq = (uint64_t)c->n_q;
+    for (int k = 0; k < rounds; k++) {
+        const SolveLog& L = c->h_log[std::min(k, VELO_MAX_SOLVES - 1)];
+        S->n_assoc_rounds++;
+        S->n_queries = c->n_q;
+        const uint64_t b_assoc = 12ull * nq + 12ull * (uint64_t)c->T->n_tgt + 28ull * nq;
+        S->assoc_bytes += b_assoc; S->algorithmic_bytes += b_assoc;
+        S->assoc_kernel_launches++;
+        velo_solve_summary ss;
+        std::memset(&ss, 0, sizeof(ss));
+        ss.termination = L.termination; ss.lm_iterations = L.iter; ss.evaluations = L.evals; ss.n_icp_valid = L.n_valid;
+        ss.initial_cost = L.initial_cost; ss.final_cost = L.final_cost;
+        if (k < VELO_MAX_SOLVES) c->pred_evals[k] = L.evals;
+        S->eval_kernel_launches += L.evals;
+        S->algorithmic_bytes += (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 224ull);
+        if (S->n_solves < VELO_MAX_SOLVES) S->solves[S->n_solves] = ss;
+        S->n_solves++;
+    }
+    c->last_n_valid = c->h_status->s.n_valid;
+    for (int k = 0; k < 6; k++) xc[k] = c->h_status->s.x[k];
+    *completed = true;
+    return VELO_OK;
+}
+
+extern "C" {
+
+int velo_chain_stats(const velo_ctx* c, int32_t* calls, int32_t* misses) {
+    if (!c) return fail(VELO_ERR_INVALID, "null ctx");
+    if (calls) *calls = c->chain_calls;
+    if (misses) *misses = c->chain_misses;
+    return VELO_OK;
+}
+
 int velo_frame_to_frame(velo_ctx* c, double x[6], double T[16], velo_summary* summary) {
     if (!c || !x) return fail(VELO_ERR_INVALID, "null argument");
     if (!c->have_target || !c->have_source) return fail(VELO_ERR_STATE, "frame_to_frame needs set_target and set_source first");
@@ -1729,6 +1857,20 @@ int velo_frame_to_frame(velo_ctx* c, double x[6], double T[16], velo_summary* su
     c->assoc_events_used = 0;
     double xc[6];
     for (int k = 0; k < 6; k++) xc[k] = x[k];
+    if (chain_eligible(c)) {
+        bool completed = false;
+        VELO_TRY(frame_to_frame_chain(c, xc, S, &completed));
+        if (completed) {
+            if (c->timing) VELO_TRY(read_assoc_timing(c, S));
+            for (int k = 0; k < 6; k++) x[k] = xc[k];
+            if (T) velo_pose_vec_to_mat(x, T);
+            return VELO_OK;
+        }
+        std::memset(S, 0, sizeof(*S));
+        S->n_target = c->T->n_tgt;
+        c->assoc_events_used = 0;
+        for (int k = 0; k < 6; k++) xc[k] = x[k];
+    }
     for (int iter = 1; iter <= c->P.f2f_iterations; iter++) {                       // velo.h:616
         VELO_TRY(do_build_visual(c, xc, false, iter, nullptr));                      // velo.h:622-792
         c->have_corr = false;
@@ -1795,6 +1937,7 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
     *groups = 0;
     if (qe <= qb) return VELO_OK;
     pose_scalars(x, &A->P);
+    A->P_dev = nullptr; A->chain_fail = nullptr;
     A->G.d = G->d; A->G.cell_start = G->cell_start.p; A->G.sorted = G->sorted.p; A->G.sring = G->sring.p;
     A->qpts = c->qpts; A->q_begin = qb; A->q_end = qe;
     A->tgt_pad = c->T->tgt_pad.p; A->tgt_off = c->T->tgt_off.p;
@@ -1826,13 +1969,16 @@ static bool assoc_batchable(const velo_ctx* c) {
 
 // All contexts share one stream here (the lock-step driver swapped it in).  launched[i] = 1 for the context that carries the timing
 // events of its launch, 0 for the others of the same launch.
-static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::array<double, 6>>& xs, int iter, std::vector<int>& launched) {
+static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::array<double, 6>>& xs, int iter, std::vector<int>& launched,
+                              const PoseRecord* pose_dev = nullptr, int* fail_dev = nullptr) {
+    // pose_dev / fail_dev (chain mode): per-context device pose records [n] the kernels read instead of xs, and failure flags [n]
     launched.assign((size_t)n, 0);
     bool all = true;
     for (int i = 0; i < n; i++) all = all && assoc_batchable(ctxs[i]);
     if (!all || n < 2) {
         for (int i = 0; i < n; i++) {
             int nv = 0;
+            if (pose_dev) return fail(VELO_ERR_STATE, "chain mode needs contexts whose rounds share a launch");
             VELO_TRY(do_associate(ctxs[i], xs[(size_t)i].data(), iter, false, false, &nv));
             int qb, qe; q_range(ctxs[i], &qb, &qe);
             launched[(size_t)i] = qe > qb ? 1 : 0;
@@ -1849,6 +1995,7 @@ static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::arr
             int groups = 0; bool asker = false;
             VELO_TRY(prepare_assoc_v5(ctxs[i], xs[(size_t)i].data(), iter, &B.item[k], &groups, &asker));
             ctxs[i]->have_corr = true;
+            if (pose_dev) { B.item[k].P_dev = pose_dev + i; B.item[k].chain_fail = fail_dev + i; }
             if (groups == 0) continue;                                  // no queries: nothing to launch for it
             if (first < 0) first = i;
             gmax = std::max(gmax, groups); any_asker = any_asker || asker; k++;
@@ -1866,9 +2013,9 @@ static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::arr
             ev = &c->assoc_events[c->assoc_events_used++];
         }
         launched[(size_t)first] = 1;
-        if (any_asker) hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, true>), dim3(gmax, k), dim3(256), 0, c->stream,
+        if (any_asker) hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, true>), dim3(gmax, k), dim3(256), c->assoc_lds_pad, c->stream,
                                              ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, B);
-        else hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, false>), dim3(gmax, k), dim3(256), 0, c->stream,
+        else hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, false>), dim3(gmax, k), dim3(256), c->assoc_lds_pad, c->stream,
                                    ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, B);
         HIP_TRY(hipGetLastError());
     }
@@ -1887,7 +2034,9 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
     struct Restore { velo_ctx** c; std::vector<hipStream_t>& s; int n; ~Restore() { for (int i = 0; i < n; i++) c[i]->stream = s[(size_t)i]; } } restore{ctxs, own, n};
     hipStream_t bs = c0->stream;
     // pinned + device scratch
-    const size_t need = (size_t)n * (sizeof(LMBatchItem) + sizeof(LMState) + 8 * sizeof(double));
+    const int rounds = P.f2f_iterations * P.icp_iterations;
+    const size_t n_item_slots = (size_t)n * (size_t)std::max(rounds, 1);                // chain mode: one item array per round
+    const size_t need = n_item_slots * sizeof(LMBatchItem) + (size_t)n * (sizeof(LMState) + 8 * sizeof(double) + sizeof(SolveLog) * VELO_MAX_SOLVES + 8);
     if (c0->h_batch_bytes < need) {
         if (c0->h_batch) (void)hipHostFree(c0->h_batch);
         c0->h_batch = nullptr; c0->h_batch_bytes = 0;
@@ -1895,9 +2044,11 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
         c0->h_batch_bytes = need;
     }
     LMBatchItem* h_items = (LMBatchItem*)c0->h_batch;
-    LMState* h_states = (LMState*)(h_items + n);
+    LMState* h_states = (LMState*)(h_items + n_item_slots);
     double* h_x = (double*)(h_states + n);
-    VELO_TRY(c0->batch_items.reserve((size_t)n)); VELO_TRY(c0->batch_states.reserve((size_t)n)); VELO_TRY(c0->batch_x.reserve((size_t)8 * n));
+    SolveLog* h_logs = (SolveLog*)(h_x + 8 * (size_t)n);
+    int* h_fail = (int*)(h_logs + (size_t)n * VELO_MAX_SOLVES);
+    VELO_TRY(c0->batch_items.reserve(n_item_slots)); VELO_TRY(c0->batch_states.reserve((size_t)n)); VELO_TRY(c0->batch_x.reserve((size_t)8 * n));
 
     std::vector<velo_summary> local((size_t)n);
     std::vector<velo_summary*> S((size_t)n);
@@ -1911,6 +2062,106 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
     }
     const int max_iters = P.max_num_iterations + 1;
     std::vector<int> assoc_launched;
+
+    // ---- chain mode (see frame_to_frame_chain): all rounds of the group as one chain of launches, one synchronisation ---------------
+    bool chain = c0->chain && c0->lm_merged < 2 && rounds >= 1 && rounds <= VELO_MAX_SOLVES;
+    for (int i = 0; i < n && chain; i++) {
+        velo_ctx* c = ctxs[i];
+        chain = assoc_batchable(c) && c->n_matches == 0 && c->P.enable_icp && !c->lm_trace_on;
+        if (chain) {
+            if (c->src_skip != std::max(c->P.icp_skip, 1) || (c->n_q > 0) != (c->P.enable_icp != 0 && c->h_q_off[c->n_src_rings] > 0)) VELO_TRY(build_query_list(c));
+            int qb, qe; q_range(c, &qb, &qe);
+            chain = qe > qb;
+        }
+    }
+    if (chain) {
+        const int margin = c0->chain_margin;
+        const bool fresh = c0->batch_pose.cap < (size_t)n;
+        VELO_TRY(c0->batch_pose.reserve((size_t)n)); VELO_TRY(c0->batch_logs.reserve((size_t)n * VELO_MAX_SOLVES)); VELO_TRY(c0->batch_fail.reserve((size_t)n));
+        if (fresh) { HIP_TRY(hipMemsetAsync(c0->batch_fail.p, 0, sizeof(int) * (size_t)n, bs)); HIP_TRY(hipMemsetAsync(c0->batch_pose.p, 0, sizeof(PoseRecord) * (size_t)n, bs)); }
+        for (int i = 0; i < n; i++) {
+            ctxs[i]->chain_calls++;
+            VELO_TRY(do_build_visual(ctxs[i], xc[(size_t)i].data(), false, 1, nullptr));      // no measurements: clears the host flags
+            ctxs[i]->have_corr = false; ctxs[i]->last_n_valid = 0;
+            for (int k = 0; k < 6; k++) h_x[8 * (size_t)i + k] = xc[(size_t)i][(size_t)k];
+        }
+        HIP_TRY(hipMemcpyAsync(c0->batch_x.p, h_x, sizeof(double) * 8 * (size_t)n, hipMemcpyHostToDevice, bs));
+        int r = 0;
+        for (int iter = 1; iter <= P.f2f_iterations; iter++) {
+            for (int icp_iter = 0; icp_iter < P.icp_iterations; icp_iter++, r++) {
+                VELO_TRY(do_associate_group(ctxs, n, xc, iter, assoc_launched, r == 0 ? nullptr : c0->batch_pose.p, c0->batch_fail.p));
+                LMBatchItem* items_r = h_items + (size_t)r * n;
+                int nb_max = 0, K = 1;
+                for (int i = 0; i < n; i++) {
+                    velo_ctx* c = ctxs[i];
+                    LMBatchItem& it = items_r[i];
+                    it.A = eval_args(c, nullptr);
+                    const EvalPlan E = eval_plan(it.A);
+                    it.S = c->state.p; it.xd = r == 0 ? c0->batch_x.p + 8 * (size_t)i : nullptr;
+                    it.n_valid = c->n_valid.p + c->nv_idx;
+                    it.nb_icp = E.nb_icp; it.nb_vis = 0; it.n_rows = E.nb_icp;
+                    it.A.vis_row0 = E.nb_icp;
+                    it.pose_out = c0->batch_pose.p + i; it.log = c0->batch_logs.p + (size_t)i * VELO_MAX_SOLVES + r;
+                    nb_max = std::max(nb_max, E.nb_icp);
+                    K = std::max(K, std::min(std::max(c->pred_evals[r], 1) + margin, max_iters));
+                    S[(size_t)i]->assoc_kernel_launches += assoc_launched[(size_t)i];
+                }
+                const LMBatchItem* d_items = c0->batch_items.p + (size_t)r * n;
+                HIP_TRY(hipMemcpyAsync(c0->batch_items.p + (size_t)r * n, items_r, sizeof(LMBatchItem) * (size_t)n, hipMemcpyHostToDevice, bs));
+                hipLaunchKernelGGL(lm_begin_batch_kernel, dim3(n), dim3(64), 0, bs, d_items);
+                for (int k = 0; k < K; k++) {
+                    hipLaunchKernelGGL(eval_icp_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, d_items);
+                    hipLaunchKernelGGL(lm_step_batch_kernel, dim3(n), dim3(256), 0, bs, Q, d_items);
+                }
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        hipLaunchKernelGGL(lm_gather_states_kernel, dim3(n), dim3(128), 0, bs, (const LMBatchItem*)c0->batch_items.p, c0->batch_states.p, 0);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h_states, c0->batch_states.p, sizeof(LMState) * (size_t)n, hipMemcpyDeviceToHost, bs));
+        HIP_TRY(hipMemcpyAsync(h_logs, c0->batch_logs.p, sizeof(SolveLog) * (size_t)n * VELO_MAX_SOLVES, hipMemcpyDeviceToHost, bs));
+        HIP_TRY(hipMemcpyAsync(h_fail, c0->batch_fail.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, bs));
+        HIP_TRY(hipStreamSynchronize(bs));
+        bool ok = true;
+        for (int i = 0; i < n; i++) ok = ok && !h_fail[i] && h_states[i].done != 0;
+        if (ok) {
+            for (int i = 0; i < n; i++) {
+                velo_ctx* c = ctxs[i];
+                velo_summary* Si = S[(size_t)i];
+                const uint64_t nq = (uint64_t)c->n_q;
+                for (int k = 0; k < rounds; k++) {
+                    const SolveLog& L = h_logs[(size_t)i * VELO_MAX_SOLVES + k];
+                    Si->n_assoc_rounds++; Si->n_queries = c->n_q;
+                    const uint64_t b_assoc = 12ull * nq + 12ull * (uint64_t)c->T->n_tgt + 28ull * nq;
+                    Si->assoc_bytes += b_assoc; Si->algorithmic_bytes += b_assoc;
+                    velo_solve_summary ss;
+                    std::memset(&ss, 0, sizeof(ss));
+                    ss.termination = L.termination; ss.lm_iterations = L.iter; ss.evaluations = L.evals; ss.n_icp_valid = L.n_valid;
+                    ss.initial_cost = L.initial_cost; ss.final_cost = L.final_cost;
+                    c->pred_evals[k] = L.evals;
+                    Si->eval_kernel_launches += L.evals;
+                    Si->algorithmic_bytes += (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 224ull);
+                    Si->solves[Si->n_solves++] = ss;
+                }
+                c->last_n_valid = h_states[i].n_valid;
+                if (c->timing) VELO_TRY(read_assoc_timing(c, Si));
+                for (int k = 0; k < 6; k++) x[6 * (size_t)i + k] = h_states[i].x[k];
+                if (T) velo_pose_vec_to_mat(x + 6 * (size_t)i, T + 16 * (size_t)i);
+            }
+            return VELO_OK;
+        }
+        // a solve outran its predicted launches: repeat the call with a host round trip per solve (same kernels, same results)
+        HIP_TRY(hipMemsetAsync(c0->batch_fail.p, 0, sizeof(int) * (size_t)n, bs));
+        for (int i = 0; i < n; i++) {
+            velo_ctx* c = ctxs[i];
+            c->chain_misses++;
+            c->nv_clean[0] = c->nv_clean[1] = false;                        // drained association launches did not clear the next round's counter
+            for (int k = 0; k < VELO_MAX_SOLVES; k++) c->pred_evals[k] += 2;
+            std::memset(S[(size_t)i], 0, sizeof(velo_summary));
+            S[(size_t)i]->n_target = c->T->n_tgt;
+            c->assoc_events_used = 0;
+        }
+    }
     for (int iter = 1; iter <= P.f2f_iterations; iter++) {                              // velo.h:616
         for (int i = 0; i < n; i++) {
             VELO_TRY(do_build_visual(ctxs[i], xc[(size_t)i].data(), false, iter, nullptr));   // velo.h:622-792
@@ -2108,7 +2359,8 @@ int velo_pose_vec_to_mat(const double x[6], double T[16]) {
     const double theta2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
     if (theta2 > std::numeric_limits<double>::epsilon()) {
         const double theta = std::sqrt(theta2), wx = x[0] / theta, wy = x[1] / theta, wz = x[2] / theta;
-        const double c = std::cos(theta), s = std::sin(theta);
+        double c, s;
+        velo_sincos(theta, &s, &c);
         T[0] = c + wx * wx * (1 - c);       T[4] = wz * s + wx * wy * (1 - c);  T[8] = -wy * s + wx * wz * (1 - c);
         T[1] = wx * wy * (1 - c) - wz * s;  T[5] = c + wy * wy * (1 - c);       T[9] = wx * s + wy * wz * (1 - c);
         T[2] = wy * s + wx * wz * (1 - c);  T[6] = -wx * s + wy * wz * (1 - c); T[10] = c + wz * wz * (1 - c);

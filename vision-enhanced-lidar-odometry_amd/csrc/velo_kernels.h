@@ -54,6 +54,39 @@ struct PoseScalars {
     int small;       // theta^2 <= DBL_EPSILON -> first-order branch
 };
 
+// the same for host and device: with the pinned sin / cos (velo_device_math.h) and correctly rounded sqrt and division the device
+// computes a round's pose scalars with the bits the host (and the oracle) gets, so a frame_to_frame can run as ONE chain of launches
+__host__ __device__ inline void pose_scalars_compute(const double x[6], PoseScalars* S) {
+    for (int k = 0; k < 3; k++) { S->w[k] = x[k]; S->t[k] = x[3 + k]; S->u[k] = 0.0; }
+    S->c = 0.0; S->s = 0.0; S->omc = 0.0;
+    const double theta2 = x[0] * x[0] + x[1] * x[1] + x[2] * x[2];
+    if (theta2 > 2.220446049250313e-16) {
+        const double theta = sqrt(theta2);
+        velo_sincos(theta, &S->s, &S->c);
+        const double ti = 1.0 / theta;
+        S->u[0] = x[0] * ti; S->u[1] = x[1] * ti; S->u[2] = x[2] * ti;
+        S->omc = 1.0 - S->c;
+        S->small = 0;
+    } else {
+        S->small = 1;
+    }
+}
+// Device-driven rounds ("chain mode"): the LM step that finishes a solve leaves the pose scalars of its result here, and the next
+// round's association kernel reads them -- no host round trip between a solve and the next association.  ready = 0 while a solve
+// is running: an association kernel that finds it so was enqueued behind a solve that needed more launches than the host had
+// predicted; it raises the chain's failure flag and everything behind it returns at once (the host then repeats the call).
+struct PoseRecord {
+    PoseScalars P;
+    int ready;
+    int pad;
+};
+// what the host wants to know about a finished solve (velo_solve_summary), left by the step that finished it
+struct SolveLog {
+    double x[6];
+    double initial_cost, final_cost;
+    int termination, iter, evals, n_valid;
+};
+
 __device__ __forceinline__ int cell_coord(float p, float o, float inv_h, int n) {
     float f = (p - o) * inv_h;
     f = fminf(fmaxf(f, -2.0f), (float)(n + 1));
@@ -886,7 +919,7 @@ __device__ __forceinline__ void top2_merge_xor(Top2& t, int mask) {
 //   * rounds after the first are warm-started from the previous round's winners (AssocOut::prev).
 template <int NW, int MINW, bool DBG, int PPT, bool ASKER>
 __device__ __forceinline__ void
-assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __restrict__ qpts, int q_begin, int q_end,
+assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_dev, int* __restrict__ chain_fail, const GridView& G, const float4* __restrict__ qpts, int q_begin, int q_end,
                      const float4* __restrict__ tgt_pad, const int* __restrict__ tgt_off,
                      unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, const AssocOut& out, int want_aux, const int* __restrict__ group_perm, int dbg, int asker_rows,
                      const int block_x) {
@@ -917,6 +950,15 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // The single-wave sections (set-up, cell boxes, finish) are done by wave `lead` of the workgroup, and `lead` rotates with the
+    // workgroup id: wave w of a workgroup sits on SIMD w of its CU, so with wave 0 everywhere the 6-7 resident workgroups of a CU
+    // queue those sections on ONE SIMD while three idle (measured: set-up + finish = 22 % of the VALU instructions but 45 % of
+    // the kernel's time).  Workgroups of one CU are 8 x 32 ids apart (XCD round-robin, then the XCD's CUs), hence the two shifts.
+    const int lead = NW > 1 ? (int)(((unsigned)block_x >> 3) + ((unsigned)block_x >> 8)) % NW : 0;
+    // chain mode: the pose scalars come from the device record of the solve that ran just ahead of this launch
+    if (chain_fail && *chain_fail) return;
+    if (P_dev && !P_dev->ready) { if (block_x == 0 && tid == 0) *chain_fail = 1; return; }
+    const PoseScalars& P = P_dev ? P_dev->P : P_in;
     // diagnostic instantiation only (DBG && dbg & 8): per-section cycle totals of wave 0, added to out.dbg[0..7]
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = (DBG && (dbg & 8)) ? (long long)__builtin_readcyclecounter() : 0;
@@ -936,7 +978,7 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
     {
         unsigned long long* sb = reinterpret_cast<unsigned long long*>(s_zg);   // [2][64] best1 / best2 keys
         int* sr = s_ring;                                                        // [2][64] their rings
-        if (wid == 0) {
+        if (wid == lead) {
             float qx = 0.f, qy = 0.f, qz = 0.f;
             if (active) {
                 // everything the set-up needs is requested at once (coalesced, no load behind another load's result)
@@ -963,7 +1005,7 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
             sb[lane] = t.b1; sb[64 + lane] = t.b2; sr[lane] = t.b1ring; sr[64 + lane] = t.b2ring;
         }
         __syncthreads();
-        if (wid != 0) {
+        if (wid != lead) {
             t.b1 = sb[lane]; t.b2 = sb[64 + lane]; t.b1ring = sr[lane]; t.b2ring = sr[64 + lane];
             t.b2d = __uint_as_float((unsigned)(t.b2 >> 32));
         }
@@ -998,7 +1040,7 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
             // Who asks for cells in this phase, with which box, and the (y, z) extent of all boxes: worked out by wave 0 only and
             // published through LDS (s_box, s_phase) -- the four waves hold identical states here, three of them would only
             // repeat ~250 VALU instructions of cell arithmetic and wave reductions per phase.
-            if (wid == 0) {
+            if (wid == lead) {
                 bool asks0 = member;
                 CellBox bb;
                 int rows_all = 0;
@@ -1295,7 +1337,7 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
         }
         pending = pending && !member;
     }
-    if (NW > 1 && wid != 0) return;
+    if (NW > 1 && wid != lead) return;
     VELO_Q(qx, qy, qz);
     // the query index is recomputed here (opaque to the compiler) instead of living, sign-extended to 64 bits, across the whole search
     int lane_fin = lane;
@@ -1321,10 +1363,10 @@ assoc_search_v5_body(const PoseScalars& P, const GridView& G, const float4* __re
 // one launch = one context's round
 template <int NW, int MINW, bool DBG, int PPT, bool ASKER>
 __global__ void __launch_bounds__(NW * 64, MINW)
-assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ qpts, int q_begin, int q_end,
+assoc_search_v5_kernel(PoseScalars P, const PoseRecord* __restrict__ P_dev, int* __restrict__ chain_fail, GridView G, const float4* __restrict__ qpts, int q_begin, int q_end,
                        const float4* __restrict__ tgt_pad, const int* __restrict__ tgt_off,
                        unsigned gate_bits, double norm_cond, int cluster_w, float h_safe, AssocOut out, int want_aux, const int* __restrict__ group_perm, int dbg, int asker_rows) {
-    assoc_search_v5_body<NW, MINW, DBG, PPT, ASKER>(P, G, qpts, q_begin, q_end, tgt_pad, tgt_off, gate_bits, norm_cond, cluster_w, h_safe, out,
+    assoc_search_v5_body<NW, MINW, DBG, PPT, ASKER>(P, P_dev, chain_fail, G, qpts, q_begin, q_end, tgt_pad, tgt_off, gate_bits, norm_cond, cluster_w, h_safe, out,
                                                     want_aux, group_perm, dbg, asker_rows, (int)blockIdx.x);
 }
 
@@ -1334,7 +1376,7 @@ assoc_search_v5_kernel(PoseScalars P, GridView G, const float4* __restrict__ qpt
 // segment, read with scalar loads.
 constexpr int kAssocBatchMax = 4;
 struct AssocArgs {
-    PoseScalars P; GridView G; const float4* qpts; int q_begin, q_end;
+    PoseScalars P; const PoseRecord* P_dev; int* chain_fail; GridView G; const float4* qpts; int q_begin, q_end;
     const float4* tgt_pad; const int* tgt_off; unsigned gate_bits; double norm_cond; int cluster_w; float h_safe;
     AssocOut out; int want_aux; const int* group_perm; int dbg; int asker_rows;
 };
@@ -1344,7 +1386,7 @@ __global__ void __launch_bounds__(NW * 64, MINW)
 assoc_search_v5_batch_kernel(AssocBatch B) {
     const AssocArgs& a = B.item[blockIdx.y];
     if ((int)blockIdx.x * 64 >= a.q_end - a.q_begin) return;
-    assoc_search_v5_body<NW, MINW, DBG, PPT, ASKER>(a.P, a.G, a.qpts, a.q_begin, a.q_end, a.tgt_pad, a.tgt_off, a.gate_bits, a.norm_cond,
+    assoc_search_v5_body<NW, MINW, DBG, PPT, ASKER>(a.P, a.P_dev, a.chain_fail, a.G, a.qpts, a.q_begin, a.q_end, a.tgt_pad, a.tgt_off, a.gate_bits, a.norm_cond,
                                                     a.cluster_w, a.h_safe, a.out, a.want_aux, a.group_perm, a.dbg, a.asker_rows, (int)blockIdx.x);
 }
 
@@ -1850,10 +1892,10 @@ __device__ __forceinline__ void accumulate_row(double acc[kNumAcc], double r, co
     for (int i = 0; i < 6; i++) acc[21 + i] += J[i] * rk;
 }
 
-// Workgroup reduction of the 28 accumulators, laid out for latency (the LM chain waits for it): one exchange with the lane 32
-// away (28 independent shuffles), the 32 x 4 partial sums of every accumulator through LDS ([accumulator][128], conflict-free
-// 8-byte stores), eight threads per accumulator add 16 values each, one thread per accumulator adds those eight and stores.
-// Two barriers, ~0.4 us; 28 KB of LDS.  Fixed order -> deterministic.
+// Workgroup reduction of the 28 accumulators, laid out for latency (the LM chain waits for it): exchanges with the lanes 32 and 16
+// away (2 x 28 independent shuffles), the 16 x 4 partial sums of every accumulator through LDS ([accumulator][64], conflict-free
+// 8-byte stores), eight threads per accumulator add 8 values each, one thread per accumulator adds those eight and stores.
+// Two barriers; 14 KB of LDS, so that a sweep workgroup fits next to four association workgroups.  Fixed order -> deterministic.
 constexpr int kScratchDoubles = 128 * kNumAcc;                    // 28,672 bytes: the sweep's reduction and the step's chunk of partial rows share it
 #ifndef VELO_REDUCE_LDS
 #define VELO_REDUCE_LDS 1
@@ -1889,16 +1931,18 @@ __device__ __forceinline__ void block_reduce_store(double acc[kNumAcc], double* 
 }
 #else
 __device__ __forceinline__ void block_reduce_store(double acc[kNumAcc], double* __restrict__ dst /* [28] */, double* __restrict__ scratch) {
-    constexpr int kCols = kEvalThreads / 2;                       // 128 partial sums per accumulator
-    static_assert(kNumAcc * kCols <= kScratchDoubles, "scratch size");
+    constexpr int kCols = kEvalThreads / 4;                       // 64 partial sums per accumulator
+    static_assert(kNumAcc * kCols <= kScratchDoubles / 2, "scratch size");
     double (*red)[kCols] = reinterpret_cast<double (*)[kCols]>(scratch);
     __shared__ double red2[kNumAcc][8];
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
 #pragma unroll
     for (int k = 0; k < kNumAcc; k++) acc[k] += __shfl_xor(acc[k], 32);
-    if (lane < 32) {
 #pragma unroll
-        for (int k = 0; k < kNumAcc; k++) red[k][wid * 32 + lane] = acc[k];
+    for (int k = 0; k < kNumAcc; k++) acc[k] += __shfl_xor(acc[k], 16);
+    if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < kNumAcc; k++) red[k][wid * 16 + lane] = acc[k];
     }
     __syncthreads();
     if (t < kNumAcc * 8) {
@@ -2013,7 +2057,7 @@ __device__ __forceinline__ void eval_icp_body(const EvalArgs& A, const int bx, c
     sweep_rows<true>(A, f, s_pt, bx, nbx, acc);
     VELO_LM_TRACE(A.trace, A.trace_eval, 2);
 #if VELO_REDUCE_LDS
-    __shared__ double s_scratch[kScratchDoubles];
+    __shared__ double s_scratch[kScratchDoubles / 2];            // 64 columns x 28: 14 KB (the sweep must fit next to association workgroups)
 #else
     double* s_scratch = nullptr;
 #endif
@@ -2035,6 +2079,8 @@ struct LMBatchItem {
     int nb_icp;            // workgroups of this context's point-to-plane sweep
     int nb_vis;            // workgroups of its visual sweep (A.vis_row0 = nb_icp)
     int n_rows;            // rows of partial sums the LM step reduces
+    PoseRecord* pose_out;  // chain mode (or null): where the step that finishes the solve leaves the next round's pose scalars
+    SolveLog* log;         //   "          and the summary of the solve
 };
 __global__ void __launch_bounds__(kEvalThreads)
 eval_icp_batch_kernel(const LMBatchItem* __restrict__ items) {
@@ -2091,7 +2137,7 @@ __device__ __forceinline__ void eval_visual_body(const EvalArgs& A, const int bx
         }
     }
 #if VELO_REDUCE_LDS
-    __shared__ double s_scratch[kScratchDoubles];
+    __shared__ double s_scratch[kScratchDoubles / 2];
 #else
     double* s_scratch = nullptr;
 #endif
@@ -2348,7 +2394,7 @@ static_assert(kStepChunk * kNumAcc == kScratchDoubles && kStepChunk * kNumAcc % 
 __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __restrict__ Sin, const double* __restrict__ partials, int n_blocks, int first,
                                            const double* __restrict__ x_in, const int* __restrict__ n_valid,
                                            double* __restrict__ s_rows, LMState* sL, LMEvalPoint* s_pt, unsigned long long* trace, int trace_eval,
-                                           const PeerComm* comm = nullptr) {
+                                           const PeerComm* comm = nullptr, PoseRecord* pose_out = nullptr, SolveLog* log = nullptr, bool writer = true) {
     __shared__ double part[8][kNumAcc];
     __shared__ double E[kNumAcc];
     constexpr int kPerThread = kStepChunk * kNumAcc / 256;
@@ -2387,6 +2433,7 @@ __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __r
             if (x_in) for (int i = 0; i < 6; i++) sL->x[i] = xin[i];
             sL->n_valid = nv;
             sL->phase = PHASE_INIT; sL->done = 0; sL->termination = 1; sL->iter = 0; sL->evals = 0; sL->invalid = 0; sL->reuse_diag = 0;
+            if (pose_out && writer) pose_out->ready = 0;     // chain mode: the next round's association must wait for THIS solve
         }
     } else if (!sL->done) {                                  // uniform: a step behind a finished solve changes nothing
         if (t < kNumAcc) { double v = 0.0; for (int p = 0; p < 8; p++) v += part[p][t]; E[t] = v; }
@@ -2397,6 +2444,20 @@ __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __r
             LMState L = *sL;
             lm_transition_local(Q, &L, E);
             *sL = L;
+            if (L.done && writer) {                          // the solve has just finished: what the host and the next round need
+                if (log) {
+                    for (int i = 0; i < 6; i++) log->x[i] = L.x[i];
+                    log->initial_cost = L.initial_cost; log->final_cost = L.cost;
+                    log->termination = L.termination; log->iter = L.iter; log->evals = L.evals; log->n_valid = L.n_valid;
+                }
+                if (pose_out) {
+                    PoseScalars S;
+                    pose_scalars_compute(L.x, &S);
+                    pose_out->P = S;
+                    __threadfence();
+                    pose_out->ready = 1;
+                }
+            }
         }
     }
     __syncthreads();
@@ -2414,13 +2475,14 @@ __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __r
 
 // two launches per iteration (sweep kernels, then this): used behind an all-reduce, with visual blocks, and by the lock-step batch driver
 __device__ __forceinline__ void lm_transition(const LMParams& Q, LMState* Sg, LMEvalPoint* pt, const double* __restrict__ partials, int n_blocks,
-                                              unsigned long long* trace = nullptr, int trace_eval = 0, const PeerComm* comm = nullptr) {
+                                              unsigned long long* trace = nullptr, int trace_eval = 0, const PeerComm* comm = nullptr,
+                                              PoseRecord* pose_out = nullptr, SolveLog* log = nullptr) {
     __shared__ LMState sL;
     __shared__ LMEvalPoint s_pt;
     __shared__ double s_rows[kScratchDoubles];
     const int t = threadIdx.x;
     VELO_LM_TRACE(trace, trace_eval, 4);
-    lm_advance(Q, Sg, partials, n_blocks, 0, nullptr, nullptr, s_rows, &sL, &s_pt, trace, trace_eval, comm);
+    lm_advance(Q, Sg, partials, n_blocks, 0, nullptr, nullptr, s_rows, &sL, &s_pt, trace, trace_eval, comm, pose_out, log);
     if (t < (int)(sizeof(LMState) / 8)) reinterpret_cast<unsigned long long*>(Sg)[t] = reinterpret_cast<const unsigned long long*>(&sL)[t];
     else if (t >= 64 && t < 64 + (int)(sizeof(LMEvalPoint) / 8)) reinterpret_cast<unsigned long long*>(pt)[t - 64] = reinterpret_cast<const unsigned long long*>(&s_pt)[t - 64];
     VELO_LM_TRACE(trace, trace_eval, 9);
@@ -2435,13 +2497,14 @@ __device__ __forceinline__ void lm_transition(const LMParams& Q, LMState* Sg, LM
 // start) instead of two each; launch 0 also does what lm_begin_kernel did.  Bit-identical to the two-launch path.
 __device__ __forceinline__ void lm_iter_body(const EvalArgs& A, const LMParams& Q, const LMState* __restrict__ Sin, LMState* __restrict__ Sout,
                                              const double* __restrict__ pin, int n_in, double* __restrict__ pout, int first,
-                                             const double* __restrict__ x_in, const int* __restrict__ n_valid, const int bx, const int nbx) {
+                                             const double* __restrict__ x_in, const int* __restrict__ n_valid, const int bx, const int nbx,
+                                             PoseRecord* pose_out = nullptr, SolveLog* log = nullptr) {
     __shared__ LMState sL;
     __shared__ LMEvalPoint s_pt;
     __shared__ double s_scratch[kScratchDoubles];
     const RowPrefetch f = prefetch_rows(A, bx, nbx);
     VELO_LM_TRACE(A.trace, A.trace_eval, 0);
-    lm_advance(Q, Sin, pin, n_in, first, x_in, n_valid, s_scratch, &sL, &s_pt, A.trace, A.trace_eval);
+    lm_advance(Q, Sin, pin, n_in, first, x_in, n_valid, s_scratch, &sL, &s_pt, A.trace, A.trace_eval, nullptr, pose_out, log, bx == 0);
     const int t = threadIdx.x;
     if (bx == 0 && t < (int)(sizeof(LMState) / 8)) reinterpret_cast<unsigned long long*>(Sout)[t] = reinterpret_cast<const unsigned long long*>(&sL)[t];
     if (sL.done) return;
@@ -2453,8 +2516,9 @@ __device__ __forceinline__ void lm_iter_body(const EvalArgs& A, const LMParams& 
 }
 __global__ void __launch_bounds__(kEvalThreads)
 lm_iter_kernel(EvalArgs A, LMParams Q, const LMState* __restrict__ Sin, LMState* __restrict__ Sout, const double* __restrict__ pin, int n_in,
-               double* __restrict__ pout, int first, const double* __restrict__ x_in, const int* __restrict__ n_valid) {
-    lm_iter_body(A, Q, Sin, Sout, pin, n_in, pout, first, x_in, n_valid, blockIdx.x, gridDim.x);
+               double* __restrict__ pout, int first, const double* __restrict__ x_in, const int* __restrict__ n_valid,
+               PoseRecord* pose_out, SolveLog* log) {
+    lm_iter_body(A, Q, Sin, Sout, pin, n_in, pout, first, x_in, n_valid, blockIdx.x, gridDim.x, pose_out, log);
 }
 // the same for the contexts of a lock-step group: blockIdx.y = context, k = index of the launch within the solve (its parity
 // selects the halves of every context's state / partial-row double buffer; `half` = doubles per half)
@@ -2463,7 +2527,7 @@ lm_iter_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int k, s
     const LMBatchItem& it = items[blockIdx.y];
     if ((int)blockIdx.x >= it.nb_icp) return;
     lm_iter_body(it.A, Q, it.S + (k & 1), it.S + ((k + 1) & 1), it.A.partials + (size_t)(k & 1) * half, it.nb_icp,
-                 it.A.partials + (size_t)((k + 1) & 1) * half, k == 0 ? 1 : 0, it.xd, it.n_valid, blockIdx.x, it.nb_icp);
+                 it.A.partials + (size_t)((k + 1) & 1) * half, k == 0 ? 1 : 0, it.xd, it.n_valid, blockIdx.x, it.nb_icp, it.pose_out, it.log);
 }
 
 __device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* S, const double* E) {
@@ -2515,11 +2579,12 @@ lm_step_peer_kernel(LMParams Q, LMState* S, LMEvalPoint* pt, const double* __res
 __global__ void lm_begin_batch_kernel(const LMBatchItem* __restrict__ items) {
     const LMBatchItem& it = items[blockIdx.x];
     lm_begin_body(it.S, const_cast<LMEvalPoint*>(it.A.pt), it.xd, it.n_valid);
+    if (threadIdx.x == 0 && it.pose_out) it.pose_out->ready = 0;       // chain mode: the next round's association waits for this solve
 }
 __global__ void __launch_bounds__(256)
 lm_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items) {
     const LMBatchItem& it = items[blockIdx.x];
-    lm_transition(Q, it.S, const_cast<LMEvalPoint*>(it.A.pt), it.A.partials, it.n_rows);
+    lm_transition(Q, it.S, const_cast<LMEvalPoint*>(it.A.pt), it.A.partials, it.n_rows, nullptr, 0, nullptr, it.pose_out, it.log);
 }
 // all states of the batch into one contiguous block (one D2H copy per chunk instead of one per context)
 __global__ void lm_gather_states_kernel(const LMBatchItem* __restrict__ items, LMState* __restrict__ out, int which) {
