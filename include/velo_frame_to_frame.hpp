@@ -134,7 +134,7 @@ struct Rig {
 
 // frameToFrame, same parameter list and meaning as velo.h:598-614.  `ctx` and `rig` are the two additions (the
 // reference keeps their equivalents in globals).  Returns the 4x4 of the solution like util::pose_mat2vec(transform).
-template <typename Mat4, typename Point2, typename Point3, typename CloudPtr, typename KdTrees>
+template <typename Mat4, typename Point2, typename Point3, typename CloudPtr, typename KdTrees, typename ResidualT>
 Mat4 frameToFrame(Context& ctx, const Rig& rig,
                   const std::vector<std::vector<std::pair<int, int>>>& matches,
                   const std::vector<std::vector<std::vector<Point2>>>& keypoints,
@@ -148,7 +148,7 @@ Mat4 frameToFrame(Context& ctx, const Rig& rig,
                   const int frame1, const int frame2,
                   double transform[6],
                   std::vector<std::vector<std::pair<int, int>>>& good_matches,
-                  std::vector<std::vector<ResidualType>>& residual_type,
+                  std::vector<std::vector<ResidualT>>& residual_type,      // the reference's own enum ResidualType (velo.h:3-8) or the one above
                   const bool enable_icp) {
     velo_params P = ctx.params();
     P.enable_icp = enable_icp ? 1 : 0;                                            // velo.h:806
@@ -202,12 +202,47 @@ Mat4 frameToFrame(Context& ctx, const Rig& rig,
     for (int cam = 0; cam < rig.num_cams; cam++) { good_matches[cam].clear(); residual_type[cam].clear(); }
     for (const auto& g : gm) {
         good_matches[g.cam].push_back(std::make_pair(g.point1, g.point2));
-        residual_type[g.cam].push_back((ResidualType)g.residual_type);
+        residual_type[g.cam].push_back((ResidualT)g.residual_type);
     }
     Mat4 out;
     for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) out(i, j) = T[i * 4 + j];
     return out;
 }
+
+// ---- the reference's EXACT parameter list (velo.h:598-614): callable unchanged from main.cpp:388-405 -----------------------------
+// The reference keeps the camera rig (kitti.h:3,46-51) and the device (cv::cuda::setDevice, main.cpp:64) in globals; so does this
+// overload: a process-default Context (created on first use on device VELO_HIP_DEFAULT_DEVICE, default 0) and a process-default Rig
+// (KITTI's, editable through default_rig() before the first call).  Like the reference's globals they are not thread-safe: one
+// driver thread, as in main.cpp.  The return type is the reference's Eigen::Matrix4d when Eigen was included before this header;
+// define VELO_HIP_MAT4 to any 4x4 type with T(i, j) to override (the tests do: this image has no Eigen).
+#ifndef VELO_HIP_DEFAULT_DEVICE
+#define VELO_HIP_DEFAULT_DEVICE 0
+#endif
+inline Context& default_context() { static Context ctx(VELO_HIP_DEFAULT_DEVICE); return ctx; }
+inline Rig& default_rig() { static Rig rig; return rig; }
+#if !defined(VELO_HIP_MAT4) && defined(EIGEN_WORLD_VERSION)
+#define VELO_HIP_MAT4 Eigen::Matrix4d
+#endif
+#ifdef VELO_HIP_MAT4
+template <typename Point2, typename Point3, typename CloudPtr, typename KdTrees, typename ResidualT>
+VELO_HIP_MAT4 frameToFrame(const std::vector<std::vector<std::pair<int, int>>>& matches,
+                           const std::vector<std::vector<std::vector<Point2>>>& keypoints,
+                           const std::vector<std::vector<std::vector<int>>>& keypoint_ids,
+                           const std::map<int, Point3>& landmarks_at_frame,
+                           const std::vector<std::vector<CloudPtr>>& keypoints_with_depth,
+                           const std::vector<std::vector<std::vector<int>>>& has_depth,
+                           const std::vector<CloudPtr>& scans_M,
+                           const std::vector<CloudPtr>& scans_S,
+                           const KdTrees& kd_trees,
+                           const int frame1, const int frame2,
+                           double transform[6],
+                           std::vector<std::vector<std::pair<int, int>>>& good_matches,
+                           std::vector<std::vector<ResidualT>>& residual_type,
+                           const bool enable_icp) {
+    return frameToFrame<VELO_HIP_MAT4>(default_context(), default_rig(), matches, keypoints, keypoint_ids, landmarks_at_frame, keypoints_with_depth,
+                                       has_depth, scans_M, scans_S, kd_trees, frame1, frame2, transform, good_matches, residual_type, enable_icp);
+}
+#endif
 
 // projectLidarToCamera, velo.h:329-334.  The rings are the ones `ctx` already holds -- `of_target` says in which slot (the
 // frame just loaded for frameToFrame), so nothing is uploaded again; `projection` and `scans_valid` are filled like the

@@ -163,6 +163,18 @@ typedef struct velo_tri_result {   /* per landmark, optional: 24 bytes */
     double final_cost;
 } velo_tri_result;
 
+/* residualStats (velo.h:921-1025): what the reference prints after every f2f iteration (velo.h:909) -- per residual type the
+ * median (sorted[size / 2]), mean and count of the block norms at the current pose, loss functions NOT applied
+ * (3D3D: |r|_2 of 3; 3D2D / 2D3D: |r|_2 of 2; 2D2D, 3DPD: |r|), plus the cost 1/2 sum r^2 of that evaluation.
+ * type[k]: k = VELO_RESIDUAL_3D3D, _3D2D, _2D3D, _2D2D, VELO_FUNCTOR_3DPD.  Computed on the device (radix select, no sort). */
+typedef struct velo_residual_stat { double median, mean; int64_t count; } velo_residual_stat;
+typedef struct velo_residual_stats {
+    velo_residual_stat type[5];
+    double cost;
+    int32_t n_blocks, n_residuals;     /* problem.NumResidualBlocks(), problem.NumResiduals() */
+} velo_residual_stats;                 /* 136 bytes */
+#define VELO_MAX_STATS 4               /* f2f iterations whose statistics a summary keeps */
+
 typedef struct velo_summary {
     int32_t n_solves;
     int32_t n_assoc_rounds;
@@ -175,6 +187,9 @@ typedef struct velo_summary {
     int32_t eval_kernel_launches;
     double eval_kernel_ms;
     velo_solve_summary solves[VELO_MAX_SOLVES];
+    int32_t n_residual_stats;          /* f2f iterations recorded below (0 unless velo_set_residual_stats(ctx, 1)) */
+    int32_t reserved;
+    velo_residual_stats residual_stats[VELO_MAX_STATS];   /* [iter - 1]: residualStats at the end of f2f iteration iter */
 } velo_summary;
 
 typedef struct velo_ctx velo_ctx;
@@ -193,6 +208,9 @@ int velo_set_params(velo_ctx* ctx, const velo_params* p);
 int velo_get_params(const velo_ctx* ctx, velo_params* p);
 /* Per-launch HIP-event timing of the association search and evaluation kernels (off by default). */
 int velo_set_timing(velo_ctx* ctx, int enable);
+/* residualStats after every f2f iteration (velo.h:909) into velo_summary::residual_stats (off by default: the reference only
+ * prints them; switched on, a call evaluates between the iterations and is therefore driven round by round from the host). */
+int velo_set_residual_stats(velo_ctx* ctx, int enable);
 
 /* --- inputs --------------------------------------------------------------------------------------- */
 /* Target = frame2 rings.  Replaces `scans_S` + `kd_trees` (velo.h:606-607) and the per-ring
@@ -296,6 +314,8 @@ typedef struct velo_functor {
 } velo_functor;   /* 80 bytes */
 int velo_evaluate_functors(velo_ctx* ctx, const velo_functor* functors, int32_t n, const double x[6],
                            double* residuals, double* jacobians);
+/* residualStats (velo.h:921-1025) of the current blocks at x. */
+int velo_residual_stats_at(velo_ctx* ctx, const double x[6], velo_residual_stats* out);
 /* One ceres::Solve (velo.h:897-902) on the current blocks, x in/out. */
 int velo_solve(velo_ctx* ctx, double x[6], velo_solve_summary* summary);
 

@@ -335,6 +335,7 @@ struct Oracle {
     std::vector<velo_good_match> good;
     int threads = 1;
     int shard_rank = 0, shard_world = 1;
+    bool want_stats = false;           // residualStats after every f2f iteration into the summary (velo.h:909)
 };
 
 void default_params(velo_params* p) {
@@ -703,6 +704,38 @@ void pose_mat_to_vec(const double T[16], double x[6]) {
     x[3] = T[3]; x[4] = T[7]; x[5] = T[11];
 }
 
+// residualStats  velo.h:921-1025: the problem evaluated WITHOUT loss functions (velo.h:929-931); one number per block --
+// sqrt(r0^2 + r1^2 + r2^2) for 3D3D (velo.h:939-946), sqrt(r0^2 + r1^2) for 3D2D / 2D3D (velo.h:949-964), |r| for 2D2D
+// (velo.h:967) and for every residual behind the visual ones = 3DPD (velo.h:975-977); sums in block order (velo.h:979-983),
+// then sort (velo.h:984-988); printed: sorted[size / 2], sum / size, size (velo.h:1001-1024).  `abs` on a double is read as
+// fabs (the same reading as row G1).  cost = what Problem::Evaluate returns without loss: 1/2 sum r^2.
+void residual_stats(const Oracle& o, const double x[6], velo_residual_stats* out) {
+    std::memset(out, 0, sizeof(*out));
+    std::vector<double> v[5];
+    double sum[5] = {0, 0, 0, 0, 0}, sq_all = 0.0;
+    auto one = [&](const Block& b) {
+        double r[3] = {0, 0, 0};
+        block_eval(b.kind, b.c, x, r, nullptr);
+        const int d = kind_dim(b.kind);
+        double val;
+        if (d == 3) val = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        else if (d == 2) val = std::sqrt(r[0] * r[0] + r[1] * r[1]);
+        else val = std::fabs(r[0]);
+        for (int k = 0; k < d; k++) sq_all += r[k] * r[k];
+        v[b.kind].push_back(val);
+        out->n_blocks++; out->n_residuals += d;
+    };
+    for (const Block& b : o.vis_blocks) one(b);
+    for (const Block& b : o.icp_blocks) one(b);
+    for (int t = 0; t < 5; t++) {
+        for (double r : v[t]) sum[t] += r;
+        std::sort(v[t].begin(), v[t].end());
+        out->type[t].count = (int64_t)v[t].size();
+        if (!v[t].empty()) { out->type[t].median = v[t][v[t].size() / 2]; out->type[t].mean = sum[t] / (double)v[t].size(); }
+    }
+    out->cost = 0.5 * sq_all;
+}
+
 // frameToFrame  velo.h:616-919 (row D1)
 void frame_to_frame(Oracle& o, double x[6], double T[16], velo_summary* sum) {
     velo_summary local;
@@ -723,6 +756,10 @@ void frame_to_frame(Oracle& o, double x[6], double T[16], velo_summary* sum) {
             S->algorithmic_bytes += (uint64_t)ss.evaluations * ((uint64_t)36 * ss.n_icp_valid + (uint64_t)32 * ss.n_visual_blocks + 224);
             if (S->n_solves < VELO_MAX_SOLVES) S->solves[S->n_solves] = ss;
             S->n_solves++;
+        }
+        if (o.want_stats && iter <= VELO_MAX_STATS) {                          // velo.h:909
+            residual_stats(o, x, &S->residual_stats[iter - 1]);
+            S->n_residual_stats = iter;
         }
     }
     if (T) pose_vec_to_mat(x, T);
@@ -1007,6 +1044,8 @@ int vo_frame_to_frame(void* h, double* x, double* T, velo_summary* s) {
     frame_to_frame(*(Oracle*)h, x, T, s);
     return 0;
 }
+int vo_set_residual_stats(void* h, int enable) { ((Oracle*)h)->want_stats = enable != 0; return 0; }
+int vo_residual_stats_at(void* h, const double* x, velo_residual_stats* out) { residual_stats(*(Oracle*)h, x, out); return 0; }
 int vo_pose_vec_to_mat(const double* x, double* T) { pose_vec_to_mat(x, T); return 0; }
 int vo_pose_mat_to_vec(const double* T, double* x) { pose_mat_to_vec(T, x); return 0; }
 

@@ -8,9 +8,13 @@
 #include <vector>
 
 #include "standins.hpp"
+#define VELO_HIP_MAT4 standin::Matrix4d          // no Eigen in this image: the exact-signature overload returns the stand-in 4x4
 #include "velo_frame_to_frame.hpp"
 
 using namespace standin;
+
+// the reference's own global enum (velo.h:3-8): the exact-signature overload fills vectors of THIS type
+enum ResidualType { RESIDUAL_3D3D, RESIDUAL_3D2D, RESIDUAL_2D3D, RESIDUAL_2D2D };
 
 static std::vector<PointCloud::Ptr> read_rings(FILE* f) {
     int32_t nr;
@@ -135,6 +139,26 @@ int main(int argc, char** argv) {
         for (int c = 0; c < num_cams; c++)
             for (size_t i = 0; i < good_matches[c].size(); i++)
                 printf("g %d %d %d %d\n", c, good_matches[c][i].first, good_matches[c][i].second, (int)residual_type[c][i]);
+        // The reference's call, character for character (main.cpp:388-405 -> velo.h:598-614): 15 arguments, no context, no rig, the
+        // reference's own enum.  The process-default context gets the test's icp_skip (a compile-time constant in kitti.h:8).
+        {
+            using velo_hip::frameToFrame;
+            velo_hip::default_context().set_params(P);
+            double t2[6];
+            for (int i = 0; i < 6; i++) t2[i] = transform0[i];
+            std::vector<std::vector<std::pair<int, int>>> gm_e(num_cams);
+            std::vector<std::vector<ResidualType>> rt_e(num_cams);
+            Matrix4d Te = frameToFrame(matches, keypoints, keypoint_ids, landmarks, kwd, has_depth, scans_M, scans_S, kd_trees,
+                                       frame1, frame2, t2, gm_e, rt_e, true);
+            bool same = true;
+            for (int i = 0; i < 6; i++) same = same && t2[i] == transform[i];
+            for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) same = same && Te(i, j) == T(i, j);
+            for (int c = 0; c < num_cams; c++) {
+                same = same && gm_e[c] == good_matches[c] && rt_e[c].size() == residual_type[c].size();
+                for (size_t i = 0; same && i < rt_e[c].size(); i++) same = (int)rt_e[c][i] == (int)residual_type[c][i];
+            }
+            printf("e %d\n", (int)same);
+        }
         // the depth rows (main.cpp:594-604) on the target rings the context still holds: the previous frame's keypoints
         rig.depth_assoc_thresh = 0.2;                  // the 128-azimuth test rings are coarser than KITTI's
         for (int c = 0; c < num_cams; c++) {

@@ -158,6 +158,16 @@ class Oracle:
         self._l.vo_solve(self._h, xv.ctypes.data_as(_dp), C.byref(s))
         return xv, s
 
+    def set_residual_stats(self, enable=True):
+        self._l.vo_set_residual_stats(self._h, C.c_int(1 if enable else 0))
+
+    def residual_stats(self, x):
+        from velo_amd.api import VeloResidualStats
+        xv = _d(x, 6).copy()
+        out = VeloResidualStats()
+        self._l.vo_residual_stats_at(self._h, xv.ctypes.data_as(_dp), C.byref(out))
+        return out
+
     def frame_to_frame(self, x0):
         xv = _d(x0, 6).copy()
         T = np.zeros(16)

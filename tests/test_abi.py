@@ -47,6 +47,7 @@ int main(void) {
          sizeof(velo_solve_summary), sizeof(velo_summary));
   printf("%zu %zu %zu %zu\n", offsetof(velo_params, weight_3D2D), offsetof(velo_match, cam), offsetof(velo_corr, p), offsetof(velo_summary, solves));
   printf("%zu %zu %zu %zu %zu\n", sizeof(velo_tri_obs), sizeof(velo_tri_result), sizeof(velo_partial), sizeof(velo_functor), offsetof(velo_functor, c));
+  printf("%zu %zu %zu\n", sizeof(velo_residual_stats), offsetof(velo_summary, residual_stats), offsetof(velo_residual_stats, cost));
   return 0; }
 '''
     with tempfile.TemporaryDirectory() as td:
@@ -64,6 +65,7 @@ int main(void) {
     assert sizes[9] == api.VeloSummary.solves.offset
     assert sizes[10:15] == [api.TRI_OBS_DTYPE.itemsize, api.TRI_RESULT_DTYPE.itemsize, api.PARTIAL_DTYPE.itemsize,
                             api.FUNCTOR_DTYPE.itemsize, api.FUNCTOR_DTYPE.fields["c"][1]]
+    assert sizes[15:18] == [C.sizeof(api.VeloResidualStats), api.VeloSummary.residual_stats.offset, api.VeloResidualStats.cost.offset]
 
 
 def test_default_params_are_the_reference_constants(lib):

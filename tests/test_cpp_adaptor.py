@@ -74,6 +74,8 @@ def test_adaptor_matches_oracle(tmp_path, oracle):
     assert cl[6:12] == cl[12:18]
     # frameToFrame with empty ring vectors registers the scans the context holds (here: loaded from the cache): same result
     assert [line for line in out if line.startswith("s ")] == ["s 1"]
+    # the exact 15-parameter signature of velo.h:598-614 (process-default context and rig) gives the same answer
+    assert [line for line in out if line.startswith("e ")] == ["e 1"]
 
     # depth rows through the adaptor: projectLidarToCamera + featureDepthAssociation on the target rings, per camera
     import oracle_lib as O

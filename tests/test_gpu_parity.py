@@ -338,7 +338,7 @@ def test_small_problem_single_launch_solve_is_bit_identical(hip_lib, monkeypatch
 
 
 @pytest.mark.parametrize("env", [{}, {"VELO_ASKER_ROWS": "0"}, {"VELO_CLUSTER_W": "2"}, {"VELO_DENSE_REF": "300"},
-                                 {"VELO_DENSE_REF": "300", "VELO_ASKER_ROWS": "0"}, {"VELO_WARM_START": "0"}])
+                                 {"VELO_DENSE_REF": "300", "VELO_ASKER_ROWS": "0"}, {"VELO_WARM_START": "0"}, {"VELO_ASSOC_LANE": "1"}])
 def test_association_random_geometry_all_paths(hip_lib, oracle, monkeypatch, env):
     """Every way through the tube kernel (tile pass / query-by-query second phase, one or many clusters, regular or
     density-shrunk grid, with or without seeds) against the oracle on clouds that look nothing like a street scan: ragged
@@ -513,3 +513,55 @@ def test_chain_mode_lockstep_batch_is_bit_identical(hip_lib, monkeypatch):
     for name in ("chain", "tight"):
         for (x0, T0, s0, r0), (x1, T1, s1, r1) in zip(res["host"][0], res[name][0]):
             assert np.array_equal(x0, x1) and np.array_equal(T0, T1) and s0 == s1 and r0 == r1
+
+
+def _stats_close(a, b):
+    assert (a.n_blocks, a.n_residuals) == (b.n_blocks, b.n_residuals)
+    assert abs(a.cost - b.cost) <= 1e-12 * max(abs(b.cost), 1e-300)
+    for k in range(5):
+        assert a.type[k].count == b.type[k].count, k
+        if b.type[k].count:
+            assert abs(a.type[k].median - b.type[k].median) <= 1e-12 * max(abs(b.type[k].median), 1e-30), (k, a.type[k].median, b.type[k].median)
+            assert abs(a.type[k].mean - b.type[k].mean) <= 1e-12 * abs(b.type[k].mean), k
+        else:
+            assert a.type[k].median == 0.0 and a.type[k].mean == 0.0
+
+
+def test_residual_stats_match_the_oracle_restatement(ctx, oracle):
+    """residualStats (velo.h:921-1025) on the device -- block norms, radix-select median, means, counts, loss-free cost -- against the
+    oracle's restatement: standalone at two poses with all five residual types present, and inside frame_to_frame (one record per
+    f2f iteration, velo.h:909) where switching the statistics on must not change the pose or the solves."""
+    d = H.small_pair(32, 400)
+    vis = api.matches_from_dict(synth.stereo_matches(300, mix="all"))
+    orc = oracle.Oracle(threads=8)
+    H.load_both(ctx, orc, d, icp_skip=2)
+    ctx.set_visual(vis); orc.set_visual(vis)
+    for it, x in ((1, d["x0"]), (2, d["x_true"] + np.array([1e-3, -1e-3, 2e-3, 0.02, -0.01, 0.03]))):
+        assert ctx.build_visual(x, it) == orc.build_visual(x, it)
+        assert ctx.associate(x, it) == orc.associate(x, it)
+        a, b = ctx.residual_stats(x), orc.residual_stats(x)
+        assert all(b.type[k].count > 0 for k in range(5))
+        _stats_close(a, b)
+    x_plain, T_plain, s_plain = ctx.frame_to_frame(d["x0"])
+    ctx.set_residual_stats(True); orc.set_residual_stats(True)
+    x1, T1, s1 = ctx.frame_to_frame(d["x0"])
+    x2, T2, s2 = orc.frame_to_frame(d["x0"])
+    ctx.set_residual_stats(False)
+    assert np.array_equal(x1, x_plain) and _summary_tuple(s1) == _summary_tuple(s_plain) and s_plain.n_residual_stats == 0
+    assert s1.n_residual_stats == s2.n_residual_stats == 2
+    assert H.pose_close(x1, x2)
+    for k in range(2):
+        a, b = s1.residual_stats[k], s2.residual_stats[k]
+        assert (a.n_blocks, a.n_residuals) == (b.n_blocks, b.n_residuals)
+        for t in range(5):
+            assert a.type[t].count == b.type[t].count
+            if b.type[t].count:          # the two sides end at poses that agree to ~1e-9, so do the statistics
+                assert abs(a.type[t].median - b.type[t].median) <= 1e-6 * max(b.type[t].median, 1e-6)
+                assert abs(a.type[t].mean - b.type[t].mean) <= 1e-6 * b.type[t].mean
+    # LiDAR-only, larger: the chain is switched off by the statistics, the batch driver falls back to one call per context
+    ctx.set_visual(None)
+    ctx.set_residual_stats(True)
+    xa, _, sa = ctx.frame_to_frame(d["x0"])
+    ctx.set_residual_stats(False)
+    xb, _, sb = ctx.frame_to_frame(d["x0"])
+    assert np.array_equal(xa, xb) and sa.n_residual_stats == 2 and sa.residual_stats[1].type[4].count == sa.solves[5].n_icp_valid

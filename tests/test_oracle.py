@@ -362,3 +362,37 @@ def test_query_shards_partition_the_work():
         acc[2] += g
     assert np.array_equal(np.concatenate(parts), whole.correspondences())
     assert abs(acc[0] - c0) < 1e-12 * c0 and H.rel_err(acc[1], H0) < 1e-12 and H.rel_err(acc[2], g0) < 1e-12
+
+
+def test_residual_stats_restatement_against_numpy(oracle):
+    """residualStats (velo.h:921-1025) restated in the oracle against an independent numpy evaluation of the same rule: unrobustified
+    rows (vo_evaluate_rows applies the loss, so the rows are rebuilt from the functor constants), block norms, median = sorted[n // 2],
+    mean, count; cost = 1/2 sum r^2."""
+    from velo_amd import api, synth
+    d = H.small_pair(16, 128)
+    o = oracle.Oracle(threads=2, icp_skip=3)
+    o.set_target(d["tgt_xyz"], d["tgt_off"]); o.set_source(d["src_xyz"], d["src_off"])
+    o.set_visual(api.matches_from_dict(synth.stereo_matches(60, mix="all")))
+    x = d["x_true"] + np.array([1e-3, -2e-3, 5e-4, 0.01, -0.02, 0.015])
+    o.build_visual(x, 1)
+    o.associate(x, 1)
+    st = o.residual_stats(x)
+    # independent: loss-free evaluation through the trivial-loss parameters (weights 1, thresholds huge -> rho(s) = s up to 1e-15)
+    good = o.good_matches()
+    corr = o.correspondences()
+    n_icp = int((corr["valid"] != 0).sum())
+    counts = {k: int((good["residual_type"] == k).sum()) for k in range(4)}
+    assert [st.type[k].count for k in range(4)] == [counts[k] for k in range(4)]
+    assert st.type[4].count == n_icp and st.n_blocks == len(good) + n_icp
+    assert st.n_residuals == 3 * counts[0] + 2 * counts[1] + 2 * counts[2] + counts[3] + n_icp
+    # 3DPD by hand: r = N . (R p + t - v0) in numpy doubles
+    from scipy.spatial.transform import Rotation
+    R = Rotation.from_rotvec(x[:3]).as_matrix()
+    v = corr[corr["valid"] != 0]
+    r = np.einsum("ij,ij->i", v["n"].astype(np.float64), (R @ v["p"].astype(np.float64).T).T + x[3:] - v["v0"].astype(np.float64))
+    a = np.abs(r)
+    assert abs(st.type[4].mean - a.mean()) <= 1e-12 * a.mean()
+    assert abs(st.type[4].median - np.sort(a)[len(a) // 2]) <= 1e-12
+    assert st.cost >= 0.5 * float((r * r).sum()) * (1 - 1e-12)
+    if counts[0] + counts[1] + counts[2] + counts[3] == 0:
+        assert abs(st.cost - 0.5 * float((r * r).sum())) <= 1e-12 * st.cost

@@ -58,6 +58,24 @@ class VeloScanRef(C.Structure):
                 ("on_device", C.c_int32)]
 
 
+VELO_MAX_STATS = 4
+RESIDUAL_TYPE_NAMES = ("3D3D", "3D2D", "2D3D", "2D2D", "3DPD")
+
+
+class VeloResidualStat(C.Structure):
+    _fields_ = [("median", C.c_double), ("mean", C.c_double), ("count", C.c_int64)]
+
+
+class VeloResidualStats(C.Structure):
+    """residualStats (velo.h:921-1025): per residual type median / mean / count of the block norms, loss not applied."""
+    _fields_ = [("type", VeloResidualStat * 5), ("cost", C.c_double), ("n_blocks", C.c_int32), ("n_residuals", C.c_int32)]
+
+    def as_dict(self):
+        d = {n: dict(median=self.type[k].median, mean=self.type[k].mean, count=self.type[k].count) for k, n in enumerate(RESIDUAL_TYPE_NAMES)}
+        d.update(cost=self.cost, n_blocks=self.n_blocks, n_residuals=self.n_residuals)
+        return d
+
+
 class VeloSummary(C.Structure):
     _fields_ = [
         ("n_solves", C.c_int32), ("n_assoc_rounds", C.c_int32), ("n_queries", C.c_int32),
@@ -66,11 +84,14 @@ class VeloSummary(C.Structure):
         ("assoc_kernel_ms", C.c_double), ("assoc_kernel_launches", C.c_int32),
         ("eval_kernel_launches", C.c_int32), ("eval_kernel_ms", C.c_double),
         ("solves", VeloSolveSummary * VELO_MAX_SOLVES),
+        ("n_residual_stats", C.c_int32), ("reserved", C.c_int32),
+        ("residual_stats", VeloResidualStats * VELO_MAX_STATS),
     ]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "solves"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("solves", "residual_stats", "reserved")}
         d["solves"] = [self.solves[i].as_dict() for i in range(min(self.n_solves, VELO_MAX_SOLVES))]
+        d["residual_stats"] = [self.residual_stats[i].as_dict() for i in range(min(self.n_residual_stats, VELO_MAX_STATS))]
         return d
 
 
@@ -190,6 +211,8 @@ SIGNATURES = {
     "velo_comm_peer_attach": (C.c_int, [_ctx, C.c_char_p, C.c_int32, C.c_int32]),
     "velo_comm_info": (C.c_int, [_ctx, _P(C.c_int32), _P(C.c_int32), _P(C.c_int32)]),
     "velo_chain_stats": (C.c_int, [_ctx, _P(C.c_int32), _P(C.c_int32)]),
+    "velo_set_residual_stats": (C.c_int, [_ctx, C.c_int]),
+    "velo_residual_stats_at": (C.c_int, [_ctx, _P(C.c_double), _P(VeloResidualStats)]),
     "velo_comm_peer_export_records": (C.c_int, [_ctx, C.c_int32, C.c_char_p]),
     "velo_comm_peer_attach_records": (C.c_int, [_ctx, C.c_char_p, C.c_int32]),
     "velo_comm_set_target_sharded": (C.c_int, [_ctx, C.c_int]),
@@ -556,6 +579,17 @@ class Context:
     def comm_peer_attach_records(self, handles, max_queries: int):
         blob = b"".join(bytes(h) for h in handles)
         self._check(self._lib.velo_comm_peer_attach_records(self._h, C.create_string_buffer(blob, len(blob)), int(max_queries)))
+
+    def set_residual_stats(self, enable: bool = True):
+        """residualStats after every f2f iteration into the summary (velo.h:909)."""
+        self._check(self._lib.velo_set_residual_stats(self._h, 1 if enable else 0))
+
+    def residual_stats(self, x):
+        """residualStats (velo.h:921-1025) of the current blocks at x."""
+        xx = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(6))
+        out = VeloResidualStats()
+        self._check(self._lib.velo_residual_stats_at(self._h, _ptr(xx), C.byref(out)))
+        return out
 
     def chain_stats(self):
         """(calls, misses) of the one-chain-per-call mode (velo_chain_stats): misses were repeated host-driven, same results."""

@@ -22,6 +22,8 @@
 #include <iterator>
 #include <list>
 #include <memory>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -177,6 +179,14 @@ struct velo_ctx {
     int assoc_lds_pad = 0;               // VELO_ASSOC_LDS_PAD: bytes of unused dynamic LDS per association workgroup -- caps the association
                                          // kernel's workgroups per CU so that LM workgroups of other pairs in flight find room at once
     // chain mode: a whole frame_to_frame as ONE chain of launches (pose scalars of the next round and the solve summaries stay on the device)
+    bool want_stats = false;             // velo_set_residual_stats
+    DevBuf<double> stat_vals, stat_part;
+    DevBuf<signed char> stat_types;
+    DevBuf<int> stat_hist;
+    DevBuf<StatWork> stat_work;
+    DevBuf<velo_residual_stats> stat_out;
+    int assoc_lane = 0;                  // VELO_ASSOC_LANE=1: rounds that start from seeds use the lane kernel (A/B; slower, see assoc_lane_body)
+    int seed_rounds = 0;                 // association rounds since the seeds were last cleared
     int chain_calls = 0;                 // calls that went down the chain
     int chain_margin = 2;                // LM launches enqueued per solve beyond the previous call's count (VELO_CHAIN_MARGIN)
     int chain_misses = 0;                // calls whose chain was too short and were repeated by the host-driven path
@@ -563,9 +573,20 @@ int attach_seeds(velo_ctx* c, AssocOut* out) {
         HIP_TRY(hipMemsetAsync(c->prev_a.p, 0xff, sizeof(float4) * nq, c->stream));
         HIP_TRY(hipMemsetAsync(c->prev_b.p, 0xff, sizeof(float4) * nq, c->stream));
         c->prev_ready = true;
+        c->seed_rounds = 0;
     }
     out->prev_a = c->prev_a.p; out->prev_b = c->prev_b.p; out->prev_r = c->prev_r.p;
     return VELO_OK;
+}
+
+// A round may use the lane kernel when it starts from seeds (a round of this source against this target has run) on the regular
+// grid (gate radius of the first iteration <= 5 cells; the density-shrunk grid of a 2M-point map keeps the tube kernel and its
+// query-by-query second phase), with the default variant and no diagnostics / placement table / partial records.
+bool lane_round(const velo_ctx* c, const Grid* G, bool partial) {
+    if (!c->assoc_lane || !c->warm_start || c->assoc_variant >= 0 || c->debug_skip || c->tube_map >= 0 || partial) return false;
+    if (!c->prev_ready || c->seed_rounds < 1) return false;
+    const int reach_cells = (int)std::ceil(std::sqrt(std::max(gate_of_iter(c->P, 1), 0.0)) / (G->h * 0.999));
+    return reach_cells <= 5;
 }
 
 int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool wait, int* n_valid, bool partial = false, const PoseRecord* P_dev = nullptr) {
@@ -588,6 +609,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         out.first_ring = c->T->tgt_first_ring; out.first_point = c->T->tgt_first_point; out.partial = partial ? c->partials_rec.p : nullptr;
         out.n_valid_next = nullptr;
         VELO_TRY(attach_seeds(c, &out));
+        const bool lane = lane_round(c, G, partial);
         if (c->debug_skip & 32) { VELO_TRY(c->wg_times.reserve((size_t)2 * cdiv(qe - qb, 64) + 2)); out.wg_times = c->wg_times.p; c->wg_times_n = cdiv(qe - qb, 64); }
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
         if (c->timing) {
@@ -603,7 +625,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         // stop (what a rocprofv3 kernel trace reports); events recorded around a launch would also count the time the launch waits
         // for the chip while other streams' kernels run.  The A/B variants keep the record-around bracket.
         const int variant_timed = c->assoc_variant >= 0 ? c->assoc_variant : 5;
-        const bool ext_timed = variant_timed == 5 || (variant_timed >= 52 && variant_timed <= 59);
+        const bool ext_timed = lane || variant_timed == 5 || (variant_timed >= 52 && variant_timed <= 59);
         if (ev && !ext_timed) HIP_TRY(hipEventRecord(ev->first, c->stream));
         const int aux = want_aux ? 1 : 0;
         const int groups = cdiv(qe - qb, 64);
@@ -624,7 +646,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         // Default = tube kernel (5) with warm start.  120k-pt scans: 69 us per launch averaged over the 6 rounds of a call (box
         // kernel 4: 121 us); 2M-pt map: 535 us vs 1.49 ms -- its cold first round is slower there (density-shrunk grid, gate radius
         // = 15 cells, every query asks for a (2e+1)^2-row box: 1.59 vs 1.45 ms) but the five warm rounds need tiny boxes.
-        const int variant = c->assoc_variant >= 0 ? c->assoc_variant : 5;
+        const int variant = lane ? 6 : (c->assoc_variant >= 0 ? c->assoc_variant : 5);
         const int reach_cells = (int)std::ceil(std::sqrt(std::max(gate_of_iter(c->P, 1), 0.0)) / (G->h * 0.999));   // > 5: density-shrunk grid
         switch (variant) {
             case 0: {
@@ -656,6 +678,14 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                                        c->T->tgt.p, c->T->tgt_off.p, c->T->tgt_ring_of.p, gbits, c->P.icp_norm_condition, h_safe, out, aux);
                 break;
             }
+            case 6: {   // lane kernel: one lane owns one query (rounds that start from seeds)
+                out.n_valid_next = c->n_valid.p + (c->nv_idx ^ 1);
+                c->nv_clean[c->nv_idx ^ 1] = true;
+                hipExtLaunchKernelGGL(assoc_lane_kernel, dim3(cdiv(groups, 4)), dim3(256), 0, c->stream, ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0,
+                                      S, P_dev, P_dev ? c->chain_fail.p : (int*)nullptr, V, c->qpts, qb, qe, (const float4*)c->T->tgt_pad.p, (const int*)c->T->tgt_off.p,
+                                      gbits, c->P.icp_norm_condition, out, aux);
+                break;
+            }
             case 5: case 55: case 52: case 56: case 57: case 58: case 59: {   // tube variant: per-row intervals, per-query phase 2 (cluster radius only when VELO_CLUSTER_W is given)
                 // tubes do not grow with the segment, so the cluster radius only has to bound the row box of pathological groups
                 // (a 64-query group straddling a gap in its ring): 96 default cells = 17 m unless VELO_CLUSTER_W says otherwise
@@ -681,6 +711,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 else if (variant == 56) VELO_LAUNCH_V5(4, 6, false, 2, false);   // occupancy A/B: 6 / 7 / 8 waves per SIMD
                 else if (variant == 57) VELO_LAUNCH_V5(4, 7, false, 2, false);
                 else if (variant == 58) VELO_LAUNCH_V5(4, 8, false, 2, false);
+                // (workgroups of 2 waves / 1 wave -- every group resident at once -- measured 66 / 134 us per launch against 62: not tail-bound)
                 else if (variant == 59) VELO_LAUNCH_V5(4, 5, false, 2, false);   // phase 2 through the row/tile machinery (A/B)
                 else if (asker_rows >= (1 << 30)) VELO_LAUNCH_V5(4, 5, false, 2, false);   // regular grid: instantiation without the query-by-query code (no spills)
                 else VELO_LAUNCH_V5(4, 5, false, 2, true);
@@ -699,6 +730,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
 #undef VELO_LAUNCH_V2
 #undef VELO_LAUNCH_V3
         HIP_TRY(hipGetLastError());
+        if (out.prev_a && (variant == 6 || variant == 5 || (variant >= 52 && variant <= 59))) c->seed_rounds++;   // these kernels leave seeds behind
         if (ev && !ext_timed) HIP_TRY(hipEventRecord(ev->second, c->stream));
 #ifdef VELO_DIAGNOSTICS
         if ((c->debug_skip & 24) && getenv("VELO_DEBUG_EACH")) {       // per-launch read-out (default: totals when the context goes)
@@ -979,6 +1011,68 @@ int source_finalize(velo_ctx* c) {
 }  // namespace
 
 // =====================================================================================================================
+// Resident host threads for the batch entry points: a step of 8 pairs used to create and join 3 (lock-step groups) or 8 (one per
+// context) std::threads inside the timed region, every step.  The workers are created on first need and then wait on a condition
+// variable between calls; a call hands out task indices 1..n-1 and runs task 0 itself.  One call at a time owns the pool -- a
+// second caller that arrives meanwhile (another host thread driving another device) spawns its own threads as before.
+class WorkerPool {
+public:
+    static WorkerPool& instance() { static WorkerPool p; return p; }
+    template <typename F>
+    void run(int n, F&& fn) {
+        if (n <= 1) { if (n == 1) fn(0); return; }
+        std::unique_lock<std::mutex> owner(owner_, std::try_to_lock);
+        if (!owner.owns_lock()) {                                   // pool busy: plain threads for this call
+            std::vector<std::thread> th;
+            for (int i = 1; i < n; i++) th.emplace_back([&fn, i]() { fn(i); });
+            fn(0);
+            for (auto& t : th) t.join();
+            return;
+        }
+        std::function<void(int)> f = [&fn](int i) { fn(i); };
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            while ((int)workers_.size() < n - 1) workers_.emplace_back([this]() { loop(); });
+            fn_ = &f; next_ = 1; n_ = n; pending_ = n - 1; generation_++;
+        }
+        wake_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this]() { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+    ~WorkerPool() {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        wake_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+private:
+    void loop() {
+        unsigned long long seen = 0;
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            wake_.wait(lk, [&]() { return stop_ || (generation_ != seen && next_ < n_); });
+            if (stop_) return;
+            while (next_ < n_) {
+                const int i = next_++;
+                const std::function<void(int)>* f = fn_;
+                lk.unlock();
+                (*f)(i);
+                lk.lock();
+                if (--pending_ == 0) done_.notify_all();
+            }
+            seen = generation_;
+        }
+    }
+    std::mutex owner_, m_;
+    std::condition_variable wake_, done_;
+    std::vector<std::thread> workers_;
+    const std::function<void(int)>* fn_ = nullptr;
+    int next_ = 0, n_ = 0, pending_ = 0;
+    unsigned long long generation_ = 0;
+    bool stop_ = false;
+};
+
 static int associate_target_sharded(velo_ctx* c, const double x[6], int iter, bool want_aux);
 static int launch_merge(velo_ctx* c, const PartialRec* tables, int world, int stride, int iter, bool want_aux);
 
@@ -1035,6 +1129,7 @@ int velo_create(velo_ctx** out, int device) {
         if (const char* e = getenv("VELO_WARM_START")) c->warm_start = atoi(e);
         if (const char* e = getenv("VELO_SMALL_SOLVE")) c->small_solve = atoi(e);
         if (const char* e = getenv("VELO_LM_MERGED")) c->lm_merged = atoi(e);
+        if (const char* e = getenv("VELO_ASSOC_LANE")) c->assoc_lane = atoi(e);
         if (const char* e = getenv("VELO_CHAIN")) c->chain = atoi(e);
         if (const char* e = getenv("VELO_CHAIN_MARGIN")) c->chain_margin = std::max(atoi(e), 0);
         if (const char* e = getenv("VELO_ASSOC_LDS_PAD")) c->assoc_lds_pad = std::max(atoi(e), 0);
@@ -1150,6 +1245,12 @@ int velo_get_params(const velo_ctx* c, velo_params* p) {
 int velo_set_timing(velo_ctx* c, int enable) {
     if (!c) return fail(VELO_ERR_INVALID, "null ctx");
     c->timing = enable != 0;
+    return VELO_OK;
+}
+
+int velo_set_residual_stats(velo_ctx* c, int enable) {
+    if (!c) return fail(VELO_ERR_INVALID, "null ctx");
+    c->want_stats = enable != 0;
     return VELO_OK;
 }
 
@@ -1732,6 +1833,39 @@ int velo_evaluate_functors(velo_ctx* c, const velo_functor* f, int32_t n, const 
     return VELO_OK;
 }
 
+int velo_residual_stats_at(velo_ctx* c, const double x[6], velo_residual_stats* out) {
+    if (!c || !x || !out) return fail(VELO_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    std::memset(out, 0, sizeof(*out));
+    if (!c->vflags_valid) VELO_TRY(do_build_visual(c, x, false, 1, nullptr));
+    std::memcpy(c->h_x, x, sizeof(double) * 6);
+    HIP_TRY(hipMemcpyAsync(c->xdev.p, c->h_x, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
+    EvalArgs A = eval_args(c, c->xdev.p);
+    const int n = 3 * A.n_matches + (A.q_end - A.q_begin);
+    int blocks = 0, residuals = 0;
+    visual_counts(c, &blocks, &residuals);
+    if (c->shard_rank != 0) { blocks = 0; residuals = 0; }
+    if (n > 0) {
+        const int nb = cdiv(n, 256);
+        VELO_TRY(c->stat_vals.reserve((size_t)n)); VELO_TRY(c->stat_types.reserve((size_t)n)); VELO_TRY(c->stat_part.reserve((size_t)nb * (kStatTypes + 1)));
+        const bool fresh = c->stat_hist.cap == 0;
+        VELO_TRY(c->stat_hist.reserve((size_t)kStatTypes * kStatBins)); VELO_TRY(c->stat_work.reserve(1)); VELO_TRY(c->stat_out.reserve(1));
+        if (fresh) HIP_TRY(hipMemsetAsync(c->stat_hist.p, 0, sizeof(int) * (size_t)kStatTypes * kStatBins, c->stream));   // the pick kernel leaves it cleared
+        hipLaunchKernelGGL(residual_norms_kernel, dim3(nb), dim3(256), 0, c->stream, (const double*)c->xdev.p, A, c->stat_vals.p, c->stat_types.p, c->stat_part.p);
+        for (int pass = 0; pass < 4; pass++) {
+            hipLaunchKernelGGL(stats_hist_kernel, dim3(nb), dim3(256), 0, c->stream, (const double*)c->stat_vals.p, (const signed char*)c->stat_types.p, n, pass, (const StatWork*)c->stat_work.p, c->stat_hist.p);
+            hipLaunchKernelGGL(stats_pick_kernel, dim3(kStatTypes), dim3(256), 0, c->stream, pass, c->stat_work.p, c->stat_hist.p);
+        }
+        hipLaunchKernelGGL(stats_final_kernel, dim3(1), dim3(64), 0, c->stream, (const double*)c->stat_part.p, nb, c->stat_work.p, c->stat_out.p);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(out, c->stat_out.p, sizeof(*out), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    out->n_blocks = blocks + (int)out->type[VELO_FUNCTOR_3DPD].count;
+    out->n_residuals = residuals + (int)out->type[VELO_FUNCTOR_3DPD].count;
+    return VELO_OK;
+}
+
 int velo_solve(velo_ctx* c, double x[6], velo_solve_summary* summary) {
     if (!c || !x) return fail(VELO_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
@@ -1752,7 +1886,7 @@ int velo_solve(velo_ctx* c, double x[6], velo_solve_summary* summary) {
 // more raises the chain's failure flag in the next association (its record is not ready), everything behind it drains, and the
 // call is repeated by the host-driven path below -- same kernels, same arithmetic, so the result does not depend on which path ran.
 static bool chain_eligible(velo_ctx* c) {
-    if (!c->chain || c->comm || c->peer_on || c->use_graphs || !c->lm_merged || c->n_matches > 0 || !c->P.enable_icp) return false;
+    if (!c->chain || c->want_stats || c->comm || c->peer_on || c->use_graphs || !c->lm_merged || c->n_matches > 0 || !c->P.enable_icp) return false;
     if (c->assoc_variant >= 0 && c->assoc_variant != 5) return false;
     if (c->debug_skip || c->lm_trace_on || c->tube_map >= 0 || c->shard_world != 1) return false;
     if (c->P.f2f_iterations * c->P.icp_iterations < 1) return false;
@@ -1898,6 +2032,10 @@ int velo_frame_to_frame(velo_ctx* c, double x[6], double T[16], velo_summary* su
             if (S->n_solves < VELO_MAX_SOLVES) S->solves[S->n_solves] = ss;
             S->n_solves++;
         }
+        if (c->want_stats && iter <= VELO_MAX_STATS) {                              // velo.h:909
+            VELO_TRY(velo_residual_stats_at(c, xc, &S->residual_stats[iter - 1]));
+            S->n_residual_stats = iter;
+        }
     }
     if (c->timing) VELO_TRY(read_assoc_timing(c, S));
     for (int k = 0; k < 6; k++) x[k] = xc[k];
@@ -1915,7 +2053,7 @@ static bool batch_can_lockstep(velo_ctx** ctxs, int n, bool targets_follow = fal
     if (n < 2 || !ctxs[0] || !ctxs[0]->batch_lockstep) return false;
     for (int i = 0; i < n; i++) {
         const velo_ctx* c = ctxs[i];
-        if (!c || c->device != ctxs[0]->device || c->comm || c->peer_on || c->use_graphs) return false;
+        if (!c || c->device != ctxs[0]->device || c->comm || c->peer_on || c->use_graphs || c->want_stats) return false;
         if ((!c->have_target && !targets_follow) || (!c->have_source && !sources_follow) || c->shard_world != 1) return false;
         if (std::memcmp(&c->P, &ctxs[0]->P, sizeof(velo_params)) != 0) return false;
         for (int j = 0; j < i; j++) if (ctxs[j] == c) return false;
@@ -1926,7 +2064,7 @@ static bool batch_can_lockstep(velo_ctx** ctxs, int n, bool targets_follow = fal
 // ---- the same association round of several contexts in ONE launch (lock-step batch driver) ---------------------------------------
 // Host-side preparation of one context's round for the tube kernel, exactly what do_associate does before its launch.
 // *groups = 0 when the context has no queries.
-static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs* A, int* groups, bool* asker) {
+static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs* A, int* groups, bool* asker, bool* lane) {
     if (!c->have_target || !c->have_source) return fail(VELO_ERR_STATE, "associate needs set_target and set_source first");
     if (c->src_skip != std::max(c->P.icp_skip, 1) || (c->n_q > 0) != (c->P.enable_icp != 0 && c->h_q_off[c->n_src_rings] > 0)) VELO_TRY(build_query_list(c));
     Grid* G = grid_for_iter(c, iter);
@@ -1951,6 +2089,8 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
     out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p + c->nv_idx; out.dbg = c->dbg.p; out.wg_times = nullptr;
     out.first_ring = c->T->tgt_first_ring; out.first_point = c->T->tgt_first_point; out.partial = nullptr;
     VELO_TRY(attach_seeds(c, &out));
+    *lane = lane_round(c, G, false);
+    if (out.prev_a) c->seed_rounds++;
     out.n_valid_next = c->n_valid.p + (c->nv_idx ^ 1);
     c->nv_clean[c->nv_idx ^ 1] = true;
     A->want_aux = 0; A->group_perm = nullptr; A->dbg = 0;
@@ -1990,10 +2130,11 @@ static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::arr
         AssocBatch B;
         std::memset(&B, 0, sizeof(B));
         int gmax = 0, k = 0, first = -1;
-        bool any_asker = false;
+        bool any_asker = false, all_lane = true;
         for (int i = b; i < b + m; i++) {
-            int groups = 0; bool asker = false;
-            VELO_TRY(prepare_assoc_v5(ctxs[i], xs[(size_t)i].data(), iter, &B.item[k], &groups, &asker));
+            int groups = 0; bool asker = false, lane = false;
+            VELO_TRY(prepare_assoc_v5(ctxs[i], xs[(size_t)i].data(), iter, &B.item[k], &groups, &asker, &lane));
+            if (groups > 0) all_lane = all_lane && lane;
             ctxs[i]->have_corr = true;
             if (pose_dev) { B.item[k].P_dev = pose_dev + i; B.item[k].chain_fail = fail_dev + i; }
             if (groups == 0) continue;                                  // no queries: nothing to launch for it
@@ -2013,7 +2154,8 @@ static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::arr
             ev = &c->assoc_events[c->assoc_events_used++];
         }
         launched[(size_t)first] = 1;
-        if (any_asker) hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, true>), dim3(gmax, k), dim3(256), c->assoc_lds_pad, c->stream,
+        if (all_lane) hipExtLaunchKernelGGL(assoc_lane_batch_kernel, dim3(cdiv(gmax, 4), k), dim3(256), 0, c->stream, ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, B);
+        else if (any_asker) hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, true>), dim3(gmax, k), dim3(256), c->assoc_lds_pad, c->stream,
                                              ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, B);
         else hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, false>), dim3(gmax, k), dim3(256), c->assoc_lds_pad, c->stream,
                                    ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, B);
@@ -2307,7 +2449,6 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
         }
         std::vector<int> gst((size_t)G, VELO_OK);
         std::vector<std::string> gerr((size_t)G);
-        std::vector<std::thread> gth;
         auto run_group = [&](int gi) {
             const int b = (int)((int64_t)n * gi / G), e = (int)((int64_t)n * (gi + 1) / G);
             // this group's index builds, then its registrations: no barrier across groups, so one group's association launches
@@ -2320,24 +2461,17 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
             gst[(size_t)gi] = f2f_batch_lockstep(ctxs + b, e - b, x + 6 * (size_t)b, T ? T + 16 * (size_t)b : nullptr, summaries ? summaries + b : nullptr);
             if (gst[(size_t)gi] != VELO_OK) gerr[(size_t)gi] = g_err;
         };
-        for (int gi = 1; gi < G; gi++) gth.emplace_back(run_group, gi);
-        run_group(0);                                            // the calling thread drives the first group itself
-        for (auto& t : gth) t.join();
+        WorkerPool::instance().run(G, run_group);                // the calling thread drives the first group itself, resident workers the others
         for (int gi = 0; gi < G; gi++) if (gst[(size_t)gi] != VELO_OK) { g_err = gerr[(size_t)gi]; return gst[(size_t)gi]; }
         return VELO_OK;
     }
     std::vector<int> status((size_t)n, VELO_OK);
     std::vector<std::string> errs((size_t)n);
-    std::vector<std::thread> th;
-    th.reserve((size_t)n);
-    for (int i = 0; i < n; i++) {
-        th.emplace_back([&, i]() {
-            status[i] = load_job(ctxs[i], target_of(i), sources ? sources + i : nullptr);
-            if (status[i] == VELO_OK) status[i] = velo_frame_to_frame(ctxs[i], x + 6 * (size_t)i, T ? T + 16 * (size_t)i : nullptr, summaries ? summaries + i : nullptr);
-            if (status[i] != VELO_OK) errs[i] = g_err;
-        });
-    }
-    for (auto& t : th) t.join();
+    WorkerPool::instance().run(n, [&](int i) {
+        status[i] = load_job(ctxs[i], target_of(i), sources ? sources + i : nullptr);
+        if (status[i] == VELO_OK) status[i] = velo_frame_to_frame(ctxs[i], x + 6 * (size_t)i, T ? T + 16 * (size_t)i : nullptr, summaries ? summaries + i : nullptr);
+        if (status[i] != VELO_OK) errs[i] = g_err;
+    });
     for (int i = 0; i < n; i++) if (status[i] != VELO_OK) { g_err = errs[i]; return status[i]; }
     return VELO_OK;
 }

@@ -1390,6 +1390,180 @@ assoc_search_v5_batch_kernel(AssocBatch B) {
                                                     a.cluster_w, a.h_safe, a.out, a.want_aux, a.group_perm, a.dbg, a.asker_rows, (int)blockIdx.x);
 }
 
+// ---- association search, lane variant: the rounds that start from seeds ------------------------------------------------------
+// The tube kernel shares every staged candidate among the 64 queries of a group: 350 candidates x 64 lanes per warm round, of
+// which a query needs the ~15 of its own bound sphere -- 9,400 lane-instructions per query.  A round that starts from the
+// previous round's winners knows a tight bound for (nearly) every query BEFORE it looks at a single cell, so sharing buys
+// nothing: here ONE LANE OWNS ONE QUERY and walks the cells of its own bound sphere straight from the cell-sorted copy in L2
+// (neighbouring lanes walk neighbouring cells, so the gathers share lines).  No tile, no run list of the group, no workgroup
+// barrier -- a workgroup is four independent waves.
+//   * easy query (bound box <= 3 x 3 rows, the rule whenever the bound is below one cell): the lane fetches the (start, end)
+//     of its <= 9 row runs at once, keeps the non-empty ones in its LDS column and then consumes them four candidates per trip
+//     (all four loads in flight together; entries behind the end of a run are real points of the next cells or the +inf
+//     sentinels behind the last point -- harmless extra candidates);
+//   * hard query (a query whose second ring is farther than a cell: no second seed, first iteration's gate = 4 cells): the
+//     wave turns all 64 lanes on that one query, as the tube kernel's asker phase does (rows over lanes -> wave prefix sum ->
+//     candidates over lanes -> xor-shuffle merge).
+// Candidate set = every point of every cell the bound sphere touches, keys and tie rules as everywhere else: the tables equal the
+// tube kernel's bit for bit (tests: warm rounds against cold rounds, against the oracle, lane against tube).
+// MEASURED (C2, one pair in flight): 88-90 us per second-iteration round against the tube kernel's 46-50, 440 us per seeded
+// first-iteration round (10-25 % hard queries, each a 9 x 9-row box) against 80.  The instruction count is what was hoped for, but
+// every lane-private 16-byte gather pulls a 128-byte line from L2 into a 16 KB L1 that 64 lanes x 8 gathers per trip thrash: the
+// kernel waits on L2->L1 line traffic (~0.8 MB per wave) that the tube kernel's coalesced staging never creates.  Kept as an
+// independent second implementation for the parity tests and as an A/B (VELO_ASSOC_LANE=1), NOT the default.
+template <bool DBG>
+__device__ __forceinline__ void
+assoc_lane_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_dev, int* __restrict__ chain_fail, const GridView& G, const float4* __restrict__ qpts, int q_begin, int q_end,
+                const float4* __restrict__ tgt_pad, const int* __restrict__ tgt_off, unsigned gate_bits, double norm_cond, const AssocOut& out, int want_aux, const int block_x) {
+    constexpr int kRows = 9;
+    __shared__ int s_j0[4][kRows][64];
+    __shared__ int s_j1[4][kRows][64];
+    __shared__ int s_cj0[4][66];
+    __shared__ int s_coff[4][66];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (chain_fail && *chain_fail) return;
+    if (P_dev && !P_dev->ready) { if (block_x == 0 && tid == 0) *chain_fail = 1; return; }
+    const PoseScalars& P = P_dev ? P_dev->P : P_in;
+    if (out.n_valid_next && block_x == 0 && tid == 0) *out.n_valid_next = 0;
+    const int group = block_x * 4 + wid;
+    if (group * 64 >= q_end - q_begin) return;                         // wave-uniform
+    const int qi = q_begin + group * 64 + lane;
+    const bool active = qi < q_end;
+    const unsigned long long key_inf = ((unsigned long long)gate_bits + 1ull) << 32;
+    Top2 t;
+    t.b1 = key_inf; t.b2 = key_inf; t.b1ring = -1; t.b2ring = -1; t.b2d = __uint_as_float(gate_bits + 1u);
+    const GridDesc g = G.d;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (active) {
+        const float4 psrc = qpts[qi];
+        const float4 sa = out.prev_a[qi], sb = out.prev_b[qi];
+        const int2 sr = out.prev_r[qi];
+        transform_query(P, psrc, &qx, &qy, &qz);
+        if (__float_as_int(sa.w) >= 0) {
+            const float d = dist2_f(sa.x, sa.y, sa.z, qx, qy, qz);
+            if (__float_as_uint(d) <= gate_bits) top2_update(t, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(__float_as_int(sa.w) + out.first_point), sr.x);
+        }
+        if (__float_as_int(sb.w) >= 0) {
+            const float d = dist2_f(sb.x, sb.y, sb.z, qx, qy, qz);
+            if (__float_as_uint(d) <= gate_bits) top2_update(t, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(__float_as_int(sb.w) + out.first_point), sr.y);
+        }
+    }
+    // the cell box of the bound sphere (padded against rounding, like the tube kernel's)
+    const float r0 = sqrtf(t.b2d) * 1.0001f + 1e-6f;
+    int x0, x1, y0, y1, z0, z1;
+    {
+        const CellBox bb = query_box(g, qx, qy, qz, 0, 0, 0, r0, false);
+        x0 = max(bb.x0, 0); x1 = min(bb.x1, g.nx - 1); y0 = max(bb.y0, 0); y1 = min(bb.y1, g.ny - 1); z0 = max(bb.z0, 0); z1 = min(bb.z1, g.nz - 1);
+    }
+    const int nyb = y1 - y0 + 1, nzb = z1 - z0 + 1;
+    const bool some = active && x0 <= x1 && nyb > 0 && nzb > 0;        // else: the sphere lies outside the grid, nothing to look at
+    const bool easy = some && nyb <= 3 && nzb <= 3;
+    const bool hard = some && !easy;
+    // ---- easy lanes: own row runs -> LDS column -> four candidates per trip ----
+    int nrun = 0;
+    if (easy) {
+        int a[kRows], b[kRows];
+#pragma unroll
+        for (int zz = 0; zz < 3; zz++) {
+#pragma unroll
+            for (int yy = 0; yy < 3; yy++) {
+                const bool on = zz < nzb && yy < nyb;
+                const int row = on ? ((z0 + zz) * g.ny + (y0 + yy)) * g.nx : 0;
+                a[zz * 3 + yy] = on ? G.cell_start[row + x0] : 0;
+                b[zz * 3 + yy] = on ? G.cell_start[row + x1 + 1] : 0;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kRows; k++) {
+            if (b[k] > a[k]) { s_j0[wid][nrun][lane] = a[k]; s_j1[wid][nrun][lane] = b[k]; nrun++; }
+        }
+    }
+    {
+        int k = 0, j = 0, jend = 0;
+        for (;;) {
+            if (j >= jend && k < nrun) { j = s_j0[wid][k][lane]; jend = s_j1[wid][k][lane]; k++; }
+            const bool have = j < jend;
+            if (__ballot(have) == 0ull) break;
+            const int jj = have ? j : 0;
+            const float4 c0 = G.sorted[jj], c1 = G.sorted[jj + 1], c2 = G.sorted[jj + 2], c3 = G.sorted[jj + 3];
+            const int g0 = G.sring[jj], g1 = G.sring[jj + 1], g2 = G.sring[jj + 2], g3 = G.sring[jj + 3];
+            const float d0 = dist2_f(qx, qy, qz, c0.x, c0.y, c0.z), d1 = dist2_f(qx, qy, qz, c1.x, c1.y, c1.z);
+            const float d2 = dist2_f(qx, qy, qz, c2.x, c2.y, c2.z), d3 = dist2_f(qx, qy, qz, c3.x, c3.y, c3.z);
+            if (have && fminf(fminf(d0, d1), fminf(d2, d3)) <= t.b2d) {
+                if (d0 <= t.b2d) top2_update(t, ((unsigned long long)__float_as_uint(d0) << 32) | (unsigned)__float_as_int(c0.w), g0);
+                if (d1 <= t.b2d) top2_update(t, ((unsigned long long)__float_as_uint(d1) << 32) | (unsigned)__float_as_int(c1.w), g1);
+                if (d2 <= t.b2d) top2_update(t, ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(c2.w), g2);
+                if (d3 <= t.b2d) top2_update(t, ((unsigned long long)__float_as_uint(d3) << 32) | (unsigned)__float_as_int(c3.w), g3);
+            }
+            j += 4;
+        }
+    }
+    // ---- hard lanes: the whole wave on one query at a time ----
+    unsigned long long hm = __ballot(hard);
+    while (hm != 0ull) {
+        const int la = (int)__ffsll((long long)hm) - 1;
+        hm &= hm - 1ull;
+        const float ax = __shfl(qx, la), ay = __shfl(qy, la), az = __shfl(qz, la);
+        Top2 tl;
+        tl.b1 = __shfl(t.b1, la); tl.b2 = __shfl(t.b2, la); tl.b1ring = __shfl(t.b1ring, la); tl.b2ring = __shfl(t.b2ring, la);
+        tl.b2d = __uint_as_float((unsigned)(tl.b2 >> 32));
+        const int bx0 = __shfl(x0, la), bx1 = __shfl(x1, la), by0 = __shfl(y0, la), bz0 = __shfl(z0, la);
+        const int ny = __shfl(nyb, la), nz = __shfl(nzb, la);
+        const int nrows_a = ny * nz;
+        const float rcp_ny = 1.0f / (float)ny;
+        for (int rb = 0; rb < nrows_a; rb += 64) {
+            const int r = rb + lane;
+            int j0 = 0, len = 0;
+            if (r < nrows_a) {
+                int zq = (int)((float)r * rcp_ny), yr = r - zq * ny;
+                if (yr < 0) { zq--; yr += ny; } else if (yr >= ny) { zq++; yr -= ny; }
+                const int row = ((bz0 + zq) * g.ny + (by0 + yr)) * g.nx;
+                j0 = G.cell_start[row + bx0]; len = G.cell_start[row + bx1 + 1] - j0;
+            }
+            int inc = len;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+            const int total = __shfl(inc, 63);
+            s_cj0[wid][lane] = j0; s_coff[wid][lane] = inc - len;
+            if (lane == 0) s_coff[wid][64] = total;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int slot = lane; slot < total; slot += 64) {
+                int lo = 0;                                            // largest i with s_coff[i] <= slot
+#pragma unroll
+                for (int step = 32; step > 0; step >>= 1) { if (s_coff[wid][lo + step] <= slot) lo += step; }
+                const int j = s_cj0[wid][lo] + (slot - s_coff[wid][lo]);
+                const float4 c = G.sorted[j];
+                const float d = dist2_f(ax, ay, az, c.x, c.y, c.z);
+                if (d <= tl.b2d) top2_update(tl, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(c.w), G.sring[j]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();                           // the run list is rewritten by the next rows
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) top2_merge_xor(tl, m);
+        if (lane == la) { t.b1 = tl.b1; t.b2 = tl.b2; t.b1ring = tl.b1ring; t.b2ring = tl.b2ring; t.b2d = tl.b2d; }
+    }
+    if (active) finish_correspondence_pad(qi, qpts, qx, qy, qz, t.b1, t.b2, t.b1ring, t.b2ring, key_inf, tgt_pad, tgt_off, norm_cond, out, want_aux != 0);
+}
+
+__global__ void __launch_bounds__(256)
+assoc_lane_kernel(PoseScalars P, const PoseRecord* __restrict__ P_dev, int* __restrict__ chain_fail, GridView G, const float4* __restrict__ qpts, int q_begin, int q_end,
+                  const float4* __restrict__ tgt_pad, const int* __restrict__ tgt_off, unsigned gate_bits, double norm_cond, AssocOut out, int want_aux) {
+    assoc_lane_body<false>(P, P_dev, chain_fail, G, qpts, q_begin, q_end, tgt_pad, tgt_off, gate_bits, norm_cond, out, want_aux, (int)blockIdx.x);
+}
+// the same round of several contexts in one launch (blockIdx.y = context)
+__global__ void __launch_bounds__(256)
+assoc_lane_batch_kernel(AssocBatch B) {
+    const AssocArgs& a = B.item[blockIdx.y];
+    if ((int)blockIdx.x * 256 >= a.q_end - a.q_begin) return;
+    assoc_lane_body<false>(a.P, a.P_dev, a.chain_fail, a.G, a.qpts, a.q_begin, a.q_end, a.tgt_pad, a.tgt_off, a.gate_bits, a.norm_cond, a.out, a.want_aux, (int)blockIdx.x);
+}
+
 // ---- association as a balanced pipeline: prepare (clusters -> work items) + persistent per-cluster search -----------------
 // The monolithic kernel above walks a group's clusters one after the other, so a 64-query group with several clusters and
 // two phases each is a long latency chain while most workgroups have already left.  Here a cheap prepare kernel (one
@@ -1862,6 +2036,119 @@ struct EvalArgs {
     unsigned long long* __restrict__ trace; // diagnostics build only (VELO_LM_TRACE): [evaluation][16 stages][first, last] s_memrealtime stamps
     int trace_eval;                         // index of this evaluation within the solve (from the host: the stamps add no loads)
 };
+
+// ---- residualStats (velo.h:921-1025): per residual type the median, mean and count of the block norms, loss NOT applied ---------
+// The reference evaluates the problem without loss functions, turns every block into one number (3D3D: sqrt(r0^2 + r1^2 + r2^2);
+// 3D2D / 2D3D: sqrt(r0^2 + r1^2); 2D2D and 3DPD: |r|), sorts each type's numbers and prints sorted[size / 2], sum / size, size.
+// Here: one thread per block slot writes its number and type; the median is a 4-pass 16-bit radix SELECT on the bit patterns (the
+// numbers are >= 0, so patterns order like values) -- no sort; sums are fixed-order block reductions (the mean can differ from the
+// reference's left-to-right sum in the last bits, the median and the counts cannot).
+constexpr int kStatTypes = 5;                 // VELO_RESIDUAL_3D3D, _3D2D, _2D3D, _2D2D, VELO_FUNCTOR_3DPD
+constexpr int kStatBins = 65536;
+struct StatWork {                             // device scratch of one statistics call
+    unsigned long long prefix[kStatTypes];    // bit pattern of the median found so far (high digits)
+    long long k[kStatTypes];                  // rank still to go inside the current prefix
+    long long count[kStatTypes];
+    double sum[kStatTypes];
+    double cost;                              // 1/2 sum r^2 over all residuals (ceres::Problem::Evaluate without loss)
+};
+__global__ void __launch_bounds__(256)
+residual_norms_kernel(const double* __restrict__ xdev, EvalArgs A, double* __restrict__ vals, signed char* __restrict__ types,
+                      double* __restrict__ part /* [gridDim.x][kStatTypes + 1] */) {
+    __shared__ PoseEval s_P;
+    __shared__ double s_red[256];
+    if (threadIdx.x == 0) {
+        double x[6];
+        for (int k = 0; k < 6; k++) x[k] = xdev[k];
+        pose_eval_init(x, &s_P, true);
+    }
+    __syncthreads();
+    const int n_vis = 3 * A.n_matches, nq = A.q_end - A.q_begin;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double v = 0.0, sq = 0.0;
+    int type = -1;
+    if (i < n_vis) {
+        const unsigned char f = A.vflags[i];
+        if (f) {
+            const VisualMatch m = A.vm[i / 3];
+            double r0, r1, r2, J[18];
+            const int d = visual_block_eval3(s_P, m, i % 3, r0, r1, r2, J);
+            type = f - 1;
+            if (d == 3) { sq = r0 * r0 + r1 * r1 + r2 * r2; v = sqrt(sq); }
+            else if (d == 2) { sq = r0 * r0 + r1 * r1; v = sqrt(sq); }
+            else { sq = r0 * r0; v = fabs(r0); }
+        }
+    } else if (i < n_vis + nq) {
+        const int qi = A.q_begin + (i - n_vis);
+        const float4 cp = A.cp[qi];
+        if (__float_as_int(cp.w)) {
+            const float4 cn = A.cn[qi], c0 = A.cv0[qi];
+            const double p[3] = {cp.x, cp.y, cp.z}, n[3] = {cn.x, cn.y, cn.z}, v0[3] = {c0.x, c0.y, c0.z};
+            double r, J[6];
+            res_3dpd(s_P.fwd, s_P.t, p, n, v0, &r, J);
+            type = VELO_FUNCTOR_3DPD; sq = r * r; v = fabs(r);
+        }
+    }
+    if (i < n_vis + nq) { vals[i] = v; types[i] = (signed char)type; }
+    // fixed-order block sums: per type, then the cost
+    for (int t = 0; t <= kStatTypes; t++) {
+        s_red[threadIdx.x] = (t < kStatTypes) ? (type == t ? v : 0.0) : sq;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) { if ((int)threadIdx.x < off) s_red[threadIdx.x] += s_red[threadIdx.x + off]; __syncthreads(); }
+        if (threadIdx.x == 0) part[(size_t)blockIdx.x * (kStatTypes + 1) + t] = s_red[0];
+        __syncthreads();
+    }
+}
+// pass p (0..3): histogram of digit p (16 bits, from the top) over the elements whose higher digits equal the prefix found so far
+__global__ void __launch_bounds__(256)
+stats_hist_kernel(const double* __restrict__ vals, const signed char* __restrict__ types, int n, int pass, const StatWork* __restrict__ W, int* __restrict__ hist) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int t = types[i];
+    if (t < 0) return;
+    const unsigned long long b = (unsigned long long)__double_as_longlong(vals[i]);
+    if (pass > 0 && (b >> (64 - 16 * pass)) != W->prefix[t]) return;
+    atomicAdd(&hist[(size_t)t * kStatBins + (int)((b >> (48 - 16 * pass)) & 0xffffull)], 1);
+}
+// one workgroup per type: the bin that holds rank k; pass 0 also derives count and k = count / 2.  Clears the bins behind itself.
+__global__ void __launch_bounds__(256)
+stats_pick_kernel(int pass, StatWork* __restrict__ W, int* __restrict__ hist) {
+    __shared__ long long s_tot[256];
+    const int t = blockIdx.x, tid = threadIdx.x;
+    int* h = hist + (size_t)t * kStatBins;
+    constexpr int per = kStatBins / 256;
+    long long mine = 0;
+    for (int u = 0; u < per; u++) mine += h[tid * per + u];
+    s_tot[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        long long total = 0;
+        for (int u = 0; u < 256; u++) total += s_tot[u];
+        if (pass == 0) { W->count[t] = total; W->k[t] = total / 2; W->prefix[t] = 0ull; }
+        long long k = W->k[t];
+        if (total > 0) {
+            int seg = 0;
+            while (seg < 255 && k >= s_tot[seg]) { k -= s_tot[seg]; seg++; }
+            int bin = seg * per;
+            while (bin < seg * per + per - 1 && k >= h[bin]) { k -= h[bin]; bin++; }
+            W->prefix[t] = (W->prefix[t] << 16) | (unsigned long long)bin;
+            W->k[t] = k;
+        }
+    }
+    __syncthreads();
+    for (int u = 0; u < per; u++) h[tid * per + u] = 0;
+}
+__global__ void stats_final_kernel(const double* __restrict__ part, int n_blocks, StatWork* __restrict__ W, velo_residual_stats* __restrict__ out) {
+    const int t = threadIdx.x;
+    if (t > kStatTypes) return;
+    double s = 0.0;
+    for (int b = 0; b < n_blocks; b++) s += part[(size_t)b * (kStatTypes + 1) + t];
+    if (t == kStatTypes) { out->cost = 0.5 * s; return; }
+    const long long n = W->count[t];
+    out->type[t].count = n;
+    out->type[t].mean = n > 0 ? s / (double)n : 0.0;
+    out->type[t].median = n > 0 ? __longlong_as_double((long long)W->prefix[t]) : 0.0;
+}
 
 // Time line of the LM chain (tools/lm_trace.py): every workgroup's thread 0 stamps the stages it passes with the 100 MHz real-time
 // counter; per evaluation and stage the buffer keeps the first and the last stamp.  Compiled only into the tools' build.
