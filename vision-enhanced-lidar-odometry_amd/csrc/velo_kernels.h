@@ -950,11 +950,8 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // The single-wave sections (set-up, cell boxes, finish) are done by wave `lead` of the workgroup, and `lead` rotates with the
-    // workgroup id: wave w of a workgroup sits on SIMD w of its CU, so with wave 0 everywhere the 6-7 resident workgroups of a CU
-    // queue those sections on ONE SIMD while three idle (measured: set-up + finish = 22 % of the VALU instructions but 45 % of
-    // the kernel's time).  Workgroups of one CU are 8 x 32 ids apart (XCD round-robin, then the XCD's CUs), hence the two shifts.
-    const int lead = NW > 1 ? (int)(((unsigned)block_x >> 3) + ((unsigned)block_x >> 8)) % NW : 0;
+    // (rotating the wave that runs the single-wave sections -- set-up, cell boxes, finish -- over the SIMDs of the CU: measured, no change)
+    constexpr int lead = 0;
     // chain mode: the pose scalars come from the device record of the solve that ran just ahead of this launch
     if (chain_fail && *chain_fail) return;
     if (P_dev && !P_dev->ready) { if (block_x == 0 && tid == 0) *chain_fail = 1; return; }
@@ -2675,7 +2672,8 @@ __global__ void lm_begin_kernel(LMState* S, LMEvalPoint* pt, const double* __res
 // issued before the first is used), the transition runs on a register copy, four lanes build the eval point.
 // first != 0: start of a solve (what lm_begin_kernel does) -- no partial rows yet, the state's bookkeeping is reset and the eval
 // point is x_in (or the state's x).  Returns with the workgroup synchronised.
-__device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* S, const double* E);
+__device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* S, const double* E, bool* need_step = nullptr);
+__device__ __forceinline__ void lm_transition_wave(const LMParams& Q, LMState* sL, const double* E, int lane);
 constexpr int kStepChunk = 128;
 static_assert(kStepChunk * kNumAcc == kScratchDoubles && kStepChunk * kNumAcc % 256 == 0 && kStepChunk % 8 == 0, "chunk geometry");
 __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __restrict__ Sin, const double* __restrict__ partials, int n_blocks, int first,
@@ -2727,23 +2725,21 @@ __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __r
         __syncthreads();
         if (comm) peer_allreduce28(*comm, E);                // query-sharded: every rank continues with the same 28 sums
         VELO_LM_TRACE(trace, trace_eval, 6);
-        if (t == 0) {
-            LMState L = *sL;
-            lm_transition_local(Q, &L, E);
-            *sL = L;
-            if (L.done && writer) {                          // the solve has just finished: what the host and the next round need
-                if (log) {
-                    for (int i = 0; i < 6; i++) log->x[i] = L.x[i];
-                    log->initial_cost = L.initial_cost; log->final_cost = L.cost;
-                    log->termination = L.termination; log->iter = L.iter; log->evals = L.evals; log->n_valid = L.n_valid;
-                }
-                if (pose_out) {
-                    PoseScalars S;
-                    pose_scalars_compute(L.x, &S);
-                    pose_out->P = S;
-                    __threadfence();
-                    pose_out->ready = 1;
-                }
+        if (t < 64) lm_transition_wave(Q, sL, E, t);
+        if (t == 0 && sL->done && writer) {                  // the solve has just finished: what the host and the next round need
+            if (log) {
+                for (int i = 0; i < 6; i++) log->x[i] = sL->x[i];
+                log->initial_cost = sL->initial_cost; log->final_cost = sL->cost;
+                log->termination = sL->termination; log->iter = sL->iter; log->evals = sL->evals; log->n_valid = sL->n_valid;
+            }
+            if (pose_out) {
+                double xf[6];
+                for (int i = 0; i < 6; i++) xf[i] = sL->x[i];
+                PoseScalars S;
+                pose_scalars_compute(xf, &S);
+                pose_out->P = S;
+                __threadfence();
+                pose_out->ready = 1;
             }
         }
     }
@@ -2817,7 +2813,8 @@ lm_iter_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int k, s
                  it.A.partials + (size_t)((k + 1) & 1) * half, k == 0 ? 1 : 0, it.xd, it.n_valid, blockIdx.x, it.nb_icp, it.pose_out, it.log);
 }
 
-__device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* S, const double* E) {
+// need_step != null: the trust-region step is left to the caller (lm_compute_step_wave), *need_step says whether one is due
+__device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* S, const double* E, bool* need_step) {
     S->evals++;
     const double ecost = E[27];
     if (S->phase == PHASE_INIT) {
@@ -2830,7 +2827,7 @@ __device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* 
         if (gm <= Q.gradient_tolerance) { S->done = 1; S->termination = 0; return; }
         for (int j = 0; j < 6; j++) S->scale[j] = 1.0 / (1.0 + sqrt(S->H[tri(j, j)]));
         S->radius = Q.initial_radius; S->decrease = 2.0; S->reuse_diag = 0; S->invalid = 0;
-        lm_compute_step(Q, S);
+        if (need_step) *need_step = true; else lm_compute_step(Q, S);
         return;
     }
     // PHASE_CAND: E is the evaluation at xc
@@ -2851,7 +2848,137 @@ __device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* 
     } else {
         S->radius = S->radius / S->decrease; S->decrease *= 2.0; S->reuse_diag = 1;
     }
-    lm_compute_step(Q, S);
+    if (need_step) *need_step = true; else lm_compute_step(Q, S);
+}
+
+// lm_compute_step by the 64 lanes of one wave.  The serial version is a chain of ~600 dependent double-precision operations on
+// one lane (3.8 us of a 14.5 us LM iteration); here the independent ones run side by side -- the 36 scaled entries, the rows of a
+// Cholesky column, the forward substitution's updates, the 36 products of d^T H d -- while every SUM keeps the serial order
+// (columns left to right, rows top to bottom), so each result is the same sequence of IEEE operations: bit-identical to
+// lm_compute_step, which the other paths (two-launch step, single-launch small solve) still run; tests compare them.
+// Lane r < 6 owns row r of the matrix; values every lane needs are computed redundantly (same cost as on one lane) or read
+// with v_readlane from the lane that owns them.
+__device__ __forceinline__ double lane_get(double v, int src_lane) {       // src_lane: compile-time constant after unrolling
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src_lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), src_lane);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ void lm_compute_step_wave(const LMParams& Q, LMState* S, int lane) {
+    const int r = lane < 6 ? lane : 5;                                 // row of this lane (lanes >= 6 shadow row 5; their values are never read)
+    double sc[6], gs[6], hrow[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { sc[i] = S->scale[i]; gs[i] = S->g[i] * sc[i]; }
+    const double scr = S->scale[r];
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        const double h = S->H[r <= c ? tri(r, c) : tri(c, r)];
+        hrow[c] = h * scr * sc[c];                                     // Hs[r][c] = h * scale[r] * scale[c]
+    }
+    const int ei = lane < 36 ? lane / 6 : 5, ej = lane < 36 ? lane % 6 : 5;   // element view for d^T Hs d: lane l < 36 owns Hs[l / 6][l % 6]
+    const double hs_e = S->H[ei <= ej ? tri(ei, ej) : tri(ej, ei)] * S->scale[ei] * S->scale[ej];
+    int iter = S->iter, invalid = S->invalid, reuse = S->reuse_diag;
+    double radius = S->radius, decrease = S->decrease;
+    double diag_r = S->diag[r];
+    for (;;) {
+        if (iter + 1 > Q.max_num_iterations) { if (lane == 0) { S->done = 1; S->termination = 1; } break; }
+        if (radius < Q.min_radius) { if (lane == 0) { S->done = 1; S->termination = 0; } break; }
+        iter++;
+        if (!reuse) {
+            double hdd = hrow[0];
+#pragma unroll
+            for (int c = 1; c < 6; c++) hdd = (r == c) ? hrow[c] : hdd;
+            diag_r = fmin(fmax(hdd, Q.min_diag), Q.max_diag);
+        }
+        const double inv_radius = 1.0 / radius;
+        const double dterm = diag_r * inv_radius;                      // D^2 = diag / radius
+        double L[6], inv[6];
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            double sj = (r == j) ? hrow[j] + dterm : hrow[j];          // A[r][j]
+#pragma unroll
+            for (int k = 0; k < j; k++) sj -= L[k] * lane_get(L[k], j);        // L[r][k] * L[j][k]; on lane j itself: L[j][k]^2
+            const double d = lane_get(sj, j);
+            if (!(d > 0.0) || !isfinite(d)) { ok = false; break; }
+            const double ljj = sqrt(d);
+            inv[j] = 1.0 / ljj;
+            L[j] = (r == j) ? ljj : sj * inv[j];
+        }
+        double y[6];
+        if (ok) {
+            double acc = gs[0];
+#pragma unroll
+            for (int c = 1; c < 6; c++) acc = (r == c) ? gs[c] : acc;  // b[r]
+            double z[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                z[k] = lane_get(acc, k) * inv[k];                      // row k has received all its k updates
+                acc -= L[k] * z[k];                                    // rows below: s -= L[i][k] * z[k], k ascending as in the serial loop
+            }
+#pragma unroll
+            for (int i = 5; i >= 0; i--) {
+                double sv = z[i];
+#pragma unroll
+                for (int k = i + 1; k < 6; k++) sv -= lane_get(L[i], k) * y[k];       // L[k][i] lives on lane k
+                y[i] = sv * inv[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; i++) ok = ok && isfinite(y[i]);
+        }
+        reuse = 1;
+        double mc = 0.0, step[6];
+        if (ok) {
+            double gd = 0.0, dHd = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) step[i] = -y[i];
+            double si = step[0], sj = step[0];
+#pragma unroll
+            for (int c = 1; c < 6; c++) { si = (ei == c) ? step[c] : si; sj = (ej == c) ? step[c] : sj; }
+            const double prod = si * hs_e * sj;                        // step[i] * Hs[i][j] * step[j]
+#pragma unroll
+            for (int i = 0; i < 6; i++) gd += gs[i] * step[i];
+#pragma unroll
+            for (int l = 0; l < 36; l++) dHd += lane_get(prod, l);     // i-major, j inner: the serial order
+            mc = -(gd + 0.5 * dHd);
+            if (!(mc > 0.0)) ok = false;
+        }
+        if (!ok) {
+            if (++invalid >= Q.max_invalid) { if (lane == 0) { S->done = 1; S->termination = 2; } break; }
+            radius = radius / decrease; decrease *= 2.0; reuse = 1;
+            continue;
+        }
+        invalid = 0;
+        if (lane == 0) {
+            double dn = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) { const double d = step[i] * sc[i]; S->xc[i] = S->x[i] + d; dn += d * d; }
+            S->step_norm = sqrt(dn);
+            S->model_change = mc;
+            S->phase = PHASE_CAND;
+        }
+        break;
+    }
+    if (lane < 6) S->diag[lane] = diag_r;
+    if (lane == 0) { S->iter = iter; S->invalid = invalid; S->reuse_diag = reuse; S->radius = radius; S->decrease = decrease; }
+}
+// the transition by the first wave of the step's workgroup: bookkeeping on lane 0, the trust-region step by all 64 lanes
+__device__ __forceinline__ void lm_transition_wave(const LMParams& Q, LMState* sL, const double* E, int lane) {
+    int need = 0;
+    if (lane == 0) {
+        LMState L = *sL;
+        bool ns = false;
+        lm_transition_local(Q, &L, E, &ns);
+        *sL = L;
+        need = ns ? 1 : 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    need = __builtin_amdgcn_readfirstlane(need);
+    if (need) lm_compute_step_wave(Q, sL, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __global__ void __launch_bounds__(256)
