@@ -362,9 +362,11 @@ def main():
 
     if rank == 0:
         rf = dict(main_leg["roofline"])
-        tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+        # the committed PMC passes: profiles/rNN_traffic.json (config 2), profiles/rNN_c4_traffic.json (config 4)
+        pat = {"c2": "r[0-9][0-9]_traffic.json", "c4": "r[0-9][0-9]_c4_traffic.json"}.get(a.workload)
+        tf = sorted(glob.glob(os.path.join(ROOT, "profiles", pat))) if pat else []
         sq = None
-        if tf and a.workload == "c2":
+        if tf:
             try:
                 tj = json.load(open(tf[-1]))
                 rf["traffic"] = tj["traffic_bytes_per_launch"]
