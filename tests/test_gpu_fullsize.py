@@ -214,6 +214,36 @@ def test_batch_entry_point_equals_single_calls(hip_lib, monkeypatch):
             c.close()
 
 
+def test_asker_list_in_single_calls_and_batches_equals_in_place_search(hip_lib, monkeypatch):
+    """Density-shrunk grid (VELO_DENSE_REF forces it on small clouds): the cold round's asking queries are searched in place
+    (VELO_ASKER_QUEUE=0), from the list by assoc_asker_kernel in single calls (default) or also in lock-step batches (=2): same poses,
+    same solves, bit for bit."""
+    pairs = [H.small_pair(16, 128), H.small_pair(32, 200), H.small_pair(16, 96, scene_seed=3)]
+    monkeypatch.setenv("VELO_DENSE_REF", "300")
+    res = {}
+    for q in ("0", "1", "2"):
+        monkeypatch.setenv("VELO_ASKER_QUEUE", q)
+        ctxs = [api.Context(0, icp_skip=1) for _ in pairs]
+        single = []
+        for c, d in zip(ctxs, pairs):
+            c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])
+            x, T, s = c.frame_to_frame(d["x0"])
+            single.append((x.copy(), [(s.solves[k].evaluations, s.solves[k].n_icp_valid, s.solves[k].final_cost) for k in range(s.n_solves)]))
+        for c, d in zip(ctxs, pairs):
+            c.set_source(d["src_xyz"], d["src_off"])          # seeds cleared: the batch starts with a cold round again
+        xs, Ts, Ss = api.frame_to_frame_batch(ctxs, [d["x0"] for d in pairs])
+        batch = [(xs[i].copy(), [(Ss[i].solves[k].evaluations, Ss[i].solves[k].n_icp_valid, Ss[i].solves[k].final_cost) for k in range(Ss[i].n_solves)]) for i in range(len(pairs))]
+        res[q] = (single, batch)
+        for c in ctxs:
+            c.close()
+    for q in ("1", "2"):
+        for part in (0, 1):
+            for (x0, s0), (x1, s1) in zip(res["0"][part], res[q][part]):
+                assert np.array_equal(x0, x1) and s0 == s1, (q, part)
+    for (x0, s0), (x1, s1) in zip(res["0"][0], res["0"][1]):
+        assert np.array_equal(x0, x1) and s0 == s1
+
+
 def test_register_batch_equals_separate_uploads_and_batch(hip_lib):
     """velo_register_batch (scans handed over with the call, indexed on the group threads) against velo_set_target + velo_set_source +
     velo_frame_to_frame_batch: same poses, same summaries, bit for bit; host and device-resident inputs; targets only / sources only."""

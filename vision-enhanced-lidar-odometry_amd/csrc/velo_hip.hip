@@ -179,6 +179,12 @@ struct velo_ctx {
     int assoc_lds_pad = 0;               // VELO_ASSOC_LDS_PAD: bytes of unused dynamic LDS per association workgroup -- caps the association
                                          // kernel's workgroups per CU so that LM workgroups of other pairs in flight find room at once
     // chain mode: a whole frame_to_frame as ONE chain of launches (pose scalars of the next round and the solve summaries stay on the device)
+    int asker_queue = 1;                 // shrunk grid: asking queries go to assoc_asker_kernel (VELO_ASKER_QUEUE=0: searched inside their group's workgroup)
+    DevBuf<int> ask_count, ask_list;
+    DevBuf<unsigned long long> ask_keys;
+    DevBuf<int2> ask_rings;
+    int ask_idx = 0;
+    bool ask_clean[2] = {false, false};
     bool want_stats = false;             // velo_set_residual_stats
     DevBuf<double> stat_vals, stat_part;
     DevBuf<signed char> stat_types;
@@ -579,6 +585,21 @@ int attach_seeds(velo_ctx* c, AssocOut* out) {
     return VELO_OK;
 }
 
+// the asker list of a tube launch on a density-shrunk grid (see assoc_asker_kernel); enable = this launch may defer its askers
+int attach_askers(velo_ctx* c, AssocOut* out, bool enable) {
+    out->ask_count = nullptr; out->ask_count_next = nullptr; out->ask_list = nullptr; out->ask_keys = nullptr; out->ask_rings = nullptr;
+    if (!enable || !c->asker_queue) return VELO_OK;
+    const size_t nq = (size_t)std::max(c->n_q, 1);
+    VELO_TRY(c->ask_count.reserve(2)); VELO_TRY(c->ask_list.reserve(nq)); VELO_TRY(c->ask_keys.reserve(2 * nq)); VELO_TRY(c->ask_rings.reserve(nq));
+    c->ask_idx ^= 1;
+    if (!c->ask_clean[c->ask_idx]) HIP_TRY(hipMemsetAsync(c->ask_count.p + c->ask_idx, 0, sizeof(int), c->stream));
+    c->ask_clean[c->ask_idx] = false;
+    c->ask_clean[c->ask_idx ^ 1] = true;                      // the launch clears the other counter
+    out->ask_count = c->ask_count.p + c->ask_idx; out->ask_count_next = c->ask_count.p + (c->ask_idx ^ 1);
+    out->ask_list = c->ask_list.p; out->ask_keys = c->ask_keys.p; out->ask_rings = c->ask_rings.p;
+    return VELO_OK;
+}
+
 // A round may use the lane kernel when it starts from seeds (a round of this source against this target has run) on the regular
 // grid (gate radius of the first iteration <= 5 cells; the density-shrunk grid of a 2M-point map keeps the tube kernel and its
 // query-by-query second phase), with the default variant and no diagnostics / placement table / partial records.
@@ -609,6 +630,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         out.first_ring = c->T->tgt_first_ring; out.first_point = c->T->tgt_first_point; out.partial = partial ? c->partials_rec.p : nullptr;
         out.n_valid_next = nullptr;
         VELO_TRY(attach_seeds(c, &out));
+        VELO_TRY(attach_askers(c, &out, false));
         const bool lane = lane_round(c, G, partial);
         if (c->debug_skip & 32) { VELO_TRY(c->wg_times.reserve((size_t)2 * cdiv(qe - qb, 64) + 2)); out.wg_times = c->wg_times.p; c->wg_times_n = cdiv(qe - qb, 64); }
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
@@ -696,9 +718,17 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 const int asker_rows = c->asker_rows >= 0 ? c->asker_rows : (reach_cells > 5 ? 0 : (1 << 30));
                 const int* perm = nullptr;
                 if (c->tube_map >= 0) { VELO_TRY(build_group_perm(c, qb, qe, c->tube_map)); perm = c->group_perm.p; }
+                // density-shrunk grid, default instantiation, COLD round (no seeds yet: half of the queries ask, the heavy ones in clumps): the asking
+                // queries go on a list and are searched by a second launch.  Measured per round on the 2M-point map, list vs in place: cold 399 vs
+                // 688 us; seeded rounds 237 / 326 / 246 / 183 / 160 vs 230 / 272 / 207 / 138 / 116 us (few askers: the second launch only adds its
+                // own ~40 us) -- hence the cold round only.
+                const bool queue = asker_rows < (1 << 30) && variant == 5 && !c->debug_skip && c->seed_rounds == 0;
+                VELO_TRY(attach_askers(c, &out, queue));
+                hipEvent_t ev_stop = ev ? ev->second : nullptr;
+                if (out.ask_list && ev) ev_stop = nullptr;              // the bracket closes behind the asker launch
 #define VELO_LAUNCH_V5(NW, MINW, DBG, PPT, ASKER)                                                                                         \
                 hipExtLaunchKernelGGL((assoc_search_v5_kernel<NW, MINW, DBG, PPT, ASKER>), dim3(groups), dim3(NW * 64), c->assoc_lds_pad, c->stream,                    \
-                                      ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, S, P_dev, P_dev ? c->chain_fail.p : (int*)nullptr, V, c->qpts, qb, qe,                      \
+                                      ev ? ev->first : nullptr, ev_stop, 0, S, P_dev, P_dev ? c->chain_fail.p : (int*)nullptr, V, c->qpts, qb, qe,                      \
                                    (const float4*)c->T->tgt_pad.p, (const int*)c->T->tgt_off.p, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux, perm, c->debug_skip, asker_rows)
                 // default: 5 waves/SIMD (96 VGPRs, no spills, no scratch traffic), 2 candidate pairs per trip.  Measured on C2:
                 // 62 us; 6 waves + 2 pairs (5 spilled VGPRs) 65; 7 waves + 2 pairs 64; 5 waves + 4 pairs 66; 6 waves + 4 pairs 71
@@ -714,7 +744,22 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 // (workgroups of 2 waves / 1 wave -- every group resident at once -- measured 66 / 134 us per launch against 62: not tail-bound)
                 else if (variant == 59) VELO_LAUNCH_V5(4, 5, false, 2, false);   // phase 2 through the row/tile machinery (A/B)
                 else if (asker_rows >= (1 << 30)) VELO_LAUNCH_V5(4, 5, false, 2, false);   // regular grid: instantiation without the query-by-query code (no spills)
-                else VELO_LAUNCH_V5(4, 5, false, 2, true);
+                else if (out.ask_list) {
+                    // through the batch entry (arguments read from one struct): as a kernel with 40 scalar arguments this instantiation
+                    // spills 17 SGPRs, which makes the dispatch set up scratch (~11 us per launch)
+                    AssocBatch B1;
+                    std::memset(&B1, 0, sizeof(B1));
+                    AssocArgs& a = B1.item[0];
+                    a.P = S; a.P_dev = P_dev; a.chain_fail = P_dev ? c->chain_fail.p : nullptr; a.G = V; a.qpts = c->qpts; a.q_begin = qb; a.q_end = qe;
+                    a.tgt_pad = c->T->tgt_pad.p; a.tgt_off = c->T->tgt_off.p; a.gate_bits = gbits; a.norm_cond = c->P.icp_norm_condition; a.cluster_w = cw;
+                    a.h_safe = h_safe; a.out = out; a.want_aux = aux; a.group_perm = perm; a.dbg = 0; a.asker_rows = asker_rows;
+                    hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, 2>), dim3(groups, 1), dim3(256), c->assoc_lds_pad, c->stream,
+                                          ev ? ev->first : nullptr, ev_stop, 0, B1);
+                    hipExtLaunchKernelGGL(assoc_asker_kernel, dim3(cdiv(qe - qb, kAskChunk)), dim3(64), 0, c->stream, nullptr, ev ? ev->second : nullptr, 0,
+                                          S, P_dev, (const int*)(P_dev ? c->chain_fail.p : nullptr), V, c->qpts, (const float4*)c->T->tgt_pad.p, (const int*)c->T->tgt_off.p,
+                                          gbits, c->P.icp_norm_condition, h_safe, out, aux);
+                }
+                else VELO_LAUNCH_V5(4, 5, false, 2, 1);
 #undef VELO_LAUNCH_V5
                 break;
             }
@@ -1130,6 +1175,7 @@ int velo_create(velo_ctx** out, int device) {
         if (const char* e = getenv("VELO_SMALL_SOLVE")) c->small_solve = atoi(e);
         if (const char* e = getenv("VELO_LM_MERGED")) c->lm_merged = atoi(e);
         if (const char* e = getenv("VELO_ASSOC_LANE")) c->assoc_lane = atoi(e);
+        if (const char* e = getenv("VELO_ASKER_QUEUE")) c->asker_queue = atoi(e);
         if (const char* e = getenv("VELO_CHAIN")) c->chain = atoi(e);
         if (const char* e = getenv("VELO_CHAIN_MARGIN")) c->chain_margin = std::max(atoi(e), 0);
         if (const char* e = getenv("VELO_ASSOC_LDS_PAD")) c->assoc_lds_pad = std::max(atoi(e), 0);
@@ -1206,6 +1252,7 @@ int velo_destroy(velo_ctx* c) {
     c->row_off_vis.release(); c->row_off_icp.release(); c->rows_r.release(); c->rows_J.release();
     if (c->h_batch) (void)hipHostFree(c->h_batch);
     c->batch_items.release(); c->batch_states.release(); c->batch_x.release();
+    c->ask_count.release(); c->ask_list.release(); c->ask_keys.release(); c->ask_rings.release();
     c->batch_pose.release(); c->batch_logs.release(); c->batch_fail.release(); c->pose_rec.release(); c->solve_log.release(); c->chain_fail.release();
     if (c->h_log) (void)hipHostFree(c->h_log);
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -1589,6 +1636,7 @@ static int launch_merge(velo_ctx* c, const PartialRec* tables, int world, int st
         AssocOut out;
         out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p + c->nv_idx;
         out.dbg = c->dbg.p; out.wg_times = nullptr; out.first_ring = c->T->tgt_first_ring; out.first_point = c->T->tgt_first_point; out.partial = nullptr; out.prev_a = nullptr; out.prev_b = nullptr; out.prev_r = nullptr; out.n_valid_next = nullptr;
+        out.ask_count = nullptr; out.ask_count_next = nullptr; out.ask_list = nullptr; out.ask_keys = nullptr; out.ask_rings = nullptr;
         const unsigned long long key_inf = ((unsigned long long)gate_bits_of(gate_of_iter(c->P, iter)) + 1ull) << 32;
         hipLaunchKernelGGL(merge_partials_kernel, dim3(cdiv(qe - qb, 256)), dim3(256), 0, c->stream, tables, world, stride, qb, qe,
                            (const float4*)c->src.p, (const int*)c->q_src.p, key_inf, c->P.icp_norm_condition, out, want_aux ? 1 : 0);
@@ -1944,6 +1992,7 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
         HIP_TRY(hipMemsetAsync(c->chain_fail.p, 0, sizeof(int), c->stream));
         for (int k = 0; k < VELO_MAX_SOLVES; k++) c->pred_evals[k] += 2;    // the host-driven repeat below records the real counts
         c->nv_clean[0] = c->nv_clean[1] = false;                            // drained association launches did not clear the next round's counter
+        c->ask_clean[0] = c->ask_clean[1] = false;
         c->chain_misses++;
         return VELO_OK;
     }
@@ -2090,7 +2139,15 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
     out.first_ring = c->T->tgt_first_ring; out.first_point = c->T->tgt_first_point; out.partial = nullptr;
     VELO_TRY(attach_seeds(c, &out));
     *lane = lane_round(c, G, false);
+    const bool cold = c->seed_rounds == 0;
     if (out.prev_a) c->seed_rounds++;
+    {
+        const int reach0 = (int)std::ceil(std::sqrt(std::max(gate_of_iter(c->P, 1), 0.0)) / (G->h * 0.999));
+        const int ar = c->asker_rows >= 0 ? c->asker_rows : (reach0 > 5 ? 0 : (1 << 30));
+        // The list pays off for ONE pair in flight (a launch's tail is idle chip); with several groups in flight other streams' kernels fill the
+        // tail anyway and the second launch only costs (8 pairs on the 2M-point map: 938 vs 957 pairs/s).  VELO_ASKER_QUEUE=2 forces it here too.
+        VELO_TRY(attach_askers(c, &out, ar < (1 << 30) && !*lane && cold && c->asker_queue >= 2));
+    }
     out.n_valid_next = c->n_valid.p + (c->nv_idx ^ 1);
     c->nv_clean[c->nv_idx ^ 1] = true;
     A->want_aux = 0; A->group_perm = nullptr; A->dbg = 0;
@@ -2154,7 +2211,20 @@ static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::arr
             ev = &c->assoc_events[c->assoc_events_used++];
         }
         launched[(size_t)first] = 1;
+        bool all_queue = true;                                       // deferral is compiled in or out: all contexts of the launch or none
+        for (int j = 0; j < k; j++) all_queue = all_queue && B.item[j].out.ask_list != nullptr;
+        if (!all_queue) {
+            for (int j = 0; j < k; j++) {
+                AssocOut& o = B.item[j].out;
+                o.ask_count = nullptr; o.ask_count_next = nullptr; o.ask_list = nullptr; o.ask_keys = nullptr; o.ask_rings = nullptr;
+            }
+            for (int i = b; i < b + m; i++) ctxs[i]->ask_clean[0] = ctxs[i]->ask_clean[1] = false;   // no launch clears a counter this round
+        }
         if (all_lane) hipExtLaunchKernelGGL(assoc_lane_batch_kernel, dim3(cdiv(gmax, 4), k), dim3(256), 0, c->stream, ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, B);
+        else if (any_asker && all_queue) {
+            hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, 2>), dim3(gmax, k), dim3(256), c->assoc_lds_pad, c->stream, ev ? ev->first : nullptr, nullptr, 0, B);
+            hipExtLaunchKernelGGL(assoc_asker_batch_kernel, dim3(cdiv(gmax * 64, kAskChunk), k), dim3(64), 0, c->stream, nullptr, ev ? ev->second : nullptr, 0, B);
+        }
         else if (any_asker) hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, true>), dim3(gmax, k), dim3(256), c->assoc_lds_pad, c->stream,
                                              ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, B);
         else hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, false>), dim3(gmax, k), dim3(256), c->assoc_lds_pad, c->stream,
@@ -2298,6 +2368,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
             velo_ctx* c = ctxs[i];
             c->chain_misses++;
             c->nv_clean[0] = c->nv_clean[1] = false;                        // drained association launches did not clear the next round's counter
+            c->ask_clean[0] = c->ask_clean[1] = false;
             for (int k = 0; k < VELO_MAX_SOLVES; k++) c->pred_evals[k] += 2;
             std::memset(S[(size_t)i], 0, sizeof(velo_summary));
             S[(size_t)i]->n_target = c->T->n_tgt;

@@ -341,6 +341,14 @@ struct AssocOut {
     float4* __restrict__ prev_a;
     float4* __restrict__ prev_b;
     int2* __restrict__ prev_r;
+    // tube kernel on a density-shrunk grid: queries that still need cells after phase 1 ("askers": a box of up to 31 x 31 rows each) are
+    // not searched inside their group's workgroup but appended here and searched by assoc_asker_kernel, a wave per kAskChunk of them
+    // (ask_list == null: searched in place).  ask_count_next: the other round's counter, cleared by the tube launch.
+    int* __restrict__ ask_count;
+    int* __restrict__ ask_count_next;
+    int* __restrict__ ask_list;                  // [n_q] query indices
+    unsigned long long* __restrict__ ask_keys;   // [2 n_q] best1 / best2 keys so far, by query
+    int2* __restrict__ ask_rings;                // [n_q] their rings
 };
 
 // Target-sharded mode (BASELINE config 5): what one rank knows about a query after searching ITS rings.
@@ -917,7 +925,7 @@ __device__ __forceinline__ void top2_merge_xor(Top2& t, int mask) {
 //     is never a third phase.
 // Tubes do not blow up with the length of the segment, so the cluster radius can be large (one cluster per group).
 //   * rounds after the first are warm-started from the previous round's winners (AssocOut::prev).
-template <int NW, int MINW, bool DBG, int PPT, bool ASKER>
+template <int NW, int MINW, bool DBG, int PPT, int ASKER>
 __device__ __forceinline__ void
 assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_dev, int* __restrict__ chain_fail, const GridView& G, const float4* __restrict__ qpts, int q_begin, int q_end,
                      const float4* __restrict__ tgt_pad, const int* __restrict__ tgt_off,
@@ -963,6 +971,7 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
     // workgroup -> group through the host-built table (XCD-aware wedges, see build_group_perm); placement affects speed only
     const int group = group_perm ? group_perm[block_x] : (int)block_x;
     if (out.n_valid_next && block_x == 0 && tid == 0) *out.n_valid_next = 0;   // its last reader ran before this launch (same stream)
+    if (ASKER == 2 && block_x == 0 && tid == 0) *out.ask_count_next = 0;
     if (DBG && out.wg_times && tid == 0) out.wg_times[2 * group] = __builtin_amdgcn_s_memrealtime();
     const int qi = q_begin + group * 64 + lane;
     const bool active = qi < q_end;
@@ -1013,6 +1022,7 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
     float* s_zg_f = reinterpret_cast<float*>(s_zg);
     const int big = 1 << 28;
     bool pending = active;
+    bool deferred = false;                                             // this lane's query went on the asker list: assoc_asker_kernel finishes it
     for (;;) {                                                         // clusters (identical control flow in every wave)
         const unsigned long long pm = __ballot(pending);
         if (pm == 0ull) break;
@@ -1234,7 +1244,28 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
             }
             VELO_STAMP(6);
         }
-        if (ASKER && asker_phase) {
+        if (ASKER == 2 && asker_phase) {     // (instantiation 2: the asking queries are deferred; 1: searched in place; 0: regular grid, no askers)
+            // ---- phase 2 handed to assoc_asker_kernel: the asking queries of this cluster go on the global list with their state ----
+            VELO_Q(qx, qy, qz);
+            const int cx = cell_coord(qx, g.ox, g.inv_h, g.nx), cy = cell_coord(qy, g.oy, g.inv_h, g.ny), cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
+            const float rq0 = sqrtf(t.b2d) * 1.0001f + 1e-6f;
+            const CellBox b2 = query_box(g, qx, qy, qz, cx, cy, cz, rq0, false);       // against the phase-1 box wave 0 left in s_box[0]
+            const bool asks = member && !(b2.x0 >= s_box[0][0][lane] && b2.x1 <= s_box[0][1][lane] && b2.y0 >= s_box[0][2][lane] &&
+                                          b2.y1 <= s_box[0][3][lane] && b2.z0 >= s_box[0][4][lane] && b2.z1 <= s_box[0][5][lane]);
+            if (wid == 0) {                                            // every wave holds the same states: one of them writes
+                const unsigned long long am = __ballot(asks);
+                int base = 0;
+                if (lane == 0 && am != 0ull) base = atomicAdd(out.ask_count, (int)__popcll(am));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (asks) {
+                    const int q_of_lane = q_begin + group * 64 + lane;
+                    out.ask_list[base + (int)__popcll(am & ((1ull << lane) - 1ull))] = q_of_lane;
+                    out.ask_keys[2 * (size_t)q_of_lane] = t.b1; out.ask_keys[2 * (size_t)q_of_lane + 1] = t.b2;
+                    out.ask_rings[q_of_lane] = make_int2(t.b1ring, t.b2ring);
+                }
+            }
+            deferred = deferred || asks;
+        } else if (ASKER == 1 && asker_phase) {
             // ---- phase 2, one asking query at a time ("asker-centric") ---------------------------------------------------------------
             // After phase 1 few queries still need cells (those whose second ring is farther than a cell), each a large box of its own
             // that shares little with the others'.  Pushing them through the row/tile machinery costs ~10 barriers and a mostly
@@ -1346,7 +1377,7 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
     if (DBG && (dbg & 128)) {                                          // diagnostic: finish without the gathers (wrong results)
         if (active) { out.p[qi] = make_float4(qx, qy, qz, 0.f); out.n[qi] = make_float4((float)(t.b1 >> 32), (float)(t.b2 >> 32), 0.f, 0.f); out.v0[qi] = make_float4(0.f, 0.f, 0.f, 0.f); }
     } else
-    if (active) finish_correspondence_pad(qi, qpts, qx, qy, qz, t.b1, t.b2, t.b1ring, t.b2ring, key_inf, tgt_pad, tgt_off, norm_cond, out, want_aux != 0);
+    if (active && !deferred) finish_correspondence_pad(qi, qpts, qx, qy, qz, t.b1, t.b2, t.b1ring, t.b2ring, key_inf, tgt_pad, tgt_off, norm_cond, out, want_aux != 0);
     VELO_STAMP(7);
     if (DBG && out.wg_times && tid == 0) out.wg_times[2 * group + 1] = __builtin_amdgcn_s_memrealtime();
     if (DBG && (dbg & 8) && tid == 0) { for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)&out.dbg[k], (unsigned long long)tacc[k]); }
@@ -1358,7 +1389,7 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
 
 
 // one launch = one context's round
-template <int NW, int MINW, bool DBG, int PPT, bool ASKER>
+template <int NW, int MINW, bool DBG, int PPT, int ASKER>
 __global__ void __launch_bounds__(NW * 64, MINW)
 assoc_search_v5_kernel(PoseScalars P, const PoseRecord* __restrict__ P_dev, int* __restrict__ chain_fail, GridView G, const float4* __restrict__ qpts, int q_begin, int q_end,
                        const float4* __restrict__ tgt_pad, const int* __restrict__ tgt_off,
@@ -1378,13 +1409,129 @@ struct AssocArgs {
     AssocOut out; int want_aux; const int* group_perm; int dbg; int asker_rows;
 };
 struct AssocBatch { AssocArgs item[kAssocBatchMax]; };
-template <int NW, int MINW, bool DBG, int PPT, bool ASKER>
+template <int NW, int MINW, bool DBG, int PPT, int ASKER>
 __global__ void __launch_bounds__(NW * 64, MINW)
 assoc_search_v5_batch_kernel(AssocBatch B) {
     const AssocArgs& a = B.item[blockIdx.y];
     if ((int)blockIdx.x * 64 >= a.q_end - a.q_begin) return;
     assoc_search_v5_body<NW, MINW, DBG, PPT, ASKER>(a.P, a.P_dev, a.chain_fail, a.G, a.qpts, a.q_begin, a.q_end, a.tgt_pad, a.tgt_off, a.gate_bits, a.norm_cond,
                                                     a.cluster_w, a.h_safe, a.out, a.want_aux, a.group_perm, a.dbg, a.asker_rows, (int)blockIdx.x);
+}
+
+// ---- the asking queries of a tube launch, searched by the whole chip ----------------------------------------------------------
+// On the density-shrunk grid of a 2M-point map the queries that still need cells after phase 1 own most of a cold round's work
+// (14 of 16 M candidate tests), and the heavy ones -- ~50 us of dependent gathers each -- come in clumps: groups of 64 consecutive
+// queries that look into space where only one ring is near.  Searched inside their group's workgroup (16 per wave, one after the
+// other) they make the launch tail-bound: workgroup duration mean 88 us, p99 466 us, max 704 us = the launch, where 1,875
+// workgroups on 1,280 slots would need ~130 us if they were equal.  Here the tube launch only lists them; this kernel gives every
+// wave kAskChunk of them TAKEN WITH A STRIDE (neighbours in the list go to different waves), searches one at a time with all 64
+// lanes exactly as the in-place code does (rows over lanes -> wave prefix sum -> candidates over lanes -> xor-shuffle merge; first
+// no farther than 4 cells, then -- if the bound still reaches beyond -- the whole sphere) and finishes its correspondences.
+constexpr int kAskChunk = 8;
+__device__ __forceinline__ void asker_search(const GridView& G, const GridDesc& g, float ax, float ay, float az, float rq, Top2& tl, int lane,
+                                             int* __restrict__ w_j0, int* __restrict__ w_off) {
+    const CellBox bb = query_box(g, ax, ay, az, 0, 0, 0, rq, false);
+    const int x0 = max(bb.x0, 0), x1 = min(bb.x1, g.nx - 1);
+    const int y0 = max(bb.y0, 0), y1 = min(bb.y1, g.ny - 1), z0 = max(bb.z0, 0), z1 = min(bb.z1, g.nz - 1);
+    const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+    const int nrows_a = (x0 <= x1 && ny > 0 && nz > 0) ? ny * nz : 0;
+    const float rcp_ny = 1.0f / (float)max(ny, 1);
+    for (int r0 = 0; r0 < nrows_a; r0 += 64) {
+        const int r = r0 + lane;
+        int j0 = 0, len = 0;
+        if (r < nrows_a) {
+            int zq = (int)((float)r * rcp_ny), yr = r - zq * ny;
+            if (yr < 0) { zq--; yr += ny; } else if (yr >= ny) { zq++; yr -= ny; }
+            const int row = ((z0 + zq) * g.ny + (y0 + yr)) * g.nx;
+            j0 = G.cell_start[row + x0]; len = G.cell_start[row + x1 + 1] - j0;
+        }
+        int inc = len;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+        const int total = __shfl(inc, 63);
+        w_j0[lane] = j0; w_off[lane] = inc - len;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int slot = lane; slot < total; slot += 128) {             // two candidates per trip: two independent search + gather chains
+            const int slot2 = slot + 64;                               // (lane-contiguous slots: a trip's gathers are coalesced; per-lane segments measured slower)
+            const bool two = slot2 < total;
+            int lo = 0, lo2 = 0;                                       // largest i with w_off[i] <= slot
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1) {
+                if (w_off[lo + step] <= slot) lo += step;
+                if (w_off[lo2 + step] <= slot2) lo2 += step;
+            }
+            const int j = w_j0[lo] + (slot - w_off[lo]);
+            const int j2 = two ? w_j0[lo2] + (slot2 - w_off[lo2]) : j;
+            const float4 c = G.sorted[j], c2 = G.sorted[j2];
+            const float d = dist2_f(ax, ay, az, c.x, c.y, c.z), d2 = dist2_f(ax, ay, az, c2.x, c2.y, c2.z);
+            if (d <= tl.b2d) top2_update(tl, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(c.w), G.sring[j]);
+            if (two && d2 <= tl.b2d) top2_update(tl, ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(c2.w), G.sring[j2]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                               // the run list is rewritten by the next rows
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) top2_merge_xor(tl, m);            // every lane now holds the query's state
+}
+
+__device__ __forceinline__ void
+assoc_asker_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_dev, const int* __restrict__ chain_fail, const GridView& G, const float4* __restrict__ qpts,
+                 const float4* __restrict__ tgt_pad, const int* __restrict__ tgt_off, unsigned gate_bits, double norm_cond, float h_safe, const AssocOut& out, int want_aux,
+                 const int chunk, const int n_waves) {
+    __shared__ int s_j0[64], s_off[66];
+    const int lane = threadIdx.x & 63;
+    if (chain_fail && *chain_fail) return;                             // the tube launch ahead of this one has raised it if the record was not ready
+    const int count = *out.ask_count;
+    const int n_chunks = (count + kAskChunk - 1) / kAskChunk;
+    if (chunk >= n_chunks) return;
+    const PoseScalars& P = P_dev ? P_dev->P : P_in;
+    const unsigned long long key_inf = ((unsigned long long)gate_bits + 1ull) << 32;
+    const GridDesc g = G.d;
+    const int my_idx = chunk + lane * n_chunks;                        // stride: the list's neighbours (a clump of heavy queries) go to different waves
+    const bool mine = lane < kAskChunk && my_idx < count;
+    int qi = 0;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    Top2 t;
+    t.b1 = key_inf; t.b2 = key_inf; t.b1ring = -1; t.b2ring = -1; t.b2d = __uint_as_float(gate_bits + 1u);
+    if (mine) {
+        qi = out.ask_list[my_idx];
+        const float4 psrc = qpts[qi];
+        t.b1 = out.ask_keys[2 * (size_t)qi]; t.b2 = out.ask_keys[2 * (size_t)qi + 1];
+        const int2 rr = out.ask_rings[qi];
+        t.b1ring = rr.x; t.b2ring = rr.y;
+        t.b2d = __uint_as_float((unsigned)(t.b2 >> 32));
+        transform_query(P, psrc, &qx, &qy, &qz);
+    }
+    const float cap = 4.0f * h_safe;
+    const unsigned long long mm = __ballot(mine);
+    for (int a = 0; a < kAskChunk; a++) {
+        if (!((mm >> a) & 1ull)) continue;                             // wave-uniform
+        const float ax = __shfl(qx, a), ay = __shfl(qy, a), az = __shfl(qz, a);
+        Top2 tl;
+        tl.b1 = __shfl(t.b1, a); tl.b2 = __shfl(t.b2, a); tl.b1ring = __shfl(t.b1ring, a); tl.b2ring = __shfl(t.b2ring, a);
+        tl.b2d = __uint_as_float((unsigned)(tl.b2 >> 32));
+        const float r0 = sqrtf(tl.b2d) * 1.0001f + 1e-6f;
+        asker_search(G, g, ax, ay, az, fminf(r0, cap), tl, lane, s_j0, s_off);
+        const float r1 = sqrtf(tl.b2d) * 1.0001f + 1e-6f;
+        if (r1 > cap) asker_search(G, g, ax, ay, az, r1, tl, lane, s_j0, s_off);      // wave-uniform: tl is merged
+        if (lane == a) { t.b1 = tl.b1; t.b2 = tl.b2; t.b1ring = tl.b1ring; t.b2ring = tl.b2ring; t.b2d = tl.b2d; }
+    }
+    if (mine) finish_correspondence_pad(qi, qpts, qx, qy, qz, t.b1, t.b2, t.b1ring, t.b2ring, key_inf, tgt_pad, tgt_off, norm_cond, out, want_aux != 0);
+}
+__global__ void __launch_bounds__(64)
+assoc_asker_kernel(PoseScalars P, const PoseRecord* __restrict__ P_dev, const int* __restrict__ chain_fail, GridView G, const float4* __restrict__ qpts,
+                   const float4* __restrict__ tgt_pad, const int* __restrict__ tgt_off, unsigned gate_bits, double norm_cond, float h_safe, AssocOut out, int want_aux) {
+    assoc_asker_body(P, P_dev, chain_fail, G, qpts, tgt_pad, tgt_off, gate_bits, norm_cond, h_safe, out, want_aux, (int)blockIdx.x, (int)gridDim.x);
+}
+__global__ void __launch_bounds__(64)
+assoc_asker_batch_kernel(AssocBatch B) {
+    const AssocArgs& a = B.item[blockIdx.y];
+    const int n_waves = (a.q_end - a.q_begin + kAskChunk - 1) / kAskChunk;
+    if (!a.out.ask_list || (int)blockIdx.x >= n_waves) return;
+    assoc_asker_body(a.P, a.P_dev, a.chain_fail, a.G, a.qpts, a.tgt_pad, a.tgt_off, a.gate_bits, a.norm_cond, a.h_safe, a.out, a.want_aux, (int)blockIdx.x, n_waves);
 }
 
 // ---- association search, lane variant: the rounds that start from seeds ------------------------------------------------------
