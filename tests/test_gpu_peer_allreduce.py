@@ -41,7 +41,7 @@ def _rank_main(rank, world, port, out_dir, shape, with_visual):
     ctx.set_target(d["tgt_xyz"], d["tgt_off"])
     ctx.set_source(d["src_xyz"], d["src_off"])
     if with_visual:
-        ctx.set_visual(synth.stereo_matches(60, mix="all"))             # visual blocks live on rank 0 only
+        ctx.set_visual(synth.stereo_matches(60, mix="all"))             # every rank sweeps its share of the visual blocks
     out = {}
     n = ctx.associate(d["x0"], 1)
     cost, Hm, g = ctx.evaluate(d["x0"])                                 # all-reduced sums: the same on every rank

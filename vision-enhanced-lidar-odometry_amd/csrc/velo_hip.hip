@@ -541,8 +541,13 @@ EvalArgs eval_args(velo_ctx* c, const double* x_override) {
     A.x_override = x_override;
     A.cp = c->cp.p; A.cn = c->cn.p; A.cv0 = c->cv0.p;
     if (c->have_corr) q_range(c, &A.q_begin, &A.q_end);
-    A.vm = c->vm.p; A.vflags = c->vflags.p;
-    A.n_matches = (c->vflags_valid && c->shard_rank == 0) ? c->n_matches : 0;   // visual blocks live on rank 0 only
+    {   // query-sharded: every rank sweeps a contiguous share of the visual matches too (the gate ran on all of them on every rank)
+        const int n = c->vflags_valid ? c->n_matches : 0;
+        const int W = std::max(c->shard_world, 1), r = c->shard_rank;
+        const int m0 = (int)((int64_t)n * r / W), m1 = (int)((int64_t)n * (r + 1) / W);
+        A.vm = c->vm.p + m0; A.vflags = c->vflags.p + (size_t)3 * m0;
+        A.n_matches = m1 - m0;
+    }
     A.loss_a_3dpd = c->P.loss_thresh_3DPD; A.w_3dpd = c->P.weight_3DPD;
     A.V = visual_params(c->P);
     A.partials = c->partials.p;
@@ -1820,12 +1825,15 @@ int velo_evaluate_rows(velo_ctx* c, const double x[6], double* residuals, double
     int qb = 0, qe = 0;
     if (c->have_corr) q_range(c, &qb, &qe);
     const int nq = qe - qb;
-    const bool vis = c->vflags_valid && c->shard_rank == 0 && c->n_matches > 0;
-    std::vector<int> h_vis((size_t)3 * (vis ? c->n_matches : 0), -1);
+    // this rank's share of the visual matches (the same split as eval_args): rows are numbered within the share
+    const int nvm = c->vflags_valid ? c->n_matches : 0, Wv = std::max(c->shard_world, 1);
+    const int m0 = (int)((int64_t)nvm * c->shard_rank / Wv), m1 = (int)((int64_t)nvm * (c->shard_rank + 1) / Wv);
+    const bool vis = m1 > m0 && c->h_vflags.size() >= (size_t)3 * m1;
+    std::vector<int> h_vis((size_t)3 * (vis ? m1 - m0 : 0), -1);
     int rows = 0;
     if (vis) {
         for (size_t s = 0; s < h_vis.size(); s++) {
-            const unsigned char f = c->h_vflags[s];
+            const unsigned char f = c->h_vflags[(size_t)3 * m0 + s];
             if (!f) continue;
             h_vis[s] = rows;
             const int t = f - 1;
