@@ -406,6 +406,14 @@ def main():
             line["shared_target"] = main_leg["shared_target"]
         if legs:
             line["configs"] = {k: {kk: vv for kk, vv in v.items() if kk not in ("solution_x",)} for k, v in legs.items()}
+            # the 2M-point map leg carries its own committed PMC pass (profiles/rNN_c4_traffic.json)
+            tf4 = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_c4_traffic.json")))
+            if tf4 and "c4" in line["configs"] and isinstance(line["configs"]["c4"].get("roofline"), dict):
+                try:
+                    line["configs"]["c4"]["roofline"]["traffic"] = json.load(open(tf4[-1]))["traffic_bytes_per_launch"]
+                    line["configs"]["c4"]["roofline"]["traffic_note"] = "HBM-side bytes per launch of ONE context's round alone (committed PMC passes)"
+                except Exception:       # noqa: BLE001
+                    pass
         if modes:
             line["modes"] = {k: {kk: vv for kk, vv in v.items() if kk not in ("solution_x", "roofline")} for k, v in modes.items()}
         if not a.no_cpu_baseline and world == 1:             # rank 0 at N = 1 only: the other runs just report the GPU side
