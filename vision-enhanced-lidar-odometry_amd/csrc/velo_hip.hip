@@ -96,7 +96,8 @@ struct Grid {
     GridDesc d{};
     double gate = 0.0;          // squared-distance gate the cell size was derived from
     double h = 0.0;             // cell size
-    DevBuf<int> cell_start;     // ncells + 1
+    DevBuf<int> cell_start;     // 3 + ncells + 1: the table starts at element 3, so that table + 1 -- what the one-pass scan and the scatter work on -- is 16-byte aligned
+    int* table() const { return cell_start.p + 3; }
     DevBuf<float4> sorted;      // cell-sorted copy {x,y,z,bits(gidx)} (+ kGridPad sentinels)
     DevBuf<int> sring;
     bool built = false;
@@ -160,7 +161,8 @@ struct velo_ctx {
 
     // target (frame2): cloud + search index, shareable between contexts (velo_share_target: many scans against one map)
     std::shared_ptr<TargetData> T = std::make_shared<TargetData>();
-    DevBuf<int> scan_tiles, cursor, scan_total;   // scratch of an index build
+    DevBuf<int> scan_tiles, cursor, scan_total;   // scratch of an index build / of the segmenter's scans
+    DevBuf<unsigned long long> lb_status;         // one-pass scan: tile status words + ticket
     DevBuf<unsigned> bbox_keys;
     bool have_target = false;
 
@@ -395,20 +397,20 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
     G.d.nx = dims[0]; G.d.ny = dims[1]; G.d.nz = dims[2];
     G.d.ncells = dims[0] * dims[1] * dims[2];
     const int nc = G.d.ncells, n = c->T->n_tgt;
-    VELO_TRY(G.cell_start.reserve((size_t)nc + 1));
+    VELO_TRY(G.cell_start.reserve((size_t)nc + 4));
     const size_t ns = (size_t)n + kGridPad;
     VELO_TRY(G.sorted.reserve(ns)); VELO_TRY(G.sring.reserve(ns));
-    VELO_TRY(c->cursor.reserve((size_t)nc + 1));
-    const int n_tiles = cdiv(nc, kScanTile);
-    VELO_TRY(c->scan_tiles.reserve((size_t)n_tiles + 1));
+    // count -> one-pass exclusive scan -> scatter, all in the table itself with an offset of one (grid_count_kernel, scan_lookback_kernel)
+    const int n_tiles = cdiv(nc, kLbTile);
+    VELO_TRY(c->lb_status.reserve((size_t)n_tiles + 1));               // tile status words + the ticket counter behind them
     VELO_TRY(c->scan_total.reserve(1));
-    HIP_TRY(hipMemsetAsync(G.cell_start.p, 0, sizeof(int) * ((size_t)nc + 1), c->stream));
-    if (n > 0) hipLaunchKernelGGL(grid_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, G.d, c->T->tgt.p, n, c->T->tgt_cell_of.p, G.cell_start.p);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(n_tiles), dim3(kScanThreads), 0, c->stream, G.cell_start.p, nc, c->scan_tiles.p);
-    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(kScanThreads), 0, c->stream, c->scan_tiles.p, n_tiles, c->scan_total.p);
-    hipLaunchKernelGGL(scan_add_kernel, dim3(cdiv(nc + 1, 256)), dim3(256), 0, c->stream, G.cell_start.p, nc, c->scan_tiles.p, c->scan_total.p, c->cursor.p);
-    hipLaunchKernelGGL(grid_scatter_kernel, dim3(cdiv(std::max(n, kGridPad), 256)), dim3(256), 0, c->stream, c->T->tgt.p, c->T->tgt_cell_of.p, c->T->tgt_ring_of.p, n, c->cursor.p,
-                       (const int*)(G.cell_start.p + nc), c->T->tgt_first_point, G.sorted.p, G.sring.p);
+    HIP_TRY(hipMemsetAsync(G.cell_start.p, 0, sizeof(int) * ((size_t)nc + 4), c->stream));
+    HIP_TRY(hipMemsetAsync(c->lb_status.p, 0, sizeof(unsigned long long) * ((size_t)n_tiles + 1), c->stream));
+    if (n > 0) hipLaunchKernelGGL(grid_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, G.d, c->T->tgt.p, n, c->T->tgt_cell_of.p, G.table());
+    hipLaunchKernelGGL(scan_lookback_kernel, dim3(n_tiles), dim3(kScanThreads), 0, c->stream, G.table() + 1, nc, c->lb_status.p,
+                       reinterpret_cast<int*>(c->lb_status.p + n_tiles), c->scan_total.p);
+    hipLaunchKernelGGL(grid_scatter_kernel, dim3(cdiv(std::max(n, kGridPad), 256)), dim3(256), 0, c->stream, c->T->tgt.p, c->T->tgt_cell_of.p, c->T->tgt_ring_of.p, n,
+                       G.table() + 1, (const int*)c->scan_total.p, c->T->tgt_first_point, G.sorted.p, G.sring.p);
     HIP_TRY(hipGetLastError());
     G.built = true;
     return VELO_OK;
@@ -629,7 +631,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         PoseScalars S;
         pose_scalars(x, &S);
         GridView V;
-        V.d = G->d; V.cell_start = G->cell_start.p; V.sorted = G->sorted.p; V.sring = G->sring.p;
+        V.d = G->d; V.cell_start = G->table(); V.sorted = G->sorted.p; V.sring = G->sring.p;
         AssocOut out;
         out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p + c->nv_idx; out.dbg = c->dbg.p; out.wg_times = nullptr;
         out.first_ring = c->T->tgt_first_ring; out.first_point = c->T->tgt_first_point; out.partial = partial ? c->partials_rec.p : nullptr;
@@ -1247,7 +1249,7 @@ int velo_destroy(velo_ctx* c) {
     if (c->peer_slab) { (void)hipFree(c->peer_slab); c->peer_slab = nullptr; }
     if (c->peer_area) { (void)hipFree(c->peer_area); c->peer_area = nullptr; }
     c->T.reset();                                            // the target goes with its last holder
-    c->scan_tiles.release(); c->cursor.release(); c->scan_total.release(); c->bbox_keys.release();
+    c->lb_status.release(); c->scan_tiles.release(); c->cursor.release(); c->scan_total.release(); c->bbox_keys.release();
     c->src.release(); c->src_off.release(); c->q_off.release(); c->q_src.release(); c->staging.release();
     c->seg_flag.release(); c->seg_excl.release(); c->seg_ring.release(); c->seg_off.release();
     c->cp.release(); c->cn.release(); c->cv0.release(); c->aux0.release(); c->aux1.release(); c->n_valid.release(); c->dbg.release(); c->wg_times.release(); c->items.release(); c->item_counters.release(); c->qpos.release(); c->partials_rec.release(); c->partials_all.release();
@@ -1507,10 +1509,10 @@ int velo_cache_store(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t of_
         std::memcpy(e.bbox, c->T->bbox, sizeof(e.bbox));
         e.grid.d = G->d; e.grid.gate = G->gate; e.grid.h = G->h; e.grid.built = true;
         const size_t nc = (size_t)G->d.ncells + 1, ns = (size_t)e.n + kGridPad;
-        if ((st = e.ring_of.reserve((size_t)std::max(e.n, 1))) == VELO_OK && (st = e.grid.cell_start.reserve(nc)) == VELO_OK &&
+        if ((st = e.ring_of.reserve((size_t)std::max(e.n, 1))) == VELO_OK && (st = e.grid.cell_start.reserve(nc + 3)) == VELO_OK &&
             (st = e.grid.sorted.reserve(ns)) == VELO_OK && (st = e.grid.sring.reserve(ns)) == VELO_OK) {
             if (e.n > 0) he = hipMemcpyAsync(e.ring_of.p, c->T->tgt_ring_of.p, sizeof(int) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream);
-            if (he == hipSuccess) he = hipMemcpyAsync(e.grid.cell_start.p, G->cell_start.p, sizeof(int) * nc, hipMemcpyDeviceToDevice, c->stream);
+            if (he == hipSuccess) he = hipMemcpyAsync(e.grid.table(), G->table(), sizeof(int) * nc, hipMemcpyDeviceToDevice, c->stream);
             if (he == hipSuccess) he = hipMemcpyAsync(e.grid.sorted.p, G->sorted.p, sizeof(float4) * ns, hipMemcpyDeviceToDevice, c->stream);
             if (he == hipSuccess) he = hipMemcpyAsync(e.grid.sring.p, G->sring.p, sizeof(int) * ns, hipMemcpyDeviceToDevice, c->stream);
         }
@@ -1559,7 +1561,7 @@ int velo_cache_load(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t as_t
     if (c->T->grids.empty()) c->T->grids.resize(1);
     Grid& G = c->T->grids[0];
     const size_t nc = (size_t)e.grid.d.ncells + 1, ns = (size_t)e.n + kGridPad;
-    VELO_TRY(G.cell_start.reserve(nc)); VELO_TRY(G.sorted.reserve(ns)); VELO_TRY(G.sring.reserve(ns));
+    VELO_TRY(G.cell_start.reserve(nc + 3)); VELO_TRY(G.sorted.reserve(ns)); VELO_TRY(G.sring.reserve(ns));
     HIP_TRY(hipMemcpyAsync(c->T->tgt_off.p, c->T->h_tgt_off.data(), sizeof(int) * ((size_t)e.n_rings + 1), hipMemcpyHostToDevice, c->stream));
     if (e.n > 0) HIP_TRY(hipMemcpyAsync(c->T->tgt_ring_of.p, e.ring_of.p, sizeof(int) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream));
     VELO_TRY(c->T->tgt_pad.reserve((size_t)e.n + 2 * (size_t)e.n_rings + 2));
@@ -1567,7 +1569,7 @@ int velo_cache_load(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t as_t
         hipLaunchKernelGGL(pad_rings_kernel, dim3(cdiv(e.n, 256)), dim3(256), 0, c->stream, (const float4*)c->T->tgt.p, (const int*)c->T->tgt_off.p, (const int*)c->T->tgt_ring_of.p, e.n, 0, c->T->tgt_pad.p);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipMemcpyAsync(G.cell_start.p, e.grid.cell_start.p, sizeof(int) * nc, hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(G.table(), e.grid.table(), sizeof(int) * nc, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(G.sorted.p, e.grid.sorted.p, sizeof(float4) * ns, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(G.sring.p, e.grid.sring.p, sizeof(int) * ns, hipMemcpyDeviceToDevice, c->stream));
     G.d = e.grid.d; G.gate = e.grid.gate; G.h = e.grid.h; G.built = true;
@@ -2133,7 +2135,7 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
     if (qe <= qb) return VELO_OK;
     pose_scalars(x, &A->P);
     A->P_dev = nullptr; A->chain_fail = nullptr;
-    A->G.d = G->d; A->G.cell_start = G->cell_start.p; A->G.sorted = G->sorted.p; A->G.sring = G->sring.p;
+    A->G.d = G->d; A->G.cell_start = G->table(); A->G.sorted = G->sorted.p; A->G.sring = G->sring.p;
     A->qpts = c->qpts; A->q_begin = qb; A->q_end = qe;
     A->tgt_pad = c->T->tgt_pad.p; A->tgt_off = c->T->tgt_off.p;
     const double gate = gate_of_iter(c->P, iter);
