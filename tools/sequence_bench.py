@@ -19,6 +19,8 @@ t0 = time.perf_counter()
 for rec in frames:
     odo.push(rec)
 dt = time.perf_counter() - t0
+calls, misses = odo.ctx.chain_stats()
 err = np.linalg.norm(odo.poses[-1][:3, 3] - truth[-1][:3, 3])
 print(f"{n} frames of {len(frames[0])} points, icp_skip=1: {dt / (n - 1) * 1e3:.2f} ms per frame ({(n - 1) / dt:.0f} frames/s); "
       f"end-point drift {err * 100:.1f} cm over {np.linalg.norm(truth[-1][:3, 3]):.1f} m")
+print(f"chain mode: {calls} calls enqueued as one chain, {misses} of them outran their predicted launch counts and were repeated host-driven")
