@@ -566,3 +566,23 @@ def test_residual_stats_match_the_oracle_restatement(ctx, oracle):
     ctx.set_residual_stats(False)
     xb, _, sb = ctx.frame_to_frame(d["x0"])
     assert np.array_equal(xa, xb) and sa.n_residual_stats == 2 and sa.residual_stats[1].type[4].count == sa.solves[5].n_icp_valid
+
+
+def test_chain_mode_with_single_launch_solves_at_the_reference_constants(hip_lib, monkeypatch):
+    """icp_skip = 200 (kitti.h:8): a solve is one single-workgroup launch, so the chain is 6 x (association + solve) with nothing to
+    predict; pose, solves and summaries equal the host-driven path bit for bit, and no call is ever repeated."""
+    d = synth.scan_pair()
+    out = {}
+    for name, chain in (("host", "0"), ("chain", "1")):
+        monkeypatch.setenv("VELO_CHAIN", chain)
+        c = api.Context(0)                                   # reference constants: 640 queries
+        c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])
+        res = []
+        for x0 in (d["x0"], d["x_true"], d["x0"]):
+            x, T, s = c.frame_to_frame(x0)
+            res.append((x.copy(), T.copy(), _summary_tuple(s), s.n_queries, s.algorithmic_bytes))
+        out[name] = (res, c.chain_stats())
+        c.close()
+    assert out["host"][1] == (0, 0) and out["chain"][1] == (3, 0)
+    for (x0, T0, s0, *r0), (x1, T1, s1, *r1) in zip(out["host"][0], out["chain"][0]):
+        assert np.array_equal(x0, x1) and np.array_equal(T0, T1) and s0 == s1 and r0 == r1 and r0[0] == 640

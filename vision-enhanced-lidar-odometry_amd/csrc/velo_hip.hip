@@ -936,7 +936,8 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
     if (!c->comm && !c->peer_on && !c->use_graphs && c->small_solve && E.total() >= 1 && E.total() <= kSmallRows) {
         // small problem (the reference's icp_skip = 200): the whole solve in one single-workgroup launch, one status copy
         hipLaunchKernelGGL(lm_solve_small_kernel, dim3(1), dim3(kEvalThreads), 0, c->stream, A, Q, c->state.p, xd,
-                           (const int*)(c->have_corr ? c->n_valid.p + c->nv_idx : nullptr), E.nb_icp, E.nb_vis, max_iters_all + 2);
+                           (const int*)(c->have_corr ? c->n_valid.p + c->nv_idx : nullptr), E.nb_icp, E.nb_vis, max_iters_all + 2,
+                           (PoseRecord*)nullptr, (SolveLog*)nullptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(&c->h_status->s, c->state.p, sizeof(LMState), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1957,12 +1958,14 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
     int qb, qe;
     q_range(c, &qb, &qe);
     if (qe <= qb) return VELO_OK;
-    {   // problems of a few workgroups run their whole solve in one launch (lm_solve_small_kernel): not a chain problem
+    bool small = false;                                              // problems of a few workgroups: a whole solve is ONE launch (lm_solve_small_kernel)
+    {
         EvalArgs A0;
         std::memset(&A0, 0, sizeof(A0));
         A0.q_begin = qb; A0.q_end = qe;
         const EvalPlan E0 = eval_plan(A0);
-        if (E0.nb_icp <= 0 || (c->small_solve && E0.total() <= kSmallRows)) return VELO_OK;
+        if (E0.nb_icp <= 0) return VELO_OK;
+        small = c->small_solve && E0.total() <= kSmallRows;
     }
     const LMParams Q = lm_params(c->P);
     const int margin = c->chain_margin;
@@ -1983,6 +1986,12 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
             const EvalPlan E = eval_plan(A);
             if (E.nb_icp <= 0 || E.nb_vis > 0) return fail(VELO_ERR_STATE, "chain mode: unexpected evaluation plan");
             const int* nvp = c->n_valid.p + c->nv_idx;
+            if (small) {                                             // no prediction needed: the launch runs the solve to its end
+                hipLaunchKernelGGL(lm_solve_small_kernel, dim3(1), dim3(kEvalThreads), 0, c->stream, A, Q, c->state.p, (const double*)(r == 0 ? c->xdev.p : nullptr),
+                                   nvp, E.nb_icp, 0, c->P.max_num_iterations + 3, c->pose_rec.p, c->solve_log.p + std::min(r, VELO_MAX_SOLVES - 1));
+                HIP_TRY(hipGetLastError());
+                continue;
+            }
             const int K = std::min(std::max(c->pred_evals[std::min(r, VELO_MAX_SOLVES - 1)], 1) + 1 + margin, max_launches);
             for (int k = 0; k < K; k++, j++) {
                 hipLaunchKernelGGL(lm_iter_kernel, dim3(E.nb_icp), dim3(kEvalThreads), 0, c->stream, A, Q, (const LMState*)(c->state.p + (j & 1)), c->state.p + ((j + 1) & 1),

@@ -3236,7 +3236,7 @@ __global__ void lm_gather_states_kernel(const LMBatchItem* __restrict__ items, L
 constexpr int kSmallRows = 4;
 __global__ void __launch_bounds__(kEvalThreads)
 lm_solve_small_kernel(EvalArgs A, LMParams Q, LMState* Sg, const double* __restrict__ x_in, const int* __restrict__ n_valid,
-                      int nb_icp, int nb_vis, int max_sweeps) {
+                      int nb_icp, int nb_vis, int max_sweeps, PoseRecord* __restrict__ pose_out, SolveLog* __restrict__ log) {
     __shared__ double rows[kSmallRows][kNumAcc];
     __shared__ double part[8][kNumAcc];
     __shared__ double E[kNumAcc];
@@ -3252,6 +3252,7 @@ lm_solve_small_kernel(EvalArgs A, LMParams Q, LMState* Sg, const double* __restr
         sL = L;
         for (int i = 0; i < 6; i++) s_x[i] = L.x[i];
         s_done = 0;
+        if (pose_out) pose_out->ready = 0;                   // chain mode: the next round's association waits for this solve
     }
     __syncthreads();
     EvalArgs B = A;
@@ -3283,7 +3284,25 @@ lm_solve_small_kernel(EvalArgs A, LMParams Q, LMState* Sg, const double* __restr
         }
         __syncthreads();
     }
-    if (t == 0) *Sg = sL;
+    if (t == 0) {
+        *Sg = sL;
+        if (sL.done) {                                       // chain mode: what the host and the next round need (see lm_advance)
+            if (log) {
+                for (int i = 0; i < 6; i++) log->x[i] = sL.x[i];
+                log->initial_cost = sL.initial_cost; log->final_cost = sL.cost;
+                log->termination = sL.termination; log->iter = sL.iter; log->evals = sL.evals; log->n_valid = sL.n_valid;
+            }
+            if (pose_out) {
+                double xf[6];
+                for (int i = 0; i < 6; i++) xf[i] = sL.x[i];
+                PoseScalars S;
+                pose_scalars_compute(xf, &S);
+                pose_out->P = S;
+                __threadfence();
+                pose_out->ready = 1;
+            }
+        }
+    }
 }
 
 // ---- seam 2 by value: a batch of residual functors (costfunctions.h:17-220) at one pose -----------------------------------
