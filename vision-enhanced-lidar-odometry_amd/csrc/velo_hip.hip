@@ -181,6 +181,8 @@ struct velo_ctx {
     int assoc_lds_pad = 0;               // VELO_ASSOC_LDS_PAD: bytes of unused dynamic LDS per association workgroup -- caps the association
                                          // kernel's workgroups per CU so that LM workgroups of other pairs in flight find room at once
     // chain mode: a whole frame_to_frame as ONE chain of launches (pose scalars of the next round and the solve summaries stay on the device)
+    int direct_max = 12288;              // sparse rounds (icp_skip >= direct_skip) of at most this many queries search one wave per query
+    int direct_skip = 4;                 // (VELO_ASSOC_DIRECT_MAX, 0 = never; VELO_ASSOC_DIRECT_SKIP)
     int asker_queue = 1;                 // shrunk grid: asking queries go to assoc_asker_kernel (VELO_ASKER_QUEUE=0: searched inside their group's workgroup)
     DevBuf<int> ask_count, ask_list;
     DevBuf<unsigned long long> ask_keys;
@@ -617,6 +619,15 @@ bool lane_round(const velo_ctx* c, const Grid* G, bool partial) {
     return reach_cells <= 5;
 }
 
+// Sparse rounds (the reference's icp_skip = 200: 640 queries, metres apart) search one wave per query (assoc_direct_kernel).
+// Measured on the 120k-point pair, us per round, tube / direct (tools/skip_sweep.py): icp_skip 200: 88 / 18, 64: 143 / 31,
+// 32: 196 / 51, 24: 201 / 63, 16: 178 / 92, 12: 148 / 115, 8 (15k queries): 101 / 167, 4: 63 / 317, 1: 61 / 1,223 -- the tube
+// kernel needs neighbouring queries in a group, the direct kernel costs ~12 ns per query.
+bool direct_round(const velo_ctx* c, int nq, bool partial) {
+    return c->direct_max > 0 && nq > 0 && nq <= c->direct_max && c->src_skip >= c->direct_skip && c->assoc_variant < 0 && !c->debug_skip && c->tube_map < 0 &&
+           !partial;
+}
+
 int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool wait, int* n_valid, bool partial = false, const PoseRecord* P_dev = nullptr) {
     if (!c->have_target || !c->have_source) return fail(VELO_ERR_STATE, "associate needs set_target and set_source first");
     if (iter < 1) return fail(VELO_ERR_INVALID, "iter must be >= 1");
@@ -638,7 +649,8 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         out.n_valid_next = nullptr;
         VELO_TRY(attach_seeds(c, &out));
         VELO_TRY(attach_askers(c, &out, false));
-        const bool lane = lane_round(c, G, partial);
+        const bool direct = direct_round(c, qe - qb, partial);
+        const bool lane = !direct && lane_round(c, G, partial);
         if (c->debug_skip & 32) { VELO_TRY(c->wg_times.reserve((size_t)2 * cdiv(qe - qb, 64) + 2)); out.wg_times = c->wg_times.p; c->wg_times_n = cdiv(qe - qb, 64); }
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
         if (c->timing) {
@@ -654,7 +666,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         // stop (what a rocprofv3 kernel trace reports); events recorded around a launch would also count the time the launch waits
         // for the chip while other streams' kernels run.  The A/B variants keep the record-around bracket.
         const int variant_timed = c->assoc_variant >= 0 ? c->assoc_variant : 5;
-        const bool ext_timed = lane || variant_timed == 5 || (variant_timed >= 52 && variant_timed <= 59);
+        const bool ext_timed = direct || lane || variant_timed == 5 || (variant_timed >= 52 && variant_timed <= 59);
         if (ev && !ext_timed) HIP_TRY(hipEventRecord(ev->first, c->stream));
         const int aux = want_aux ? 1 : 0;
         const int groups = cdiv(qe - qb, 64);
@@ -675,7 +687,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         // Default = tube kernel (5) with warm start.  120k-pt scans: 69 us per launch averaged over the 6 rounds of a call (box
         // kernel 4: 121 us); 2M-pt map: 535 us vs 1.49 ms -- its cold first round is slower there (density-shrunk grid, gate radius
         // = 15 cells, every query asks for a (2e+1)^2-row box: 1.59 vs 1.45 ms) but the five warm rounds need tiny boxes.
-        const int variant = lane ? 6 : (c->assoc_variant >= 0 ? c->assoc_variant : 5);
+        const int variant = direct ? 7 : lane ? 6 : (c->assoc_variant >= 0 ? c->assoc_variant : 5);
         const int reach_cells = (int)std::ceil(std::sqrt(std::max(gate_of_iter(c->P, 1), 0.0)) / (G->h * 0.999));   // > 5: density-shrunk grid
         switch (variant) {
             case 0: {
@@ -705,6 +717,14 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 else
                     hipLaunchKernelGGL((assoc_cluster_kernel<4, 6>), dim3(wgs), dim3(256), 0, c->stream, V, Q, c->src.p, c->q_src.p, qb, qe,
                                        c->T->tgt.p, c->T->tgt_off.p, c->T->tgt_ring_of.p, gbits, c->P.icp_norm_condition, h_safe, out, aux);
+                break;
+            }
+            case 7: {   // sparse round: one wave per query
+                out.n_valid_next = c->n_valid.p + (c->nv_idx ^ 1);
+                c->nv_clean[c->nv_idx ^ 1] = true;
+                hipExtLaunchKernelGGL(assoc_direct_kernel, dim3(qe - qb), dim3(64), 0, c->stream, ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0,
+                                      S, P_dev, P_dev ? c->chain_fail.p : (int*)nullptr, V, c->qpts, qb, qe, (const float4*)c->T->tgt_pad.p, (const int*)c->T->tgt_off.p,
+                                      gbits, c->P.icp_norm_condition, h_safe, out, aux);
                 break;
             }
             case 6: {   // lane kernel: one lane owns one query (rounds that start from seeds)
@@ -782,7 +802,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
 #undef VELO_LAUNCH_V2
 #undef VELO_LAUNCH_V3
         HIP_TRY(hipGetLastError());
-        if (out.prev_a && (variant == 6 || variant == 5 || (variant >= 52 && variant <= 59))) c->seed_rounds++;   // these kernels leave seeds behind
+        if (out.prev_a && (variant == 7 || variant == 6 || variant == 5 || (variant >= 52 && variant <= 59))) c->seed_rounds++;   // these kernels leave seeds behind
         if (ev && !ext_timed) HIP_TRY(hipEventRecord(ev->second, c->stream));
 #ifdef VELO_DIAGNOSTICS
         if ((c->debug_skip & 24) && getenv("VELO_DEBUG_EACH")) {       // per-launch read-out (default: totals when the context goes)
@@ -1184,6 +1204,8 @@ int velo_create(velo_ctx** out, int device) {
         if (const char* e = getenv("VELO_LM_MERGED")) c->lm_merged = atoi(e);
         if (const char* e = getenv("VELO_ASSOC_LANE")) c->assoc_lane = atoi(e);
         if (const char* e = getenv("VELO_ASKER_QUEUE")) c->asker_queue = atoi(e);
+        if (const char* e = getenv("VELO_ASSOC_DIRECT_MAX")) c->direct_max = std::max(atoi(e), 0);
+        if (const char* e = getenv("VELO_ASSOC_DIRECT_SKIP")) c->direct_skip = std::max(atoi(e), 1);
         if (const char* e = getenv("VELO_CHAIN")) c->chain = atoi(e);
         if (const char* e = getenv("VELO_CHAIN_MARGIN")) c->chain_margin = std::max(atoi(e), 0);
         if (const char* e = getenv("VELO_ASSOC_LDS_PAD")) c->assoc_lds_pad = std::max(atoi(e), 0);
@@ -2132,7 +2154,7 @@ static bool batch_can_lockstep(velo_ctx** ctxs, int n, bool targets_follow = fal
 // ---- the same association round of several contexts in ONE launch (lock-step batch driver) ---------------------------------------
 // Host-side preparation of one context's round for the tube kernel, exactly what do_associate does before its launch.
 // *groups = 0 when the context has no queries.
-static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs* A, int* groups, bool* asker, bool* lane) {
+static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs* A, int* groups, bool* asker, bool* lane, bool* direct) {
     if (!c->have_target || !c->have_source) return fail(VELO_ERR_STATE, "associate needs set_target and set_source first");
     if (c->src_skip != std::max(c->P.icp_skip, 1) || (c->n_q > 0) != (c->P.enable_icp != 0 && c->h_q_off[c->n_src_rings] > 0)) VELO_TRY(build_query_list(c));
     Grid* G = grid_for_iter(c, iter);
@@ -2157,7 +2179,8 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
     out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p + c->nv_idx; out.dbg = c->dbg.p; out.wg_times = nullptr;
     out.first_ring = c->T->tgt_first_ring; out.first_point = c->T->tgt_first_point; out.partial = nullptr;
     VELO_TRY(attach_seeds(c, &out));
-    *lane = lane_round(c, G, false);
+    *direct = direct_round(c, qe - qb, false);
+    *lane = !*direct && lane_round(c, G, false);
     const bool cold = c->seed_rounds == 0;
     if (out.prev_a) c->seed_rounds++;
     {
@@ -2165,7 +2188,7 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
         const int ar = c->asker_rows >= 0 ? c->asker_rows : (reach0 > 5 ? 0 : (1 << 30));
         // The list pays off for ONE pair in flight (a launch's tail is idle chip); with several groups in flight other streams' kernels fill the
         // tail anyway and the second launch only costs (8 pairs on the 2M-point map: 938 vs 957 pairs/s).  VELO_ASKER_QUEUE=2 forces it here too.
-        VELO_TRY(attach_askers(c, &out, ar < (1 << 30) && !*lane && cold && c->asker_queue >= 2));
+        VELO_TRY(attach_askers(c, &out, ar < (1 << 30) && !*lane && !*direct && cold && c->asker_queue >= 2));
     }
     out.n_valid_next = c->n_valid.p + (c->nv_idx ^ 1);
     c->nv_clean[c->nv_idx ^ 1] = true;
@@ -2206,11 +2229,12 @@ static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::arr
         AssocBatch B;
         std::memset(&B, 0, sizeof(B));
         int gmax = 0, k = 0, first = -1;
-        bool any_asker = false, all_lane = true;
+        bool any_asker = false, all_lane = true, all_direct = true;
+        int nq_max = 0;
         for (int i = b; i < b + m; i++) {
-            int groups = 0; bool asker = false, lane = false;
-            VELO_TRY(prepare_assoc_v5(ctxs[i], xs[(size_t)i].data(), iter, &B.item[k], &groups, &asker, &lane));
-            if (groups > 0) all_lane = all_lane && lane;
+            int groups = 0; bool asker = false, lane = false, direct = false;
+            VELO_TRY(prepare_assoc_v5(ctxs[i], xs[(size_t)i].data(), iter, &B.item[k], &groups, &asker, &lane, &direct));
+            if (groups > 0) { all_lane = all_lane && lane; all_direct = all_direct && direct; nq_max = std::max(nq_max, B.item[k].q_end - B.item[k].q_begin); }
             ctxs[i]->have_corr = true;
             if (pose_dev) { B.item[k].P_dev = pose_dev + i; B.item[k].chain_fail = fail_dev + i; }
             if (groups == 0) continue;                                  // no queries: nothing to launch for it
@@ -2239,7 +2263,8 @@ static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::arr
             }
             for (int i = b; i < b + m; i++) ctxs[i]->ask_clean[0] = ctxs[i]->ask_clean[1] = false;   // no launch clears a counter this round
         }
-        if (all_lane) hipExtLaunchKernelGGL(assoc_lane_batch_kernel, dim3(cdiv(gmax, 4), k), dim3(256), 0, c->stream, ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, B);
+        if (all_direct) hipExtLaunchKernelGGL(assoc_direct_batch_kernel, dim3(nq_max, k), dim3(64), 0, c->stream, ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, B);
+        else if (all_lane) hipExtLaunchKernelGGL(assoc_lane_batch_kernel, dim3(cdiv(gmax, 4), k), dim3(256), 0, c->stream, ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, B);
         else if (any_asker && all_queue) {
             hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, 2>), dim3(gmax, k), dim3(256), c->assoc_lds_pad, c->stream, ev ? ev->first : nullptr, nullptr, 0, B);
             hipExtLaunchKernelGGL(assoc_asker_batch_kernel, dim3(cdiv(gmax * 64, kAskChunk), k), dim3(64), 0, c->stream, nullptr, ev ? ev->second : nullptr, 0, B);

@@ -1607,6 +1607,64 @@ assoc_asker_batch_kernel(AssocBatch B) {
     assoc_asker_body(a.P, a.P_dev, a.chain_fail, a.G, a.qpts, a.tgt_pad, a.tgt_off, a.gate_bits, a.norm_cond, a.h_safe, a.out, a.want_aux, (int)blockIdx.x, n_waves);
 }
 
+// ---- sparse queries: one wave per query -------------------------------------------------------------------------------------
+// With the reference's own constants (icp_skip = 200, kitti.h:8) a round has 640 queries, 6 m apart along their rings: the 64
+// queries of a tube group share nothing, its tube is 64 separate boxes, and ten workgroups walk them one row chunk after the other
+// (55-150 us per round -- more than the six solves of the call together).  Here every query gets a wave of its own: the 64 lanes
+// search its bound sphere exactly as assoc_asker_kernel does for a listed query (seeds first, then no farther than 4 cells,
+// then the whole sphere if the bound still reaches beyond), lane 0 finishes the correspondence.  640 waves, all resident at once.
+__device__ __forceinline__ void
+assoc_direct_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_dev, int* __restrict__ chain_fail, const GridView& G, const float4* __restrict__ qpts,
+                  int q_begin, int q_end, const float4* __restrict__ tgt_pad, const int* __restrict__ tgt_off, unsigned gate_bits, double norm_cond, float h_safe,
+                  const AssocOut& out, int want_aux, const int block_x) {
+    __shared__ int s_j0[64], s_off[66];
+    const int lane = threadIdx.x & 63;
+    if (chain_fail && *chain_fail) return;
+    if (P_dev && !P_dev->ready) { if (block_x == 0 && lane == 0) *chain_fail = 1; return; }
+    const PoseScalars& P = P_dev ? P_dev->P : P_in;
+    if (out.n_valid_next && block_x == 0 && lane == 0) *out.n_valid_next = 0;
+    const int qi = q_begin + block_x;
+    if (qi >= q_end) return;
+    const unsigned long long key_inf = ((unsigned long long)gate_bits + 1ull) << 32;
+    const GridDesc g = G.d;
+    Top2 tl;
+    tl.b1 = key_inf; tl.b2 = key_inf; tl.b1ring = -1; tl.b2ring = -1; tl.b2d = __uint_as_float(gate_bits + 1u);
+    float qx, qy, qz;
+    {   // every lane holds the same query (uniform loads, the transform costs what it costs on one lane)
+        const float4 psrc = qpts[qi];
+        transform_query(P, psrc, &qx, &qy, &qz);
+        if (out.prev_a) {
+            const float4 sa = out.prev_a[qi], sb = out.prev_b[qi];
+            const int2 sr = out.prev_r[qi];
+            if (__float_as_int(sa.w) >= 0) {
+                const float d = dist2_f(sa.x, sa.y, sa.z, qx, qy, qz);
+                if (__float_as_uint(d) <= gate_bits) top2_update(tl, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(__float_as_int(sa.w) + out.first_point), sr.x);
+            }
+            if (__float_as_int(sb.w) >= 0) {
+                const float d = dist2_f(sb.x, sb.y, sb.z, qx, qy, qz);
+                if (__float_as_uint(d) <= gate_bits) top2_update(tl, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(__float_as_int(sb.w) + out.first_point), sr.y);
+            }
+        }
+    }
+    const float cap = 4.0f * h_safe;
+    const float r0 = sqrtf(tl.b2d) * 1.0001f + 1e-6f;
+    asker_search(G, g, qx, qy, qz, fminf(r0, cap), tl, lane, s_j0, s_off);
+    const float r1 = sqrtf(tl.b2d) * 1.0001f + 1e-6f;
+    if (r1 > cap) asker_search(G, g, qx, qy, qz, r1, tl, lane, s_j0, s_off);
+    if (lane == 0) finish_correspondence_pad(qi, qpts, qx, qy, qz, tl.b1, tl.b2, tl.b1ring, tl.b2ring, key_inf, tgt_pad, tgt_off, norm_cond, out, want_aux != 0);
+}
+__global__ void __launch_bounds__(64)
+assoc_direct_kernel(PoseScalars P, const PoseRecord* __restrict__ P_dev, int* __restrict__ chain_fail, GridView G, const float4* __restrict__ qpts, int q_begin, int q_end,
+                    const float4* __restrict__ tgt_pad, const int* __restrict__ tgt_off, unsigned gate_bits, double norm_cond, float h_safe, AssocOut out, int want_aux) {
+    assoc_direct_body(P, P_dev, chain_fail, G, qpts, q_begin, q_end, tgt_pad, tgt_off, gate_bits, norm_cond, h_safe, out, want_aux, (int)blockIdx.x);
+}
+__global__ void __launch_bounds__(64)
+assoc_direct_batch_kernel(AssocBatch B) {
+    const AssocArgs& a = B.item[blockIdx.y];
+    if ((int)blockIdx.x >= a.q_end - a.q_begin) return;
+    assoc_direct_body(a.P, a.P_dev, a.chain_fail, a.G, a.qpts, a.q_begin, a.q_end, a.tgt_pad, a.tgt_off, a.gate_bits, a.norm_cond, a.h_safe, a.out, a.want_aux, (int)blockIdx.x);
+}
+
 // ---- association search, lane variant: the rounds that start from seeds ------------------------------------------------------
 // The tube kernel shares every staged candidate among the 64 queries of a group: 350 candidates x 64 lanes per warm round, of
 // which a query needs the ~15 of its own bound sphere -- 9,400 lane-instructions per query.  A round that starts from the
