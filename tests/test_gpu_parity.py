@@ -586,3 +586,39 @@ def test_chain_mode_with_single_launch_solves_at_the_reference_constants(hip_lib
     assert out["host"][1] == (0, 0) and out["chain"][1] == (3, 0)
     for (x0, T0, s0, *r0), (x1, T1, s1, *r1) in zip(out["host"][0], out["chain"][0]):
         assert np.array_equal(x0, x1) and np.array_equal(T0, T1) and s0 == s1 and r0 == r1 and r0[0] == 640
+
+
+def test_chain_mode_with_visual_blocks_is_bit_identical(hip_lib, oracle, monkeypatch):
+    """With stereo matches the residual-type choice + outlier gate of every f2f iteration runs on the device at the pose the device
+    holds, and the chain carries sweep + visual sweep + step launches; pose, solves (incl. the visual block / residual counts per
+    solve), good matches and bytes equal the host-driven path bit for bit -- large and single-launch-solve problems, tight margin."""
+    cases = [(H.small_pair(32, 400), 1, synth.stereo_matches(300, mix="all")),          # 12,800 queries: launch-per-iteration solves
+             (synth.scan_pair(), 200, synth.stereo_matches(40, mix="all")),             # reference constants: single-launch solves
+             (H.small_pair(32, 400), 1, synth.stereo_matches(150))]                     # reprojection blocks only
+    for d, skip, vis in cases:
+        vis = api.matches_from_dict(vis)
+        res = {}
+        for name, env in (("host", {"VELO_CHAIN": "0"}), ("chain", {"VELO_CHAIN": "1"}), ("tight", {"VELO_CHAIN": "1", "VELO_CHAIN_MARGIN": "0"})):
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            c = api.Context(0, icp_skip=skip)
+            monkeypatch.delenv("VELO_CHAIN_MARGIN", raising=False)
+            c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"]); c.set_visual(vis)
+            out = []
+            for x0 in (d["x0"], d["x_true"]):
+                x, T, s = c.frame_to_frame(x0)
+                vis_counts = [(s.solves[k].n_visual_blocks, s.solves[k].n_visual_residuals) for k in range(s.n_solves)]
+                out.append((x.copy(), T.copy(), _summary_tuple(s), vis_counts, s.algorithmic_bytes, c.good_matches().tobytes()))
+            res[name] = (out, c.chain_stats())
+            c.close()
+        assert res["host"][1] == (0, 0) and res["chain"][1][0] == 2
+        for name in ("chain", "tight"):
+            for (x0, T0, s0, v0, b0, g0), (x1, T1, s1, v1, b1, g1) in zip(res["host"][0], res[name][0]):
+                assert np.array_equal(x0, x1) and np.array_equal(T0, T1) and s0 == s1 and v0 == v1 and b0 == b1 and g0 == g1
+                assert v0[0][0] > 0
+        # and against the oracle
+        orc = oracle.Oracle(threads=8, icp_skip=skip)
+        orc.set_target(d["tgt_xyz"], d["tgt_off"]); orc.set_source(d["src_xyz"], d["src_off"]); orc.set_visual(vis)
+        xo, To, so = orc.frame_to_frame(d["x0"])
+        assert H.pose_close(res["chain"][0][0][0], xo)
+        assert [(so.solves[k].n_visual_blocks, so.solves[k].n_visual_residuals) for k in range(so.n_solves)] == res["chain"][0][0][3]

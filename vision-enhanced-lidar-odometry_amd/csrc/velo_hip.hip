@@ -161,6 +161,7 @@ struct velo_ctx {
 
     // target (frame2): cloud + search index, shareable between contexts (velo_share_target: many scans against one map)
     std::shared_ptr<TargetData> T = std::make_shared<TargetData>();
+    DevBuf<int> vis_counts;                       // chain mode: [f2f iteration][blocks, residuals] selected by the device-side gate
     DevBuf<int> scan_tiles, cursor, scan_total;   // scratch of an index build / of the segmenter's scans
     DevBuf<unsigned long long> lb_status;         // one-pass scan: tile status words + ticket
     DevBuf<unsigned> bbox_keys;
@@ -849,7 +850,7 @@ int do_build_visual(velo_ctx* c, const double* x_host, bool x_on_state, int iter
         HIP_TRY(hipMemcpyAsync(c->xdev.p, c->h_x, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
         xd = c->xdev.p;
     }
-    hipLaunchKernelGGL(visual_gate_kernel, dim3(cdiv(n, 128)), dim3(128), 0, c->stream, xd, visual_params(c->P), c->vm.p, n, iter, c->vflags.p);
+    hipLaunchKernelGGL(visual_gate_kernel, dim3(cdiv(n, 128)), dim3(128), 0, c->stream, xd, visual_params(c->P), c->vm.p, n, iter, c->vflags.p, (int*)nullptr);
     HIP_TRY(hipGetLastError());
     c->h_vflags.resize((size_t)3 * n);
     HIP_TRY(hipMemcpyAsync(c->h_vflags.data(), c->vflags.p, (size_t)3 * n, hipMemcpyDeviceToHost, c->stream));
@@ -884,9 +885,9 @@ int enqueue_lm_iteration(velo_ctx* c, const EvalArgs& A_in, const EvalPlan& E, c
         // every rank reaches this call the same number of times: `done` is identical on all ranks, and when it is
         // set the kernels above exit early and the buffer keeps its previous (identical) content
         NCCL_TRY(ncclAllReduce(c->reduced.p, c->reduced.p + kNumAcc, kNumAcc, ncclDouble, ncclSum, c->comm, c->stream));
-        hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, c->eval_pt.p, (const double*)(c->reduced.p + kNumAcc), 1, A.trace, A.trace_eval);
+        hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, c->eval_pt.p, (const double*)(c->reduced.p + kNumAcc), 1, A.trace, A.trace_eval, (PoseRecord*)nullptr, (SolveLog*)nullptr);
     } else {
-        hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, c->eval_pt.p, (const double*)c->partials.p, nblocks, A.trace, A.trace_eval);
+        hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, c->eval_pt.p, (const double*)c->partials.p, nblocks, A.trace, A.trace_eval, (PoseRecord*)nullptr, (SolveLog*)nullptr);
     }
     HIP_TRY(hipGetLastError());
     return VELO_OK;
@@ -985,7 +986,8 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
             chunk = 3;
         }
     } else {
-    hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->state.p, c->eval_pt.p, xd, (const int*)(c->have_corr ? c->n_valid.p + c->nv_idx : nullptr));
+    hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->state.p, c->eval_pt.p, xd, (const int*)(c->have_corr ? c->n_valid.p + c->nv_idx : nullptr),
+                       (PoseRecord*)nullptr);
     int launched = 0;
     int chunk = first_chunk;                // LM iterations per host round trip
     const int max_iters = c->P.max_num_iterations + 1;
@@ -1272,7 +1274,7 @@ int velo_destroy(velo_ctx* c) {
     if (c->peer_slab) { (void)hipFree(c->peer_slab); c->peer_slab = nullptr; }
     if (c->peer_area) { (void)hipFree(c->peer_area); c->peer_area = nullptr; }
     c->T.reset();                                            // the target goes with its last holder
-    c->lb_status.release(); c->scan_tiles.release(); c->cursor.release(); c->scan_total.release(); c->bbox_keys.release();
+    c->vis_counts.release(); c->lb_status.release(); c->scan_tiles.release(); c->cursor.release(); c->scan_total.release(); c->bbox_keys.release();
     c->src.release(); c->src_off.release(); c->q_off.release(); c->q_src.release(); c->staging.release();
     c->seg_flag.release(); c->seg_excl.release(); c->seg_ring.release(); c->seg_off.release();
     c->cp.release(); c->cn.release(); c->cv0.release(); c->aux0.release(); c->aux1.release(); c->n_valid.release(); c->dbg.release(); c->wg_times.release(); c->items.release(); c->item_counters.release(); c->qpos.release(); c->partials_rec.release(); c->partials_all.release();
@@ -1967,7 +1969,7 @@ int velo_solve(velo_ctx* c, double x[6], velo_solve_summary* summary) {
 // more raises the chain's failure flag in the next association (its record is not ready), everything behind it drains, and the
 // call is repeated by the host-driven path below -- same kernels, same arithmetic, so the result does not depend on which path ran.
 static bool chain_eligible(velo_ctx* c) {
-    if (!c->chain || c->want_stats || c->comm || c->peer_on || c->use_graphs || !c->lm_merged || c->n_matches > 0 || !c->P.enable_icp) return false;
+    if (!c->chain || c->want_stats || c->comm || c->peer_on || c->use_graphs || !c->lm_merged || !c->P.enable_icp) return false;
     if (c->assoc_variant >= 0 && c->assoc_variant != 5) return false;
     if (c->debug_skip || c->lm_trace_on || c->tube_map >= 0 || c->shard_world != 1) return false;
     if (c->P.f2f_iterations * c->P.icp_iterations < 1) return false;
@@ -1995,22 +1997,50 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
     const int max_launches = c->P.max_num_iterations + 2;
     std::memcpy(c->h_x, xc, sizeof(double) * 6);
     HIP_TRY(hipMemcpyAsync(c->xdev.p, c->h_x, sizeof(double) * 6, hipMemcpyHostToDevice, c->stream));
-    VELO_TRY(do_build_visual(c, xc, false, 1, nullptr));             // no measurements: only clears the host flags
+    // Visual blocks: the residual-type choice + outlier gate of every f2f iteration (velo.h:622-792) runs on the device at the pose
+    // the device holds (iteration 1: the initial guess, later: the state's x); block / residual counts per iteration and the
+    // last iteration's flags come back with everything else at the end.  The solves then take sweep + visual sweep + step launches.
+    const bool visual = c->n_matches > 0;
+    if (visual) {
+        VELO_TRY(c->vis_counts.reserve(2 * VELO_MAX_STATS));
+        HIP_TRY(hipMemsetAsync(c->vis_counts.p, 0, sizeof(int) * 2 * VELO_MAX_STATS, c->stream));
+        if (c->P.f2f_iterations > VELO_MAX_STATS) return VELO_OK;
+        c->vflags_valid = true;
+    } else {
+        VELO_TRY(do_build_visual(c, xc, false, 1, nullptr));         // no measurements: only clears the host flags
+    }
     c->have_corr = false;
     c->chain_calls++;
     int j = 0, r = 0;                                                // launch counter (its parity selects the double-buffer halves), round
     const int rounds = c->P.f2f_iterations * c->P.icp_iterations;
     for (int iter = 1; iter <= c->P.f2f_iterations; iter++) {
+        if (visual) {
+            hipLaunchKernelGGL(visual_gate_kernel, dim3(cdiv(c->n_matches, 128)), dim3(128), 0, c->stream, (const double*)(iter == 1 ? c->xdev.p : c->state.p->x),
+                               visual_params(c->P), c->vm.p, c->n_matches, iter, c->vflags.p, c->vis_counts.p + 2 * (iter - 1));
+            HIP_TRY(hipGetLastError());
+        }
         for (int icp_iter = 0; icp_iter < c->P.icp_iterations; icp_iter++, r++) {
             int nv = 0;
             VELO_TRY(do_associate(c, xc, iter, false, false, &nv, false, r == 0 ? nullptr : c->pose_rec.p));
             const EvalArgs A = eval_args(c, nullptr);
             const EvalPlan E = eval_plan(A);
-            if (E.nb_icp <= 0 || E.nb_vis > 0) return fail(VELO_ERR_STATE, "chain mode: unexpected evaluation plan");
+            if (E.nb_icp <= 0 || (E.nb_vis > 0) != visual) return fail(VELO_ERR_STATE, "chain mode: unexpected evaluation plan");
             const int* nvp = c->n_valid.p + c->nv_idx;
-            if (small) {                                             // no prediction needed: the launch runs the solve to its end
+            SolveLog* logp = c->solve_log.p + std::min(r, VELO_MAX_SOLVES - 1);
+            if (small && (!visual || E.total() <= kSmallRows)) {     // no prediction needed: the launch runs the solve to its end
                 hipLaunchKernelGGL(lm_solve_small_kernel, dim3(1), dim3(kEvalThreads), 0, c->stream, A, Q, c->state.p, (const double*)(r == 0 ? c->xdev.p : nullptr),
-                                   nvp, E.nb_icp, 0, c->P.max_num_iterations + 3, c->pose_rec.p, c->solve_log.p + std::min(r, VELO_MAX_SOLVES - 1));
+                                   nvp, E.nb_icp, E.nb_vis, c->P.max_num_iterations + 3, c->pose_rec.p, logp);
+                HIP_TRY(hipGetLastError());
+                continue;
+            }
+            if (visual) {                                            // sweep + visual sweep + step per LM iteration, state single-buffered
+                const int Kv = std::min(std::max(c->pred_evals[std::min(r, VELO_MAX_SOLVES - 1)], 1) + margin, max_launches);
+                hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->state.p, c->eval_pt.p, (const double*)(r == 0 ? c->xdev.p : nullptr), nvp, c->pose_rec.p);
+                for (int k = 0; k < Kv; k++) {
+                    launch_eval(c, A, E);
+                    hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, c->eval_pt.p, (const double*)c->partials.p, E.total(),
+                                       (unsigned long long*)nullptr, 0, c->pose_rec.p, logp);
+                }
                 HIP_TRY(hipGetLastError());
                 continue;
             }
@@ -2028,6 +2058,12 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
     HIP_TRY(hipMemcpyAsync(c->h_log, c->solve_log.p, sizeof(SolveLog) * (size_t)std::min(rounds, VELO_MAX_SOLVES), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(h_fail, c->chain_fail.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&c->h_status->s, c->state.p + (j & 1), sizeof(LMState), hipMemcpyDeviceToHost, c->stream));
+    int* h_vis_counts = h_fail + 1;                                  // 2 x VELO_MAX_STATS ints behind the failure flag (the pinned block has 64 spare bytes)
+    if (visual) {
+        c->h_vflags.resize((size_t)3 * c->n_matches);
+        HIP_TRY(hipMemcpyAsync(c->h_vflags.data(), c->vflags.p, (size_t)3 * c->n_matches, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(h_vis_counts, c->vis_counts.p, sizeof(int) * 2 * VELO_MAX_STATS, hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (*h_fail || !c->h_status->s.done) {
         HIP_TRY(hipMemsetAsync(c->chain_fail.p, 0, sizeof(int), c->stream));
@@ -2049,9 +2085,13 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
         std::memset(&ss, 0, sizeof(ss));
         ss.termination = L.termination; ss.lm_iterations = L.iter; ss.evaluations = L.evals; ss.n_icp_valid = L.n_valid;
         ss.initial_cost = L.initial_cost; ss.final_cost = L.final_cost;
+        if (visual) {                                                // the blocks of the f2f iteration this solve belongs to
+            const int it0 = std::min(k / std::max(c->P.icp_iterations, 1), VELO_MAX_STATS - 1);
+            ss.n_visual_blocks = h_vis_counts[2 * it0]; ss.n_visual_residuals = h_vis_counts[2 * it0 + 1];
+        }
         if (k < VELO_MAX_SOLVES) c->pred_evals[k] = L.evals;
         S->eval_kernel_launches += L.evals;
-        S->algorithmic_bytes += (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 224ull);
+        S->algorithmic_bytes += (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull);
         if (S->n_solves < VELO_MAX_SOLVES) S->solves[S->n_solves] = ss;
         S->n_solves++;
     }

@@ -2173,8 +2173,9 @@ __device__ __forceinline__ int visual_block_eval(const PoseEval& P, const Visual
 }
 
 // flags[3*m + slot]: 0 = no block, 1 + residual_type = block present
+// counts (chain mode, may be null): [0] += blocks, [1] += residuals selected here -- the host reads them once, at the end of the call
 __global__ void visual_gate_kernel(const double* __restrict__ xdev, VisualParams V, const VisualMatch* __restrict__ matches, int n, int iter,
-                                   unsigned char* __restrict__ flags) {
+                                   unsigned char* __restrict__ flags, int* __restrict__ counts) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double x[6];
@@ -2208,6 +2209,11 @@ __global__ void visual_gate_kernel(const double* __restrict__ xdev, VisualParams
         }
     }
     flags[3 * i + 0] = f0; flags[3 * i + 1] = f1; flags[3 * i + 2] = f2;
+    if (counts) {
+        const int nb = (f0 ? 1 : 0) + (f1 ? 1 : 0) + (f2 ? 1 : 0);
+        const int nr = (f0 ? (f0 - 1 == VELO_RESIDUAL_3D3D ? 3 : 1) : 0) + (f1 ? 2 : 0) + (f2 ? 2 : 0);     // f0: 3D3D (3 rows) or 2D2D (1 row)
+        if (nb) { atomicAdd(&counts[0], nb); atomicAdd(&counts[1], nr); }
+    }
 }
 
 // ---- LM state (row S1) ------------------------------------------------------------------------------------------------------
@@ -2939,8 +2945,9 @@ __device__ __forceinline__ void lm_begin_body(LMState* S, LMEvalPoint* pt, const
     }
     if (t < 4) eval_point_column(x, 0, t, pt);
 }
-__global__ void lm_begin_kernel(LMState* S, LMEvalPoint* pt, const double* __restrict__ x_in, const int* __restrict__ n_valid) {
+__global__ void lm_begin_kernel(LMState* S, LMEvalPoint* pt, const double* __restrict__ x_in, const int* __restrict__ n_valid, PoseRecord* __restrict__ pose_out) {
     lm_begin_body(S, pt, x_in, n_valid);
+    if (threadIdx.x == 0 && pose_out) pose_out->ready = 0;              // chain mode: the next round's association waits for this solve
 }
 
 // The LM step of one solve, by one 256-thread workgroup: fixed-order sum of the per-workgroup partial rows [n_blocks][28] (or of
@@ -3260,8 +3267,9 @@ __device__ __forceinline__ void lm_transition_wave(const LMParams& Q, LMState* s
 }
 
 __global__ void __launch_bounds__(256)
-lm_step_kernel(LMParams Q, LMState* S, LMEvalPoint* pt, const double* __restrict__ partials, int n_blocks, unsigned long long* trace, int trace_eval) {
-    lm_transition(Q, S, pt, partials, n_blocks, trace, trace_eval);
+lm_step_kernel(LMParams Q, LMState* S, LMEvalPoint* pt, const double* __restrict__ partials, int n_blocks, unsigned long long* trace, int trace_eval,
+               PoseRecord* __restrict__ pose_out, SolveLog* __restrict__ log) {
+    lm_transition(Q, S, pt, partials, n_blocks, trace, trace_eval, nullptr, pose_out, log);
 }
 // the LM step of a query-sharded solve: my partial rows, the peer all-reduce, the transition -- one launch
 __global__ void __launch_bounds__(256)
