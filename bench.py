@@ -319,7 +319,9 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
             "valid_correspondences_last_round": int(s0.solves[s0.n_solves - 1].n_icp_valid),
             "algorithmic_bytes_per_pair": per_pair_bytes,
             "achieved_hbm_GBs_whole_path": per_pair_bytes * (total_pairs / dt) / 1e9,
-            "roofline": {"bound": "hbm", "kernel": "assoc_search_v5_batch_kernel" if batched else "assoc_search_v5_kernel",
+            # sparse rounds (icp_skip >= 4 and <= 12,288 queries: the c1 leg) are searched one wave per query, the others by the tube kernel
+            "roofline": {"bound": "hbm", "kernel": (("assoc_direct_batch_kernel" if batched else "assoc_direct_kernel") if (icp_skip >= 4 and int(s0.n_queries) <= 12288)
+                                                    else ("assoc_search_v5_batch_kernel" if batched else "assoc_search_v5_kernel")),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": b_launch},
             "solution_x": [float(v) for v in results[0][0]],
