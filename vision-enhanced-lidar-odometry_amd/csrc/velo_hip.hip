@@ -391,7 +391,8 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
             dims[k] = (int)std::min(dk, 8192.0);
             total *= dk;
         }
-        if (ok && total <= 33554432.0) break;
+        static const double cell_cap = getenv("VELO_GRID_CAP") ? std::max(atof(getenv("VELO_GRID_CAP")), 4096.0) : 33554432.0;
+        if (ok && total <= cell_cap) break;
         h *= 1.26;
     }
     G.d.ox = c->T->bbox[0]; G.d.oy = c->T->bbox[1]; G.d.oz = c->T->bbox[2];
