@@ -354,13 +354,27 @@ def main():
             for name, steps in (("c1", 100), ("c3", 40), ("c4", 12)):
                 if name != a.workload:
                     legs[name] = run_leg(rig, a, name, "replicas", a.batch, steps, 3)
-        if world > 1 and a.mode == "replicas":
-            # the north_star's multi-GPU modes, next to the replicas: one pair per step, strong scaling
-            modes["sharded"] = run_leg(rig, a, a.workload, "sharded", 1, max(20, a.steps // 4), 5, single_leg=False, comm=a.comm)
-            try:
-                modes["target_sharded"] = run_leg(rig, a, "c4", "target-sharded", 1, 10, 3, single_leg=False, comm=a.comm)
-            except Exception as e:           # noqa: BLE001  (reported in the line, not fatal for the headline)
-                modes["target_sharded"] = {"error": str(e)[:300]}
+        if world > 1 and a.mode == "replicas" and os.environ.get("VELO_BENCH_MODES", "1") != "0":
+            # the north_star's multi-GPU modes, next to the replicas: one pair per step, strong scaling.  Never fatal for the headline:
+            # a leg that fails on any rank is reported as an error by all of them (the ranks agree after every attempt), and a failed
+            # peer-slab attempt is repeated over RCCL.
+            def mode_leg(workload, mode, steps, warmup):
+                out = None
+                for comm in ([a.comm, "rccl"] if a.comm == "peer" else [a.comm]):
+                    try:
+                        res, ok = run_leg(rig, a, workload, mode, 1, steps, warmup, single_leg=False, comm=comm), True
+                    except Exception as e:       # noqa: BLE001
+                        res, ok = {"error": f"{comm}: {str(e)[:300]}"}, False
+                    got = [None] * world
+                    rig.dist.all_gather_object(got, ok)
+                    if all(got):
+                        if out is not None:
+                            res["first_attempt"] = out
+                        return res
+                    out = res if not ok else {"error": f"{comm}: another rank failed"}
+                return out
+            modes["sharded"] = mode_leg(a.workload, "sharded", max(20, a.steps // 4), 5)
+            modes["target_sharded"] = mode_leg("c4", "target-sharded", 10, 3)
 
     if rank == 0:
         rf = dict(main_leg["roofline"])

@@ -1,0 +1,36 @@
+"""-m gpu: bench.py as the driver launches it for N > 1 (one process per rank through torch.distributed.run), here with two
+ranks forced onto the one GPU of the box and gloo for the barrier: the JSON line must carry the replicas headline AND the
+north_star's two multi-GPU modes, each with the communicator kind and the ranks read back from it."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_bench_line_reports_both_sharded_modes(hip_lib):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--dist-backend", "gloo", "--force-device", "0", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    for mode in ("sharded", "target_sharded"):
+        m = line["modes"][mode]
+        assert "error" not in m or m["error"] is None, m
+        assert m["communicator"]["ranks"] == 2 and m["communicator"]["kind"] in ("peer slabs (hipIpc)", "rccl")
+        assert m["pairs_per_s"] > 0
