@@ -880,7 +880,7 @@ int enqueue_lm_iteration(velo_ctx* c, const EvalArgs& A_in, const EvalPlan& E, c
     launch_eval(c, A, E);
     const int nblocks = E.total();
     if (c->peer_on) {
-        hipLaunchKernelGGL(lm_step_peer_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, c->eval_pt.p, (const double*)c->partials.p, nblocks, c->peer);
+        hipLaunchKernelGGL(lm_step_peer_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, c->eval_pt.p, (const double*)c->partials.p, nblocks, c->peer, (PoseRecord*)nullptr, (SolveLog*)nullptr);
     } else if (c->comm) {
         hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(64), 0, c->stream, (const LMState*)c->state.p, (const double*)c->partials.p, nblocks, c->reduced.p);
         // every rank reaches this call the same number of times: `done` is identical on all ranks, and when it is
@@ -1970,9 +1970,14 @@ int velo_solve(velo_ctx* c, double x[6], velo_solve_summary* summary) {
 // more raises the chain's failure flag in the next association (its record is not ready), everything behind it drains, and the
 // call is repeated by the host-driven path below -- same kernels, same arithmetic, so the result does not depend on which path ran.
 static bool chain_eligible(velo_ctx* c) {
-    if (!c->chain || c->want_stats || c->comm || c->peer_on || c->use_graphs || !c->lm_merged || !c->P.enable_icp) return false;
+    if (!c->chain || c->want_stats || c->comm || c->use_graphs || !c->lm_merged || !c->P.enable_icp) return false;
     if (c->assoc_variant >= 0 && c->assoc_variant != 5) return false;
-    if (c->debug_skip || c->lm_trace_on || c->tube_map >= 0 || c->shard_world != 1) return false;
+    if (c->debug_skip || c->lm_trace_on || c->tube_map >= 0) return false;
+    // several ranks: only the query-sharded mode over peer slabs (every rank holds the same state, so every rank computes the same
+    // record and the same launch counts; the all-reduce lives inside the step kernel, no host in between)
+    if (c->shard_world != 1 && !(c->peer_on && !c->target_sharded)) return false;
+    if (c->peer_on && c->target_sharded) return false;
+    if (c->peer_on && c->n_q < 64 * c->shard_world) return false;    // (a rank-uniform test: every rank must take the same path, and n_q is the global count)
     if (c->P.f2f_iterations * c->P.icp_iterations < 1) return false;
     return true;
 }
@@ -2025,22 +2030,25 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
             VELO_TRY(do_associate(c, xc, iter, false, false, &nv, false, r == 0 ? nullptr : c->pose_rec.p));
             const EvalArgs A = eval_args(c, nullptr);
             const EvalPlan E = eval_plan(A);
-            if (E.nb_icp <= 0 || (E.nb_vis > 0) != visual) return fail(VELO_ERR_STATE, "chain mode: unexpected evaluation plan");
+            if (E.total() <= 0) return fail(VELO_ERR_STATE, "chain mode: unexpected evaluation plan");
             const int* nvp = c->n_valid.p + c->nv_idx;
             SolveLog* logp = c->solve_log.p + std::min(r, VELO_MAX_SOLVES - 1);
-            if (small && (!visual || E.total() <= kSmallRows)) {     // no prediction needed: the launch runs the solve to its end
+            const bool peer = c->peer_on;
+            if (small && !peer && (!visual || E.total() <= kSmallRows)) {     // no prediction needed: the launch runs the solve to its end
                 hipLaunchKernelGGL(lm_solve_small_kernel, dim3(1), dim3(kEvalThreads), 0, c->stream, A, Q, c->state.p, (const double*)(r == 0 ? c->xdev.p : nullptr),
                                    nvp, E.nb_icp, E.nb_vis, c->P.max_num_iterations + 3, c->pose_rec.p, logp);
                 HIP_TRY(hipGetLastError());
                 continue;
             }
-            if (visual) {                                            // sweep + visual sweep + step per LM iteration, state single-buffered
+            if (visual || peer) {                                    // sweep (+ visual sweep) + step per LM iteration, state single-buffered
                 const int Kv = std::min(std::max(c->pred_evals[std::min(r, VELO_MAX_SOLVES - 1)], 1) + margin, max_launches);
                 hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->state.p, c->eval_pt.p, (const double*)(r == 0 ? c->xdev.p : nullptr), nvp, c->pose_rec.p);
                 for (int k = 0; k < Kv; k++) {
                     launch_eval(c, A, E);
-                    hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, c->eval_pt.p, (const double*)c->partials.p, E.total(),
-                                       (unsigned long long*)nullptr, 0, c->pose_rec.p, logp);
+                    if (peer) hipLaunchKernelGGL(lm_step_peer_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, c->eval_pt.p, (const double*)c->partials.p, E.total(),
+                                                 c->peer, c->pose_rec.p, logp);
+                    else hipLaunchKernelGGL(lm_step_kernel, dim3(1), dim3(256), 0, c->stream, Q, c->state.p, c->eval_pt.p, (const double*)c->partials.p, E.total(),
+                                            (unsigned long long*)nullptr, 0, c->pose_rec.p, logp);
                 }
                 HIP_TRY(hipGetLastError());
                 continue;
@@ -2066,6 +2074,10 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
         HIP_TRY(hipMemcpyAsync(h_vis_counts, c->vis_counts.p, sizeof(int) * 2 * VELO_MAX_STATS, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->peer_on) {
+        HIP_TRY(hipMemcpy(c->h_int, c->peer_err.p, sizeof(int), hipMemcpyDeviceToHost));
+        if (c->h_int[0]) return fail(VELO_ERR_COMM, "peer all-reduce timed out: a rank of the communicator did not arrive");
+    }
     if (*h_fail || !c->h_status->s.done) {
         HIP_TRY(hipMemsetAsync(c->chain_fail.p, 0, sizeof(int), c->stream));
         for (int k = 0; k < VELO_MAX_SOLVES; k++) c->pred_evals[k] += 2;    // the host-driven repeat below records the real counts
@@ -2086,7 +2098,7 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
         std::memset(&ss, 0, sizeof(ss));
         ss.termination = L.termination; ss.lm_iterations = L.iter; ss.evaluations = L.evals; ss.n_icp_valid = L.n_valid;
         ss.initial_cost = L.initial_cost; ss.final_cost = L.final_cost;
-        if (visual) {                                                // the blocks of the f2f iteration this solve belongs to
+        if (visual && c->shard_rank == 0) {                          // the blocks of the f2f iteration this solve belongs to (rank 0 reports them)
             const int it0 = std::min(k / std::max(c->P.icp_iterations, 1), VELO_MAX_STATS - 1);
             ss.n_visual_blocks = h_vis_counts[2 * it0]; ss.n_visual_residuals = h_vis_counts[2 * it0 + 1];
         }

@@ -3273,8 +3273,9 @@ lm_step_kernel(LMParams Q, LMState* S, LMEvalPoint* pt, const double* __restrict
 }
 // the LM step of a query-sharded solve: my partial rows, the peer all-reduce, the transition -- one launch
 __global__ void __launch_bounds__(256)
-lm_step_peer_kernel(LMParams Q, LMState* S, LMEvalPoint* pt, const double* __restrict__ partials, int n_blocks, PeerComm C) {
-    lm_transition(Q, S, pt, partials, n_blocks, nullptr, 0, &C);
+lm_step_peer_kernel(LMParams Q, LMState* S, LMEvalPoint* pt, const double* __restrict__ partials, int n_blocks, PeerComm C,
+                    PoseRecord* __restrict__ pose_out, SolveLog* __restrict__ log) {
+    lm_transition(Q, S, pt, partials, n_blocks, nullptr, 0, &C, pose_out, log);
 }
 __global__ void lm_begin_batch_kernel(const LMBatchItem* __restrict__ items) {
     const LMBatchItem& it = items[blockIdx.x];
