@@ -127,7 +127,10 @@ def test_single_rank_comm_target_sharded_path(hip_lib, oracle):
     finally:
         c.comm_set_target_sharded(False)
         c.comm_destroy()
-    assert np.array_equal(x_plain, x_ts)
+    # same correspondences, same LM decisions; the plain path keeps its query list in patch order, the record-exchanging path in ring
+    # order, so the 28 sums of an evaluation are added up in a different order: equal to rounding, not bit for bit
+    assert np.abs(x_plain - x_ts).max() <= 1e-11
+    assert [(s_ts.solves[k].lm_iterations, s_ts.solves[k].evaluations) for k in range(6)] == [(s_plain.solves[k].lm_iterations, s_plain.solves[k].evaluations) for k in range(6)]
     assert [s_ts.solves[k].n_icp_valid for k in range(6)] == [s_plain.solves[k].n_icp_valid for k in range(6)]
     assert n == c.associate(d["x_true"], 1)
     H.assert_corr_equal(tab, c.correspondences())

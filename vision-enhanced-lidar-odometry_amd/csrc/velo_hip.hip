@@ -182,6 +182,9 @@ struct velo_ctx {
     int assoc_lds_pad = 0;               // VELO_ASSOC_LDS_PAD: bytes of unused dynamic LDS per association workgroup -- caps the association
                                          // kernel's workgroups per CU so that LM workgroups of other pairs in flight find room at once
     // chain mode: a whole frame_to_frame as ONE chain of launches (pose scalars of the next round and the solve summaries stay on the device)
+    int patch_order = 1;                 // query list in patch order (VELO_PATCH_ORDER=0: the reference's ring order)
+    bool q_patch = false;                // the current list is in patch order
+    bool ring_order_forced = false;      // this context exchanges per-query records with others (target-sharded workflow): the list stays in the reference's order
     int direct_max = 12288;              // sparse rounds (icp_skip >= direct_skip) of at most this many queries search one wave per query
     int direct_skip = 4;                 // (VELO_ASSOC_DIRECT_MAX, 0 = never; VELO_ASSOC_DIRECT_SKIP)
     int asker_queue = 1;                 // shrunk grid: asking queries go to assoc_asker_kernel (VELO_ASKER_QUEUE=0: searched inside their group's workgroup)
@@ -431,6 +434,23 @@ int build_grids(velo_ctx* c) {
 
 Grid* grid_for_iter(velo_ctx* c, int) { return (!c->T->grids.empty() && c->T->grids[0].built) ? &c->T->grids[0] : nullptr; }
 
+// patch order serves the unsharded list only: query shards are defined on the reference's order (the oracle's shard rule), and the
+// placement table of VELO_TUBE_MAP reads ring positions off it
+// ... and the regular grid only: on the density-shrunk grid of a big map (cells of 5 cm) a patch spans more rows than a ring segment
+// and the rounds get slower (2M-point map: 2.87 vs 2.52 ms per registration), so there the list keeps the reference's order.
+bool want_patch(const velo_ctx* c) {
+    if (c->patch_order == 0 || c->shard_world != 1 || c->tube_map >= 0 || c->ring_order_forced || c->target_sharded) return false;
+    if (c->patch_order >= 2) return true;                             // A/B: patch order whatever the grid
+    if (c->have_target && c->T && !c->T->grids.empty() && c->T->grids[0].built) {
+        const int reach = (int)std::ceil(std::sqrt(std::max(gate_of_iter(c->P, 1), 0.0)) / (c->T->grids[0].h * 0.999));
+        if (reach > 5) return false;
+    }
+    return true;
+}
+bool query_list_stale(const velo_ctx* c) {
+    return c->src_skip != std::max(c->P.icp_skip, 1) || (c->n_q > 0) != (c->P.enable_icp != 0 && c->h_q_off[c->n_src_rings] > 0) || c->q_patch != want_patch(c);
+}
+
 int build_query_list(velo_ctx* c) {
     const int skip = std::max(c->P.icp_skip, 1);
     c->prev_ready = false;                                            // seeds are indexed by query
@@ -445,11 +465,13 @@ int build_query_list(velo_ctx* c) {
     VELO_TRY(c->q_src.reserve((size_t)std::max(c->n_q, 1)));
     HIP_TRY(hipMemcpyAsync(c->q_off.p, c->h_q_off.data(), sizeof(int) * ((size_t)c->n_src_rings + 1), hipMemcpyHostToDevice, c->stream));
     if (c->n_q > 0) {
-        hipLaunchKernelGGL(query_list_kernel, dim3(cdiv(c->n_q, 256)), dim3(256), 0, c->stream, c->src_off.p, c->q_off.p, c->n_src_rings, skip, c->n_q, c->q_src.p);
+        hipLaunchKernelGGL(query_list_kernel, dim3(cdiv(c->n_q, 256)), dim3(256), 0, c->stream, c->src_off.p, c->q_off.p, c->n_src_rings, skip, c->n_q,
+                           want_patch(c) ? 1 : 0, c->q_src.p);
         HIP_TRY(hipGetLastError());
     }
+    c->q_patch = want_patch(c);
     const size_t nq = (size_t)std::max(c->n_q, 1);
-    if (skip == 1) c->qpts = c->src.p;                                    // q_src[i] == i
+    if (skip == 1 && !c->q_patch) c->qpts = c->src.p;                     // q_src[i] == i
     else {
         VELO_TRY(c->qpts_buf.reserve(nq));
         if (c->n_q > 0) hipLaunchKernelGGL(gather_queries_kernel, dim3(cdiv(c->n_q, 256)), dim3(256), 0, c->stream, (const float4*)c->src.p, (const int*)c->q_src.p, c->n_q, c->qpts_buf.p);
@@ -633,7 +655,7 @@ bool direct_round(const velo_ctx* c, int nq, bool partial) {
 int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool wait, int* n_valid, bool partial = false, const PoseRecord* P_dev = nullptr) {
     if (!c->have_target || !c->have_source) return fail(VELO_ERR_STATE, "associate needs set_target and set_source first");
     if (iter < 1) return fail(VELO_ERR_INVALID, "iter must be >= 1");
-    if (c->src_skip != std::max(c->P.icp_skip, 1) || (c->n_q > 0) != (c->P.enable_icp != 0 && c->h_q_off[c->n_src_rings] > 0)) VELO_TRY(build_query_list(c));
+    if (query_list_stale(c)) VELO_TRY(build_query_list(c));
     Grid* G = grid_for_iter(c, iter);
     if (!G) return fail(VELO_ERR_STATE, "the target's search index has not been built");
     int qb, qe;
@@ -1208,6 +1230,7 @@ int velo_create(velo_ctx** out, int device) {
         if (const char* e = getenv("VELO_ASSOC_LANE")) c->assoc_lane = atoi(e);
         if (const char* e = getenv("VELO_ASKER_QUEUE")) c->asker_queue = atoi(e);
         if (const char* e = getenv("VELO_ASSOC_DIRECT_MAX")) c->direct_max = std::max(atoi(e), 0);
+        if (const char* e = getenv("VELO_PATCH_ORDER")) c->patch_order = atoi(e);
         if (const char* e = getenv("VELO_ASSOC_DIRECT_SKIP")) c->direct_skip = std::max(atoi(e), 1);
         if (const char* e = getenv("VELO_CHAIN")) c->chain = atoi(e);
         if (const char* e = getenv("VELO_CHAIN_MARGIN")) c->chain_margin = std::max(atoi(e), 0);
@@ -1718,6 +1741,7 @@ static int associate_target_sharded(velo_ctx* c, const double x[6], int iter, bo
 int velo_associate_partial(velo_ctx* c, const double x[6], int32_t iter) {
     if (!c || !x) return fail(VELO_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(c->device));
+    c->ring_order_forced = true;                                      // the records are an exchange format: one order for every rank
     return do_associate(c, x, iter, false, true, nullptr, true);
 }
 
@@ -1736,6 +1760,8 @@ int velo_merge_partials(velo_ctx* c, const velo_partial* const* tables, int32_t 
     if (!c || !tables || world < 1) return fail(VELO_ERR_INVALID, "bad merge arguments");
     if (!c->have_source) return fail(VELO_ERR_STATE, "merge needs set_source first");
     HIP_TRY(hipSetDevice(c->device));
+    c->ring_order_forced = true;
+    if (query_list_stale(c)) VELO_TRY(build_query_list(c));
     int qb, qe;
     q_range(c, &qb, &qe);
     const int share = std::max(qe - qb, 1);
@@ -1770,20 +1796,22 @@ int velo_get_correspondences(velo_ctx* c, velo_corr* out, int32_t capacity, int3
     HIP_TRY(hipMemcpy(a1.data(), c->aux1.p + qb, sizeof(float4) * n, hipMemcpyDeviceToHost));
     const int skip = c->src_skip;
     int ring = 0;
-    for (int i = 0; i < std::min(n, capacity); i++) {
+    for (int i = 0; i < std::min(n, capacity); i++) {            // record i = query i of the reference's order (ring by ring)
         const int qi = qb + i;
         while (ring + 1 < c->n_src_rings && c->h_q_off[ring + 1] <= qi) ring++;
         while (c->h_q_off[ring + 1] <= qi && ring + 1 < c->n_src_rings) ring++;
+        // where the list keeps it (patch order is unsharded only, so qb = 0 there)
+        const int t = c->q_patch ? patch_position(c->h_q_off.data(), c->n_src_rings, ring, qi - c->h_q_off[ring]) : i;
         velo_corr& o = out[i];
         std::memset(&o, 0, sizeof(o));
-        int valid; std::memcpy(&valid, &p[i].w, 4);
-        int idx_k; std::memcpy(&idx_k, &a1[i].x, 4);
-        o.valid = valid; o.ring_i = a0[i].x; o.idx_i = a0[i].y; o.ring_j = a0[i].z; o.idx_j = a0[i].w; o.idx_k = idx_k;
+        int valid; std::memcpy(&valid, &p[t].w, 4);
+        int idx_k; std::memcpy(&idx_k, &a1[t].x, 4);
+        o.valid = valid; o.ring_i = a0[t].x; o.idx_i = a0[t].y; o.ring_j = a0[t].z; o.idx_j = a0[t].w; o.idx_k = idx_k;
         o.src_ring = ring; o.src_idx = (qi - c->h_q_off[ring]) * skip;
-        o.dist_i = a1[i].y; o.dist_j = a1[i].z;
-        o.p[0] = p[i].x; o.p[1] = p[i].y; o.p[2] = p[i].z;
-        o.n[0] = nn[i].x; o.n[1] = nn[i].y; o.n[2] = nn[i].z;
-        o.v0[0] = v0[i].x; o.v0[1] = v0[i].y; o.v0[2] = v0[i].z;
+        o.dist_i = a1[t].y; o.dist_j = a1[t].z;
+        o.p[0] = p[t].x; o.p[1] = p[t].y; o.p[2] = p[t].z;
+        o.n[0] = nn[t].x; o.n[1] = nn[t].y; o.n[2] = nn[t].z;
+        o.v0[0] = v0[t].x; o.v0[1] = v0[t].y; o.v0[2] = v0[t].z;
     }
     return VELO_OK;
 }
@@ -1872,7 +1900,14 @@ int velo_evaluate_rows(velo_ctx* c, const double x[6], double* residuals, double
     if (nq > 0) {
         std::vector<float4> p(nq);
         HIP_TRY(hipMemcpy(p.data(), c->cp.p + qb, sizeof(float4) * nq, hipMemcpyDeviceToHost));
-        for (int i = 0; i < nq; i++) { int valid; std::memcpy(&valid, &p[i].w, 4); if (valid) h_icp[qb + i] = rows++; }
+        int ring = 0;
+        for (int i = 0; i < nq; i++) {                              // rows in the reference's query order; the table may be in patch order
+            const int qi = qb + i;
+            while (ring + 1 < c->n_src_rings && c->h_q_off[ring + 1] <= qi) ring++;
+            const int t = c->q_patch ? patch_position(c->h_q_off.data(), c->n_src_rings, ring, qi - c->h_q_off[ring]) : qi;
+            int valid; std::memcpy(&valid, &p[t - qb].w, 4);
+            if (valid) h_icp[t] = rows++;
+        }
     }
     if (n_rows) *n_rows = rows;
     if (!residuals || !jacobian) return VELO_OK;
@@ -1984,7 +2019,7 @@ static bool chain_eligible(velo_ctx* c) {
 
 static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool* completed) {
     *completed = false;
-    if (c->src_skip != std::max(c->P.icp_skip, 1) || (c->n_q > 0) != (c->P.enable_icp != 0 && c->h_q_off[c->n_src_rings] > 0)) VELO_TRY(build_query_list(c));
+    if (query_list_stale(c)) VELO_TRY(build_query_list(c));
     int qb, qe;
     q_range(c, &qb, &qe);
     if (qe <= qb) return VELO_OK;
@@ -2209,7 +2244,7 @@ static bool batch_can_lockstep(velo_ctx** ctxs, int n, bool targets_follow = fal
 // *groups = 0 when the context has no queries.
 static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs* A, int* groups, bool* asker, bool* lane, bool* direct) {
     if (!c->have_target || !c->have_source) return fail(VELO_ERR_STATE, "associate needs set_target and set_source first");
-    if (c->src_skip != std::max(c->P.icp_skip, 1) || (c->n_q > 0) != (c->P.enable_icp != 0 && c->h_q_off[c->n_src_rings] > 0)) VELO_TRY(build_query_list(c));
+    if (query_list_stale(c)) VELO_TRY(build_query_list(c));
     Grid* G = grid_for_iter(c, iter);
     if (!G) return fail(VELO_ERR_STATE, "the target's search index has not been built");
     int qb, qe;
@@ -2378,7 +2413,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
         velo_ctx* c = ctxs[i];
         chain = assoc_batchable(c) && c->n_matches == 0 && c->P.enable_icp && !c->lm_trace_on;
         if (chain) {
-            if (c->src_skip != std::max(c->P.icp_skip, 1) || (c->n_q > 0) != (c->P.enable_icp != 0 && c->h_q_off[c->n_src_rings] > 0)) VELO_TRY(build_query_list(c));
+            if (query_list_stale(c)) VELO_TRY(build_query_list(c));
             int qb, qe; q_range(c, &qb, &qe);
             chain = qe > qb;
         }

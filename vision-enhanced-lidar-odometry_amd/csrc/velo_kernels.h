@@ -133,14 +133,42 @@ __global__ void gather_queries_kernel(const float4* __restrict__ src, const int*
     if (i < nq) qpts[i] = src[q_src[i]];
 }
 
-// query list: query i -> global source index.  Ring r contributes ceil(n_r / skip) queries (velo.h:806-807).
+// ---- patch order of the queries ---------------------------------------------------------------------------------------------------
+// The tube kernel gives 64 consecutive queries to a workgroup.  In ring order that is a 2 m long line of one ring (a tube of ~125
+// cells); the same 64 queries taken as 8 neighbouring rings x 8 consecutive points are a patch of ~0.5 m x 0.25 m (~60 cells):
+// fewer rows, fewer staged candidates, tighter bounds.  So the query LIST is laid out in patch order: bands of kPatchRings source
+// rings, each ring of a band cut into the same number M of segments (M = ceil(longest ring of the band / kPatchLen)); the list runs
+// band by band, segment by segment, ring by ring, point by point.  Everything indexed by query (seeds, table, LM rows) follows the
+// list; the results per query are what they were, and the calls that hand tables out restore ring order (patch_position is the map,
+// the same integer arithmetic on host and device).  Closed form, no sort: segment j of a ring with n queries starts at ceil(j n / M).
+constexpr int kPatchRings = 8, kPatchLen = 8;
+__host__ __device__ inline int patch_first(int j, int n, int M) { return (int)(((long long)j * n + M - 1) / M); }
+__host__ __device__ inline int patch_position(const int* q_off, int n_rings, int r, int k) {
+    const int r0 = (r / kPatchRings) * kPatchRings, r1 = (r0 + kPatchRings < n_rings) ? r0 + kPatchRings : n_rings;
+    int nmax = 0;
+    for (int rr = r0; rr < r1; rr++) { const int nn = q_off[rr + 1] - q_off[rr]; nmax = nn > nmax ? nn : nmax; }
+    const int M = (nmax + kPatchLen - 1) / kPatchLen > 1 ? (nmax + kPatchLen - 1) / kPatchLen : 1;
+    const int n = q_off[r + 1] - q_off[r];
+    const int j = (int)((long long)k * M / n);                        // segment of this query: first(j) <= k < first(j + 1)
+    int pos = q_off[r0];                                               // the earlier bands
+    for (int rr = r0; rr < r1; rr++) {
+        const int nn = q_off[rr + 1] - q_off[rr];
+        const int f = patch_first(j, nn, M);
+        pos += f;                                                      // the earlier segments of every ring of the band
+        if (rr < r) pos += patch_first(j + 1, nn, M) - f;              // this segment of the earlier rings
+    }
+    return pos + (k - patch_first(j, n, M));
+}
+// query list: position -> global source index.  Ring r contributes ceil(n_r / skip) queries (velo.h:806-807); patch != 0: the list is
+// in patch order, else in the reference's order (ring by ring).
 __global__ void query_list_kernel(const int* __restrict__ src_off, const int* __restrict__ q_off, int n_rings,
-                                  int skip, int nq, int* __restrict__ q_src) {
+                                  int skip, int nq, int patch, int* __restrict__ q_src) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
     int lo = 0, hi = n_rings;
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (q_off[mid] <= i) lo = mid; else hi = mid; }
-    q_src[i] = src_off[lo] + (i - q_off[lo]) * skip;
+    const int k = i - q_off[lo];
+    q_src[patch ? patch_position(q_off, n_rings, lo, k) : i] = src_off[lo] + k * skip;
 }
 
 // ---- scan ingestion on the device: KITTI records -> camera-0-frame rings (kitti.h:121-185), "next" row 1 of SURVEY 8(f) ----
