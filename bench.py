@@ -431,7 +431,7 @@ def main():
                 except Exception:       # noqa: BLE001
                     pass
         if modes:
-            line["modes"] = {k: {kk: vv for kk, vv in v.items() if kk not in ("solution_x", "roofline")} for k, v in modes.items()}
+            line["modes"] = {k: {kk: vv for kk, vv in v.items() if kk not in ("roofline",)} for k, v in modes.items()}   # solution_x stays: tests compare it with a single-rank call
         if not a.no_cpu_baseline and world == 1:             # rank 0 at N = 1 only: the other runs just report the GPU side
             d, vis, _, icp_skip = make_workload(a.workload)
             cb = cpu_baseline(d, vis, a.cpu_sample_skip, icp_skip)

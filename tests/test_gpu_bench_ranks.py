@@ -34,3 +34,14 @@ def test_two_rank_bench_line_reports_both_sharded_modes(hip_lib):
         assert "error" not in m or m["error"] is None, m
         assert m["communicator"]["ranks"] == 2 and m["communicator"]["kind"] in ("peer slabs (hipIpc)", "rccl")
         assert m["pairs_per_s"] > 0
+    # what the sharded ranks computed is what ONE rank computes: the 120k-point pair split by queries, and the 120k scan against the
+    # 2M-point map split by target rings (BASELINE configs[4]'s shape with two ranks; every rank searched its ring block of the full map)
+    import numpy as np
+    from velo_amd import api, synth
+    for mode, d in (("sharded", synth.scan_pair()), ("target_sharded", synth.scan_to_map(2_000_000))):
+        c = api.Context(0, icp_skip=1)
+        c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])
+        x, T, s = c.frame_to_frame(d["x0"])
+        c.close()
+        got = np.array(line["modes"][mode]["solution_x"])
+        assert np.abs(got - x).max() <= 1e-9, (mode, got, x)

@@ -45,6 +45,21 @@ def run(order, label):
     c.close()
 
 
+os.environ["VELO_PATCH_ORDER"] = "0"          # the library must not re-order the probe's lists
+
+
+def morton_order(cell):
+    p = d["src_xyz"].astype(np.float64)
+    q = np.floor((p - p.min(0)) / cell).astype(np.int64)
+    key = np.zeros(len(p), dtype=np.int64)
+    for b in range(12):
+        for a in range(3):
+            key |= ((q[:, a] >> b) & 1) << (3 * b + a)
+    return np.argsort(key, kind="stable")
+
+
 run(np.arange(off[-1]), "ring order (as is)")
+for cell in (0.18, 0.36, 0.72, 1.5):
+    run(morton_order(cell), f"morton, cell {cell} m")
 for bh, sl in ((8, 8), (4, 16), (16, 4), (2, 32), (8, 4), (4, 8)):
     run(patch_order(bh, sl), f"patches {bh} rings x {sl} pts")
