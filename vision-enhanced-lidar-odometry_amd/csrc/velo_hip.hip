@@ -262,6 +262,9 @@ struct velo_ctx {
     std::vector<unsigned char> chunk_graph_sig[2];   // bytes of everything baked into the nodes
     bool use_graphs = false;             // LM chunks as hipGraphs (VELO_GRAPHS=1): measured no gain, replay overhead ~ launches saved
     int pred_evals[VELO_MAX_SOLVES];     // evaluations each solve of the previous frame_to_frame needed (chunk sizing)
+    int eval_hist[VELO_MAX_SOLVES][4];   // ... and of the last four calls: how far a solve's count moves decides the chain's margin
+    int eval_hist_n[VELO_MAX_SOLVES];
+    bool chain_margin_fixed = false;     // VELO_CHAIN_MARGIN given: that margin, always
     HostStatus* h_status = nullptr;      // pinned
     double* h_x = nullptr;               // pinned, 8 doubles
     int* h_int = nullptr;                // pinned scratch
@@ -1208,7 +1211,7 @@ int velo_create(velo_ctx** out, int device) {
     // (stream, pinned buffers, events, device buffers) instead of leaking it behind a NULL *out
     auto init = [&]() -> int {
         default_params(&c->P);
-        for (int k = 0; k < VELO_MAX_SOLVES; k++) c->pred_evals[k] = (k == 0) ? 12 : 5;
+        for (int k = 0; k < VELO_MAX_SOLVES; k++) { c->pred_evals[k] = (k == 0) ? 12 : 5; c->eval_hist_n[k] = 0; }
         if (const char* e = getenv("VELO_ASSOC_VARIANT")) c->assoc_variant = atoi(e);
         if (const char* e = getenv("VELO_CLUSTER_W")) { c->cluster_w = std::max(atoi(e), 0); c->cluster_w_set = true; }
         if (const char* e = getenv("VELO_TRI_VARIANT")) c->tri_variant = atoi(e);
@@ -1233,7 +1236,7 @@ int velo_create(velo_ctx** out, int device) {
         if (const char* e = getenv("VELO_PATCH_ORDER")) c->patch_order = atoi(e);
         if (const char* e = getenv("VELO_ASSOC_DIRECT_SKIP")) c->direct_skip = std::max(atoi(e), 1);
         if (const char* e = getenv("VELO_CHAIN")) c->chain = atoi(e);
-        if (const char* e = getenv("VELO_CHAIN_MARGIN")) c->chain_margin = std::max(atoi(e), 0);
+        if (const char* e = getenv("VELO_CHAIN_MARGIN")) { c->chain_margin = std::max(atoi(e), 0); c->chain_margin_fixed = true; }
         if (const char* e = getenv("VELO_ASSOC_LDS_PAD")) c->assoc_lds_pad = std::max(atoi(e), 0);
         if (const char* e = getenv("VELO_ASKER_ROWS")) c->asker_rows = atoi(e);
         if (const char* e = getenv("VELO_PERSISTENT_WGS")) c->persistent_wgs = std::max(atoi(e), 1);
@@ -2004,6 +2007,26 @@ int velo_solve(velo_ctx* c, double x[6], velo_solve_summary* summary) {
 // previous call needed plus a margin (launches behind the end of a solve copy the state through, ~3 us each); a solve that needs
 // more raises the chain's failure flag in the next association (its record is not ready), everything behind it drains, and the
 // call is repeated by the host-driven path below -- same kernels, same arithmetic, so the result does not depend on which path ran.
+// Launch-count prediction of solve k = what the same solve of the previous call needed + a margin.  The margin follows how far that
+// count has moved over the last four calls (1 + spread, between 1 and 3); until four calls have been seen, and after a miss, it is
+// the default 2.  A launch behind the end of a solve costs ~3.5 us, a miss a whole repeated call.
+static void note_evals(velo_ctx* c, int k, int evals) {
+    if (k < 0 || k >= VELO_MAX_SOLVES) return;
+    c->pred_evals[k] = evals;
+    c->eval_hist[k][c->eval_hist_n[k] & 3] = evals;
+    c->eval_hist_n[k]++;
+}
+static int margin_for(const velo_ctx* c, int k) {
+    k = std::min(std::max(k, 0), VELO_MAX_SOLVES - 1);
+    if (c->chain_margin_fixed || c->eval_hist_n[k] < 4) return c->chain_margin;
+    int mn = c->eval_hist[k][0], mx = mn;
+    for (int i = 1; i < 4; i++) { mn = std::min(mn, c->eval_hist[k][i]); mx = std::max(mx, c->eval_hist[k][i]); }
+    return std::min(std::max(1 + (mx - mn), 1), 3);
+}
+static void note_miss(velo_ctx* c) {
+    for (int k = 0; k < VELO_MAX_SOLVES; k++) { c->pred_evals[k] += 2; c->eval_hist_n[k] = 0; }    // the host-driven repeat records the real counts
+}
+
 static bool chain_eligible(velo_ctx* c) {
     if (!c->chain || c->want_stats || c->comm || c->use_graphs || !c->lm_merged || !c->P.enable_icp) return false;
     if (c->assoc_variant >= 0 && c->assoc_variant != 5) return false;
@@ -2033,7 +2056,6 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
         small = c->small_solve && E0.total() <= kSmallRows;
     }
     const LMParams Q = lm_params(c->P);
-    const int margin = c->chain_margin;
     const size_t half = (size_t)(kMaxEvalBlocks + kMaxVisBlocks) * kNumAcc;
     const int max_launches = c->P.max_num_iterations + 2;
     std::memcpy(c->h_x, xc, sizeof(double) * 6);
@@ -2076,7 +2098,7 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
                 continue;
             }
             if (visual || peer) {                                    // sweep (+ visual sweep) + step per LM iteration, state single-buffered
-                const int Kv = std::min(std::max(c->pred_evals[std::min(r, VELO_MAX_SOLVES - 1)], 1) + margin, max_launches);
+                const int Kv = std::min(std::max(c->pred_evals[std::min(r, VELO_MAX_SOLVES - 1)], 1) + margin_for(c, r), max_launches);
                 hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->state.p, c->eval_pt.p, (const double*)(r == 0 ? c->xdev.p : nullptr), nvp, c->pose_rec.p);
                 for (int k = 0; k < Kv; k++) {
                     launch_eval(c, A, E);
@@ -2088,7 +2110,7 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
                 HIP_TRY(hipGetLastError());
                 continue;
             }
-            const int K = std::min(std::max(c->pred_evals[std::min(r, VELO_MAX_SOLVES - 1)], 1) + 1 + margin, max_launches);
+            const int K = std::min(std::max(c->pred_evals[std::min(r, VELO_MAX_SOLVES - 1)], 1) + 1 + margin_for(c, r), max_launches);
             for (int k = 0; k < K; k++, j++) {
                 hipLaunchKernelGGL(lm_iter_kernel, dim3(E.nb_icp), dim3(kEvalThreads), 0, c->stream, A, Q, (const LMState*)(c->state.p + (j & 1)), c->state.p + ((j + 1) & 1),
                                    (const double*)(c->partials.p + (size_t)(j & 1) * half), E.nb_icp, c->partials.p + (size_t)((j + 1) & 1) * half, k == 0 ? 1 : 0,
@@ -2115,7 +2137,7 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
     }
     if (*h_fail || !c->h_status->s.done) {
         HIP_TRY(hipMemsetAsync(c->chain_fail.p, 0, sizeof(int), c->stream));
-        for (int k = 0; k < VELO_MAX_SOLVES; k++) c->pred_evals[k] += 2;    // the host-driven repeat below records the real counts
+        note_miss(c);
         c->nv_clean[0] = c->nv_clean[1] = false;                            // drained association launches did not clear the next round's counter
         c->ask_clean[0] = c->ask_clean[1] = false;
         c->chain_misses++;
@@ -2137,7 +2159,7 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
             const int it0 = std::min(k / std::max(c->P.icp_iterations, 1), VELO_MAX_STATS - 1);
             ss.n_visual_blocks = h_vis_counts[2 * it0]; ss.n_visual_residuals = h_vis_counts[2 * it0 + 1];
         }
-        if (k < VELO_MAX_SOLVES) c->pred_evals[k] = L.evals;
+        note_evals(c, k, L.evals);
         S->eval_kernel_launches += L.evals;
         S->algorithmic_bytes += (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull);
         if (S->n_solves < VELO_MAX_SOLVES) S->solves[S->n_solves] = ss;
@@ -2204,7 +2226,7 @@ int velo_frame_to_frame(velo_ctx* c, double x[6], double T[16], velo_summary* su
             const int solve_idx = std::min(S->n_solves, VELO_MAX_SOLVES - 1);
             // consecutive frames behave alike: size the first chunk to the evaluations this solve needed last time (+1)
             VELO_TRY(do_solve(c, xc, xc, &ss, &evals, std::min(std::max(c->pred_evals[solve_idx] + 1, 2), c->P.max_num_iterations + 1)));   // velo.h:897-902
-            c->pred_evals[solve_idx] = ss.evaluations;
+            note_evals(c, solve_idx, ss.evaluations);
             S->eval_kernel_launches += evals;
             S->algorithmic_bytes += (uint64_t)ss.evaluations * (36ull * (uint64_t)ss.n_icp_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull);
             if (S->n_solves < VELO_MAX_SOLVES) S->solves[S->n_solves] = ss;
@@ -2419,7 +2441,6 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
         }
     }
     if (chain) {
-        const int margin = c0->chain_margin;
         const bool fresh = c0->batch_pose.cap < (size_t)n;
         VELO_TRY(c0->batch_pose.reserve((size_t)n)); VELO_TRY(c0->batch_logs.reserve((size_t)n * VELO_MAX_SOLVES)); VELO_TRY(c0->batch_fail.reserve((size_t)n));
         if (fresh) { HIP_TRY(hipMemsetAsync(c0->batch_fail.p, 0, sizeof(int) * (size_t)n, bs)); HIP_TRY(hipMemsetAsync(c0->batch_pose.p, 0, sizeof(PoseRecord) * (size_t)n, bs)); }
@@ -2447,7 +2468,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                     it.A.vis_row0 = E.nb_icp;
                     it.pose_out = c0->batch_pose.p + i; it.log = c0->batch_logs.p + (size_t)i * VELO_MAX_SOLVES + r;
                     nb_max = std::max(nb_max, E.nb_icp);
-                    K = std::max(K, std::min(std::max(c->pred_evals[r], 1) + margin, max_iters));
+                    K = std::max(K, std::min(std::max(c->pred_evals[r], 1) + margin_for(c, r), max_iters));
                     S[(size_t)i]->assoc_kernel_launches += assoc_launched[(size_t)i];
                 }
                 const LMBatchItem* d_items = c0->batch_items.p + (size_t)r * n;
@@ -2482,7 +2503,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                     std::memset(&ss, 0, sizeof(ss));
                     ss.termination = L.termination; ss.lm_iterations = L.iter; ss.evaluations = L.evals; ss.n_icp_valid = L.n_valid;
                     ss.initial_cost = L.initial_cost; ss.final_cost = L.final_cost;
-                    c->pred_evals[k] = L.evals;
+                    note_evals(c, k, L.evals);
                     Si->eval_kernel_launches += L.evals;
                     Si->algorithmic_bytes += (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 224ull);
                     Si->solves[Si->n_solves++] = ss;
@@ -2501,7 +2522,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
             c->chain_misses++;
             c->nv_clean[0] = c->nv_clean[1] = false;                        // drained association launches did not clear the next round's counter
             c->ask_clean[0] = c->ask_clean[1] = false;
-            for (int k = 0; k < VELO_MAX_SOLVES; k++) c->pred_evals[k] += 2;
+            note_miss(c);
             std::memset(S[(size_t)i], 0, sizeof(velo_summary));
             S[(size_t)i]->n_target = c->T->n_tgt;
             c->assoc_events_used = 0;
@@ -2580,7 +2601,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                 visual_counts(c, &ss.n_visual_blocks, &ss.n_visual_residuals);
                 ss.initial_cost = st.initial_cost; ss.final_cost = st.cost;
                 const int solve_idx = std::min(Si->n_solves, VELO_MAX_SOLVES - 1);
-                c->pred_evals[solve_idx] = ss.evaluations;
+                note_evals(c, solve_idx, ss.evaluations);
                 Si->eval_kernel_launches += st.evals;
                 Si->algorithmic_bytes += (uint64_t)ss.evaluations * (36ull * (uint64_t)ss.n_icp_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull);
                 if (Si->n_solves < VELO_MAX_SOLVES) Si->solves[Si->n_solves] = ss;

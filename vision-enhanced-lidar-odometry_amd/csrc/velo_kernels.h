@@ -1145,6 +1145,9 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
         const float r1 = sqrtf(t.b2d) * 1.0001f + 1e-6f;               // bound radius phase 1 works with (padded against rounding)
         bool asker_phase = false;
         for (int ph = 0; ph < 2; ph++) {
+            // No second phase at all when no member's bound reaches beyond one cell: the box of a radius <= h lies inside the query's own
+            // cell +- 1, which is what phase 1 visited -- nobody can ask (s_phase[7] was published with phase 1's boxes).
+            if (ph == 1 && s_phase[7] == 0) break;
             // Who asks for cells in this phase, with which box, and the (y, z) extent of all boxes: worked out by wave 0 only and
             // published through LDS (s_box, s_phase) -- the four waves hold identical states here, three of them would only
             // repeat ~250 VALU instructions of cell arithmetic and wave reductions per phase.
@@ -1167,11 +1170,13 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
                 s_box[ph][0][lane] = bb.x0; s_box[ph][1][lane] = bb.x1; s_box[ph][2][lane] = bb.y0;
                 s_box[ph][3][lane] = bb.y1; s_box[ph][4][lane] = bb.z0; s_box[ph][5][lane] = bb.z1;
                 const unsigned long long am0 = __ballot(asks0);
+                const unsigned long long far0 = (ph == 0) ? __ballot(member && r1 > h_safe) : 1ull;
                 const int y0 = wave_min_i(asks0 ? bb.y0 : big), y1 = wave_max_i(asks0 ? bb.y1 : -big);
                 const int z0 = wave_min_i(asks0 ? bb.z0 : big), z1 = wave_max_i(asks0 ? bb.z1 : -big);
                 if (lane == 0) {
                     s_phase[0] = max(y0, 0); s_phase[1] = min(y1, g.ny - 1); s_phase[2] = max(z0, 0); s_phase[3] = min(z1, g.nz - 1);
                     s_phase[4] = (int)(unsigned)(am0 & 0xffffffffull); s_phase[5] = (int)(unsigned)(am0 >> 32); s_phase[6] = rows_all;
+                    if (ph == 0) s_phase[7] = far0 != 0ull ? 1 : 0;
                 }
             }
             __syncthreads();
