@@ -184,6 +184,7 @@ struct velo_ctx {
     // chain mode: a whole frame_to_frame as ONE chain of launches (pose scalars of the next round and the solve summaries stay on the device)
     int patch_order = 1;                 // query list in patch order (VELO_PATCH_ORDER=0: the reference's ring order)
     bool q_patch = false;                // the current list is in patch order
+    int patch_rings = kPatchRingsDefault, patch_len = kPatchLenDefault;   // VELO_PATCH_SHAPE=rings,points
     bool ring_order_forced = false;      // this context exchanges per-query records with others (target-sharded workflow): the list stays in the reference's order
     int direct_max = 12288;              // sparse rounds (icp_skip >= direct_skip) of at most this many queries search one wave per query
     int direct_skip = 4;                 // (VELO_ASSOC_DIRECT_MAX, 0 = never; VELO_ASSOC_DIRECT_SKIP)
@@ -469,7 +470,7 @@ int build_query_list(velo_ctx* c) {
     HIP_TRY(hipMemcpyAsync(c->q_off.p, c->h_q_off.data(), sizeof(int) * ((size_t)c->n_src_rings + 1), hipMemcpyHostToDevice, c->stream));
     if (c->n_q > 0) {
         hipLaunchKernelGGL(query_list_kernel, dim3(cdiv(c->n_q, 256)), dim3(256), 0, c->stream, c->src_off.p, c->q_off.p, c->n_src_rings, skip, c->n_q,
-                           want_patch(c) ? 1 : 0, c->q_src.p);
+                           want_patch(c) ? 1 : 0, c->patch_rings, c->patch_len, c->q_src.p);
         HIP_TRY(hipGetLastError());
     }
     c->q_patch = want_patch(c);
@@ -1234,6 +1235,7 @@ int velo_create(velo_ctx** out, int device) {
         if (const char* e = getenv("VELO_ASKER_QUEUE")) c->asker_queue = atoi(e);
         if (const char* e = getenv("VELO_ASSOC_DIRECT_MAX")) c->direct_max = std::max(atoi(e), 0);
         if (const char* e = getenv("VELO_PATCH_ORDER")) c->patch_order = atoi(e);
+        if (const char* e = getenv("VELO_PATCH_SHAPE")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 1) { c->patch_rings = a; c->patch_len = b; } }
         if (const char* e = getenv("VELO_ASSOC_DIRECT_SKIP")) c->direct_skip = std::max(atoi(e), 1);
         if (const char* e = getenv("VELO_CHAIN")) c->chain = atoi(e);
         if (const char* e = getenv("VELO_CHAIN_MARGIN")) { c->chain_margin = std::max(atoi(e), 0); c->chain_margin_fixed = true; }
@@ -1804,7 +1806,7 @@ int velo_get_correspondences(velo_ctx* c, velo_corr* out, int32_t capacity, int3
         while (ring + 1 < c->n_src_rings && c->h_q_off[ring + 1] <= qi) ring++;
         while (c->h_q_off[ring + 1] <= qi && ring + 1 < c->n_src_rings) ring++;
         // where the list keeps it (patch order is unsharded only, so qb = 0 there)
-        const int t = c->q_patch ? patch_position(c->h_q_off.data(), c->n_src_rings, ring, qi - c->h_q_off[ring]) : i;
+        const int t = c->q_patch ? patch_position(c->h_q_off.data(), c->n_src_rings, ring, qi - c->h_q_off[ring], c->patch_rings, c->patch_len) : i;
         velo_corr& o = out[i];
         std::memset(&o, 0, sizeof(o));
         int valid; std::memcpy(&valid, &p[t].w, 4);
@@ -1907,7 +1909,7 @@ int velo_evaluate_rows(velo_ctx* c, const double x[6], double* residuals, double
         for (int i = 0; i < nq; i++) {                              // rows in the reference's query order; the table may be in patch order
             const int qi = qb + i;
             while (ring + 1 < c->n_src_rings && c->h_q_off[ring + 1] <= qi) ring++;
-            const int t = c->q_patch ? patch_position(c->h_q_off.data(), c->n_src_rings, ring, qi - c->h_q_off[ring]) : qi;
+            const int t = c->q_patch ? patch_position(c->h_q_off.data(), c->n_src_rings, ring, qi - c->h_q_off[ring], c->patch_rings, c->patch_len) : qi;
             int valid; std::memcpy(&valid, &p[t - qb].w, 4);
             if (valid) h_icp[t] = rows++;
         }

@@ -141,9 +141,9 @@ __global__ void gather_queries_kernel(const float4* __restrict__ src, const int*
 // band by band, segment by segment, ring by ring, point by point.  Everything indexed by query (seeds, table, LM rows) follows the
 // list; the results per query are what they were, and the calls that hand tables out restore ring order (patch_position is the map,
 // the same integer arithmetic on host and device).  Closed form, no sort: segment j of a ring with n queries starts at ceil(j n / M).
-constexpr int kPatchRings = 8, kPatchLen = 8;
+constexpr int kPatchRingsDefault = 8, kPatchLenDefault = 8;      // (4 x 16, 16 x 4, 2 x 32, 8 x 4, 4 x 8 measured within 3 % or worse)
 __host__ __device__ inline int patch_first(int j, int n, int M) { return (int)(((long long)j * n + M - 1) / M); }
-__host__ __device__ inline int patch_position(const int* q_off, int n_rings, int r, int k) {
+__host__ __device__ inline int patch_position(const int* q_off, int n_rings, int r, int k, int kPatchRings = 8, int kPatchLen = 8) {
     const int r0 = (r / kPatchRings) * kPatchRings, r1 = (r0 + kPatchRings < n_rings) ? r0 + kPatchRings : n_rings;
     int nmax = 0;
     for (int rr = r0; rr < r1; rr++) { const int nn = q_off[rr + 1] - q_off[rr]; nmax = nn > nmax ? nn : nmax; }
@@ -162,13 +162,13 @@ __host__ __device__ inline int patch_position(const int* q_off, int n_rings, int
 // query list: position -> global source index.  Ring r contributes ceil(n_r / skip) queries (velo.h:806-807); patch != 0: the list is
 // in patch order, else in the reference's order (ring by ring).
 __global__ void query_list_kernel(const int* __restrict__ src_off, const int* __restrict__ q_off, int n_rings,
-                                  int skip, int nq, int patch, int* __restrict__ q_src) {
+                                  int skip, int nq, int patch, int patch_rings, int patch_len, int* __restrict__ q_src) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
     int lo = 0, hi = n_rings;
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (q_off[mid] <= i) lo = mid; else hi = mid; }
     const int k = i - q_off[lo];
-    q_src[patch ? patch_position(q_off, n_rings, lo, k) : i] = src_off[lo] + k * skip;
+    q_src[patch ? patch_position(q_off, n_rings, lo, k, patch_rings, patch_len) : i] = src_off[lo] + k * skip;
 }
 
 // ---- scan ingestion on the device: KITTI records -> camera-0-frame rings (kitti.h:121-185), "next" row 1 of SURVEY 8(f) ----
