@@ -194,6 +194,7 @@ struct velo_ctx {
     DevBuf<int2> ask_rings;
     int ask_idx = 0;
     bool ask_clean[2] = {false, false};
+    bool lm_trace_vis_off = false;       // VELO_LM_MERGED_VIS=0: calls with visual blocks keep sweep + visual sweep + step as three launches (A/B)
     bool want_stats = false;             // velo_set_residual_stats
     DevBuf<double> stat_vals, stat_part;
     DevBuf<signed char> stat_types;
@@ -990,7 +991,7 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
         HIP_TRY(hipMemcpyAsync(&c->h_status->s, c->state.p, sizeof(LMState), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (!c->h_status->s.done) return fail(VELO_ERR_STATE, "LM did not terminate after %d sweeps", max_iters_all + 2);
-    } else if (!c->comm && !c->peer_on && !c->use_graphs && c->lm_merged && x_in && E.nb_icp > 0 && E.nb_vis == 0) {
+    } else if (!c->comm && !c->peer_on && !c->use_graphs && c->lm_merged && x_in && E.nb_icp > 0 && !c->lm_trace_vis_off) {
         // one launch per LM iteration: every sweep workgroup consumes the previous sweep's partial rows itself (lm_iter_kernel).
         // Launch k reads state / partial rows [k & 1] and writes [(k + 1) & 1]; launch 0 starts the solve.  A solve of n
         // evaluations needs n + 1 launches (the last one only finds the solve done); launches behind that copy the state through.
@@ -1002,6 +1003,11 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
             for (int j = 0; j < chunk; j++, k++) {
                 EvalArgs Ak = A;
                 Ak.trace_eval = k;
+                if (E.nb_vis > 0)       // the visual blocks ride in the same launch (workgroups behind the point-to-plane ones)
+                    hipLaunchKernelGGL(lm_iter_vis_kernel, dim3(E.total()), dim3(kEvalThreads), 0, c->stream, Ak, Q, (const LMState*)(c->state.p + (k & 1)), c->state.p + ((k + 1) & 1),
+                                       (const double*)(c->partials.p + (size_t)(k & 1) * half), E.total(), c->partials.p + (size_t)((k + 1) & 1) * half, k == 0 ? 1 : 0, xd, nvp,
+                                       (PoseRecord*)nullptr, (SolveLog*)nullptr, E.nb_icp, E.nb_vis);
+                else
                 hipLaunchKernelGGL(lm_iter_kernel, dim3(E.nb_icp), dim3(kEvalThreads), 0, c->stream, Ak, Q, (const LMState*)(c->state.p + (k & 1)), c->state.p + ((k + 1) & 1),
                                    (const double*)(c->partials.p + (size_t)(k & 1) * half), E.nb_icp, c->partials.p + (size_t)((k + 1) & 1) * half, k == 0 ? 1 : 0, xd, nvp, (PoseRecord*)nullptr, (SolveLog*)nullptr);
             }
@@ -1232,6 +1238,7 @@ int velo_create(velo_ctx** out, int device) {
         if (const char* e = getenv("VELO_SMALL_SOLVE")) c->small_solve = atoi(e);
         if (const char* e = getenv("VELO_LM_MERGED")) c->lm_merged = atoi(e);
         if (const char* e = getenv("VELO_ASSOC_LANE")) c->assoc_lane = atoi(e);
+        if (const char* e = getenv("VELO_LM_MERGED_VIS")) c->lm_trace_vis_off = atoi(e) == 0;
         if (const char* e = getenv("VELO_ASKER_QUEUE")) c->asker_queue = atoi(e);
         if (const char* e = getenv("VELO_ASSOC_DIRECT_MAX")) c->direct_max = std::max(atoi(e), 0);
         if (const char* e = getenv("VELO_PATCH_ORDER")) c->patch_order = atoi(e);
@@ -2080,7 +2087,8 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
     const int rounds = c->P.f2f_iterations * c->P.icp_iterations;
     for (int iter = 1; iter <= c->P.f2f_iterations; iter++) {
         if (visual) {
-            hipLaunchKernelGGL(visual_gate_kernel, dim3(cdiv(c->n_matches, 128)), dim3(128), 0, c->stream, (const double*)(iter == 1 ? c->xdev.p : c->state.p->x),
+            // (x of a later iteration: the state buffer the last launch wrote -- index j & 1 with one-launch iterations, else buffer 0)
+            hipLaunchKernelGGL(visual_gate_kernel, dim3(cdiv(c->n_matches, 128)), dim3(128), 0, c->stream, (const double*)(iter == 1 ? c->xdev.p : (c->state.p + (j & 1))->x),
                                visual_params(c->P), c->vm.p, c->n_matches, iter, c->vflags.p, c->vis_counts.p + 2 * (iter - 1));
             HIP_TRY(hipGetLastError());
         }
@@ -2099,7 +2107,7 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
                 HIP_TRY(hipGetLastError());
                 continue;
             }
-            if (visual || peer) {                                    // sweep (+ visual sweep) + step per LM iteration, state single-buffered
+            if (peer || (visual && c->lm_trace_vis_off)) {           // sweep (+ visual sweep) + step per LM iteration, state single-buffered
                 const int Kv = std::min(std::max(c->pred_evals[std::min(r, VELO_MAX_SOLVES - 1)], 1) + margin_for(c, r), max_launches);
                 hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->state.p, c->eval_pt.p, (const double*)(r == 0 ? c->xdev.p : nullptr), nvp, c->pose_rec.p);
                 for (int k = 0; k < Kv; k++) {
@@ -2114,6 +2122,11 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
             }
             const int K = std::min(std::max(c->pred_evals[std::min(r, VELO_MAX_SOLVES - 1)], 1) + 1 + margin_for(c, r), max_launches);
             for (int k = 0; k < K; k++, j++) {
+                if (visual)
+                    hipLaunchKernelGGL(lm_iter_vis_kernel, dim3(E.total()), dim3(kEvalThreads), 0, c->stream, A, Q, (const LMState*)(c->state.p + (j & 1)), c->state.p + ((j + 1) & 1),
+                                       (const double*)(c->partials.p + (size_t)(j & 1) * half), E.total(), c->partials.p + (size_t)((j + 1) & 1) * half, k == 0 ? 1 : 0,
+                                       (const double*)((r == 0 && k == 0) ? c->xdev.p : nullptr), nvp, c->pose_rec.p, logp, E.nb_icp, E.nb_vis);
+                else
                 hipLaunchKernelGGL(lm_iter_kernel, dim3(E.nb_icp), dim3(kEvalThreads), 0, c->stream, A, Q, (const LMState*)(c->state.p + (j & 1)), c->state.p + ((j + 1) & 1),
                                    (const double*)(c->partials.p + (size_t)(j & 1) * half), E.nb_icp, c->partials.p + (size_t)((j + 1) & 1) * half, k == 0 ? 1 : 0,
                                    (const double*)((r == 0 && k == 0) ? c->xdev.p : nullptr), nvp, c->pose_rec.p, c->solve_log.p + std::min(r, VELO_MAX_SOLVES - 1));

@@ -2690,21 +2690,19 @@ eval_icp_batch_kernel(const LMBatchItem* __restrict__ items) {
     eval_icp_body(it.A, blockIdx.x, it.nb_icp);
 }
 // visual blocks (rows R2-R5; losses velo.h:688,714-717,748-751,781-784)
-__device__ __forceinline__ void eval_visual_body(const EvalArgs& A, const int bx, const int nbx) {
-    __shared__ LMEvalPoint s_pt;
-    if (!eval_point_load(A, &s_pt)) return;
+// the visual blocks of workgroup bx of nbx at the eval point pt (in LDS), summed into acc[28]
+__device__ __forceinline__ void visual_sweep_acc(const EvalArgs& A, const LMEvalPoint& pt, const int bx, const int nbx, double acc[kNumAcc]) {
     // the rotation constants of R(omega) and R(-omega) once per workgroup, read from LDS where a block needs them (in registers
     // they, the 56 accumulator registers and the 6-wide duals of the epipolar block push the kernel into scratch memory)
     __shared__ PoseEval s_P;
     if (threadIdx.x == 0) {
         double x[6];
 #pragma unroll
-        for (int k = 0; k < 6; k++) x[k] = s_pt.x[k];
+        for (int k = 0; k < 6; k++) x[k] = pt.x[k];
         pose_eval_init(x, &s_P, true);
     }
     __syncthreads();
     const PoseEval& P = s_P;
-    double acc[kNumAcc];
 #pragma unroll
     for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
     const int tid = bx * blockDim.x + threadIdx.x, nthreads = nbx * blockDim.x;
@@ -2737,6 +2735,12 @@ __device__ __forceinline__ void eval_visual_body(const EvalArgs& A, const int bx
             for (int c = 0; c < 18; c++) if (c < 6 * d) A.rows_J[(size_t)row * 6 + c] = J[c] * sr;
         }
     }
+}
+__device__ __forceinline__ void eval_visual_body(const EvalArgs& A, const int bx, const int nbx) {
+    __shared__ LMEvalPoint s_pt;
+    if (!eval_point_load(A, &s_pt)) return;
+    double acc[kNumAcc];
+    visual_sweep_acc(A, s_pt, bx, nbx, acc);
 #if VELO_REDUCE_LDS
     __shared__ double s_scratch[kScratchDoubles / 2];
 #else
@@ -3096,21 +3100,27 @@ __device__ __forceinline__ void lm_transition(const LMParams& Q, LMState* Sg, LM
 // stores the state), because a fast workgroup must not overwrite what a slow one has yet to read.  Per iteration this is one
 // kernel boundary and one cold-load latency (partial rows, state and this workgroup's correspondences are all requested at the
 // start) instead of two each; launch 0 also does what lm_begin_kernel did.  Bit-identical to the two-launch path.
+// VIS: the launch also carries the visual blocks -- workgroups [nbx, nbx + nb_vis) take them (same transition, then the visual sweep of
+// eval_visual_kernel at the new point; their partial rows follow the point-to-plane ones, as in the two-launch path).  A separate
+// instantiation: the visual sweep needs 256 VGPRs + AGPRs, the LiDAR-only kernel stays as it is.
+template <bool VIS>
 __device__ __forceinline__ void lm_iter_body(const EvalArgs& A, const LMParams& Q, const LMState* __restrict__ Sin, LMState* __restrict__ Sout,
                                              const double* __restrict__ pin, int n_in, double* __restrict__ pout, int first,
                                              const double* __restrict__ x_in, const int* __restrict__ n_valid, const int bx, const int nbx,
-                                             PoseRecord* pose_out = nullptr, SolveLog* log = nullptr) {
+                                             PoseRecord* pose_out = nullptr, SolveLog* log = nullptr, const int nb_vis = 0) {
     __shared__ LMState sL;
     __shared__ LMEvalPoint s_pt;
     __shared__ double s_scratch[kScratchDoubles];
-    const RowPrefetch f = prefetch_rows(A, bx, nbx);
+    const bool icp_wg = !VIS || bx < nbx;                              // wave-uniform: this workgroup sweeps point-to-plane rows
+    const RowPrefetch f = prefetch_rows(A, icp_wg ? bx : 0, nbx);
     VELO_LM_TRACE(A.trace, A.trace_eval, 0);
     lm_advance(Q, Sin, pin, n_in, first, x_in, n_valid, s_scratch, &sL, &s_pt, A.trace, A.trace_eval, nullptr, pose_out, log, bx == 0);
     const int t = threadIdx.x;
     if (bx == 0 && t < (int)(sizeof(LMState) / 8)) reinterpret_cast<unsigned long long*>(Sout)[t] = reinterpret_cast<const unsigned long long*>(&sL)[t];
     if (sL.done) return;
     double acc[kNumAcc];
-    sweep_rows<false>(A, f, s_pt, bx, nbx, acc);
+    if (icp_wg) sweep_rows<false>(A, f, s_pt, bx, nbx, acc);
+    else if (VIS) visual_sweep_acc(A, s_pt, bx - nbx, nb_vis, acc);
     VELO_LM_TRACE(A.trace, A.trace_eval, 2);
     block_reduce_store(acc, pout + (size_t)bx * kNumAcc, s_scratch);
     VELO_LM_TRACE(A.trace, A.trace_eval, 3);
@@ -3119,7 +3129,14 @@ __global__ void __launch_bounds__(kEvalThreads)
 lm_iter_kernel(EvalArgs A, LMParams Q, const LMState* __restrict__ Sin, LMState* __restrict__ Sout, const double* __restrict__ pin, int n_in,
                double* __restrict__ pout, int first, const double* __restrict__ x_in, const int* __restrict__ n_valid,
                PoseRecord* pose_out, SolveLog* log) {
-    lm_iter_body(A, Q, Sin, Sout, pin, n_in, pout, first, x_in, n_valid, blockIdx.x, gridDim.x, pose_out, log);
+    lm_iter_body<false>(A, Q, Sin, Sout, pin, n_in, pout, first, x_in, n_valid, blockIdx.x, gridDim.x, pose_out, log);
+}
+// grid = nb_icp + nb_vis workgroups
+__global__ void __launch_bounds__(kEvalThreads)
+lm_iter_vis_kernel(EvalArgs A, LMParams Q, const LMState* __restrict__ Sin, LMState* __restrict__ Sout, const double* __restrict__ pin, int n_in,
+                   double* __restrict__ pout, int first, const double* __restrict__ x_in, const int* __restrict__ n_valid,
+                   PoseRecord* pose_out, SolveLog* log, int nb_icp, int nb_vis) {
+    lm_iter_body<true>(A, Q, Sin, Sout, pin, n_in, pout, first, x_in, n_valid, blockIdx.x, nb_icp, pose_out, log, nb_vis);
 }
 // the same for the contexts of a lock-step group: blockIdx.y = context, k = index of the launch within the solve (its parity
 // selects the halves of every context's state / partial-row double buffer; `half` = doubles per half)
@@ -3127,7 +3144,7 @@ __global__ void __launch_bounds__(kEvalThreads)
 lm_iter_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int k, size_t half) {
     const LMBatchItem& it = items[blockIdx.y];
     if ((int)blockIdx.x >= it.nb_icp) return;
-    lm_iter_body(it.A, Q, it.S + (k & 1), it.S + ((k + 1) & 1), it.A.partials + (size_t)(k & 1) * half, it.nb_icp,
+    lm_iter_body<false>(it.A, Q, it.S + (k & 1), it.S + ((k + 1) & 1), it.A.partials + (size_t)(k & 1) * half, it.nb_icp,
                  it.A.partials + (size_t)((k + 1) & 1) * half, k == 0 ? 1 : 0, it.xd, it.n_valid, blockIdx.x, it.nb_icp, it.pose_out, it.log);
 }
 
