@@ -680,7 +680,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         VELO_TRY(attach_askers(c, &out, false));
         const bool direct = direct_round(c, qe - qb, partial);
         const bool lane = !direct && lane_round(c, G, partial);
-        if (c->debug_skip & 32) { VELO_TRY(c->wg_times.reserve((size_t)2 * cdiv(qe - qb, 64) + 2)); out.wg_times = c->wg_times.p; c->wg_times_n = cdiv(qe - qb, 64); }
+        if (c->debug_skip & 32) { VELO_TRY(c->wg_times.reserve((size_t)16 * cdiv(qe - qb, 64) + 2)); HIP_TRY(hipMemsetAsync(c->wg_times.p, 0, sizeof(unsigned long long) * ((size_t)16 * cdiv(qe - qb, 64) + 2), c->stream)); out.wg_times = c->wg_times.p; c->wg_times_n = cdiv(qe - qb, 64); }
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
         if (c->timing) {
             if (c->assoc_events_used >= 256) c->assoc_events_used = 0;      // standalone velo_associate calls: recycle
@@ -1286,7 +1286,7 @@ int velo_destroy(velo_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if ((c->debug_skip & 32) && c->wg_times.p && c->wg_times_n > 0) {
-        std::vector<unsigned long long> h((size_t)2 * c->wg_times_n);
+        std::vector<unsigned long long> h((size_t)16 * c->wg_times_n);
         if (hipMemcpy(h.data(), c->wg_times.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
             unsigned long long t0 = ~0ull, t1 = 0; std::vector<double> dur, st;
             for (int i = 0; i < c->wg_times_n; i++) { t0 = std::min(t0, h[2 * i]); t1 = std::max(t1, h[2 * i + 1]); }
@@ -1294,6 +1294,16 @@ int velo_destroy(velo_ctx* c) {
             std::sort(dur.begin(), dur.end()); std::sort(st.begin(), st.end());
             auto pc = [&](std::vector<double>& v, double p) { return v[(size_t)(p * (v.size() - 1))]; };
             double mean = 0; for (double d : dur) mean += d; mean /= dur.size();
+            {   // the five slowest groups: which queries are they?
+                std::vector<std::pair<double, int>> slow;
+                for (int i = 0; i < c->wg_times_n; i++) slow.emplace_back((h[2 * i + 1] - h[2 * i]) * 0.01, i);
+                std::sort(slow.begin(), slow.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first > y.first; });
+                for (int k = 0; k < 5 && k < (int)slow.size(); k++) fprintf(stderr, "[velo dbg]   slow group %d: %.1f us (queries %d..%d of the list)\n", slow[(size_t)k].second, slow[(size_t)k].first, slow[(size_t)k].second * 64, slow[(size_t)k].second * 64 + 63),
+                    [&](const unsigned long long* g) {
+                        fprintf(stderr, "[velo dbg]     clusters %llu chunks %llu candidates %llu askers %llu asker-candidates %llu asker-time %.1f us | wave-0 kcycles: setup %.1f boxes+rows %.1f runlist %.1f stage %.1f sweep %.1f sweepbar %.1f merge+askers %.1f finish %.1f\n",
+                                g[0], g[1], g[2], g[3], g[4], g[5] * 0.01, g[6] * 1e-3, g[7] * 1e-3, g[8] * 1e-3, g[9] * 1e-3, g[10] * 1e-3, g[11] * 1e-3, g[12] * 1e-3, g[13] * 1e-3);
+                    }(h.data() + 2 * (size_t)c->wg_times_n + 14 * (size_t)slow[(size_t)k].second);
+            }
             fprintf(stderr, "[velo dbg] last assoc launch: %d WGs, span %.1f us | WG duration us: mean %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f | WG start us: p50 %.1f p90 %.1f p99 %.1f max %.1f\n",
                     c->wg_times_n, (t1 - t0) * 0.01, mean, pc(dur, .5), pc(dur, .9), pc(dur, .99), dur.back(), pc(st, .5), pc(st, .9), pc(st, .99), st.back());
         }

@@ -1043,7 +1043,7 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
     __shared__ int s_wave_tot[NW];
     __shared__ int s_lo[NT], s_hi[NT], s_plo[NT], s_phi[NT];   // per-row x-interval of this phase / of what phase 1 visited
     __shared__ int s_box[2][6][64];                            // per-query cell box of phase 1 / phase 2 (x0, x1, y0, y1, z0, z1)
-    __shared__ int s_phase[8];                                 // Y0, Y1, Z0, Z1, asking-lane mask (lo, hi), total rows asked for
+    __shared__ int s_phase[8];                                 // Y0, Y1, Z0, Z1, asking-lane mask (lo, hi), total rows asked for, any bound beyond one cell
     // The transformed queries live HERE, not in registers: lane i of every wave re-reads query i where it needs it (cell boxes, the
     // rare exact-distance path of the sweep, the finish).  Three registers less across the sweep is what keeps the kernel at
     // 96 VGPRs -- five waves per SIMD -- without a single spilled register (a kernel that touches scratch pays ~11 us per launch).
@@ -1124,6 +1124,7 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
     const int big = 1 << 28;
     bool pending = active;
     bool deferred = false;                                             // this lane's query went on the asker list: assoc_asker_kernel finishes it
+    unsigned long long gstat[6] = {0, 0, 0, 0, 0, 0};                   // diagnostics (dbg & 32): clusters, chunks, candidates, askers, asker candidates, asker time
     for (;;) {                                                         // clusters (identical control flow in every wave)
         const unsigned long long pm = __ballot(pending);
         if (pm == 0ull) break;
@@ -1137,6 +1138,7 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
             member = pending && abs(cx - scx) <= cluster_w && abs(cy - scy) <= cluster_w && abs(cz - scz) <= cluster_w;
         }
         if (DBG && (dbg & 16) && tid == 0) atomicAdd(&out.dbg[0], 1ull);
+        if (DBG && (dbg & 32)) gstat[0]++;
         // Per-query cell boxes.  Everything closer to the query than r = sqrt(b2d) lies in the cells [cell(q - r), cell(q + r)] per
         // axis (the cell function is monotone; r is padded against rounding).  Phase 1 visits that box clipped to the query's
         // own cell +- 1: with warm-start seeds r is a few centimetres and the box is 1-2 cells per axis instead of 3, without
@@ -1195,13 +1197,25 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
             const int nrows = (nyb > 0 && nzb > 0) ? nyb * nzb : 0;
             const float rcp_nyb = 1.0f / (float)max(nyb, 1);
             for (int rbase = 0; rbase < ((DBG && (dbg & 4)) ? 0 : nrows); rbase += NT) {          // row chunks (one row per thread)
+                // z-layers that have rows in this chunk (rows are z-major): a query only walks those layers of its box, so a box
+                // that spans several chunks costs its rows once, not once per chunk
+                const int zc0 = Z0 + (int)((float)rbase * rcp_nyb) - 1, zc1 = Z0 + (int)((float)(rbase + NT - 1) * rcp_nyb) + 1;
+                // A chunk no asking query's box reaches into is skipped before it costs a barrier (every wave holds the same boxes, so
+                // the test is workgroup-uniform).
+                {
+                    bool hit = asks && s_box[ph][4][lane] <= zc1 && s_box[ph][5][lane] >= zc0;
+                    if (hit && nyb >= NT / 4) {                        // wide layers: a chunk is a slice of one or two of them, so test the y-range as well
+                        hit = false;
+                        const int ya = max(s_box[ph][2][lane], Y0) - Y0 - rbase, yb = min(s_box[ph][3][lane], Y1) - Y0 - rbase;
+                        for (int z = max(max(s_box[ph][4][lane], zc0), Z0); z <= min(min(s_box[ph][5][lane], zc1), Z1); z++)
+                            hit = hit || ((z - Z0) * nyb + yb >= 0 && (z - Z0) * nyb + ya < NT);
+                    }
+                    if (__ballot(hit) == 0ull) continue;
+                }
                 // ---- 0. per-row x-intervals ----
                 s_lo[tid] = big; s_hi[tid] = -big;
                 if (ph == 1) { s_plo[tid] = big; s_phi[tid] = -big; }
                 __syncthreads();
-                // z-layers that have rows in this chunk (rows are z-major): a query only walks those layers of its box, so a box
-                // that spans several chunks costs its rows once, not once per chunk
-                const int zc0 = Z0 + (int)((float)rbase * rcp_nyb) - 1, zc1 = Z0 + (int)((float)(rbase + NT - 1) * rcp_nyb) + 1;
                 if (asks) {                                            // the rows of this query's box: z-layers dealt over the waves
                     const int bx0 = s_box[ph][0][lane], bx1 = s_box[ph][1][lane], by0 = s_box[ph][2][lane], by1 = s_box[ph][3][lane];
                     const int bz0 = s_box[ph][4][lane], bz1 = s_box[ph][5][lane];
@@ -1266,6 +1280,7 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
                 __syncthreads();
                 VELO_STAMP(2);
                 if (DBG && (dbg & 2)) total = 0;
+                if (DBG && (dbg & 32)) { gstat[1]++; gstat[2] += (unsigned long long)total; }
                 if (DBG && (dbg & 16) && tid == 0) { atomicAdd(&out.dbg[1], 1ull); atomicAdd(&out.dbg[2], (unsigned long long)total); if (ph == 1) atomicAdd(&out.dbg[3], (unsigned long long)total); atomicAdd(&out.dbg[4], (unsigned long long)nrows); }
                 // ---- 2./3. tiles ----
                 for (int tbase = 0; tbase < total; tbase += kTileCap) {
@@ -1398,6 +1413,8 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
             if (stage == 1) asks = asks && rnow > cap;                 // the others have seen their whole bound sphere in stage 0
             unsigned long long am = __ballot(asks);
             if (DBG && (dbg & 1024)) am = 0ull;
+            const unsigned long long t_ask0 = (DBG && (dbg & 32)) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+            if (DBG && (dbg & 32)) gstat[3] += (unsigned long long)__popcll(am);
             if (am != 0ull) {
                 // LPA lanes per asker (64: one asker per wave at a time; 16 -- four at a time -- measured slower on the map: 314 vs 244 us)
                 constexpr int LPA = 64;
@@ -1441,6 +1458,7 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (DBG && (dbg & 32)) gstat[4] += (unsigned long long)total;
                         if (DBG && (dbg & 16) && sl == 0) { atomicAdd(&out.dbg[2], (unsigned long long)total); atomicAdd(&out.dbg[3], (unsigned long long)total); atomicAdd(&out.dbg[4], (unsigned long long)min(LPA, nrows_a - r0)); }
                         for (int slot = sl; slot < total; slot += LPA) {
                             int lo = 0;                                // largest i with w_off[i] <= slot
@@ -1466,6 +1484,7 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
                 }
                 __syncthreads();                                       // the scratch aliases the tile of the next cluster
             }
+            if (DBG && (dbg & 32)) gstat[5] += __builtin_amdgcn_s_memrealtime() - t_ask0;
             }
             VELO_STAMP(6);
         }
@@ -1485,7 +1504,12 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
     } else
     if (active && !deferred) finish_correspondence_pad(qi, qpts, qx, qy, qz, t.b1, t.b2, t.b1ring, t.b2ring, key_inf, tgt_pad, tgt_off, norm_cond, out, want_aux != 0);
     VELO_STAMP(7);
-    if (DBG && out.wg_times && tid == 0) out.wg_times[2 * group + 1] = __builtin_amdgcn_s_memrealtime();
+    if (DBG && out.wg_times && tid == 0) {
+        out.wg_times[2 * group + 1] = __builtin_amdgcn_s_memrealtime();
+        const int n_groups = (q_end - q_begin + 63) / 64;              // the tube kernel's own counters follow the start/end stamps
+        for (int k = 0; k < 6; k++) out.wg_times[2 * (size_t)n_groups + 14 * (size_t)group + k] = gstat[k];
+        for (int k = 0; k < 8; k++) out.wg_times[2 * (size_t)n_groups + 14 * (size_t)group + 6 + k] = (unsigned long long)tacc[k];
+    }
     if (DBG && (dbg & 8) && tid == 0) { for (int k = 0; k < 8; k++) atomicAdd((unsigned long long*)&out.dbg[k], (unsigned long long)tacc[k]); }
 #undef VELO_STAMP
 #undef VELO_Q
