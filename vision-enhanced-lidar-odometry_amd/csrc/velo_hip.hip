@@ -211,6 +211,7 @@ struct velo_ctx {
     DevBuf<SolveLog> solve_log;
     DevBuf<int> chain_fail;
     SolveLog* h_log = nullptr;           // pinned: VELO_MAX_SOLVES logs + the failure flag behind them
+    int lm_fused = 1;                    // VELO_LM_FUSED=0: the lock-step batch driver launches sweep and LM step separately (A/B, identical results)
     int lm_merged = 1;                   // VELO_LM_MERGED=0: sweep and LM step as two launches per iteration also where one would do (A/B, identical results)
     int small_solve = 1;                 // VELO_SMALL_SOLVE=0: small problems go through the launch-per-iteration path too (A/B, identical results)
     int asker_rows = -1;                 // tube kernel (VELO_ASKER_ROWS): phase 2 goes query by query when the asking queries' boxes have more
@@ -255,6 +256,7 @@ struct velo_ctx {
     DevBuf<LMEvalPoint> eval_pt;         // where the next sweep evaluates: written by lm_begin / the LM step, read by the sweep workgroups
     DevBuf<double> partials, reduced, xdev;
     DevBuf<int> ticket;
+    DevBuf<int> batch_tickets;                    // fused sweep + step of a lock-step group: one ticket counter per context (0 at launch boundaries)
     DevBuf<unsigned long long> lm_trace;  // diagnostics build, VELO_LM_TRACE=1: stage stamps of the LM chain (tools/lm_trace.py)
     bool lm_trace_on = false;
     int lm_trace_idx = 0;                 // launches of the current solve so far
@@ -270,6 +272,10 @@ struct velo_ctx {
     HostStatus* h_status = nullptr;      // pinned
     double* h_x = nullptr;               // pinned, 8 doubles
     int* h_int = nullptr;                // pinned scratch
+    // pinned staging for the small host tables a load sends to the device (source ring offsets, query offsets): the copy is asynchronous
+    // and the slot's event says when the host may write the slot again -- no stream synchronisation at the end of a load
+    struct PinSlot { int* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };
+    PinSlot pin[2];
     DevBuf<int> row_off_vis, row_off_icp;
     DevBuf<double> rows_r, rows_J;
 
@@ -456,6 +462,24 @@ bool query_list_stale(const velo_ctx* c) {
     return c->src_skip != std::max(c->P.icp_skip, 1) || (c->n_q > 0) != (c->P.enable_icp != 0 && c->h_q_off[c->n_src_rings] > 0) || c->q_patch != want_patch(c);
 }
 
+int pin_acquire(velo_ctx* c, int k, size_t n, int** out) {
+    velo_ctx::PinSlot& s = c->pin[k];
+    if (s.pending) { HIP_TRY(hipEventSynchronize(s.ev)); s.pending = false; }
+    if (s.cap < n) {
+        if (s.p) { (void)hipHostFree(s.p); s.p = nullptr; s.cap = 0; }
+        HIP_TRY(hipHostMalloc((void**)&s.p, (n + 64) * sizeof(int)));
+        s.cap = n + 64;
+    }
+    if (!s.ev) HIP_TRY(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+    *out = s.p;
+    return VELO_OK;
+}
+int pin_release(velo_ctx* c, int k) {
+    HIP_TRY(hipEventRecord(c->pin[k].ev, c->stream));
+    c->pin[k].pending = true;
+    return VELO_OK;
+}
+
 int build_query_list(velo_ctx* c) {
     const int skip = std::max(c->P.icp_skip, 1);
     c->prev_ready = false;                                            // seeds are indexed by query
@@ -468,7 +492,13 @@ int build_query_list(velo_ctx* c) {
     c->src_skip = skip;
     VELO_TRY(c->q_off.reserve((size_t)c->n_src_rings + 1));
     VELO_TRY(c->q_src.reserve((size_t)std::max(c->n_q, 1)));
-    HIP_TRY(hipMemcpyAsync(c->q_off.p, c->h_q_off.data(), sizeof(int) * ((size_t)c->n_src_rings + 1), hipMemcpyHostToDevice, c->stream));
+    {
+        int* pin = nullptr;
+        VELO_TRY(pin_acquire(c, 1, (size_t)c->n_src_rings + 1, &pin));
+        std::memcpy(pin, c->h_q_off.data(), sizeof(int) * ((size_t)c->n_src_rings + 1));
+        HIP_TRY(hipMemcpyAsync(c->q_off.p, pin, sizeof(int) * ((size_t)c->n_src_rings + 1), hipMemcpyHostToDevice, c->stream));
+        VELO_TRY(pin_release(c, 1));
+    }
     if (c->n_q > 0) {
         hipLaunchKernelGGL(query_list_kernel, dim3(cdiv(c->n_q, 256)), dim3(256), 0, c->stream, c->src_off.p, c->q_off.p, c->n_src_rings, skip, c->n_q,
                            want_patch(c) ? 1 : 0, c->patch_rings, c->patch_len, c->q_src.p);
@@ -486,9 +516,7 @@ int build_query_list(velo_ctx* c) {
     VELO_TRY(c->cp.reserve(nq)); VELO_TRY(c->cn.reserve(nq)); VELO_TRY(c->cv0.reserve(nq));
     VELO_TRY(c->aux0.reserve(nq)); VELO_TRY(c->aux1.reserve(nq));
     c->have_corr = false;
-    // the pageable h_q_off copy must finish before the vector can change again
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    return VELO_OK;
+    return VELO_OK;                                                       // (no host wait: the offsets went through a pinned slot)
 }
 
 // Workgroup -> group map of the association kernel.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8) and each
@@ -1073,7 +1101,10 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
 }
 
 // common tail of every way a target enters the context: ring table, ring ids, bounding box, grid
-int target_finalize(velo_ctx* c) {
+// target_finalize = target_finalize_begin (everything up to the request for the bounding box, no host wait) + target_finalize_end (the
+// one synchronisation of set_target, then the index).  The batch driver begins all contexts of a group before it ends the first,
+// so one context's wait is covered by the next one's uploads.
+int target_finalize_begin(velo_ctx* c) {
     const int n = c->T->n_tgt, n_rings = c->T->n_tgt_rings;
     c->prev_ready = false;                                            // seeds refer to points of the old target
     for (int r = 0; r < n_rings; r++) if (c->T->h_tgt_off[r + 1] <= c->T->h_tgt_off[r]) return fail(VELO_ERR_INVALID, "target ring %d is empty", r);
@@ -1094,6 +1125,9 @@ int target_finalize(velo_ctx* c) {
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(c->h_int + 8, c->bbox_keys.p, sizeof(init), hipMemcpyDeviceToHost, c->stream));
+    return VELO_OK;
+}
+int target_finalize_end(velo_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     unsigned keys[6];
     std::memcpy(keys, c->h_int + 8, sizeof(keys));
@@ -1108,9 +1142,20 @@ int target_finalize(velo_ctx* c) {
     return VELO_OK;
 }
 
+int target_finalize(velo_ctx* c) {
+    VELO_TRY(target_finalize_begin(c));
+    return target_finalize_end(c);
+}
+
 int source_finalize(velo_ctx* c) {
     VELO_TRY(c->src_off.reserve((size_t)c->n_src_rings + 1));
-    HIP_TRY(hipMemcpyAsync(c->src_off.p, c->h_src_off.data(), sizeof(int) * ((size_t)c->n_src_rings + 1), hipMemcpyHostToDevice, c->stream));
+    {
+        int* pin = nullptr;
+        VELO_TRY(pin_acquire(c, 0, (size_t)c->n_src_rings + 1, &pin));
+        std::memcpy(pin, c->h_src_off.data(), sizeof(int) * ((size_t)c->n_src_rings + 1));
+        HIP_TRY(hipMemcpyAsync(c->src_off.p, pin, sizeof(int) * ((size_t)c->n_src_rings + 1), hipMemcpyHostToDevice, c->stream));
+        VELO_TRY(pin_release(c, 0));
+    }
     VELO_TRY(build_query_list(c));
     c->have_source = true;
     return VELO_OK;
@@ -1237,6 +1282,7 @@ int velo_create(velo_ctx** out, int device) {
         if (const char* e = getenv("VELO_WARM_START")) c->warm_start = atoi(e);
         if (const char* e = getenv("VELO_SMALL_SOLVE")) c->small_solve = atoi(e);
         if (const char* e = getenv("VELO_LM_MERGED")) c->lm_merged = atoi(e);
+        if (const char* e = getenv("VELO_LM_FUSED")) c->lm_fused = atoi(e);
         if (const char* e = getenv("VELO_ASSOC_LANE")) c->assoc_lane = atoi(e);
         if (const char* e = getenv("VELO_LM_MERGED_VIS")) c->lm_trace_vis_off = atoi(e) == 0;
         if (const char* e = getenv("VELO_ASKER_QUEUE")) c->asker_queue = atoi(e);
@@ -1331,11 +1377,12 @@ int velo_destroy(velo_ctx* c) {
     if (c->h_batch) (void)hipHostFree(c->h_batch);
     c->batch_items.release(); c->batch_states.release(); c->batch_x.release();
     c->ask_count.release(); c->ask_list.release(); c->ask_keys.release(); c->ask_rings.release();
-    c->batch_pose.release(); c->batch_logs.release(); c->batch_fail.release(); c->pose_rec.release(); c->solve_log.release(); c->chain_fail.release();
+    c->batch_tickets.release(); c->batch_pose.release(); c->batch_logs.release(); c->batch_fail.release(); c->pose_rec.release(); c->solve_log.release(); c->chain_fail.release();
     if (c->h_log) (void)hipHostFree(c->h_log);
     if (c->h_status) (void)hipHostFree(c->h_status);
     if (c->h_x) (void)hipHostFree(c->h_x);
     if (c->h_int) (void)hipHostFree(c->h_int);
+    for (auto& ps : c->pin) { if (ps.ev) (void)hipEventDestroy(ps.ev); if (ps.p) (void)hipHostFree(ps.p); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto& e : c->assoc_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1383,7 +1430,7 @@ int velo_set_target(velo_ctx* c, const float* xyz, int64_t stride, const int32_t
     return velo_set_target_part(c, xyz, stride, off, n_rings, 0, 0, on_device);
 }
 
-int velo_set_target_part(velo_ctx* c, const float* xyz, int64_t stride, const int32_t* off, int32_t n_rings, int32_t first_ring, int32_t first_point, int on_device) {
+static int set_target_begin(velo_ctx* c, const float* xyz, int64_t stride, const int32_t* off, int32_t n_rings, int32_t first_ring, int32_t first_point, int on_device) {
     if (!c || !off || n_rings < 0 || first_ring < 0 || first_point < 0) return fail(VELO_ERR_INVALID, "null/negative argument");
     if (stride < 12) return fail(VELO_ERR_INVALID, "stride_bytes must be >= 12");
     if (off[0] != 0) return fail(VELO_ERR_INVALID, "ring_offsets[0] must be 0");
@@ -1400,10 +1447,14 @@ int velo_set_target_part(velo_ctx* c, const float* xyz, int64_t stride, const in
     c->T->tgt_first_ring = first_ring; c->T->tgt_first_point = first_point;
     c->T->h_tgt_off.assign(off, off + n_rings + 1);
     VELO_TRY(upload_cloud(c, xyz, stride, n, on_device, c->T->tgt));
-    return target_finalize(c);
+    return target_finalize_begin(c);
+}
+int velo_set_target_part(velo_ctx* c, const float* xyz, int64_t stride, const int32_t* off, int32_t n_rings, int32_t first_ring, int32_t first_point, int on_device) {
+    VELO_TRY(set_target_begin(c, xyz, stride, off, n_rings, first_ring, first_point, on_device));
+    return target_finalize_end(c);
 }
 
-int velo_set_source(velo_ctx* c, const float* xyz, int64_t stride, const int32_t* off, int32_t n_rings, int on_device) {
+static int set_source_begin(velo_ctx* c, const float* xyz, int64_t stride, const int32_t* off, int32_t n_rings, int on_device) {
     if (!c || !off || n_rings < 0) return fail(VELO_ERR_INVALID, "null/negative argument");
     if (stride < 12) return fail(VELO_ERR_INVALID, "stride_bytes must be >= 12");
     if (off[0] != 0) return fail(VELO_ERR_INVALID, "ring_offsets[0] must be 0");
@@ -1414,8 +1465,13 @@ int velo_set_source(velo_ctx* c, const float* xyz, int64_t stride, const int32_t
     c->have_source = false; c->have_corr = false;
     c->n_src = n; c->n_src_rings = n_rings;
     c->h_src_off.assign(off, off + n_rings + 1);
-    VELO_TRY(upload_cloud(c, xyz, stride, n, on_device, c->src));
-    return source_finalize(c);
+    return upload_cloud(c, xyz, stride, n, on_device, c->src);
+}
+int velo_set_source(velo_ctx* c, const float* xyz, int64_t stride, const int32_t* off, int32_t n_rings, int on_device) {
+    VELO_TRY(set_source_begin(c, xyz, stride, off, n_rings, on_device));
+    VELO_TRY(source_finalize(c));
+    HIP_TRY(hipStreamSynchronize(c->stream));                             // the caller's buffer has been read when the call returns
+    return VELO_OK;
 }
 
 // kitti.h:121-185 on the device ("next" row 1 of SURVEY.md 8(f)): raw Velodyne records (x, y, z, reflectance; any stride
@@ -2440,6 +2496,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
     SolveLog* h_logs = (SolveLog*)(h_x + 8 * (size_t)n);
     int* h_fail = (int*)(h_logs + (size_t)n * VELO_MAX_SOLVES);
     VELO_TRY(c0->batch_items.reserve(n_item_slots)); VELO_TRY(c0->batch_states.reserve((size_t)n)); VELO_TRY(c0->batch_x.reserve((size_t)8 * n));
+    if (c0->batch_tickets.cap < (size_t)n) { VELO_TRY(c0->batch_tickets.reserve((size_t)n)); HIP_TRY(hipMemsetAsync(c0->batch_tickets.p, 0, sizeof(int) * c0->batch_tickets.cap, bs)); }
 
     std::vector<velo_summary> local((size_t)n);
     std::vector<velo_summary*> S((size_t)n);
@@ -2476,6 +2533,8 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
             for (int k = 0; k < 6; k++) h_x[8 * (size_t)i + k] = xc[(size_t)i][(size_t)k];
         }
         HIP_TRY(hipMemcpyAsync(c0->batch_x.p, h_x, sizeof(double) * 8 * (size_t)n, hipMemcpyHostToDevice, bs));
+        // (A/B, measured: the LM launches on a high-priority stream of their own halve the throughput -- 1,530 vs 3,020 pairs/s: more than four
+        //  active hardware queues are time-sliced, the same effect as GPU_MAX_HW_QUEUES=8)
         int r = 0;
         for (int iter = 1; iter <= P.f2f_iterations; iter++) {
             for (int icp_iter = 0; icp_iter < P.icp_iterations; icp_iter++, r++) {
@@ -2500,10 +2559,12 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                 HIP_TRY(hipMemcpyAsync(c0->batch_items.p + (size_t)r * n, items_r, sizeof(LMBatchItem) * (size_t)n, hipMemcpyHostToDevice, bs));
                 hipLaunchKernelGGL(lm_begin_batch_kernel, dim3(n), dim3(64), 0, bs, d_items);
                 for (int k = 0; k < K; k++) {
+                    if (c0->lm_fused) { hipLaunchKernelGGL(eval_step_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, d_items, c0->batch_tickets.p); continue; }
                     hipLaunchKernelGGL(eval_icp_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, d_items);
                     hipLaunchKernelGGL(lm_step_batch_kernel, dim3(n), dim3(256), 0, bs, Q, d_items);
                 }
                 HIP_TRY(hipGetLastError());
+
             }
         }
         hipLaunchKernelGGL(lm_gather_states_kernel, dim3(n), dim3(128), 0, bs, (const LMBatchItem*)c0->batch_items.p, c0->batch_states.p, 0);
@@ -2589,7 +2650,9 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
             // (measured with 8 pairs in flight: 2,040-2,120 pairs/s against 2,410-2,450 with sweep + step as two launches -- the redundant
             //  transitions keep 118 workgroups per context resident for 5 us longer, and at one wave per SIMD; hence VELO_LM_MERGED=2 only)
             bool merged = c0->lm_merged >= 2 && nbv_max == 0;
-            for (int i = 0; i < n; i++) merged = merged && h_items[i].nb_icp > 0;
+            bool fused = c0->lm_fused != 0 && nbv_max == 0;                             // sweep + step in one launch, the last workgroup of a context steps
+            for (int i = 0; i < n; i++) { merged = merged && h_items[i].nb_icp > 0; fused = fused && h_items[i].nb_icp > 0; }
+            fused = fused && !merged;
             const size_t half = (size_t)(kMaxEvalBlocks + kMaxVisBlocks) * kNumAcc;
             int launched = 0, chunk = first_chunk + (merged ? 1 : 0);
             if (!merged) hipLaunchKernelGGL(lm_begin_batch_kernel, dim3(n), dim3(64), 0, bs, (const LMBatchItem*)c0->batch_items.p);
@@ -2599,6 +2662,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                         hipLaunchKernelGGL(lm_iter_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p, launched + k, half);
                         continue;
                     }
+                    if (fused) { hipLaunchKernelGGL(eval_step_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p, c0->batch_tickets.p); continue; }
                     if (nb_max > 0) hipLaunchKernelGGL(eval_icp_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, (const LMBatchItem*)c0->batch_items.p);
                     if (nbv_max > 0) hipLaunchKernelGGL(eval_visual_batch_kernel, dim3(nbv_max, n), dim3(kEvalThreads), 0, bs, (const LMBatchItem*)c0->batch_items.p);
                     hipLaunchKernelGGL(lm_step_batch_kernel, dim3(n), dim3(256), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p);
@@ -2649,6 +2713,17 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
 static int load_job(velo_ctx* c, const velo_scan_ref* tg, const velo_scan_ref* sr) {
     if (tg) VELO_TRY(velo_set_target(c, tg->xyz, tg->stride_bytes, tg->ring_offsets, tg->n_rings, tg->on_device & 1));
     if (sr) VELO_TRY(velo_set_source(c, sr->xyz, sr->stride_bytes, sr->ring_offsets, sr->n_rings, sr->on_device & 1));
+    return VELO_OK;
+}
+// the same in two halves: everything that needs no answer from the device (uploads, ring tables, the bounding-box request), then the rest
+static int load_job_begin(velo_ctx* c, const velo_scan_ref* tg, const velo_scan_ref* sr) {
+    if (tg) VELO_TRY(set_target_begin(c, tg->xyz, tg->stride_bytes, tg->ring_offsets, tg->n_rings, 0, 0, tg->on_device & 1));
+    if (sr) VELO_TRY(set_source_begin(c, sr->xyz, sr->stride_bytes, sr->ring_offsets, sr->n_rings, sr->on_device & 1));
+    return VELO_OK;
+}
+static int load_job_end(velo_ctx* c, bool tg, bool sr) {
+    if (tg) VELO_TRY(target_finalize_end(c));
+    if (sr) VELO_TRY(source_finalize(c));
     return VELO_OK;
 }
 
@@ -2703,8 +2778,13 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
             // this group's index builds, then its registrations: no barrier across groups, so one group's association launches
             // run under another group's index builds.  (Helper threads that load a group's contexts in parallel were measured
             // slower, 2.32-2.34 k vs 2.42-2.47 k pairs/s: more host threads contending for the runtime's submission path.)
+            // (in two passes: all contexts' uploads and bounding-box requests are in flight before the first context waits for its answer)
             for (int i = b; i < e; i++) {
-                const int st = load_job(ctxs[i], target_of(i), sources ? sources + i : nullptr);
+                const int st = load_job_begin(ctxs[i], target_of(i), sources ? sources + i : nullptr);
+                if (st != VELO_OK) { gst[(size_t)gi] = st; gerr[(size_t)gi] = g_err; return; }
+            }
+            for (int i = b; i < e; i++) {
+                const int st = load_job_end(ctxs[i], target_of(i) != nullptr, sources != nullptr);
                 if (st != VELO_OK) { gst[(size_t)gi] = st; gerr[(size_t)gi] = g_err; return; }
             }
             gst[(size_t)gi] = f2f_batch_lockstep(ctxs + b, e - b, x + 6 * (size_t)b, T ? T + 16 * (size_t)b : nullptr, summaries ? summaries + b : nullptr);

@@ -2555,6 +2555,12 @@ __device__ __forceinline__ void block_reduce_store(double acc[kNumAcc], double* 
     }
 }
 #else
+// Agent-scope accesses for data one workgroup hands to another INSIDE a launch (the partial rows of the fused sweep + step): the
+// store is written through to where every XCD sees it, the load does not stop at an L2 line another XCD's store has made stale.
+// No release/acquire fence anywhere on that path -- on this chip an agent-scope fence writes back / invalidates a whole L2.
+__device__ __forceinline__ void store_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double load_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool COHERENT = false>
 __device__ __forceinline__ void block_reduce_store(double acc[kNumAcc], double* __restrict__ dst /* [28] */, double* __restrict__ scratch) {
     constexpr int kCols = kEvalThreads / 4;                       // 64 partial sums per accumulator
     static_assert(kNumAcc * kCols <= kScratchDoubles / 2, "scratch size");
@@ -2582,7 +2588,7 @@ __device__ __forceinline__ void block_reduce_store(double acc[kNumAcc], double* 
         double v = 0.0;
 #pragma unroll
         for (int i = 0; i < 8; i++) v += red2[t][i];
-        dst[t] = v;
+        if (COHERENT) store_agent(dst + t, v); else dst[t] = v;
     }
 }
 #endif
@@ -3022,6 +3028,7 @@ __device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* 
 __device__ __forceinline__ void lm_transition_wave(const LMParams& Q, LMState* sL, const double* E, int lane);
 constexpr int kStepChunk = 128;
 static_assert(kStepChunk * kNumAcc == kScratchDoubles && kStepChunk * kNumAcc % 256 == 0 && kStepChunk % 8 == 0, "chunk geometry");
+template <bool COHERENT = false>
 __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __restrict__ Sin, const double* __restrict__ partials, int n_blocks, int first,
                                            const double* __restrict__ x_in, const int* __restrict__ n_valid,
                                            double* __restrict__ s_rows, LMState* sL, LMEvalPoint* s_pt, unsigned long long* trace, int trace_eval,
@@ -3048,7 +3055,7 @@ __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __r
             const double* __restrict__ src = partials + (size_t)c0 * kNumAcc;
             double a[kPerThread];
 #pragma unroll
-            for (int u = 0; u < kPerThread; u++) { const int i = t + 256 * u; a[u] = (i < total) ? src[i] : 0.0; }
+            for (int u = 0; u < kPerThread; u++) { const int i = t + 256 * u; a[u] = (i < total) ? (COHERENT ? load_agent(src + i) : src[i]) : 0.0; }
             if (c0 > 0) __syncthreads();                        // the previous chunk has been summed
 #pragma unroll
             for (int u = 0; u < kPerThread; u++) { const int i = t + 256 * u; if (i < total) s_rows[i] = a[u]; }
@@ -3360,6 +3367,42 @@ __global__ void __launch_bounds__(256)
 lm_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items) {
     const LMBatchItem& it = items[blockIdx.x];
     lm_transition(Q, it.S, const_cast<LMEvalPoint*>(it.A.pt), it.A.partials, it.n_rows, nullptr, 0, nullptr, it.pose_out, it.log);
+}
+// Sweep AND step of a lock-step group in ONE launch per LM iteration (point-to-plane rows only): every workgroup sweeps its rows
+// and publishes its partial row with agent-scope stores; the workgroup of a context that draws the last ticket then does what
+// lm_step_batch_kernel does -- the same fixed-order sum over the same rows, the same transition, so the results are bit-identical
+// to the two-launch path -- and leaves state and eval point for the next launch.  One kernel boundary per iteration instead of two
+// and ONE transition per context (the one-launch iteration of the single-pair path repeats it in every workgroup, which costs a
+// group of 2-4 contexts more residency than the boundary it saves: measured, see the batch driver).
+// Ordering: the 28 stores of a row are agent-scope write-through stores; their thread waits for them (s_waitcnt vmcnt(0)) ahead of
+// the workgroup barrier behind which thread 0 draws the ticket, so whoever sees ticket n - 1 finds every row where its agent-scope
+// loads look.  tickets[context] is 0 at every launch boundary (the last workgroup resets it).
+__global__ void __launch_bounds__(kEvalThreads)
+eval_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets) {
+    const LMBatchItem& it = items[blockIdx.y];
+    const int bx = blockIdx.x, nbx = it.nb_icp;
+    if (bx >= nbx) return;
+    const EvalArgs& A = it.A;
+    const RowPrefetch f = prefetch_rows(A, bx, nbx);
+    __shared__ LMEvalPoint s_pt;
+    __shared__ LMState sL;
+    __shared__ double s_scratch[kScratchDoubles];
+    __shared__ int s_last;
+    if (!eval_point_load(A, &s_pt)) return;                           // a launch behind the end of the solve: nothing to do, the ticket stays 0
+    double acc[kNumAcc];
+    sweep_rows<true>(A, f, s_pt, bx, nbx, acc);
+    block_reduce_store<true>(acc, A.partials + (size_t)bx * kNumAcc, s_scratch);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this thread's row entries have been written through
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(tickets + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nbx - 1 ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(tickets + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    lm_advance<true>(Q, it.S, A.partials, it.n_rows, 0, nullptr, nullptr, s_scratch, &sL, &s_pt, nullptr, 0, nullptr, it.pose_out, it.log);
+    const int t = threadIdx.x;
+    LMEvalPoint* pt = const_cast<LMEvalPoint*>(A.pt);
+    if (t < (int)(sizeof(LMState) / 8)) reinterpret_cast<unsigned long long*>(it.S)[t] = reinterpret_cast<const unsigned long long*>(&sL)[t];
+    else if (t >= 64 && t < 64 + (int)(sizeof(LMEvalPoint) / 8)) reinterpret_cast<unsigned long long*>(pt)[t - 64] = reinterpret_cast<const unsigned long long*>(&s_pt)[t - 64];
 }
 // all states of the batch into one contiguous block (one D2H copy per chunk instead of one per context)
 __global__ void lm_gather_states_kernel(const LMBatchItem* __restrict__ items, LMState* __restrict__ out, int which) {
