@@ -29,6 +29,7 @@
 #include <thread>
 #include <unordered_map>
 #include <vector>
+#include <chrono>
 
 #include "../../include/velo_hip.h"
 #include "velo_kernels.h"
@@ -2773,8 +2774,11 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
         }
         std::vector<int> gst((size_t)G, VELO_OK);
         std::vector<std::string> gerr((size_t)G);
+        static const bool batch_trace = getenv("VELO_BATCH_TRACE") != nullptr;       // dev aid: host-side timeline of every group to stderr
+        const auto t_call = std::chrono::steady_clock::now();
         auto run_group = [&](int gi) {
             const int b = (int)((int64_t)n * gi / G), e = (int)((int64_t)n * (gi + 1) / G);
+            const auto t0 = std::chrono::steady_clock::now();
             // this group's index builds, then its registrations: no barrier across groups, so one group's association launches
             // run under another group's index builds.  (Helper threads that load a group's contexts in parallel were measured
             // slower, 2.32-2.34 k vs 2.42-2.47 k pairs/s: more host threads contending for the runtime's submission path.)
@@ -2783,12 +2787,19 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
                 const int st = load_job_begin(ctxs[i], target_of(i), sources ? sources + i : nullptr);
                 if (st != VELO_OK) { gst[(size_t)gi] = st; gerr[(size_t)gi] = g_err; return; }
             }
+            const auto t1 = std::chrono::steady_clock::now();
             for (int i = b; i < e; i++) {
                 const int st = load_job_end(ctxs[i], target_of(i) != nullptr, sources != nullptr);
                 if (st != VELO_OK) { gst[(size_t)gi] = st; gerr[(size_t)gi] = g_err; return; }
             }
+            const auto t2 = std::chrono::steady_clock::now();
             gst[(size_t)gi] = f2f_batch_lockstep(ctxs + b, e - b, x + 6 * (size_t)b, T ? T + 16 * (size_t)b : nullptr, summaries ? summaries + b : nullptr);
             if (gst[(size_t)gi] != VELO_OK) gerr[(size_t)gi] = g_err;
+            if (batch_trace) {
+                const auto t3 = std::chrono::steady_clock::now();
+                auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point bb) { return std::chrono::duration<double, std::micro>(bb - a).count(); };
+                fprintf(stderr, "[velo batch] group %d: start +%.0f us, loads begun %.0f, loads ended %.0f, registrations %.0f us\n", gi, us(t_call, t0), us(t0, t1), us(t1, t2), us(t2, t3));
+            }
         };
         WorkerPool::instance().run(G, run_group);                // the calling thread drives the first group itself, resident workers the others
         for (int gi = 0; gi < G; gi++) if (gst[(size_t)gi] != VELO_OK) { g_err = gerr[(size_t)gi]; return gst[(size_t)gi]; }

@@ -3390,7 +3390,7 @@ eval_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* _
     __shared__ int s_last;
     if (!eval_point_load(A, &s_pt)) return;                           // a launch behind the end of the solve: nothing to do, the ticket stays 0
     double acc[kNumAcc];
-    sweep_rows<true>(A, f, s_pt, bx, nbx, acc);
+    sweep_rows<false>(A, f, s_pt, bx, nbx, acc);                      // matrices in registers: the kernel runs two waves per SIMD either way
     block_reduce_store<true>(acc, A.partials + (size_t)bx * kNumAcc, s_scratch);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this thread's row entries have been written through
     __syncthreads();
