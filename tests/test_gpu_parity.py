@@ -490,10 +490,14 @@ def test_chain_mode_is_bit_identical_and_survives_mispredictions(hip_lib, oracle
 
 
 def test_chain_mode_lockstep_batch_is_bit_identical(hip_lib, monkeypatch):
+    """Lock-step batch: host-driven vs chain mode, and sweep + LM step as ONE launch per iteration (eval_step_batch_kernel: the last
+    workgroup of a context steps) vs two launches (VELO_LM_FUSED=0) -- poses, solves, counts and bytes equal bit for bit."""
     pairs = [synth.scan_pair(n_beams=32, n_azimuth=400, scene_seed=10 + k, sigma=0.02 * (k + 1)) for k in range(3)]
     pairs[2]["x0"] = np.array([0.01, -0.02, 0.0, 0.3, 0.0, 0.4])
     res = {}
-    for name, env in (("host", {"VELO_CHAIN": "0"}), ("chain", {"VELO_CHAIN": "1"}), ("tight", {"VELO_CHAIN": "1", "VELO_CHAIN_MARGIN": "0"})):
+    for name, env in (("host", {"VELO_CHAIN": "0", "VELO_LM_FUSED": "0"}), ("chain", {"VELO_CHAIN": "1", "VELO_LM_FUSED": "1"}),
+                      ("tight", {"VELO_CHAIN": "1", "VELO_CHAIN_MARGIN": "0", "VELO_LM_FUSED": "1"}),
+                      ("host_fused", {"VELO_CHAIN": "0", "VELO_LM_FUSED": "1"}), ("chain_two", {"VELO_CHAIN": "1", "VELO_LM_FUSED": "0"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         ctxs = [api.Context(0, icp_skip=1) for _ in pairs]
@@ -508,10 +512,10 @@ def test_chain_mode_lockstep_batch_is_bit_identical(hip_lib, monkeypatch):
         res[name] = (out, [c.chain_stats() for c in ctxs])
         for c in ctxs:
             c.close()
-    assert all(st == (0, 0) for st in res["host"][1])
-    assert all(st[0] == 3 for st in res["chain"][1])
+    assert all(st == (0, 0) for st in res["host"][1]) and all(st == (0, 0) for st in res["host_fused"][1])
+    assert all(st[0] == 3 for st in res["chain"][1]) and all(st[0] == 3 for st in res["chain_two"][1])
     assert any(st[1] >= 1 for st in res["tight"][1])
-    for name in ("chain", "tight"):
+    for name in ("chain", "tight", "host_fused", "chain_two"):
         for (x0, T0, s0, r0), (x1, T1, s1, r1) in zip(res["host"][0], res[name][0]):
             assert np.array_equal(x0, x1) and np.array_equal(T0, T1) and s0 == s1 and r0 == r1
 

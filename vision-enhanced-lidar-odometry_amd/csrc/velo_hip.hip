@@ -2653,7 +2653,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
             bool merged = c0->lm_merged >= 2 && nbv_max == 0;
             bool fused = c0->lm_fused != 0 && nbv_max == 0;                             // sweep + step in one launch, the last workgroup of a context steps
             for (int i = 0; i < n; i++) { merged = merged && h_items[i].nb_icp > 0; fused = fused && h_items[i].nb_icp > 0; }
-            fused = fused && !merged;
+            fused = fused && !merged;                                                   // (with visual blocks: measured no gain over three launches)
             const size_t half = (size_t)(kMaxEvalBlocks + kMaxVisBlocks) * kNumAcc;
             int launched = 0, chunk = first_chunk + (merged ? 1 : 0);
             if (!merged) hipLaunchKernelGGL(lm_begin_batch_kernel, dim3(n), dim3(64), 0, bs, (const LMBatchItem*)c0->batch_items.p);
