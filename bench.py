@@ -232,11 +232,16 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
             results[i] = ctxs[i].frame_to_frame(d["x0"])
 
         pool = ThreadPoolExecutor(max_workers=B) if B > 1 else None
-        batch_refs = (api.scan_refs([(tgt, tgt_off)] * B, rig.local_rank), api.scan_refs([(src, d["src_off"])] * B, rig.local_rank)) if B > 1 else None
+        # (B == 1, whole target: the same single library call with one job -- velo_register_batch routes it to the single-pair path)
+        one_call = B == 1 and a.batch_api and tgt_first_ring == 0 and tgt_first_point == 0 and mode == "replicas"
+        batch_refs = (api.scan_refs([(tgt, tgt_off)] * B, rig.local_rank), api.scan_refs([(src, d["src_off"])] * B, rig.local_rank)) if (B > 1 or one_call) else None
         x0s = np.tile(np.asarray(d["x0"], dtype=np.float64), (B, 1))
 
         def step():
-            if pool is None:
+            if pool is None and one_call:
+                xs, Ts, Ss = api.register_batch(ctxs, None, None, x0s, refs=batch_refs)
+                results[0] = (xs[0], Ts[0], Ss[0])
+            elif pool is None:
                 one_pair(0)
             elif a.batch_api and a.separate_loads:
                 list(pool.map(load_pair, range(B)))

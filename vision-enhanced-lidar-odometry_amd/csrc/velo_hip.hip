@@ -2761,6 +2761,10 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
         if (!tgt_local.empty()) return tgt_local[(size_t)i].n_rings < 0 ? nullptr : &tgt_local[(size_t)i];
         return targets + i;
     };
+    if (n == 1) {                                                     // one job: the single-pair path (one chain of launches, one-launch LM iterations)
+        VELO_TRY(load_job(ctxs[0], target_of(0), sources));
+        return velo_frame_to_frame(ctxs[0], x, T, summaries);
+    }
     if (batch_can_lockstep(ctxs, n, targets != nullptr, sources != nullptr)) {
         // G lock-step groups, one host thread and one stream each: while one group is in its (chip-filling) association
         // launches or waits for a status copy, another group's LM launches run -- the groups hide each other's bubbles
