@@ -339,7 +339,8 @@ int velo_frame_to_frame_batch(velo_ctx** ctxs, int32_t n, double* x /* n*6 */, d
 /* The same with the scans of every job handed over in the call (seam 1 takes scans_M / scans_S per call, velo.h:606-607): job i's
  * target and source go into context i exactly as velo_set_target / velo_set_source would put them, on the thread that then
  * drives that context's group -- a group starts registering as soon as ITS scans are indexed, no barrier across the batch.
- * targets / sources may be NULL (keep what the contexts hold). */
+ * targets / sources may be NULL (keep what the contexts hold).  n == 1 is velo_set_target + velo_set_source + velo_frame_to_frame
+ * in one call (the single-pair path: one chain of launches, one host synchronisation). */
 #define VELO_SCAN_ON_DEVICE 1   /* xyz is a device pointer */
 #define VELO_SCAN_SHARED 2      /* targets only: jobs with IDENTICAL descriptors carrying this flag share one device copy and one
                                  * index (scan-to-map: many scans against one map) -- built once, held by reference */
