@@ -267,10 +267,16 @@ def test_register_batch_equals_separate_uploads_and_batch(hip_lib):
     tgt_dev = torch.from_numpy(d["tgt_xyz"]).to("cuda:0")
     xd, _, _ = api.register_batch(b, [(tgt_dev, d["tgt_off"])] * n, None, x0s)
     assert np.array_equal(xd, xa)
+    # ONE job: velo_register_batch takes the single-pair path (set_target + set_source + frame_to_frame in one call)
+    x1, T1, S1 = api.register_batch(b[:1], [(d["tgt_xyz"], d["tgt_off"])], [(src_dev, d["src_off"])], x0s[:1])
+    assert np.array_equal(x1[0], xa[0]) and np.array_equal(T1[0], Ta[0])
+    assert [S1[0].solves[k].lm_iterations for k in range(S1[0].n_solves)] == [Sa[0].solves[k].lm_iterations for k in range(Sa[0].n_solves)]
     # a bad job is reported, not ignored
     bad_off = d["tgt_off"].copy(); bad_off[3] = bad_off[2]
     with pytest.raises(api.VeloError):
         api.register_batch(b, [(d["tgt_xyz"], bad_off)] * n, None, x0s)
+    with pytest.raises(api.VeloError):
+        api.register_batch(b[:1], [(d["tgt_xyz"], bad_off)], None, x0s[:1])
     for c in a + b:
         c.close()
 
