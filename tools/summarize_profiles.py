@@ -15,7 +15,7 @@ if f:
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
         for r in rows:
             w.writerow([r["Name"].split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
-    wl = "c4" if tag.endswith("_c4") else "c2"
+    wl = tag.rsplit("_", 1)[1] if tag.rsplit("_", 1)[-1] in ("c1", "c3", "c4") else "c2"
     lines.append(f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-legs --workload {wl}  (default batch: 8 pairs in flight)")
     for r in rows[:8]:
         lines.append(f"  {r['Name'].split('(')[0][:58]:58s} calls {r['Calls']:>6}  avg {float(r['AverageNs'])/1e3:8.1f} us  {r['Percentage']}%")
