@@ -2651,9 +2651,10 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
             // (measured with 8 pairs in flight: 2,040-2,120 pairs/s against 2,410-2,450 with sweep + step as two launches -- the redundant
             //  transitions keep 118 workgroups per context resident for 5 us longer, and at one wave per SIMD; hence VELO_LM_MERGED=2 only)
             bool merged = c0->lm_merged >= 2 && nbv_max == 0;
-            bool fused = c0->lm_fused != 0 && nbv_max == 0;                             // sweep + step in one launch, the last workgroup of a context steps
+            bool fused = c0->lm_fused != 0;                                             // point-to-plane sweep + step in one launch, the last workgroup of a context steps
             for (int i = 0; i < n; i++) { merged = merged && h_items[i].nb_icp > 0; fused = fused && h_items[i].nb_icp > 0; }
-            fused = fused && !merged;                                                   // (with visual blocks: measured no gain over three launches)
+            fused = fused && !merged;                                                   // (visual blocks: their sweep stays a launch of its own AHEAD of that one -- the
+                                                                                        //  step then sums its rows too; riding in the same launch measured no gain)
             const size_t half = (size_t)(kMaxEvalBlocks + kMaxVisBlocks) * kNumAcc;
             int launched = 0, chunk = first_chunk + (merged ? 1 : 0);
             if (!merged) hipLaunchKernelGGL(lm_begin_batch_kernel, dim3(n), dim3(64), 0, bs, (const LMBatchItem*)c0->batch_items.p);
@@ -2663,7 +2664,11 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                         hipLaunchKernelGGL(lm_iter_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p, launched + k, half);
                         continue;
                     }
-                    if (fused) { hipLaunchKernelGGL(eval_step_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p, c0->batch_tickets.p); continue; }
+                    if (fused) {
+                        if (nbv_max > 0) hipLaunchKernelGGL(eval_visual_batch_kernel, dim3(nbv_max, n), dim3(kEvalThreads), 0, bs, (const LMBatchItem*)c0->batch_items.p);
+                        hipLaunchKernelGGL(eval_step_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p, c0->batch_tickets.p);
+                        continue;
+                    }
                     if (nb_max > 0) hipLaunchKernelGGL(eval_icp_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, (const LMBatchItem*)c0->batch_items.p);
                     if (nbv_max > 0) hipLaunchKernelGGL(eval_visual_batch_kernel, dim3(nbv_max, n), dim3(kEvalThreads), 0, bs, (const LMBatchItem*)c0->batch_items.p);
                     hipLaunchKernelGGL(lm_step_batch_kernel, dim3(n), dim3(256), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p);
