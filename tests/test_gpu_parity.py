@@ -520,6 +520,34 @@ def test_chain_mode_lockstep_batch_is_bit_identical(hip_lib, monkeypatch):
             assert np.array_equal(x0, x1) and np.array_equal(T0, T1) and s0 == s1 and r0 == r1
 
 
+def test_lockstep_batch_at_the_reference_constants_uses_single_launch_solves(hip_lib, monkeypatch):
+    """icp_skip = 200 (kitti.h:8) in a lock-step batch: every solve of the group is one single-workgroup launch per context
+    (lm_solve_small_batch_kernel, the body of the single-pair kernel); poses, solves and counts equal single calls bit for bit, with the
+    launch-per-iteration path (VELO_SMALL_SOLVE=0) and with the host-driven batch."""
+    pairs = [synth.scan_pair(scene_seed=20 + k, sigma=0.01 * (k + 1)) for k in range(3)]
+    singles = []
+    for d in pairs:
+        c = api.Context(0)                                   # reference constants: 640 queries
+        c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])
+        x, T, s = c.frame_to_frame(d["x0"])
+        singles.append((x.copy(), T.copy(), _summary_tuple(s)))
+        c.close()
+    for env in ({}, {"VELO_SMALL_SOLVE": "0"}, {"VELO_CHAIN": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctxs = [api.Context(0) for _ in pairs]
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+        for rep in range(2):
+            for c, d in zip(ctxs, pairs):
+                c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])
+            x, T, S = api.frame_to_frame_batch(ctxs, [d["x0"] for d in pairs])
+            for i, (xs, Ts, ss) in enumerate(singles):
+                assert np.array_equal(x[i], xs) and np.array_equal(T[i], Ts) and _summary_tuple(S[i]) == ss, (env, rep, i)
+        for c in ctxs:
+            c.close()
+
+
 def _stats_close(a, b):
     assert (a.n_blocks, a.n_residuals) == (b.n_blocks, b.n_residuals)
     assert abs(a.cost - b.cost) <= 1e-12 * max(abs(b.cost), 1e-300)

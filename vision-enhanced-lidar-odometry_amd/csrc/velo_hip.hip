@@ -2558,6 +2558,19 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                 }
                 const LMBatchItem* d_items = c0->batch_items.p + (size_t)r * n;
                 HIP_TRY(hipMemcpyAsync(c0->batch_items.p + (size_t)r * n, items_r, sizeof(LMBatchItem) * (size_t)n, hipMemcpyHostToDevice, bs));
+                bool small = c0->small_solve != 0;                      // every solve of the group is ONE single-workgroup launch (lm_solve_small_kernel's body)
+                for (int i = 0; i < n; i++) small = small && items_r[i].n_rows >= 1 && items_r[i].n_rows <= kSmallRows;
+                if (small) {
+                    for (int b0 = 0; b0 < n; b0 += kItemsByValue) {     // (the items copied above serve lm_gather_states_kernel)
+                        LMBatchPack pack;
+                        std::memset(&pack, 0, sizeof(pack));
+                        const int m = std::min(kItemsByValue, n - b0);
+                        for (int i = 0; i < m; i++) pack.item[i] = items_r[b0 + i];
+                        hipLaunchKernelGGL(lm_solve_small_batch_kernel, dim3(m), dim3(kEvalThreads), 0, bs, Q, pack, max_iters + 1);
+                    }
+                    HIP_TRY(hipGetLastError());
+                    continue;
+                }
                 hipLaunchKernelGGL(lm_begin_batch_kernel, dim3(n), dim3(64), 0, bs, d_items);
                 for (int k = 0; k < K; k++) {
                     if (c0->lm_fused) { hipLaunchKernelGGL(eval_step_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, d_items, c0->batch_tickets.p); continue; }

@@ -3418,9 +3418,9 @@ __global__ void lm_gather_states_kernel(const LMBatchItem* __restrict__ items, L
 // index and block count, so every partial row is bit-identical to the multi-launch path -- reduces them in the same order,
 // thread 0 does the transition, and the loop continues on the device.  State and partial rows live in LDS for the duration.
 constexpr int kSmallRows = 4;
-__global__ void __launch_bounds__(kEvalThreads)
-lm_solve_small_kernel(EvalArgs A, LMParams Q, LMState* Sg, const double* __restrict__ x_in, const int* __restrict__ n_valid,
-                      int nb_icp, int nb_vis, int max_sweeps, PoseRecord* __restrict__ pose_out, SolveLog* __restrict__ log) {
+__device__ __forceinline__ void
+lm_solve_small_body(const EvalArgs& A, const LMParams& Q, LMState* Sg, const double* __restrict__ x_in, const int* __restrict__ n_valid,
+                    int nb_icp, int nb_vis, int max_sweeps, PoseRecord* __restrict__ pose_out, SolveLog* __restrict__ log) {
     __shared__ double rows[kSmallRows][kNumAcc];
     __shared__ double part[8][kNumAcc];
     __shared__ double E[kNumAcc];
@@ -3487,6 +3487,22 @@ lm_solve_small_kernel(EvalArgs A, LMParams Q, LMState* Sg, const double* __restr
             }
         }
     }
+}
+__global__ void __launch_bounds__(kEvalThreads)
+lm_solve_small_kernel(EvalArgs A, LMParams Q, LMState* Sg, const double* __restrict__ x_in, const int* __restrict__ n_valid,
+                      int nb_icp, int nb_vis, int max_sweeps, PoseRecord* __restrict__ pose_out, SolveLog* __restrict__ log) {
+    lm_solve_small_body(A, Q, Sg, x_in, n_valid, nb_icp, nb_vis, max_sweeps, pose_out, log);
+}
+// the solves of a lock-step group, one workgroup per context (the reference's constants in batches: 640 queries per pair).  The items
+// come BY VALUE, up to kItemsByValue per launch: read through a pointer their fields stay live across the body's stores (424 bytes of
+// scratch, ~11 us per launch); in the argument segment they are constants the compiler reloads where it needs them.
+constexpr int kItemsByValue = 4;
+struct LMBatchPack { LMBatchItem item[kItemsByValue]; };
+static_assert(sizeof(LMBatchPack) + 256 <= 4096, "the pack must fit the kernel argument segment");
+__global__ void __launch_bounds__(kEvalThreads)
+lm_solve_small_batch_kernel(LMParams Q, LMBatchPack P, int max_sweeps) {
+    const LMBatchItem& it = P.item[blockIdx.x];
+    lm_solve_small_body(it.A, Q, it.S, it.xd, it.n_valid, it.nb_icp, it.nb_vis, max_sweeps, it.pose_out, it.log);
 }
 
 // ---- seam 2 by value: a batch of residual functors (costfunctions.h:17-220) at one pose -----------------------------------
