@@ -546,6 +546,16 @@ def test_lockstep_batch_at_the_reference_constants_uses_single_launch_solves(hip
                 assert np.array_equal(x[i], xs) and np.array_equal(T[i], Ts) and _summary_tuple(S[i]) == ss, (env, rep, i)
         for c in ctxs:
             c.close()
+    # twelve contexts: two groups of six, so a group's solves take two launches (four items by value each)
+    ctxs = [api.Context(0) for _ in range(12)]
+    for c, d in zip(ctxs, pairs * 4):
+        c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])
+    x, T, S = api.frame_to_frame_batch(ctxs, [d["x0"] for d in pairs * 4])
+    for i in range(12):
+        xs, Ts, ss = singles[i % 3]
+        assert np.array_equal(x[i], xs) and np.array_equal(T[i], Ts) and _summary_tuple(S[i]) == ss, i
+    for c in ctxs:
+        c.close()
 
 
 def _stats_close(a, b):
