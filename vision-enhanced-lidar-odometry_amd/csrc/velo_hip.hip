@@ -2789,7 +2789,9 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
         // Measured on C2 (pairs/s, 3 runs each): 8 contexts: 1 group 1,425, 2 groups 1,790-1,920, 4 groups 1,990-2,200, one thread per
         // context 1,600; 16 contexts: 2 groups 2,010-2,110, 4 groups 1,420-1,510 (four association kernels interleave), 8 groups 1,740-1,780.
         static const int groups_env = getenv("VELO_BATCH_GROUPS") ? std::max(atoi(getenv("VELO_BATCH_GROUPS")), 1) : 0;
-        const int G = groups_env > 0 ? std::min(groups_env, n / 2) : (n >= 12 ? 2 : std::min(4, n / 2));
+        // (round 2, pairs/s by contexts / groups: 9: 3 groups 3,070, 4 groups 2,820; 10: 2 / 3 / 4 / 5 groups 1,990 / 2,900 / 2,490 / 2,590;
+        //  11: 3 groups 2,490, 4 groups 2,700 -- a launch serves up to four contexts, so groups of five split theirs 4 + 1)
+        const int G = groups_env > 0 ? std::min(groups_env, n / 2) : (n >= 12 ? 2 : ((n == 9 || n == 10) ? 3 : std::min(4, n / 2)));
         if (G <= 1) {
             for (int i = 0; i < n; i++) VELO_TRY(load_job(ctxs[i], target_of(i), sources ? sources + i : nullptr));
             return f2f_batch_lockstep(ctxs, n, x, T, summaries);
