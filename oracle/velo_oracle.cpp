@@ -81,6 +81,12 @@ inline void pinned_sincos(double x, double* s, double* c) {
                  C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
     const double invpio2 = 6.36619772367581382433e-01, pio2_1 = 1.57079632673412561417e+00, pio2_2 = 6.07710050630396597660e-11,
                  pio2_3 = 2.02226624871116645580e-21;
+#ifdef VELO_ORACLE_LIBM
+    // `make -C oracle libm`: the reference's own arithmetic -- ceres::AngleAxisRotatePoint calls sin() / cos() of the linked libm
+    // (utility.h:99, costfunctions.h:44).  tests/test_oracle_libm.py bounds what the pin above changes against this build.
+    *s = std::sin(x); *c = std::cos(x);
+    return;
+#endif
     if (!(x == x) || x - x != 0.0) { *s = x - x; *c = x - x; return; }
     double r = x;
     long long n = 0;
@@ -1054,6 +1060,15 @@ int vo_pose_mat_to_vec(const double* T, double* x) { pose_mat_to_vec(T, x); retu
 int vo_functor(int kind, const double* c, const double* x, double* r, double* J) { block_eval(kind, c, x, r, J); return kind_dim(kind); }
 int vo_loss(int type, double a, double w, double s, double* rho) { loss_eval(Loss{type, a, w}, s, rho); return 0; }
 int vo_transform_point(const float* p, const double* x, float* out) { transform_point(p, x, out); return 0; }
+// which sin / cos this build carries (1 = libm, 0 = the pinned routine) and the routine itself, for tests/test_oracle_libm.py
+int vo_uses_libm(void) {
+#ifdef VELO_ORACLE_LIBM
+    return 1;
+#else
+    return 0;
+#endif
+}
+int vo_sincos(const double* x, int32_t n, double* s, double* c) { for (int32_t i = 0; i < n; i++) pinned_sincos(x[i], s + i, c + i); return 0; }
 int vo_rotate_point(const double* w, const double* p, double* out) { angle_axis_rotate_point<double>(w, p, out); return 0; }
 // exact 1-NN of q in ring r by the tree and by brute force (lowest index on ties); returns found count
 int vo_ring_nn(void* h, int ring, const float* q, int* idx_tree, float* d_tree, int* idx_brute, float* d_brute) {

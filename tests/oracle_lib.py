@@ -19,31 +19,44 @@ ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "libvelo_oracle.so")
 ORACLE_SO_OVERRIDE = os.environ.get("VELO_ORACLE_SO")
 
 _dp = C.POINTER(C.c_double)
-_lib = None
+ORACLE_SO_LIBM = os.path.join(ORACLE_DIR, "_build", "libvelo_oracle_libm.so")   # -DVELO_ORACLE_LIBM: the host libm's sin / cos
+_libs = {}
 
 
-def build_oracle(force: bool = False) -> str:
-    if ORACLE_SO_OVERRIDE:
+def build_oracle(force: bool = False, libm: bool = False) -> str:
+    """Builds (make -C oracle) when stale.  libm=True: the build that calls the host libm's sin / cos -- what the reference's
+    ceres::AngleAxisRotatePoint does -- instead of the pinned routine the HIP library shares (tests/test_oracle_libm.py)."""
+    if ORACLE_SO_OVERRIDE and not libm:
         return ORACLE_SO_OVERRIDE
     src = os.path.join(ORACLE_DIR, "velo_oracle.cpp")
     hdr = os.path.join(ROOT, "include", "velo_hip.h")
-    if (force or not os.path.exists(ORACLE_SO)
-            or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+    so = ORACLE_SO_LIBM if libm else ORACLE_SO
+    if (force or not os.path.exists(so)
+            or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
         subprocess.run(["make", "-C", ORACLE_DIR, "-B"], check=True, stdout=subprocess.DEVNULL)
-    return ORACLE_SO
+    return so
 
 
-def lib() -> C.CDLL:
-    global _lib
-    if _lib is None:
-        _lib = C.CDLL(build_oracle())
-        _lib.vo_create.restype = C.c_void_p
+def lib(libm: bool = False) -> C.CDLL:
+    if libm not in _libs:
+        l = C.CDLL(build_oracle(libm=libm))
+        l.vo_create.restype = C.c_void_p
         for name in ("vo_destroy", "vo_set_params", "vo_set_threads", "vo_set_target", "vo_set_source",
                      "vo_set_visual", "vo_associate", "vo_get_correspondences", "vo_build_visual",
                      "vo_get_good_matches", "vo_evaluate", "vo_evaluate_rows", "vo_solve", "vo_frame_to_frame",
-                     "vo_ring_nn", "vo_set_query_shard", "vo_max_threads"):
-            getattr(_lib, name).restype = C.c_int
-    return _lib
+                     "vo_ring_nn", "vo_set_query_shard", "vo_max_threads", "vo_uses_libm", "vo_sincos"):
+            getattr(l, name).restype = C.c_int
+        assert l.vo_uses_libm() == (1 if libm else 0)
+        _libs[libm] = l
+    return _libs[libm]
+
+
+def sincos(x, libm: bool = False):
+    """sin / cos as this oracle build computes them inside AngleAxisRotatePoint (pinned routine, or the host libm)."""
+    xv = np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1))
+    s, c = np.zeros_like(xv), np.zeros_like(xv)
+    lib(libm).vo_sincos(xv.ctypes.data_as(_dp), C.c_int32(xv.size), s.ctypes.data_as(_dp), c.ctypes.data_as(_dp))
+    return s, c
 
 
 def _d(a, n):
@@ -63,8 +76,8 @@ def max_threads() -> int:
 
 
 class Oracle:
-    def __init__(self, threads: int = 1, **params):
-        self._l = lib()
+    def __init__(self, threads: int = 1, libm: bool = False, **params):
+        self._l = lib(libm)
         self._h = C.c_void_p(self._l.vo_create())
         self._l.vo_set_threads(self._h, int(threads))
         self.params = default_params()
