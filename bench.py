@@ -4,15 +4,20 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one batch of B complete scan-pair registrations: from the two raw ring clouds already resident
-in HBM to the solved pose -- target index build (velo_set_target), query list (velo_set_source) and
-velo_frame_to_frame (6 association rounds + 6 Levenberg-Marquardt solves to Ceres-default tolerances).
-The headline (`value`) is workload configs[1] of BASELINE.json: synthetic HDL-64E pair, 64 x 1875 = 120,000 points each,
+One "step" = one batch of B complete scan-pair registrations: from the raw ring clouds already resident in HBM to the solved
+poses -- target index build, query list and frame_to_frame (6 association rounds + 6 Levenberg-Marquardt solves to Ceres-default
+tolerances) of every pair, through ONE library call (velo_register_batch).  The B pairs of a step are DIFFERENT pairs
+(synth.distinct_pairs: own scene, noise, place on the road, motion and initial guess), so the lock-step groups of the batch
+driver diverge and the chain's launch prediction works from real history; `chain` reports its calls and misses.
+The headline (`value`) is workload configs[1] of BASELINE.json: synthetic HDL-64E pairs, 64 x 1875 = 120,000 points each,
 icp_skip = 1; at N > 1 every rank registers its own pairs (replicas, no data-path collective -> "scaling": "weak").
 
 The same JSON line also carries
-  configs   short legs of the other single-GPU workloads (c1: reference constants, c3: + 2,000 stereo blocks, c4: 2M-point map),
-            each with pairs/s, launches, algorithmic bytes and its own roofline object                       (N = 1)
+  roofline  the kernel with the largest share of the timed region's kernel time (HIP events on the launching stream, per kernel
+            name, velo_set_timing(ctx, 2)) with its algorithmic bytes, achieved GB/s and fraction of the HBM peak; `kernels` = the
+            same for the top three
+  configs   short legs of the other single-GPU workloads (c1: reference constants -- on KITTI frames when VELO_KITTI_ROOT names a
+            dataset root --, c3: + 2,000 stereo blocks, c4: 2M-point map), each a complete bench of its own               (N = 1)
   modes     N > 1 only: the north_star's multi-GPU modes next to the replicas --
             sharded          ONE pair per step, queries split 1/N per rank, the 28-double normal-equation block all-reduced
                              every LM evaluation (peer-mapped slabs inside the LM step; --comm rccl: ncclAllReduce)  -> strong scaling
@@ -50,8 +55,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--mode", choices=["replicas", "sharded", "target-sharded"], default="replicas")
     ap.add_argument("--workload", choices=["c1", "c2", "c3", "c4"], default="c2",
-                    help="c2: 120k pair; c3: + 2000 stereo blocks; c4: 120k scan vs 2M-point map; c1: reference constants (icp_skip=200)")
+                    help="c2: 120k pairs; c3: + 2000 stereo blocks; c4: 120k scans vs 2M-point map; c1: reference constants (icp_skip=200)")
     ap.add_argument("--batch", type=int, default=8, help="independent pairs in flight per GPU (one context + stream each)")
+    ap.add_argument("--same-pair", action="store_true", help="A/B: every context registers the canonical pair (what rounds 1-2 measured)")
     ap.add_argument("--threads-per-pair", dest="batch_api", action="store_false",
                     help="drive every pair from its own host thread (frame_to_frame) instead of velo_register_batch")
     ap.add_argument("--separate-loads", action="store_true",
@@ -61,63 +67,102 @@ def parse():
     ap.add_argument("--comm", choices=["peer", "rccl"], default="peer", help="all-reduce of the sharded mode: peer-mapped slabs or RCCL")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL)")
     ap.add_argument("--force-device", type=int, default=None, help="testing only: every rank uses this device (with --dist-backend gloo)")
-    ap.add_argument("--cpu-sample-skip", type=int, default=4)
+    ap.add_argument("--timing", type=int, default=2, help="velo_set_timing level inside the timed region (2: per-kernel brackets; 1: association only)")
     return ap.parse_args()
 
 
 _cache = {}
 
 
-def make_workload(name):
-    """-> (scan pair, visual matches or None, label, icp_skip)"""
-    from velo_amd import synth
-    if name in _cache:
-        return _cache[name]
-    if name == "c1":
-        # configs[0], the reference's own constants (kitti.h:8: icp_skip = 200 -> 640 queries per round).  KITTI seq 00 is not in
-        # this image: the synthetic pair stands in, in the same ring layout the KITTI reader produces.
-        out = (synth.scan_pair(), None, "configs[0] stand-in: synthetic 120k-pt pair, reference constants (icp_skip=200)", 200)
-    elif name == "c4":
-        out = (synth.scan_to_map(2_000_000), None, "synthetic HDL-64E 120k-pt scan vs 2M-pt accumulated map (configs[3]), icp_skip=1", 1)
-    elif name == "c3":
-        out = (synth.scan_pair(), synth.stereo_matches(1000), "configs[2]: 120k-pt pair + 2000 stereo reprojection blocks, icp_skip=1", 1)
+def kitti_pairs(root, n):
+    """BASELINE configs[0] on real data: consecutive frame pairs k -> k+1 of KITTI odometry sequence 00 under
+    VELO_KITTI_ROOT (the dataset root with sequences/00/velodyne/*.bin, or a directory of .bin files), segmented ON THE DEVICE by
+    velo_set_scan_velodyne (kitti.h:121-185) with the sequence's calib.txt `Tr` when present.  None when the files are not there."""
+    from velo_amd import api, synth
+    for vd in (os.path.join(root, "sequences", "00", "velodyne"), os.path.join(root, "velodyne"), root):
+        files = sorted(glob.glob(os.path.join(vd, "*.bin")))
+        if len(files) >= 2:
+            break
     else:
-        out = (synth.scan_pair(), None, "synthetic HDL-64E 64x1875=120k-pt scan pair (configs[1]), icp_skip=1, point-to-plane ICP", 1)
-    _cache[name] = out
+        return None
+    M = synth.VELO_TO_CAM.astype(np.float32)
+    calib = os.path.join(os.path.dirname(vd.rstrip("/")), "calib.txt")
+    if os.path.exists(calib):
+        for ln in open(calib):
+            if ln.startswith("Tr:") or ln.startswith("Tr "):
+                v = np.array(ln.split()[1:13], dtype=np.float64).reshape(3, 4)
+                M = np.vstack([v, [0, 0, 0, 1]]).astype(np.float32)
+    ctx = api.Context(int(os.environ.get("LOCAL_RANK", "0")))
+    scans = []
+    for f in files[:n + 1]:                                  # the device segmenter gives the ring clouds the path takes
+        rec = np.fromfile(f, dtype=np.float32).reshape(-1, 4)
+        ctx.set_scan_velodyne(False, rec, M)
+        scans.append((ctx.cloud(False), ctx.ring_offsets(False)))
+    ctx.close()
+    x0 = synth.INITIAL_GUESS.copy()                          # main.cpp:170; later frames would use the previous motion
+    return [dict(tgt_xyz=scans[k][0], tgt_off=scans[k][1], src_xyz=scans[k + 1][0], src_off=scans[k + 1][1], x0=x0, x_true=None)
+            for k in range(min(n, len(scans) - 1))]
+
+
+def make_workload(name, B, same_pair=False):
+    """-> dict(label, icp_skip, pairs: list of B dicts (tgt_xyz, tgt_off, src_xyz, src_off, x0, vis), shared_map: bool, distinct: int)"""
+    from velo_amd import synth
+    key = (name, B, same_pair)
+    if key in _cache:
+        return _cache[key]
+    n = 1 if same_pair else B
+    if name == "c4":
+        m = synth.scan_to_map(2_000_000, n_queries=n)
+        qs = m.get("queries") or [m]
+        pairs = [dict(tgt_xyz=m["tgt_xyz"], tgt_off=m["tgt_off"], src_xyz=q["src_xyz"], src_off=q["src_off"], x0=q["x0"], vis=None) for q in qs]
+        label, skip = "synthetic HDL-64E 120k-pt scans vs 2M-pt accumulated map (configs[3]), icp_skip=1", 1
+    else:
+        src = None
+        if name == "c1" and os.environ.get("VELO_KITTI_ROOT"):
+            src = kitti_pairs(os.environ["VELO_KITTI_ROOT"], n)
+        kitti = src is not None
+        if src is None:
+            src = synth.distinct_pairs(n)
+        pairs = [dict(d, vis=None) for d in src]
+        if name == "c3":
+            for k, d in enumerate(pairs):
+                d["vis"] = synth.stereo_matches(1000, seed=3 + k, x_true=d["x_true"])
+        label, skip = {
+            "c1": (("configs[0]: KITTI seq 00 consecutive frames under VELO_KITTI_ROOT" if kitti else
+                    "configs[0] stand-in: synthetic 120k-pt pairs in the KITTI ring layout") + ", reference constants (icp_skip=200)", 200),
+            "c3": ("configs[2]: 120k-pt pairs + 2000 stereo reprojection blocks each, icp_skip=1", 1),
+            "c2": ("synthetic HDL-64E 64x1875=120k-pt scan pairs (configs[1]), icp_skip=1, point-to-plane ICP", 1),
+        }[name]
+    distinct = len(pairs)
+    pairs = [pairs[i % len(pairs)] for i in range(B)]
+    out = dict(label=label, icp_skip=skip, pairs=pairs, shared_map=(name == "c4"), distinct=distinct)
+    _cache[key] = out
     return out
 
 
-def cpu_baseline(d, vis, sample_skip, icp_skip=1):
-    """The CPU restatement (oracle = 'port') timed on this host: (i) all cores on the full pair,
-    (ii) one thread -- the reference's configuration (velo.h:900) -- on a 1/sample_skip query sample (the whole pair when the
-    queries are sparse already, icp_skip > 1: nothing extrapolated there)."""
+def cpu_baseline(d, vis, icp_skip=1):
+    """The CPU restatement (oracle = 'port') timed on this host on the canonical pair of the workload: (i) all cores, (ii) ONE thread --
+    the reference's configuration (velo.h:900) -- on the WHOLE pair, nothing extrapolated (about 15 s at icp_skip = 1)."""
     import oracle_lib
     cores = oracle_lib.max_threads()
-    o = oracle_lib.Oracle(threads=cores, icp_skip=icp_skip)
-    if icp_skip > 1:
-        sample_skip = 1
-    t0 = time.perf_counter()
-    o.set_target(d["tgt_xyz"], d["tgt_off"])
-    o.set_source(d["src_xyz"], d["src_off"])
-    if vis is not None:
-        o.set_visual(vis)
-    x, _, s = o.frame_to_frame(d["x0"])
-    t_all = time.perf_counter() - t0
-    o1 = oracle_lib.Oracle(threads=1, icp_skip=icp_skip * sample_skip)
-    t0 = time.perf_counter()
-    o1.set_target(d["tgt_xyz"], d["tgt_off"])
-    o1.set_source(d["src_xyz"], d["src_off"])
-    if vis is not None:
-        o1.set_visual(vis)
-    o1.frame_to_frame(d["x0"])
-    t_meas = time.perf_counter() - t0
-    t_one = t_meas * sample_skip
-    single = (f"single thread (the reference's configuration) on the whole pair = {t_one:.2f} s" if sample_skip == 1 else
-              f"single thread (the reference's configuration) measured on a 1/{sample_skip} query sample = {t_meas:.1f} s, x {sample_skip} = {t_one:.1f} s/pair")
+
+    def one(threads):
+        o = oracle_lib.Oracle(threads=threads, icp_skip=icp_skip)
+        t0 = time.perf_counter()
+        o.set_target(d["tgt_xyz"], d["tgt_off"])
+        o.set_source(d["src_xyz"], d["src_off"])
+        if vis is not None:
+            o.set_visual(vis)
+        x, _, _ = o.frame_to_frame(d["x0"])
+        return time.perf_counter() - t0, x
+
+    t_all, x = one(cores)
+    t_one, _ = one(1)
     return {
         "value": 1.0 / t_all, "unit": "scan-pairs/s", "cores": cores, "kind": "port",
-        "sample": f"1 full pair (icp_skip={icp_skip}) on {cores} OpenMP threads = {t_all:.2f} s; {single}",
-        "single_thread_pairs_per_s": 1.0 / t_one, "single_thread_extrapolated": sample_skip != 1,
+        "sample": f"the canonical pair of the workload (icp_skip={icp_skip}), whole: {cores} OpenMP threads = {t_all:.2f} s; "
+                  f"1 thread (the reference's configuration, velo.h:900) = {t_one:.2f} s",
+        "single_thread_pairs_per_s": 1.0 / t_one, "single_thread_s_per_pair": t_one, "single_thread_extrapolated": False,
         "x": [float(v) for v in x],
     }
 
@@ -162,32 +207,59 @@ class Rig:
         return float(t.item())
 
 
+def kernel_table(acc):
+    """{name: [ms, launches, bytes]} -> rows sorted by share of the summed kernel time, each with its roofline figures"""
+    total = sum(v[0] for v in acc.values()) or 1.0
+    rows = []
+    for name, (ms, n, b) in acc.items():
+        if n <= 0:
+            continue
+        ach = (b / 1e9) / (ms / 1e3) if ms > 0 and b > 0 else 0.0
+        rows.append({"kernel": name, "share": ms / total, "launches": int(n), "avg_launch_us": 1e3 * ms / n,
+                     "algorithmic_bytes_per_launch": b / n, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach / HBM_PEAK_GBS})
+    rows.sort(key=lambda r: -r["share"])
+    return rows
+
+
 def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="peer"):
     """One timed leg: `steps` steps of B registrations (B = 1 in the sharded modes) bracketed by barrier + synchronize, max over ranks."""
     import velo_amd  # noqa: F401
     from velo_amd import api
     torch = rig.torch
-    d, vis, label, icp_skip = make_workload(workload)
     world, rank = rig.world, rig.rank
     B = 1 if mode != "replicas" else max(1, B)
-    tgt_off, tgt_first_ring, tgt_first_point = d["tgt_off"], 0, 0
-    tgt_np = d["tgt_xyz"]
-    if mode == "target-sharded" and world > 1:
+    W = make_workload(workload, B, a.same_pair or mode != "replicas")
+    pairs, icp_skip, label = W["pairs"], W["icp_skip"], W["label"]
+    d0 = pairs[0]
+    tgt_off0, tgt_first_ring, tgt_first_point = d0["tgt_off"], 0, 0
+    sharded_part = mode == "target-sharded" and world > 1
+    if sharded_part:
         from velo_amd import shard
-        r0, r1, p0, tgt_off = shard.target_ring_block(d["tgt_off"], rank, world)
+        r0, r1, p0, tgt_off0 = shard.target_ring_block(d0["tgt_off"], rank, world)
         tgt_first_ring, tgt_first_point = r0, p0
-        tgt_np = d["tgt_xyz"][p0:p0 + int(tgt_off[-1])]
-    # inputs resident in HBM before the timed region
-    tgt = torch.from_numpy(np.ascontiguousarray(tgt_np)).to(rig.dev)
-    src = torch.from_numpy(d["src_xyz"]).to(rig.dev)
+    # inputs resident in HBM before the timed region: one tensor per DIFFERENT cloud (contexts that register the same cloud share it)
+    dev_of = {}
+
+    def resident(arr):
+        k = id(arr)
+        if k not in dev_of:
+            dev_of[k] = torch.from_numpy(np.ascontiguousarray(arr)).to(rig.dev)
+        return dev_of[k]
+
+    if sharded_part:
+        tgts = [(resident(d0["tgt_xyz"][p0:p0 + int(tgt_off0[-1])]), tgt_off0)]
+    else:
+        tgts = [(resident(d["tgt_xyz"]), d["tgt_off"]) for d in pairs]
+    srcs = [(resident(d["src_xyz"]), d["src_off"]) for d in pairs]
     torch.cuda.synchronize()
     ctxs = [api.Context(rig.local_rank, icp_skip=icp_skip) for _ in range(B)]
     comm_info = None
     try:
-        for c in ctxs:
-            c.set_timing(True)
-            if vis is not None:
-                c.set_visual(vis)
+        for c, d in zip(ctxs, pairs):
+            c.set_timing(a.timing)
+            if d["vis"] is not None:
+                c.set_visual(d["vis"])
         if mode != "replicas" and world > 1:
             ok = comm == "peer"
             if ok:
@@ -206,7 +278,7 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
                 handles = agreed(c0.comm_peer_export)
                 ok = handles is not None and agreed(lambda: (c0.comm_peer_attach(handles, rank, world), 1)[1]) is not None
                 if ok and mode == "target-sharded":
-                    nq_max = int(d["src_xyz"].shape[0])
+                    nq_max = int(d0["src_xyz"].shape[0])
                     rh = agreed(lambda: c0.comm_peer_export_records(nq_max))
                     ok = rh is not None and agreed(lambda: (c0.comm_peer_attach_records(rh, nq_max), 1)[1]) is not None
                     if ok:
@@ -223,19 +295,20 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
             comm_info = {"kind": {1: "rccl", 2: "peer slabs (hipIpc)"}.get(kind, "none"), "ranks": n_ranks}
         results = [None] * B
 
-        def load_pair(i):
-            ctxs[i].set_target_part(tgt, tgt_off, tgt_first_ring, tgt_first_point)
-            ctxs[i].set_source(src, d["src_off"])
+        def load_pair(i, k=None):
+            k = i if k is None else k                        # context i takes pair k
+            ctxs[i].set_target_part(tgts[k % len(tgts)][0], tgts[k % len(tgts)][1], tgt_first_ring, tgt_first_point)
+            ctxs[i].set_source(srcs[k][0], srcs[k][1])
 
-        def one_pair(i):
-            load_pair(i)
-            results[i] = ctxs[i].frame_to_frame(d["x0"])
+        def one_pair(i, k=None):
+            load_pair(i, k)
+            results[i] = ctxs[i].frame_to_frame(pairs[i if k is None else k]["x0"])
 
         pool = ThreadPoolExecutor(max_workers=B) if B > 1 else None
         # (B == 1, whole target: the same single library call with one job -- velo_register_batch routes it to the single-pair path)
-        one_call = B == 1 and a.batch_api and tgt_first_ring == 0 and tgt_first_point == 0 and mode == "replicas"
-        batch_refs = (api.scan_refs([(tgt, tgt_off)] * B, rig.local_rank), api.scan_refs([(src, d["src_off"])] * B, rig.local_rank)) if (B > 1 or one_call) else None
-        x0s = np.tile(np.asarray(d["x0"], dtype=np.float64), (B, 1))
+        one_call = B == 1 and a.batch_api and not sharded_part and mode == "replicas"
+        batch_refs = (api.scan_refs(tgts, rig.local_rank), api.scan_refs(srcs, rig.local_rank)) if (B > 1 or one_call) else None
+        x0s = np.stack([np.asarray(d["x0"], dtype=np.float64) for d in pairs])
 
         def step():
             if pool is None and one_call:
@@ -258,6 +331,9 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
 
         for _ in range(warmup):
             step()
+        for c in ctxs:
+            c.kernel_times(reset=True)                       # the per-kernel log starts with the timed region
+        chain0 = [c.chain_stats() for c in ctxs]
         rig.barrier(ctxs)
         t0 = time.perf_counter()
         assoc_ms, assoc_n, alg_bytes, assoc_bytes, evals = 0.0, 0, 0, 0, 0
@@ -272,28 +348,40 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
                 evals += sum(s.solves[k].evaluations for k in range(s.n_solves))
         rig.barrier(ctxs)
         dt = rig.max_over_ranks(time.perf_counter() - t0)
+        chain1 = [c.chain_stats() for c in ctxs]
+        kacc = {}
+        for c in ctxs:
+            for name, (ms, n, b) in c.kernel_times(reset=True).items():
+                e = kacc.setdefault(name, [0.0, 0, 0])
+                e[0] += ms; e[1] += n; e[2] += b
+        solutions = [[float(v) for v in r[0]] for r in results]
 
         single = None
         if single_leg and world == 1 and mode == "replicas" and B > 1:
-            # SURVEY 8(d) asks for the single-pair latency next to the throughput: one pair in flight, after the timed region
-            for _ in range(3):
-                one_pair(0)
+            # SURVEY 8(d) asks for the single-pair latency next to the throughput: ONE pair in flight, a sequence that walks through
+            # the step's different pairs (a drive is a sequence, main.cpp:305-413), after the timed region
+            for k in range(3):
+                one_pair(0, k % B)
             ctxs[0].synchronize()
+            ctxs[0].kernel_times(reset=True)
             t1 = time.perf_counter()
-            n1, a_ms, a_n = 20, 0.0, 0
-            for _ in range(n1):
-                one_pair(0)
+            n1, a_ms, a_n = 24, 0.0, 0
+            for k in range(n1):
+                one_pair(0, k % B)
                 a_ms += results[0][2].assoc_kernel_ms
                 a_n += results[0][2].assoc_kernel_launches
             ctxs[0].synchronize()
             lat = (time.perf_counter() - t1) / n1
-            single = {"pairs_in_flight": 1, "ms_per_pair": 1e3 * lat, "pairs_per_s": 1.0 / lat, "assoc_avg_launch_us": 1e3 * a_ms / max(a_n, 1)}
+            single = {"pairs_in_flight": 1, "pairs_walked": min(B, n1), "ms_per_pair": 1e3 * lat, "pairs_per_s": 1.0 / lat,
+                      "assoc_avg_launch_us": 1e3 * a_ms / max(a_n, 1),
+                      "kernels": [{k: r[k] for k in ("kernel", "share", "avg_launch_us", "frac")} for r in kernel_table(ctxs[0].kernel_times(reset=True))[:3]]}
+            one_pair(0, 0)                                   # context 0 holds its own pair again
 
         shared = None
-        if workload == "c4" and mode == "replicas" and B > 1 and a.batch_api:
+        if W["shared_map"] and mode == "replicas" and B > 1 and a.batch_api:
             # scan-to-map as it is used: B scans against ONE map -- the jobs name the same target with VELO_SCAN_SHARED, the library
             # indexes it once per step and the B contexts hold it by reference (one 110 MB map in HBM instead of B)
-            refs_sh = (api.scan_refs([(tgt, tgt_off)] * B, rig.local_rank, shared=True), batch_refs[1])
+            refs_sh = (api.scan_refs([tgts[0]] * B, rig.local_rank, shared=True), batch_refs[1])
             for _ in range(2):
                 api.register_batch(ctxs, None, None, x0s, refs=refs_sh)
             rig.barrier(ctxs)
@@ -310,13 +398,19 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
         n_pairs_rank = steps * B
         total_pairs = n_pairs_rank * (world if mode == "replicas" else 1)
         s0 = results[0][2]
-        b_launch = assoc_bytes / max(assoc_n, 1)        # the batch driver serves the same round of several contexts with one launch
-        avg_ms = assoc_ms / max(assoc_n, 1)
-        achieved = (b_launch / 1e9) / (avg_ms / 1e3) if avg_ms > 0 else 0.0
         per_pair_bytes = alg_bytes / max(n_pairs_rank, 1)
-        batched = B > 1 and a.batch_api
+        ktab = kernel_table(kacc)
+        if ktab:
+            rf = dict(ktab[0])
+        else:      # --timing 1: only the association launches were bracketed
+            b_launch, avg_ms = assoc_bytes / max(assoc_n, 1), assoc_ms / max(assoc_n, 1)
+            ach = (b_launch / 1e9) / (avg_ms / 1e3) if avg_ms > 0 else 0.0
+            rf = {"kernel": "association search", "share": None, "launches": assoc_n, "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": b_launch,
+                  "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+        rf["traffic"] = None
         leg = {
-            "workload": label, "mode": mode, "pairs_in_flight_per_gpu": B, "steps": steps, "warmup": warmup,
+            "workload": label, "mode": mode, "pairs_in_flight_per_gpu": B, "distinct_pairs": W["distinct"] if mode == "replicas" else 1,
+            "steps": steps, "warmup": warmup,
             "pairs_per_s": total_pairs / dt, "ms_per_step": 1e3 * dt / steps,
             "Nq": int(s0.n_queries), "Nt": int(s0.n_target),
             "lm_evaluations_per_pair": evals / max(n_pairs_rank, 1),
@@ -324,12 +418,11 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
             "valid_correspondences_last_round": int(s0.solves[s0.n_solves - 1].n_icp_valid),
             "algorithmic_bytes_per_pair": per_pair_bytes,
             "achieved_hbm_GBs_whole_path": per_pair_bytes * (total_pairs / dt) / 1e9,
-            # sparse rounds (icp_skip >= 4 and <= 12,288 queries: the c1 leg) are searched one wave per query, the others by the tube kernel
-            "roofline": {"bound": "hbm", "kernel": (("assoc_direct_batch_kernel" if batched else "assoc_direct_kernel") if (icp_skip >= 4 and int(s0.n_queries) <= 12288)
-                                                    else ("assoc_search_v5_batch_kernel" if batched else "assoc_search_v5_kernel")),
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "avg_launch_us": avg_ms * 1e3, "algorithmic_bytes_per_launch": b_launch},
-            "solution_x": [float(v) for v in results[0][0]],
+            "chain": {"calls": sum(b[0] - a_[0] for a_, b in zip(chain0, chain1)), "misses": sum(b[1] - a_[1] for a_, b in zip(chain0, chain1)),
+                      "note": "calls enqueued as one chain of launches / calls whose predicted launch count was too short and were repeated host-driven"},
+            "roofline": rf,
+            "kernels": ktab[:3],
+            "solution_x": solutions[0], "solutions": solutions,
         }
         if single is not None:
             leg["single_pair"] = single
@@ -343,7 +436,7 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
             rig.dist.barrier()
         for c in ctxs:
             c.close()
-        del tgt, src
+        dev_of.clear()
         torch.cuda.empty_cache()
 
 
@@ -383,40 +476,51 @@ def main():
 
     if rank == 0:
         rf = dict(main_leg["roofline"])
-        # the committed PMC passes: profiles/rNN_traffic.json (config 2), profiles/rNN_c4_traffic.json (config 4)
+        # the committed PMC passes: profiles/rNN_traffic.json (config 2), profiles/rNN_c4_traffic.json (config 4): HBM-side bytes per launch
+        # of the kernels measured alone, keyed by kernel name ("traffic_by_kernel"); older files carry the association kernel only
         pat = {"c2": "r[0-9][0-9]_traffic.json", "c4": "r[0-9][0-9]_c4_traffic.json"}.get(a.workload)
         tf = sorted(glob.glob(os.path.join(ROOT, "profiles", pat))) if pat else []
         sq = None
         if tf:
             try:
                 tj = json.load(open(tf[-1]))
-                rf["traffic"] = tj["traffic_bytes_per_launch"]
+                by = tj.get("traffic_by_kernel") or {}
+                base = rf["kernel"].replace("_batch", "").replace("_lean", "")
+                rf["traffic"] = by.get(rf["kernel"], by.get(base, tj["traffic_bytes_per_launch"] if "assoc" in rf["kernel"] else None))
+                for kr in main_leg["kernels"]:
+                    kb = kr["kernel"].replace("_batch", "").replace("_lean", "")
+                    kr["traffic"] = by.get(kr["kernel"], by.get(kb, tj["traffic_bytes_per_launch"] if "assoc" in kr["kernel"] else None))
                 sq = tj.get("sq_per_launch")
+                rf["traffic_source"] = os.path.basename(tf[-1])
             except Exception:       # noqa: BLE001
                 pass
-        rf["note"] = ("with several pairs in flight one association launch serves the same round of up to 4 contexts "
-                      "(algorithmic_bytes_per_launch says how many); launch duration from HIP events (hipExtLaunchKernelGGL start/stop) on the "
-                      "context stream over the timed region; with several pairs in flight a launch shares the chip with other streams' kernels "
-                      "and its start marker waits for the command processor, so this reads higher than a kernel trace of the same run "
-                      "(profiles/*_summary.txt splits the trace by phase); single_pair.assoc_avg_launch_us is the kernel alone; traffic = HBM-side "
-                      "bytes per launch of the kernel alone from the committed PMC passes (profiles/*_traffic.json)")
+        rf["note"] = ("the kernel with the largest share of the timed region's summed kernel time; launch durations from HIP events "
+                      "(hipExtLaunchKernelGGL start/stop on the launching stream), accumulated per kernel name inside the library; a lock-step "
+                      "group's launch serves its two contexts (algorithmic_bytes_per_launch says how much); with several pairs in flight a launch "
+                      "shares the chip with the other groups' kernels and its start marker waits for the command processor, so the brackets read "
+                      "higher than the kernel alone (single_pair.kernels); traffic = HBM-side bytes per launch of ONE context's launch of that kernel "
+                      "alone, from the committed PMC passes (profiles/*_traffic.json)")
         single = main_leg.get("single_pair")
         if sq and sq.get("SQ_INSTS_VALU"):
-            t_alone = (single or {}).get("assoc_avg_launch_us", rf["avg_launch_us"]) * 1e-6
-            rf["valu"] = {"wave_insts_per_launch": sq["SQ_INSTS_VALU"], "salu": sq.get("SQ_INSTS_SALU"), "lds": sq.get("SQ_INSTS_LDS"),
-                          "issue_slots_per_launch_at_2p4GHz": 1024 * 2.4e9 / 4 * t_alone,
-                          "note": "from the committed PMC pass (profiles/*_traffic.json); launch time = the kernel alone"}
+            t_alone = (single or {}).get("assoc_avg_launch_us", 0.0) * 1e-6
+            rf["valu"] = {"kernel": "assoc_search_v5_kernel", "wave_insts_per_launch": sq["SQ_INSTS_VALU"], "salu": sq.get("SQ_INSTS_SALU"), "lds": sq.get("SQ_INSTS_LDS"),
+                          "issue_slots_per_launch_at_2p4GHz": 1024 * 2.4e9 / 2 * t_alone,
+                          "note": "association kernel, from the committed PMC pass (profiles/*_traffic.json); launch time = the kernel alone; a wave64 VALU "
+                                  "instruction occupies a SIMD-32 for 2 cycles (MI355X_MICROARCH.md), packed-f32 and f64 ones for more"}
         line = {
             "metric": METRIC, "value": main_leg["pairs_per_s"], "unit": "scan-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True,
             "scaling": "weak" if a.mode == "replicas" else "strong", "vs_baseline": None,
             "dtype": "f32 association / f64 residuals+solve", "data": "synthetic",
-            "config": {"workload": main_leg["workload"], "pairs_in_flight_per_gpu": main_leg["pairs_in_flight_per_gpu"], "mode": a.mode,
+            "config": {"workload": main_leg["workload"], "pairs_in_flight_per_gpu": main_leg["pairs_in_flight_per_gpu"],
+                       "distinct_pairs": main_leg["distinct_pairs"], "mode": a.mode,
                        "Nq": main_leg["Nq"], "Nt": main_leg["Nt"], "lm_evaluations_per_pair": main_leg["lm_evaluations_per_pair"],
                        "valid_correspondences_last_round": main_leg["valid_correspondences_last_round"],
                        "algorithmic_bytes_per_pair": main_leg["algorithmic_bytes_per_pair"]},
             "achieved_hbm_GBs_whole_path": main_leg["achieved_hbm_GBs_whole_path"],
+            "chain": main_leg["chain"],
             "roofline": rf,
+            "kernels": main_leg["kernels"],
             "solution_x": main_leg["solution_x"],
         }
         if "communicator" in main_leg:
@@ -426,20 +530,25 @@ def main():
         if "shared_target" in main_leg:
             line["shared_target"] = main_leg["shared_target"]
         if legs:
-            line["configs"] = {k: {kk: vv for kk, vv in v.items() if kk not in ("solution_x",)} for k, v in legs.items()}
+            line["configs"] = {k: {kk: vv for kk, vv in v.items() if kk not in ("solution_x", "solutions")} for k, v in legs.items()}
             # the 2M-point map leg carries its own committed PMC pass (profiles/rNN_c4_traffic.json)
             tf4 = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_c4_traffic.json")))
             if tf4 and "c4" in line["configs"] and isinstance(line["configs"]["c4"].get("roofline"), dict):
                 try:
-                    line["configs"]["c4"]["roofline"]["traffic"] = json.load(open(tf4[-1]))["traffic_bytes_per_launch"]
-                    line["configs"]["c4"]["roofline"]["traffic_note"] = "HBM-side bytes per launch of ONE context's round alone (committed PMC passes)"
+                    t4 = json.load(open(tf4[-1]))
+                    r4 = line["configs"]["c4"]["roofline"]
+                    by4 = t4.get("traffic_by_kernel") or {}
+                    r4["traffic"] = by4.get(r4["kernel"], by4.get(r4["kernel"].replace("_batch", "").replace("_lean", ""),
+                                                                  t4["traffic_bytes_per_launch"] if "assoc" in r4["kernel"] else None))
+                    r4["traffic_note"] = "HBM-side bytes per launch of ONE context's launch alone (committed PMC passes)"
                 except Exception:       # noqa: BLE001
                     pass
         if modes:
-            line["modes"] = {k: {kk: vv for kk, vv in v.items() if kk not in ("roofline",)} for k, v in modes.items()}   # solution_x stays: tests compare it with a single-rank call
+            line["modes"] = {k: {kk: vv for kk, vv in v.items() if kk not in ("roofline", "kernels", "solutions")} for k, v in modes.items()}   # solution_x stays: tests compare it with a single-rank call
         if not a.no_cpu_baseline and world == 1:             # rank 0 at N = 1 only: the other runs just report the GPU side
-            d, vis, _, icp_skip = make_workload(a.workload)
-            cb = cpu_baseline(d, vis, a.cpu_sample_skip, icp_skip)
+            W = make_workload(a.workload, a.batch, a.same_pair)
+            d = W["pairs"][0]
+            cb = cpu_baseline(d, d["vis"], W["icp_skip"])
             xo = np.array(cb.pop("x"))
             xg = np.array(main_leg["solution_x"])
             cb["pose_diff_vs_gpu"] = {"dt_m": float(np.linalg.norm(xo[3:] - xg[3:])), "dw_rad": float(np.linalg.norm(xo[:3] - xg[:3]))}

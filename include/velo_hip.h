@@ -15,6 +15,17 @@
  * and never throws; the caller owns host buffers, the context owns device buffers; one context per host
  * thread (a context is not internally thread-safe), several contexts may share one GPU.
  * x = (omega[3], t[3]) is the reference's `double transform[6]` (velo.h:610): p_prev = R(omega) p_cur + t.
+ *
+ * Environment: the library reads exactly five variables, at velo_create / at the first batch call; none of them changes a result
+ * (every setting gives bit-identical poses, tables and summaries; tests/test_gpu_parity.py compares them):
+ *     VELO_CHAIN=0           frame_to_frame with a host round trip after every solve instead of one chain of launches per call
+ *     VELO_CHAIN_MARGIN=n    LM launches enqueued per solve beyond the previous call's count (default: 1..3 from the recent history)
+ *     VELO_BATCH_LOCKSTEP=0  velo_frame_to_frame_batch / velo_register_batch with one host thread per context instead of lock-step groups
+ *     VELO_BATCH_GROUPS=n    number of lock-step groups of a batch (default: by batch size, at most 4)
+ *     VELO_SPIN=1            hipDeviceScheduleSpin for the calling process
+ * The reference's own knobs are compile-time constants (kitti.h:3-35) and arrive through velo_params.  Kernel variants, grid shapes and
+ * diagnostics are NOT an environment surface of this library: they exist only in the tools' build (-DVELO_DIAGNOSTICS,
+ * libvelo_hip_diag.so; tools/README.md), which the variant parity tests and the dev tools load explicitly.
  */
 #ifndef VELO_HIP_H_
 #define VELO_HIP_H_
@@ -206,8 +217,21 @@ const char* velo_version(void);
 int velo_default_params(velo_params* p);
 int velo_set_params(velo_ctx* ctx, const velo_params* p);
 int velo_get_params(const velo_ctx* ctx, velo_params* p);
-/* Per-launch HIP-event timing of the association search and evaluation kernels (off by default). */
+/* Launch timing with HIP events (off by default).  enable = 1: the association launches of a call, summed into
+ * velo_summary::assoc_kernel_ms.  enable = 2: every instrumented launch -- association, LM (sweep + step), target index build -- is
+ * bracketed by the kernel's own start / stop events (hipExtLaunchKernelGGL); the brackets are read after the call's final
+ * synchronisation and accumulated per kernel NAME until velo_get_kernel_times collects them (what bench.py's `kernels` list reports).
+ * algorithmic_bytes: SURVEY.md 8(d)'s figure for the launches of that kernel -- B_assoc per association round served, B_eval per LM
+ * evaluation -- and, for the index-build kernels, what the kernel must move given the index layout.  Launches shared by the contexts
+ * of a lock-step group are logged on the group's first context. */
 int velo_set_timing(velo_ctx* ctx, int enable);
+typedef struct velo_kernel_time {
+    char name[56];
+    double ms;                         /* sum of launch durations */
+    int64_t launches;
+    uint64_t algorithmic_bytes;
+} velo_kernel_time;                    /* 80 bytes */
+int velo_get_kernel_times(velo_ctx* ctx, velo_kernel_time* out, int32_t capacity, int32_t* n, int32_t reset);
 /* residualStats after every f2f iteration (velo.h:909) into velo_summary::residual_stats (off by default: the reference only
  * prints them; switched on, a call evaluates between the iterations and is therefore driven round by round from the host). */
 int velo_set_residual_stats(velo_ctx* ctx, int enable);
@@ -371,7 +395,10 @@ int velo_comm_destroy(velo_ctx* ctx);
  * which maps the peers' slabs.  Each LM step then writes its 28 doubles straight into every peer's slab and adds the world's
  * blocks in rank order inside the step kernel: deterministic, identical on all ranks, a few microseconds over xGMI instead of a
  * collective launch.  world <= 8.  Ranks may be processes on different GPUs of one node or -- for tests -- on the same GPU.
- * A peer that never arrives makes the wait time out (5 s): the call in flight returns VELO_ERR_COMM. */
+ * A peer that never arrives makes the wait time out (5 s): the call in flight (velo_frame_to_frame, velo_solve, velo_evaluate,
+ * velo_associate in target-sharded mode) returns VELO_ERR_COMM, and the communicator must be exported and attached again on every rank
+ * (the slabs' sequence numbers are out of step).  velo_comm_peer_export clears the slab: every rank must have exported before any rank
+ * attaches -- gathering the handles is that barrier -- and no barrier is needed between attach and the first call. */
 int velo_comm_peer_export(velo_ctx* ctx, char handle[64]);
 int velo_comm_peer_attach(velo_ctx* ctx, const char* handles /* world * 64 bytes, rank order */, int32_t rank, int32_t world);
 /* Target-sharded mode over the same peers (instead of RCCL send/recv): the receive area for the per-query records of up to

@@ -34,6 +34,16 @@ def hip_lib():
 
 
 @pytest.fixture(scope="session")
+def diag_lib(hip_lib):
+    """The -DVELO_DIAGNOSTICS build of the same source: the only build that honours the A/B environment switches (kernel variants,
+    grid shapes, two-launch LM iterations ...).  The product library ignores them, so the tests that sweep variants create their
+    contexts on this one: api.Context(0, lib=diag_lib).  Loaded AFTER the product library (both are built with -Bsymbolic)."""
+    import velo_amd  # noqa: F401
+    from velo_amd import api
+    return api.load_diagnostics_library()
+
+
+@pytest.fixture(scope="session")
 def oracle():
     import oracle_lib
     oracle_lib.lib()

@@ -130,3 +130,22 @@ def test_product_never_touches_the_oracle():
                 assert "oracle_lib" not in text and "libvelo_oracle" not in text and "velo_oracle" not in text, (dirpath, f)
     out = subprocess.run(["ldd", build.LIB], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+PRODUCT_KNOBS = {"VELO_CHAIN", "VELO_CHAIN_MARGIN", "VELO_BATCH_GROUPS", "VELO_BATCH_LOCKSTEP", "VELO_SPIN"}
+
+
+def test_product_library_reads_only_the_documented_environment_knobs():
+    """The product library's environment surface is the five result-preserving knobs include/velo_hip.h documents; every A/B switch
+    (kernel variants, grid shapes, diagnostics) lives in the -DVELO_DIAGNOSTICS build only -- checked on the binaries themselves."""
+    import re
+    def names(path):
+        data = open(path, "rb").read()
+        return {m.decode() for m in re.findall(rb"(?<![A-Z_0-9])VELO_[A-Z_0-9]+(?=\x00)", data)}
+    assert names(build.LIB) == PRODUCT_KNOBS, names(build.LIB)
+    diag = build.build_hip(diagnostics=True)
+    extra = names(diag) - PRODUCT_KNOBS
+    assert {"VELO_ASSOC_VARIANT", "VELO_DEBUG_SKIP", "VELO_WARM_START", "VELO_DENSE_REF", "VELO_LM_FUSED"} <= extra
+    header = open(os.path.join(ROOT, "include", "velo_hip.h")).read()
+    for k in PRODUCT_KNOBS:
+        assert k in header, k                              # documented where the boundary is declared

@@ -48,14 +48,17 @@ def test_full_size_shard_is_index_exact(full_ctx, oracle, pair, iter_, shard):
         full_ctx.set_query_shard(0, 1)
 
 
-def test_full_size_reference_kernel_agrees_with_shell_walk(hip_lib, pair):
+def test_full_size_reference_kernel_agrees_with_shell_walk(hip_lib, diag_lib, pair):
     tables = []
-    for variant in ("0", "5", "4", "1"):          # per-lane reference, tube (default), box walk with 4 waves / 1 wave
-        os.environ["VELO_ASSOC_VARIANT"] = variant
-        try:
+    for variant in ("product", "0", "5", "4", "1"):   # the product library's kernel; then, on the diagnostics build: per-lane reference, tube, box walk with 4 waves / 1 wave
+        if variant == "product":
             c = api.Context(0, icp_skip=1)
-        finally:
-            os.environ.pop("VELO_ASSOC_VARIANT", None)
+        else:
+            os.environ["VELO_ASSOC_VARIANT"] = variant
+            try:
+                c = api.Context(0, lib=diag_lib, icp_skip=1)
+            finally:
+                os.environ.pop("VELO_ASSOC_VARIANT", None)
         c.set_target(pair["tgt_xyz"], pair["tgt_off"])
         c.set_source(pair["src_xyz"], pair["src_off"])
         t = []
@@ -70,14 +73,13 @@ def test_full_size_reference_kernel_agrees_with_shell_walk(hip_lib, pair):
             H.assert_corr_equal(a, b)
 
 
-def test_warm_started_rounds_equal_cold_rounds(hip_lib, pair, monkeypatch):
+def test_warm_started_rounds_equal_cold_rounds(hip_lib, diag_lib, pair, monkeypatch):
     """Rounds after the first start from the previous round's winners (AssocOut::prev).  Seeds are ordinary candidates entered
     early, so every table must equal the one of a context that never has seeds -- also when the pose jumps, the gate shrinks
     (iter 2), grows again, or the source / target is replaced in between."""
-    monkeypatch.setenv("VELO_WARM_START", "1")
-    warm = api.Context(0, icp_skip=1)
-    monkeypatch.setenv("VELO_WARM_START", "0")
-    cold = api.Context(0, icp_skip=1)
+    warm = api.Context(0, icp_skip=1)                        # the product library (warm start is what it does)
+    monkeypatch.setenv("VELO_WARM_START", "0")                # the switch exists in the diagnostics build only
+    cold = api.Context(0, lib=diag_lib, icp_skip=1)
     for c in (warm, cold):
         c.set_target(pair["tgt_xyz"], pair["tgt_off"])
         c.set_source(pair["src_xyz"], pair["src_off"])
@@ -214,7 +216,7 @@ def test_batch_entry_point_equals_single_calls(hip_lib, monkeypatch):
             c.close()
 
 
-def test_asker_list_in_single_calls_and_batches_equals_in_place_search(hip_lib, monkeypatch):
+def test_asker_list_in_single_calls_and_batches_equals_in_place_search(hip_lib, diag_lib, monkeypatch):
     """Density-shrunk grid (VELO_DENSE_REF forces it on small clouds): the cold round's asking queries are searched in place
     (VELO_ASKER_QUEUE=0), from the list by assoc_asker_kernel in single calls (default) or also in lock-step batches (=2): same poses,
     same solves, bit for bit."""
@@ -223,7 +225,7 @@ def test_asker_list_in_single_calls_and_batches_equals_in_place_search(hip_lib, 
     res = {}
     for q in ("0", "1", "2"):
         monkeypatch.setenv("VELO_ASKER_QUEUE", q)
-        ctxs = [api.Context(0, icp_skip=1) for _ in pairs]
+        ctxs = [api.Context(0, lib=diag_lib, icp_skip=1) for _ in pairs]
         single = []
         for c, d in zip(ctxs, pairs):
             c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])

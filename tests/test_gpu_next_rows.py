@@ -266,15 +266,15 @@ def test_triangulation_matches_oracle(hip_lib):
     c.close()
 
 
-def test_triangulation_kernels_agree_bit_for_bit(hip_lib, monkeypatch):
+def test_triangulation_kernels_agree_bit_for_bit(hip_lib, diag_lib, monkeypatch):
     # one wave per landmark (default) and one thread per landmark sum every accumulator in the same order
     pr = synth.triangulation_problem(1500, n_frames=40, seed=5)       # up to ~100 observations: more than one 64-lane chunk
     assert np.diff(pr["obs_offsets"]).max() > 64
     args = (pr["camera_poses"], pr["cam_trans"], pr["obs"], pr["obs_offsets"], pr["points0"], pr["initial_guess"])
     out = []
     for variant in ("1", "0"):
-        monkeypatch.setenv("VELO_TRI_VARIANT", variant)
-        c = api.Context(0)
+        monkeypatch.setenv("VELO_TRI_VARIANT", variant)        # "0" exists in the diagnostics build only
+        c = api.Context(0, lib=diag_lib if variant == "0" else None)
         out.append(c.triangulate_points(*args))
         c.close()
     assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))

@@ -315,7 +315,7 @@ def test_non_finite_points_and_degenerate_inputs(ctx, oracle):
         ctx.associate(d["x0"], 0)
 
 
-def test_small_problem_single_launch_solve_is_bit_identical(hip_lib, monkeypatch):
+def test_small_problem_single_launch_solve_is_bit_identical(hip_lib, diag_lib, monkeypatch):
     """Problems whose sweep fits a few workgroups (the reference's icp_skip = 200) run a whole solve in one single-workgroup launch
     (lm_solve_small_kernel); it walks the same virtual blocks with the same arithmetic, so poses, costs and iteration counts
     equal the launch-per-iteration path bit for bit."""
@@ -323,8 +323,8 @@ def test_small_problem_single_launch_solve_is_bit_identical(hip_lib, monkeypatch
     vis = api.matches_from_dict(synth.stereo_matches(40, mix="all"))
     out = []
     for small in ("1", "0"):
-        monkeypatch.setenv("VELO_SMALL_SOLVE", small)
-        c = api.Context(0)                                   # reference constants: icp_skip = 200 -> 640 queries
+        monkeypatch.setenv("VELO_SMALL_SOLVE", small)         # honoured by the diagnostics build only: "1" runs on the product library
+        c = api.Context(0, lib=diag_lib if small == "0" else None)   # reference constants: icp_skip = 200 -> 640 queries
         c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"]); c.set_visual(vis)
         out.append(c.frame_to_frame(d["x0"]))
         c.close()
@@ -340,7 +340,7 @@ def test_small_problem_single_launch_solve_is_bit_identical(hip_lib, monkeypatch
 @pytest.mark.parametrize("env", [{}, {"VELO_ASKER_ROWS": "0"}, {"VELO_CLUSTER_W": "2"}, {"VELO_DENSE_REF": "300"},
                                  {"VELO_DENSE_REF": "300", "VELO_ASKER_ROWS": "0"}, {"VELO_WARM_START": "0"}, {"VELO_ASSOC_LANE": "1"},
                                  {"VELO_DENSE_REF": "300", "VELO_ASKER_QUEUE": "0"}, {"VELO_DENSE_REF": "300", "VELO_ASKER_ROWS": "0", "VELO_ASKER_QUEUE": "0"}])
-def test_association_random_geometry_all_paths(hip_lib, oracle, monkeypatch, env):
+def test_association_random_geometry_all_paths(hip_lib, diag_lib, oracle, monkeypatch, env):
     """Every way through the tube kernel (tile pass / query-by-query second phase, one or many clusters, regular or
     density-shrunk grid, with or without seeds) against the oracle on clouds that look nothing like a street scan: ragged
     rings, dense clumps next to voids, points far outside the bulk, repeated rounds at moving poses."""
@@ -357,7 +357,7 @@ def test_association_random_geometry_all_paths(hip_lib, oracle, monkeypatch, env
     slens = rng.integers(1, 90, 17)
     soff = np.concatenate([[0], np.cumsum(slens)]).astype(np.int32)
     src = (centres[rng.integers(0, 6, soff[-1])] + rng.normal(0, 0.5, (soff[-1], 3))).astype(np.float32)
-    c = api.Context(0, icp_skip=1)
+    c = api.Context(0, lib=diag_lib if env else None, icp_skip=1)   # {}: the product library; the switches: the diagnostics build
     o = oracle.Oracle(icp_skip=1)
     for obj in (c, o):
         obj.set_target(tgt, off)
@@ -489,7 +489,7 @@ def test_chain_mode_is_bit_identical_and_survives_mispredictions(hip_lib, oracle
     assert np.abs(res["chain"][0][0][0] - xo).max() <= 1e-9
 
 
-def test_chain_mode_lockstep_batch_is_bit_identical(hip_lib, monkeypatch):
+def test_chain_mode_lockstep_batch_is_bit_identical(hip_lib, diag_lib, monkeypatch):
     """Lock-step batch: host-driven vs chain mode, and sweep + LM step as ONE launch per iteration (eval_step_batch_kernel: the last
     workgroup of a context steps) vs two launches (VELO_LM_FUSED=0) -- poses, solves, counts and bytes equal bit for bit."""
     pairs = [synth.scan_pair(n_beams=32, n_azimuth=400, scene_seed=10 + k, sigma=0.02 * (k + 1)) for k in range(3)]
@@ -500,7 +500,8 @@ def test_chain_mode_lockstep_batch_is_bit_identical(hip_lib, monkeypatch):
                       ("host_fused", {"VELO_CHAIN": "0", "VELO_LM_FUSED": "1"}), ("chain_two", {"VELO_CHAIN": "1", "VELO_LM_FUSED": "0"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        ctxs = [api.Context(0, icp_skip=1) for _ in pairs]
+        # VELO_LM_FUSED exists in the diagnostics build only; the product library fuses (its three variants run on the product library)
+        ctxs = [api.Context(0, lib=diag_lib if env["VELO_LM_FUSED"] == "0" else None, icp_skip=1) for _ in pairs]
         monkeypatch.delenv("VELO_CHAIN_MARGIN", raising=False)
         out = []
         for rep in range(3):
@@ -520,7 +521,7 @@ def test_chain_mode_lockstep_batch_is_bit_identical(hip_lib, monkeypatch):
             assert np.array_equal(x0, x1) and np.array_equal(T0, T1) and s0 == s1 and r0 == r1
 
 
-def test_lockstep_batch_at_the_reference_constants_uses_single_launch_solves(hip_lib, monkeypatch):
+def test_lockstep_batch_at_the_reference_constants_uses_single_launch_solves(hip_lib, diag_lib, monkeypatch):
     """icp_skip = 200 (kitti.h:8) in a lock-step batch: every solve of the group is one single-workgroup launch per context
     (lm_solve_small_batch_kernel, the body of the single-pair kernel); poses, solves and counts equal single calls bit for bit, with the
     launch-per-iteration path (VELO_SMALL_SOLVE=0) and with the host-driven batch."""
@@ -535,7 +536,7 @@ def test_lockstep_batch_at_the_reference_constants_uses_single_launch_solves(hip
     for env in ({}, {"VELO_SMALL_SOLVE": "0"}, {"VELO_CHAIN": "0"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        ctxs = [api.Context(0) for _ in pairs]
+        ctxs = [api.Context(0, lib=diag_lib if "VELO_SMALL_SOLVE" in env else None) for _ in pairs]
         for k in env:
             monkeypatch.delenv(k, raising=False)
         for rep in range(2):

@@ -1,6 +1,7 @@
 import os, sys
 sys.path.insert(0, "/root/repo")
 os.environ["VELO_DEBUG_SKIP"] = "8"; os.environ["VELO_ASSOC_VARIANT"] = "5"
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _diag  # noqa: E702  the A/B switches exist in the diagnostics build only
 import velo_amd
 from velo_amd import api, synth
 d = synth.scan_pair()

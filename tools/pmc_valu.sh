@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 for skip in 64 65 66 68; do
   OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_valu_$skip
   rm -rf $OUT; mkdir -p $OUT
-  export VELO_DEBUG_SKIP=$skip VELO_ASSOC_VARIANT=5
+  export VELO_DEBUG_SKIP=$skip VELO_ASSOC_VARIANT=5 VELO_LIB_PATH=$GRAFT_REPO_ROOT/vision-enhanced-lidar-odometry_amd/csrc/libvelo_hip_diag.so
   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --output-format csv -d $OUT -- python3 $GRAFT_REPO_ROOT/tools/prof_assoc.py c2 > /dev/null 2> $OUT.err
   python3 - $OUT $skip <<'PY'
 import csv, glob, sys, collections

@@ -3,6 +3,7 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _diag  # noqa: E702  the A/B switches exist in the diagnostics build only
 import velo_amd
 from velo_amd import api, synth
 wl = sys.argv[1] if len(sys.argv) > 1 else "c2"

@@ -4,6 +4,7 @@ one-wave-per-query kernel (VELO_ASSOC_DIRECT_MAX) takes over from the tube kerne
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _diag  # noqa: E702  the A/B switches exist in the diagnostics build only
 import velo_amd
 from velo_amd import api, synth
 d = synth.scan_pair()

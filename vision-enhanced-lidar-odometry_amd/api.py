@@ -120,6 +120,10 @@ assert MATCH_DTYPE.itemsize == 68 and GOOD_DTYPE.itemsize == 16 and CORR_DTYPE.i
 assert TRI_OBS_DTYPE.itemsize == 24 and TRI_RESULT_DTYPE.itemsize == 24 and FUNCTOR_DTYPE.itemsize == 80
 
 
+KERNEL_TIME_DTYPE = np.dtype([("name", "S56"), ("ms", "<f8"), ("launches", "<i8"), ("algorithmic_bytes", "<u8")])
+assert KERNEL_TIME_DTYPE.itemsize == 80
+
+
 def matches_from_dict(rec: dict) -> np.ndarray:
     """synth.stereo_matches() dict -> packed velo_match array."""
     n = len(rec["cam"])
@@ -173,6 +177,7 @@ SIGNATURES = {
     "velo_set_params": (C.c_int, [_ctx, _P(VeloParams)]),
     "velo_get_params": (C.c_int, [_ctx, _P(VeloParams)]),
     "velo_set_timing": (C.c_int, [_ctx, C.c_int]),
+    "velo_get_kernel_times": (C.c_int, [_ctx, C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.c_int32]),
     "velo_set_target": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int]),
     "velo_set_target_part": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int]),
     "velo_set_source": (C.c_int, [_ctx, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int]),
@@ -226,13 +231,18 @@ SIGNATURES = {
 }
 
 _lib = None
+_libs_by_path = {}
+LIB_PATH_DIAG = os.path.join(os.path.dirname(LIB_PATH), "libvelo_hip_diag.so")
 
 
 def load_library(path: Optional[str] = None) -> C.CDLL:
-    """dlopen the HIP library and type every entry point.  Raises VeloError when it has not been built."""
+    """dlopen the HIP library and type every entry point.  Raises VeloError when it has not been built.
+    path: another build of the same source (the tools' / variant tests' diagnostics build, see load_diagnostics_library)."""
     global _lib
     if _lib is not None and path is None:
         return _lib
+    if path is not None and path in _libs_by_path:
+        return _libs_by_path[path]
     p = path or os.environ.get("VELO_LIB_PATH") or LIB_PATH      # VELO_LIB_PATH: A/B builds on one GPU box
     if not os.path.exists(p):
         raise VeloError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -243,7 +253,16 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         fn.restype, fn.argtypes = res, args
     if path is None:
         _lib = lib
+    else:
+        _libs_by_path[path] = lib
     return lib
+
+
+def load_diagnostics_library() -> C.CDLL:
+    """The -DVELO_DIAGNOSTICS build of the same source (libvelo_hip_diag.so): the only build that honours the A/B environment switches
+    (kernel variants, grid shapes, VELO_DEBUG_SKIP ...).  The product library reads five documented knobs and ignores the rest, so the
+    parity tests that sweep variants, and the dev tools, create their contexts on this one: Context(device, lib=load_diagnostics_library())."""
+    return load_library(LIB_PATH_DIAG)
 
 
 def _dvec(a, n):
@@ -260,8 +279,8 @@ def _ptr(arr: np.ndarray):
 class Context:
     """One scan-matching context = one `velo_ctx*` (device buffers + a HIP stream on `device`)."""
 
-    def __init__(self, device: int = 0, **params):
-        self._lib = load_library()
+    def __init__(self, device: int = 0, lib: Optional[C.CDLL] = None, **params):
+        self._lib = lib if lib is not None else load_library()
         self._h = _ctx()
         self._device = int(device)
         self._check(self._lib.velo_create(C.byref(self._h), int(device)))
@@ -303,8 +322,17 @@ class Context:
             setattr(p, k, v)
         self._check(self._lib.velo_set_params(self._h, C.byref(p)))
 
-    def set_timing(self, enable: bool):
-        self._check(self._lib.velo_set_timing(self._h, int(bool(enable))))
+    def set_timing(self, enable):
+        """0 / False: off; 1 / True: association launches into the summary; 2: every instrumented launch by kernel name (kernel_times)."""
+        self._check(self._lib.velo_set_timing(self._h, int(enable)))
+
+    def kernel_times(self, reset: bool = True):
+        """{kernel name: (ms, launches, algorithmic bytes)} accumulated since the last reset (velo_set_timing(ctx, 2))."""
+        n = C.c_int32(0)
+        self._check(self._lib.velo_get_kernel_times(self._h, None, 0, C.byref(n), 0))
+        out = np.zeros(max(n.value, 1), dtype=KERNEL_TIME_DTYPE)
+        self._check(self._lib.velo_get_kernel_times(self._h, C.c_void_p(out.ctypes.data), n.value, C.byref(n), int(bool(reset))))
+        return {bytes(r["name"]).split(b"\0")[0].decode(): (float(r["ms"]), int(r["launches"]), int(r["algorithmic_bytes"])) for r in out[:n.value]}
 
     # -- inputs ----------------------------------------------------------------------------------------
     @staticmethod
@@ -608,8 +636,8 @@ class ScanCache:
     """Device-resident scan cache (velo_cache_*): the reference's ScansLRU (lru.h:31-61, 50 scans) with the scans and their
     search index kept in HBM.  store() copies the scan a context holds; load() hands it to any context as target or source."""
 
-    def __init__(self, device: int = 0, capacity: int = 50):
-        self._lib = load_library()
+    def __init__(self, device: int = 0, capacity: int = 50, lib: Optional[C.CDLL] = None):
+        self._lib = lib if lib is not None else load_library()
         self._h = C.c_void_p()
         status = self._lib.velo_cache_create(C.byref(self._h), int(device), int(capacity))
         if status != 0:
@@ -661,7 +689,7 @@ def comm_unique_id() -> bytes:
 def frame_to_frame_batch(ctxs, x0s):
     """B independent scan pairs in flight, one context each.  The library advances them in lock-step on one stream with shared LM
     launches when it can (same device and parameters, no communicator, no visual blocks), else with a host thread per context."""
-    lib = load_library()
+    lib = ctxs[0]._lib if len(ctxs) else load_library()      # the build the contexts were created on
     n = len(ctxs)
     arr = (_ctx * n)(*[c.handle for c in ctxs])
     x = np.ascontiguousarray(np.asarray(x0s, dtype=np.float64).reshape(n, 6)).copy()
@@ -703,7 +731,7 @@ def register_batch(ctxs, targets, sources, x0s, refs=None):
     """velo_register_batch: job i's target / source scans go into context i and the batch is registered, all inside the library
     (the index builds run on the threads that drive the groups).  targets / sources: lists of (xyz, ring_offsets) or None to keep
     what the contexts hold; refs = (target_refs, source_refs) from scan_refs() to reuse prepared descriptors across calls."""
-    lib = load_library()
+    lib = ctxs[0]._lib if len(ctxs) else load_library()      # the build the contexts were created on
     n = len(ctxs)
     arr = (_ctx * n)(*[c.handle for c in ctxs])
     if refs is None:

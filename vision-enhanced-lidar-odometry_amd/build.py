@@ -28,6 +28,9 @@ HIPCC_FLAGS = [
     # the SLP vectoriser re-packs the plain f32 candidate sweep into v_pk_* instructions and costs 7 more VGPRs (measured: slower)
     "-fno-slp-vectorize",
     "-Wall", "-Wno-unused-function", "-Wno-unused-result",
+    # calls between the library's own entry points bind inside the library: the product build and the diagnostics build export the
+    # same C names, and a process that loads both (the variant tests) must not have one build's batch driver call the other's loaders
+    "-Wl,-Bsymbolic",
 ]
 
 
@@ -63,6 +66,8 @@ def build_hip(force: bool = False, verbose: bool = False, extra_flags=(), diagno
 
 
 def build_all(force: bool = False, verbose: bool = False):
+    """product library + the diagnostics build the variant tests and dev tools load (both travel to the GPU box)"""
+    build_hip(force, verbose, diagnostics=True)
     return build_hip(force, verbose)
 
 

@@ -126,6 +126,20 @@ void default_params(velo_params* p) {
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Environment surface.  The PRODUCT library reads five documented, result-preserving knobs (include/velo_hip.h, "environment"):
+// VELO_CHAIN, VELO_CHAIN_MARGIN, VELO_BATCH_GROUPS, VELO_BATCH_LOCKSTEP, VELO_SPIN.  Every other switch -- kernel variants, grid
+// shapes, A/B paths, diagnostics -- exists only in the tools' build (-DVELO_DIAGNOSTICS, libvelo_hip_diag.so): a drop-in
+// frameToFrame whose kernel selection followed leaked environment variables would not be a product surface (the reference's knobs
+// are compile-time constants, kitti.h:3-35).  The parity tests that sweep variants load the diagnostics library.
+inline const char* dev_env(const char* name) {
+#ifdef VELO_DIAGNOSTICS
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 }  // namespace
 
 // What set_target builds: the target cloud and its search index.  Held through a shared_ptr: contexts that register different
@@ -147,7 +161,7 @@ struct velo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     velo_params P;
-    bool timing = false;
+    int timing = 0;                      // 0 off, 1 association launches (velo_summary::assoc_kernel_ms), 2 every instrumented launch by kernel name
     int assoc_variant = -1;              // VELO_ASSOC_VARIANT: -1 = default (tube kernel 5); 0 = per-lane reference kernel; 1/2/4/8 = waves per group
                                          // of the box walk; 5 = tube kernel
     int cluster_w = 6;                   // cluster radius of the box kernels, in cells of the default grid (VELO_CLUSTER_W)
@@ -180,8 +194,11 @@ struct velo_ctx {
     DevBuf<int2> prev_r;                 // and their rings; reset with every new source / target
     bool prev_ready = false;             // the seed arrays hold n_q initialised entries for the current source and target
     int warm_start = 1;                  // VELO_WARM_START=0 turns the seeds off (A/B; results are identical either way)
-    int assoc_lds_pad = 0;               // VELO_ASSOC_LDS_PAD: bytes of unused dynamic LDS per association workgroup -- caps the association
-                                         // kernel's workgroups per CU so that LM workgroups of other pairs in flight find room at once
+    int assoc_lds_pad = 0;               // bytes of unused dynamic LDS per association workgroup -- caps the association kernel's workgroups per
+                                         // CU so that LM workgroups of other pairs in flight find room at once.  Set by the lock-step batch
+                                         // driver when several groups share the chip (kAssocPadShared); VELO_ASSOC_LDS_PAD (diagnostics build) fixes it
+    bool assoc_lds_pad_fixed = false;
+    int lm_lean = -1;                    // lean fused LM kernel in lock-step groups: -1 = when several groups share the chip; VELO_LM_LEAN (diagnostics build) forces 0 / 1
     // chain mode: a whole frame_to_frame as ONE chain of launches (pose scalars of the next round and the solve summaries stay on the device)
     int patch_order = 1;                 // query list in patch order (VELO_PATCH_ORDER=0: the reference's ring order)
     bool q_patch = false;                // the current list is in patch order
@@ -328,10 +345,44 @@ struct velo_ctx {
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> assoc_events;   // reused pool
+    std::vector<std::pair<const char*, uint64_t>> assoc_event_info;  // kernel name + algorithmic bytes of the launch behind each pair
     int assoc_events_used = 0;
+    // velo_set_timing(ctx, 2): every instrumented launch (association, LM, index build) is bracketed by the start / stop events of
+    // hipExtLaunchKernelGGL; a call's brackets are read after its final synchronisation and added up per kernel name (velo_get_kernel_times)
+    struct TimedLaunch { hipEvent_t a = nullptr, b = nullptr; const char* name = nullptr; uint64_t bytes = 0; };
+    std::vector<TimedLaunch> klog;
+    int klog_used = 0;
+    struct KernelAcc { const char* name; double ms; int64_t launches; uint64_t bytes; };
+    std::vector<KernelAcc> kacc;
+    const char* lm_kernel_name = nullptr;    // the LM kernel the last call launched (its evaluations' algorithmic bytes are known only afterwards)
 };
 
 namespace {
+
+// ---- per-kernel launch times (velo_set_timing(ctx, 2)) ----
+void kacc_add(velo_ctx* c, const char* name, double ms, int64_t launches, uint64_t bytes) {
+    if (!name) return;
+    for (auto& a : c->kacc) if (a.name == name || std::strcmp(a.name, name) == 0) { a.ms += ms; a.launches += launches; a.bytes += bytes; return; }
+    c->kacc.push_back({name, ms, launches, bytes});
+}
+// an event pair for the launch that follows, or null when the context does not time every launch (or the call's log is full)
+velo_ctx::TimedLaunch* klog_slot(velo_ctx* c, const char* name, uint64_t bytes) {
+    if (c->timing < 2 || c->klog_used >= 1024) return nullptr;
+    if (c->klog_used >= (int)c->klog.size()) {
+        velo_ctx::TimedLaunch t;
+        if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        c->klog.push_back(t);
+    }
+    velo_ctx::TimedLaunch* t = &c->klog[(size_t)c->klog_used++];
+    t->name = name; t->bytes = bytes;
+    return t;
+}
+// launch `kernel` on `stream`, bracketed by the next event pair of context c's log when it times every launch
+#define VELO_LAUNCH_T(c, name, bytes, kernel, grid, block, lds, stream, ...)                                                        \
+    do {                                                                                                                            \
+        velo_ctx::TimedLaunch* tl__ = klog_slot(c, name, bytes);                                                                    \
+        hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, tl__ ? tl__->a : nullptr, tl__ ? tl__->b : nullptr, 0, __VA_ARGS__); \
+    } while (0)
 
 // a context about to load a NEW target: a TargetData other contexts still hold is left to them
 void own_target(velo_ctx* c) {
@@ -392,7 +443,7 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
     // Points lie on surfaces, so points-per-cell grows like N * h^2: for clouds denser than one HDL-64E sweep (accumulated
     // maps, BASELINE config 4) shrink the cell like N^-1/2 to keep the per-cell population -- and with it the candidates
     // per query -- at the level the kernel is tuned for.  Any cell size is exact (the box walk handles every gate).
-    const double dense_ref = getenv("VELO_DENSE_REF") ? atof(getenv("VELO_DENSE_REF")) : 150000.0;
+    const double dense_ref = dev_env("VELO_DENSE_REF") ? atof(dev_env("VELO_DENSE_REF")) : 150000.0;
     if (dense_ref > 0.0 && (double)c->T->n_tgt > dense_ref) h *= std::sqrt(dense_ref / (double)c->T->n_tgt);
     h = std::max(h, 1e-6);
     const double ext[3] = {(double)c->T->bbox[3] - c->T->bbox[0], (double)c->T->bbox[4] - c->T->bbox[1], (double)c->T->bbox[5] - c->T->bbox[2]};
@@ -406,7 +457,7 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
             dims[k] = (int)std::min(dk, 8192.0);
             total *= dk;
         }
-        static const double cell_cap = getenv("VELO_GRID_CAP") ? std::max(atof(getenv("VELO_GRID_CAP")), 4096.0) : 33554432.0;
+        static const double cell_cap = dev_env("VELO_GRID_CAP") ? std::max(atof(dev_env("VELO_GRID_CAP")), 4096.0) : 33554432.0;
         if (ok && total <= cell_cap) break;
         h *= 1.26;
     }
@@ -425,11 +476,12 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
     VELO_TRY(c->scan_total.reserve(1));
     HIP_TRY(hipMemsetAsync(G.cell_start.p, 0, sizeof(int) * ((size_t)nc + 4), c->stream));
     HIP_TRY(hipMemsetAsync(c->lb_status.p, 0, sizeof(unsigned long long) * ((size_t)n_tiles + 1), c->stream));
-    if (n > 0) hipLaunchKernelGGL(grid_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, G.d, c->T->tgt.p, n, c->T->tgt_cell_of.p, G.table());
-    hipLaunchKernelGGL(scan_lookback_kernel, dim3(n_tiles), dim3(kScanThreads), 0, c->stream, G.table() + 1, nc, c->lb_status.p,
-                       reinterpret_cast<int*>(c->lb_status.p + n_tiles), c->scan_total.p);
-    hipLaunchKernelGGL(grid_scatter_kernel, dim3(cdiv(std::max(n, kGridPad), 256)), dim3(256), 0, c->stream, c->T->tgt.p, c->T->tgt_cell_of.p, c->T->tgt_ring_of.p, n,
-                       G.table() + 1, (const int*)c->scan_total.p, c->T->tgt_first_point, G.sorted.p, G.sring.p);
+    // (bytes: what each kernel must move given this index layout -- count: cloud in, cell ids out; scan: table in + out; scatter: cloud + ids in, sorted copy out)
+    if (n > 0) VELO_LAUNCH_T(c, "grid_count_kernel", 20ull * (uint64_t)n, grid_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, G.d, c->T->tgt.p, n, c->T->tgt_cell_of.p, G.table());
+    VELO_LAUNCH_T(c, "scan_lookback_kernel", 8ull * (uint64_t)nc, scan_lookback_kernel, dim3(n_tiles), dim3(kScanThreads), 0, c->stream, G.table() + 1, nc, c->lb_status.p,
+                  reinterpret_cast<int*>(c->lb_status.p + n_tiles), c->scan_total.p);
+    VELO_LAUNCH_T(c, "grid_scatter_kernel", 44ull * (uint64_t)n, grid_scatter_kernel, dim3(cdiv(std::max(n, kGridPad), 256)), dim3(256), 0, c->stream, c->T->tgt.p, c->T->tgt_cell_of.p, c->T->tgt_ring_of.p, n,
+                  G.table() + 1, (const int*)c->scan_total.p, c->T->tgt_first_point, G.sorted.p, G.sring.p);
     HIP_TRY(hipGetLastError());
     G.built = true;
     return VELO_OK;
@@ -439,7 +491,7 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
 int build_grids(velo_ctx* c) {
     double gmin = gate_of_iter(c->P, 1);
     for (int it = 2; it <= c->P.f2f_iterations; it++) gmin = std::min(gmin, gate_of_iter(c->P, it));
-    if (const char* e = getenv("VELO_GRID_GATE")) gmin = atof(e);
+    if (const char* e = dev_env("VELO_GRID_GATE")) gmin = atof(e);
     if (c->T->grids.empty()) c->T->grids.resize(1);
     return build_grid(c, c->T->grids[0], gmin);
 }
@@ -621,7 +673,7 @@ EvalArgs eval_args(velo_ctx* c, const double* x_override) {
 EvalPlan eval_plan(const EvalArgs& A) {
     EvalPlan E;
     const int nq = A.q_end - A.q_begin;
-    static const int per_thread = getenv("VELO_EVAL_PER_THREAD") ? std::max(atoi(getenv("VELO_EVAL_PER_THREAD")), 1) : kEvalPerThread;
+    static const int per_thread = dev_env("VELO_EVAL_PER_THREAD") ? std::max(atoi(dev_env("VELO_EVAL_PER_THREAD")), 1) : kEvalPerThread;
     E.nb_icp = nq > 0 ? std::min(std::max(cdiv(nq, kEvalThreads * per_thread), 1), kMaxEvalBlocks) : 0;
     E.nb_vis = A.n_matches > 0 ? std::min(std::max(cdiv(3 * A.n_matches, kEvalThreads), 1), kMaxVisBlocks) : 0;
     return E;
@@ -717,7 +769,10 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 hipEvent_t a, b;
                 HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
                 c->assoc_events.emplace_back(a, b);
+                c->assoc_event_info.emplace_back(nullptr, 0);
             }
+            c->assoc_event_info[(size_t)c->assoc_events_used] = {direct ? "assoc_direct_kernel" : "assoc_search_v5_kernel",
+                                                                 12ull * (uint64_t)(qe - qb) + 12ull * (uint64_t)c->T->n_tgt + 28ull * (uint64_t)(qe - qb)};
             ev = &c->assoc_events[c->assoc_events_used++];
         }
         // The tube kernel is launched with hipExtLaunchKernelGGL, which stamps the two events with the KERNEL's own start and
@@ -748,6 +803,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         const int variant = direct ? 7 : lane ? 6 : (c->assoc_variant >= 0 ? c->assoc_variant : 5);
         const int reach_cells = (int)std::ceil(std::sqrt(std::max(gate_of_iter(c->P, 1), 0.0)) / (G->h * 0.999));   // > 5: density-shrunk grid
         switch (variant) {
+#ifdef VELO_DIAGNOSTICS   // the A/B kernels (per-lane reference walk, pipelined prepare + persistent search): tools' build only
             case 0: {
                 const int reach = (int)std::ceil(std::sqrt(std::max(gate, 0.0)) / (G->h * 0.999)) ;
                 hipLaunchKernelGGL(assoc_search_kernel, dim3(cdiv(qe - qb, kAssocThreads)), dim3(kAssocThreads), 0, c->stream,
@@ -777,6 +833,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                                        c->T->tgt.p, c->T->tgt_off.p, c->T->tgt_ring_of.p, gbits, c->P.icp_norm_condition, h_safe, out, aux);
                 break;
             }
+#endif
             case 7: {   // sparse round: one wave per query
                 out.n_valid_next = c->n_valid.p + (c->nv_idx ^ 1);
                 c->nv_clean[c->nv_idx ^ 1] = true;
@@ -785,6 +842,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                                       gbits, c->P.icp_norm_condition, h_safe, out, aux);
                 break;
             }
+#ifdef VELO_DIAGNOSTICS
             case 6: {   // lane kernel: one lane owns one query (rounds that start from seeds)
                 out.n_valid_next = c->n_valid.p + (c->nv_idx ^ 1);
                 c->nv_clean[c->nv_idx ^ 1] = true;
@@ -793,6 +851,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                                       gbits, c->P.icp_norm_condition, out, aux);
                 break;
             }
+#endif
             case 5: case 55: case 52: case 56: case 57: case 58: case 59: {   // tube variant: per-row intervals, per-query phase 2 (cluster radius only when VELO_CLUSTER_W is given)
                 // tubes do not grow with the segment, so the cluster radius only has to bound the row box of pathological groups
                 // (a 64-query group straddling a gap in its ring): 96 default cells = 17 m unless VELO_CLUSTER_W says otherwise
@@ -819,16 +878,16 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 // 62 us; 6 waves + 2 pairs (5 spilled VGPRs) 65; 7 waves + 2 pairs 64; 5 waves + 4 pairs 66; 6 waves + 4 pairs 71
 #ifdef VELO_DIAGNOSTICS
                 if (c->debug_skip) VELO_LAUNCH_V5(4, 5, true, 2, true);
-                else
-#endif
-                if (variant == 55) VELO_LAUNCH_V5(4, 5, false, 4, true);
+                else if (variant == 55) VELO_LAUNCH_V5(4, 5, false, 4, true);
                 else if (variant == 52) VELO_LAUNCH_V5(4, 6, false, 2, true);
                 else if (variant == 56) VELO_LAUNCH_V5(4, 6, false, 2, false);   // occupancy A/B: 6 / 7 / 8 waves per SIMD
                 else if (variant == 57) VELO_LAUNCH_V5(4, 7, false, 2, false);
                 else if (variant == 58) VELO_LAUNCH_V5(4, 8, false, 2, false);
                 // (workgroups of 2 waves / 1 wave -- every group resident at once -- measured 66 / 134 us per launch against 62: not tail-bound)
                 else if (variant == 59) VELO_LAUNCH_V5(4, 5, false, 2, false);   // phase 2 through the row/tile machinery (A/B)
-                else if (asker_rows >= (1 << 30)) VELO_LAUNCH_V5(4, 5, false, 2, false);   // regular grid: instantiation without the query-by-query code (no spills)
+                else
+#endif
+                if (asker_rows >= (1 << 30)) VELO_LAUNCH_V5(4, 5, false, 2, false);   // regular grid: instantiation without the query-by-query code (no spills)
                 else if (out.ask_list) {
                     // through the batch entry (arguments read from one struct): as a kernel with 40 scalar arguments this instantiation
                     // spills 17 SGPRs, which makes the dispatch set up scratch (~11 us per launch)
@@ -848,6 +907,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
 #undef VELO_LAUNCH_V5
                 break;
             }
+#ifdef VELO_DIAGNOSTICS   // box-walk kernel (the second independent implementation the variant tests compare against)
             case 1: VELO_LAUNCH_V2(1, 1); break;
             case 2: VELO_LAUNCH_V2(2, 1); break;
             case 8: VELO_LAUNCH_V2(8, 8); break;
@@ -856,6 +916,9 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
             case 47: VELO_LAUNCH_V2(4, 7); break;
             case 48: VELO_LAUNCH_V2(4, 8); break;
             default: VELO_LAUNCH_V2(4, 6); break;
+#else
+            default: return fail(VELO_ERR_STATE, "association variant %d exists only in the diagnostics build", variant);
+#endif
         }
 #undef VELO_LAUNCH_V2
 #undef VELO_LAUNCH_V3
@@ -863,7 +926,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         if (out.prev_a && (variant == 7 || variant == 6 || variant == 5 || (variant >= 52 && variant <= 59))) c->seed_rounds++;   // these kernels leave seeds behind
         if (ev && !ext_timed) HIP_TRY(hipEventRecord(ev->second, c->stream));
 #ifdef VELO_DIAGNOSTICS
-        if ((c->debug_skip & 24) && getenv("VELO_DEBUG_EACH")) {       // per-launch read-out (default: totals when the context goes)
+        if ((c->debug_skip & 24) && dev_env("VELO_DEBUG_EACH")) {       // per-launch read-out (default: totals when the context goes)
             unsigned long long h[8];
             HIP_TRY(hipStreamSynchronize(c->stream));
             HIP_TRY(hipMemcpy(h, c->dbg.p, sizeof(h), hipMemcpyDeviceToHost));
@@ -883,15 +946,31 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
     return VELO_OK;
 }
 
-// timing on: the association launches of the call just finished, summed (HIP events)
+// after a stream synchronisation behind peer traffic: a wait that ran into its time limit has set the error word.  The slabs' sequence
+// numbers are out of step from then on: the communicator must be attached again (velo_comm_peer_export + _attach on every rank).
+int peer_check(velo_ctx* c) {
+    if (!c->peer_on) return VELO_OK;
+    HIP_TRY(hipMemcpy(c->h_int, c->peer_err.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (c->h_int[0]) return fail(VELO_ERR_COMM, "peer exchange timed out: a rank of the communicator did not arrive (attach the communicator again)");
+    return VELO_OK;
+}
+
+// timing on: the association launches of the call just finished, summed (HIP events); level 2: every logged launch by kernel name
 int read_assoc_timing(velo_ctx* c, velo_summary* S) {
     double ms = 0.0;
     for (int k = 0; k < c->assoc_events_used; k++) {
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, c->assoc_events[k].first, c->assoc_events[k].second));
         ms += t;
+        if (c->timing >= 2 && k < (int)c->assoc_event_info.size()) kacc_add(c, c->assoc_event_info[(size_t)k].first, t, 1, c->assoc_event_info[(size_t)k].second);
     }
-    S->assoc_kernel_ms = ms;
+    if (S) S->assoc_kernel_ms = ms;
+    for (int k = 0; k < c->klog_used; k++) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, c->klog[(size_t)k].a, c->klog[(size_t)k].b));
+        kacc_add(c, c->klog[(size_t)k].name, t, 1, c->klog[(size_t)k].bytes);
+    }
+    c->klog_used = 0;
     return VELO_OK;
 }
 
@@ -1062,10 +1141,7 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
         chunk = 3;
     }
     }
-    if (c->peer_on) {
-        HIP_TRY(hipMemcpy(c->h_int, c->peer_err.p, sizeof(int), hipMemcpyDeviceToHost));
-        if (c->h_int[0]) return fail(VELO_ERR_COMM, "peer all-reduce timed out: a rank of the communicator did not arrive");
-    }
+    VELO_TRY(peer_check(c));
     const LMState& s = c->h_status->s;
 #ifdef VELO_DIAGNOSTICS
     if (c->lm_trace_on) {
@@ -1265,37 +1341,38 @@ int velo_create(velo_ctx** out, int device) {
     auto init = [&]() -> int {
         default_params(&c->P);
         for (int k = 0; k < VELO_MAX_SOLVES; k++) { c->pred_evals[k] = (k == 0) ? 12 : 5; c->eval_hist_n[k] = 0; }
-        if (const char* e = getenv("VELO_ASSOC_VARIANT")) c->assoc_variant = atoi(e);
-        if (const char* e = getenv("VELO_CLUSTER_W")) { c->cluster_w = std::max(atoi(e), 0); c->cluster_w_set = true; }
-        if (const char* e = getenv("VELO_TRI_VARIANT")) c->tri_variant = atoi(e);
+        if (const char* e = dev_env("VELO_ASSOC_VARIANT")) c->assoc_variant = atoi(e);
+        if (const char* e = dev_env("VELO_CLUSTER_W")) { c->cluster_w = std::max(atoi(e), 0); c->cluster_w_set = true; }
+        if (const char* e = dev_env("VELO_TRI_VARIANT")) c->tri_variant = atoi(e);
 #ifdef VELO_DIAGNOSTICS
-        if (getenv("VELO_LM_TRACE") && atoi(getenv("VELO_LM_TRACE"))) {
+        if (dev_env("VELO_LM_TRACE") && atoi(dev_env("VELO_LM_TRACE"))) {
             c->lm_trace_on = true;
             VELO_TRY(c->lm_trace.reserve((size_t)kTraceMaxEvals * kTraceStages * kTraceWgs));
         }
         // the diagnostic instantiations (cycle stamps, counters, sections switched off -- some bits give WRONG results on purpose) exist
         // only in the tools' build of this file (build.py: libvelo_hip_diag.so); the product library ignores the variable
-        if (const char* e = getenv("VELO_DEBUG_SKIP")) c->debug_skip = atoi(e);
+        if (const char* e = dev_env("VELO_DEBUG_SKIP")) c->debug_skip = atoi(e);
 #endif
-        if (const char* e = getenv("VELO_GRAPHS")) c->use_graphs = atoi(e) != 0;
-        if (const char* e = getenv("VELO_XCD_MAP")) c->xcd_map = atoi(e);
-        if (const char* e = getenv("VELO_TUBE_MAP")) c->tube_map = atoi(e);
-        if (const char* e = getenv("VELO_WARM_START")) c->warm_start = atoi(e);
-        if (const char* e = getenv("VELO_SMALL_SOLVE")) c->small_solve = atoi(e);
-        if (const char* e = getenv("VELO_LM_MERGED")) c->lm_merged = atoi(e);
-        if (const char* e = getenv("VELO_LM_FUSED")) c->lm_fused = atoi(e);
-        if (const char* e = getenv("VELO_ASSOC_LANE")) c->assoc_lane = atoi(e);
-        if (const char* e = getenv("VELO_LM_MERGED_VIS")) c->lm_trace_vis_off = atoi(e) == 0;
-        if (const char* e = getenv("VELO_ASKER_QUEUE")) c->asker_queue = atoi(e);
-        if (const char* e = getenv("VELO_ASSOC_DIRECT_MAX")) c->direct_max = std::max(atoi(e), 0);
-        if (const char* e = getenv("VELO_PATCH_ORDER")) c->patch_order = atoi(e);
-        if (const char* e = getenv("VELO_PATCH_SHAPE")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 1) { c->patch_rings = a; c->patch_len = b; } }
-        if (const char* e = getenv("VELO_ASSOC_DIRECT_SKIP")) c->direct_skip = std::max(atoi(e), 1);
+        if (const char* e = dev_env("VELO_GRAPHS")) c->use_graphs = atoi(e) != 0;
+        if (const char* e = dev_env("VELO_XCD_MAP")) c->xcd_map = atoi(e);
+        if (const char* e = dev_env("VELO_TUBE_MAP")) c->tube_map = atoi(e);
+        if (const char* e = dev_env("VELO_WARM_START")) c->warm_start = atoi(e);
+        if (const char* e = dev_env("VELO_SMALL_SOLVE")) c->small_solve = atoi(e);
+        if (const char* e = dev_env("VELO_LM_MERGED")) c->lm_merged = atoi(e);
+        if (const char* e = dev_env("VELO_LM_FUSED")) c->lm_fused = atoi(e);
+        if (const char* e = dev_env("VELO_ASSOC_LANE")) c->assoc_lane = atoi(e);
+        if (const char* e = dev_env("VELO_LM_MERGED_VIS")) c->lm_trace_vis_off = atoi(e) == 0;
+        if (const char* e = dev_env("VELO_ASKER_QUEUE")) c->asker_queue = atoi(e);
+        if (const char* e = dev_env("VELO_ASSOC_DIRECT_MAX")) c->direct_max = std::max(atoi(e), 0);
+        if (const char* e = dev_env("VELO_PATCH_ORDER")) c->patch_order = atoi(e);
+        if (const char* e = dev_env("VELO_PATCH_SHAPE")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 1) { c->patch_rings = a; c->patch_len = b; } }
+        if (const char* e = dev_env("VELO_ASSOC_DIRECT_SKIP")) c->direct_skip = std::max(atoi(e), 1);
         if (const char* e = getenv("VELO_CHAIN")) c->chain = atoi(e);
         if (const char* e = getenv("VELO_CHAIN_MARGIN")) { c->chain_margin = std::max(atoi(e), 0); c->chain_margin_fixed = true; }
-        if (const char* e = getenv("VELO_ASSOC_LDS_PAD")) c->assoc_lds_pad = std::max(atoi(e), 0);
-        if (const char* e = getenv("VELO_ASKER_ROWS")) c->asker_rows = atoi(e);
-        if (const char* e = getenv("VELO_PERSISTENT_WGS")) c->persistent_wgs = std::max(atoi(e), 1);
+        if (const char* e = dev_env("VELO_ASSOC_LDS_PAD")) { c->assoc_lds_pad = std::max(atoi(e), 0); c->assoc_lds_pad_fixed = true; }
+        if (const char* e = dev_env("VELO_LM_LEAN")) c->lm_lean = atoi(e);
+        if (const char* e = dev_env("VELO_ASKER_ROWS")) c->asker_rows = atoi(e);
+        if (const char* e = dev_env("VELO_PERSISTENT_WGS")) c->persistent_wgs = std::max(atoi(e), 1);
         if (const char* e = getenv("VELO_BATCH_LOCKSTEP")) c->batch_lockstep = atoi(e);
         HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_TRY(hipHostMalloc((void**)&c->h_status, sizeof(HostStatus), hipHostMallocDefault));
@@ -1387,6 +1464,7 @@ int velo_destroy(velo_ctx* c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto& e : c->assoc_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto& e : c->klog) { if (e.a) (void)hipEventDestroy(e.a); if (e.b) (void)hipEventDestroy(e.b); }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return VELO_OK;
@@ -1417,7 +1495,7 @@ int velo_get_params(const velo_ctx* c, velo_params* p) {
 
 int velo_set_timing(velo_ctx* c, int enable) {
     if (!c) return fail(VELO_ERR_INVALID, "null ctx");
-    c->timing = enable != 0;
+    c->timing = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     return VELO_OK;
 }
 
@@ -1680,7 +1758,7 @@ int velo_cache_load(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t as_t
     // the cached index serves when it was built for the gates this context works with (same cell size rule, same cloud)
     double gmin = gate_of_iter(c->P, 1);
     for (int iter = 2; iter <= c->P.f2f_iterations; iter++) gmin = std::min(gmin, gate_of_iter(c->P, iter));
-    if (const char* env = getenv("VELO_GRID_GATE")) gmin = atof(env);
+    if (const char* env = dev_env("VELO_GRID_GATE")) gmin = atof(env);
     if (!e.has_index || e.grid.gate != gmin) return target_finalize(c);
     c->prev_ready = false;
     VELO_TRY(c->T->tgt_off.reserve((size_t)e.n_rings + 1));
@@ -1757,7 +1835,7 @@ int velo_associate(velo_ctx* c, const double x[6], int32_t iter, int32_t* n_vali
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->last_n_valid = c->h_int[0];
         if (n_valid) *n_valid = c->last_n_valid;
-        return VELO_OK;
+        return peer_check(c);                                  // a timed-out record exchange merged stale areas
     }
     return do_associate(c, x, iter, true, true, n_valid);
 }
@@ -1943,6 +2021,7 @@ int velo_evaluate(velo_ctx* c, const double x[6], double* cost, double JtJ[36], 
     }
     HIP_TRY(hipMemcpyAsync(c->h_x + 8, res, sizeof(double) * kNumAcc, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    VELO_TRY(peer_check(c));                                   // a timed-out all-reduce summed stale slab contents
     const double* E = c->h_x + 8;
     if (cost) *cost = E[27];
     if (JtJ) {
@@ -2169,8 +2248,9 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
             SolveLog* logp = c->solve_log.p + std::min(r, VELO_MAX_SOLVES - 1);
             const bool peer = c->peer_on;
             if (small && !peer && (!visual || E.total() <= kSmallRows)) {     // no prediction needed: the launch runs the solve to its end
-                hipLaunchKernelGGL(lm_solve_small_kernel, dim3(1), dim3(kEvalThreads), 0, c->stream, A, Q, c->state.p, (const double*)(r == 0 ? c->xdev.p : nullptr),
-                                   nvp, E.nb_icp, E.nb_vis, c->P.max_num_iterations + 3, c->pose_rec.p, logp);
+                c->lm_kernel_name = "lm_solve_small_kernel";
+                VELO_LAUNCH_T(c, c->lm_kernel_name, 0, lm_solve_small_kernel, dim3(1), dim3(kEvalThreads), 0, c->stream, A, Q, c->state.p, (const double*)(r == 0 ? c->xdev.p : nullptr),
+                              nvp, E.nb_icp, E.nb_vis, c->P.max_num_iterations + 3, c->pose_rec.p, logp);
                 HIP_TRY(hipGetLastError());
                 continue;
             }
@@ -2188,15 +2268,16 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
                 continue;
             }
             const int K = std::min(std::max(c->pred_evals[std::min(r, VELO_MAX_SOLVES - 1)], 1) + 1 + margin_for(c, r), max_launches);
+            c->lm_kernel_name = visual ? "lm_iter_vis_kernel" : "lm_iter_kernel";
             for (int k = 0; k < K; k++, j++) {
                 if (visual)
-                    hipLaunchKernelGGL(lm_iter_vis_kernel, dim3(E.total()), dim3(kEvalThreads), 0, c->stream, A, Q, (const LMState*)(c->state.p + (j & 1)), c->state.p + ((j + 1) & 1),
-                                       (const double*)(c->partials.p + (size_t)(j & 1) * half), E.total(), c->partials.p + (size_t)((j + 1) & 1) * half, k == 0 ? 1 : 0,
-                                       (const double*)((r == 0 && k == 0) ? c->xdev.p : nullptr), nvp, c->pose_rec.p, logp, E.nb_icp, E.nb_vis);
+                    VELO_LAUNCH_T(c, c->lm_kernel_name, 0, lm_iter_vis_kernel, dim3(E.total()), dim3(kEvalThreads), 0, c->stream, A, Q, (const LMState*)(c->state.p + (j & 1)), c->state.p + ((j + 1) & 1),
+                                  (const double*)(c->partials.p + (size_t)(j & 1) * half), E.total(), c->partials.p + (size_t)((j + 1) & 1) * half, k == 0 ? 1 : 0,
+                                  (const double*)((r == 0 && k == 0) ? c->xdev.p : nullptr), nvp, c->pose_rec.p, logp, E.nb_icp, E.nb_vis);
                 else
-                hipLaunchKernelGGL(lm_iter_kernel, dim3(E.nb_icp), dim3(kEvalThreads), 0, c->stream, A, Q, (const LMState*)(c->state.p + (j & 1)), c->state.p + ((j + 1) & 1),
-                                   (const double*)(c->partials.p + (size_t)(j & 1) * half), E.nb_icp, c->partials.p + (size_t)((j + 1) & 1) * half, k == 0 ? 1 : 0,
-                                   (const double*)((r == 0 && k == 0) ? c->xdev.p : nullptr), nvp, c->pose_rec.p, c->solve_log.p + std::min(r, VELO_MAX_SOLVES - 1));
+                    VELO_LAUNCH_T(c, c->lm_kernel_name, 0, lm_iter_kernel, dim3(E.nb_icp), dim3(kEvalThreads), 0, c->stream, A, Q, (const LMState*)(c->state.p + (j & 1)), c->state.p + ((j + 1) & 1),
+                                  (const double*)(c->partials.p + (size_t)(j & 1) * half), E.nb_icp, c->partials.p + (size_t)((j + 1) & 1) * half, k == 0 ? 1 : 0,
+                                  (const double*)((r == 0 && k == 0) ? c->xdev.p : nullptr), nvp, c->pose_rec.p, c->solve_log.p + std::min(r, VELO_MAX_SOLVES - 1));
             }
             HIP_TRY(hipGetLastError());
         }
@@ -2213,10 +2294,7 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
         HIP_TRY(hipMemcpyAsync(h_vis_counts, c->vis_counts.p, sizeof(int) * 2 * VELO_MAX_STATS, hipMemcpyDeviceToHost, c->stream));
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->peer_on) {
-        HIP_TRY(hipMemcpy(c->h_int, c->peer_err.p, sizeof(int), hipMemcpyDeviceToHost));
-        if (c->h_int[0]) return fail(VELO_ERR_COMM, "peer all-reduce timed out: a rank of the communicator did not arrive");
-    }
+    VELO_TRY(peer_check(c));
     if (*h_fail || !c->h_status->s.done) {
         HIP_TRY(hipMemsetAsync(c->chain_fail.p, 0, sizeof(int), c->stream));
         note_miss(c);
@@ -2244,6 +2322,7 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
         note_evals(c, k, L.evals);
         S->eval_kernel_launches += L.evals;
         S->algorithmic_bytes += (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull);
+        if (c->timing >= 2) kacc_add(c, c->lm_kernel_name, 0.0, 0, (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull));
         if (S->n_solves < VELO_MAX_SOLVES) S->solves[S->n_solves] = ss;
         S->n_solves++;
     }
@@ -2254,6 +2333,18 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
 }
 
 extern "C" {
+
+int velo_get_kernel_times(velo_ctx* c, velo_kernel_time* out, int32_t capacity, int32_t* n, int32_t reset) {
+    if (!c) return fail(VELO_ERR_INVALID, "null ctx");
+    if (n) *n = (int32_t)c->kacc.size();
+    for (int i = 0; out && i < capacity && i < (int)c->kacc.size(); i++) {
+        std::memset(&out[i], 0, sizeof(out[i]));
+        std::snprintf(out[i].name, sizeof(out[i].name), "%s", c->kacc[(size_t)i].name);
+        out[i].ms = c->kacc[(size_t)i].ms; out[i].launches = c->kacc[(size_t)i].launches; out[i].algorithmic_bytes = c->kacc[(size_t)i].bytes;
+    }
+    if (reset) c->kacc.clear();
+    return VELO_OK;
+}
 
 int velo_chain_stats(const velo_ctx* c, int32_t* calls, int32_t* misses) {
     if (!c) return fail(VELO_ERR_INVALID, "null ctx");
@@ -2394,7 +2485,7 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
 
 // contexts whose round may share a launch: default tube kernel, no diagnostics, no placement table, whole (unsharded) query list
 static bool assoc_batchable(const velo_ctx* c) {
-    static const bool on = getenv("VELO_ASSOC_BATCH") ? atoi(getenv("VELO_ASSOC_BATCH")) != 0 : true;
+    static const bool on = dev_env("VELO_ASSOC_BATCH") ? atoi(dev_env("VELO_ASSOC_BATCH")) != 0 : true;
     return on && (c->assoc_variant < 0 || c->assoc_variant == 5) && !c->debug_skip && c->tube_map < 0 && !c->comm && !c->peer_on;
 }
 
@@ -2442,7 +2533,12 @@ static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::arr
                 hipEvent_t e0, e1;
                 HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
                 c->assoc_events.emplace_back(e0, e1);
+                c->assoc_event_info.emplace_back(nullptr, 0);
             }
+            uint64_t bytes = 0;                                       // B_assoc of every context this launch serves
+            for (int j = 0; j < k; j++) bytes += 40ull * (uint64_t)(B.item[j].q_end - B.item[j].q_begin);
+            for (int i = b; i < b + m; i++) { int q0, q1; q_range(ctxs[i], &q0, &q1); if (q1 > q0) bytes += 12ull * (uint64_t)ctxs[i]->T->n_tgt; }
+            c->assoc_event_info[(size_t)c->assoc_events_used] = {all_direct ? "assoc_direct_batch_kernel" : "assoc_search_v5_batch_kernel", bytes};
             ev = &c->assoc_events[c->assoc_events_used++];
         }
         launched[(size_t)first] = 1;
@@ -2456,7 +2552,9 @@ static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::arr
             for (int i = b; i < b + m; i++) ctxs[i]->ask_clean[0] = ctxs[i]->ask_clean[1] = false;   // no launch clears a counter this round
         }
         if (all_direct) hipExtLaunchKernelGGL(assoc_direct_batch_kernel, dim3(nq_max, k), dim3(64), 0, c->stream, ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, B);
+#ifdef VELO_DIAGNOSTICS
         else if (all_lane) hipExtLaunchKernelGGL(assoc_lane_batch_kernel, dim3(cdiv(gmax, 4), k), dim3(256), 0, c->stream, ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, B);
+#endif
         else if (any_asker && all_queue) {
             hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, 2>), dim3(gmax, k), dim3(256), c->assoc_lds_pad, c->stream, ev ? ev->first : nullptr, nullptr, 0, B);
             hipExtLaunchKernelGGL(assoc_asker_batch_kernel, dim3(cdiv(gmax * 64, kAskChunk), k), dim3(64), 0, c->stream, nullptr, ev ? ev->second : nullptr, 0, B);
@@ -2470,9 +2568,21 @@ static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::arr
     return VELO_OK;
 }
 
-static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo_summary* summaries) {
+// Several lock-step groups share the chip (shared_chip): a group's LM launches arrive while other groups' association kernels fill
+// every CU.  The tube kernel's workgroup is 22 KB of LDS and 72 VGPRs per lane: seven fit a CU and leave 8 of 512 VGPRs per SIMD, so
+// an LM workgroup (240 VGPRs, 33 KB) had to wait until FOUR of them had drained -- 21 us per LM launch alone, ~35 us in the mix, the
+// largest single item of a step.  There the association workgroups get kAssocPadShared bytes of unused dynamic LDS (27.9 KB each: five
+// per CU, 360 VGPRs per SIMD) and the LM launches use the lean instantiation (<= 152 VGPRs, 19 KB), which always fits beside them.
+constexpr int kAssocPadShared = 5632;
+static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo_summary* summaries, bool shared_chip = false) {
     velo_ctx* c0 = ctxs[0];
     HIP_TRY(hipSetDevice(c0->device));
+    const bool lean = c0->lm_lean >= 0 ? c0->lm_lean != 0 : shared_chip;
+    struct PadRestore { velo_ctx** c; int n; std::vector<int> old; ~PadRestore() { for (int i = 0; i < n; i++) c[i]->assoc_lds_pad = old[(size_t)i]; } } pad_restore{ctxs, n, {}};
+    for (int i = 0; i < n; i++) {
+        pad_restore.old.push_back(ctxs[i]->assoc_lds_pad);
+        if (!ctxs[i]->assoc_lds_pad_fixed) ctxs[i]->assoc_lds_pad = (lean && shared_chip) ? kAssocPadShared : 0;
+    }
     const velo_params P = c0->P;
     const LMParams Q = lm_params(P);
     // everything queued on the contexts' own streams (set_target / set_source) must be done before the shared stream uses it
@@ -2566,14 +2676,20 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                         std::memset(&pack, 0, sizeof(pack));
                         const int m = std::min(kItemsByValue, n - b0);
                         for (int i = 0; i < m; i++) pack.item[i] = items_r[b0 + i];
-                        hipLaunchKernelGGL(lm_solve_small_batch_kernel, dim3(m), dim3(kEvalThreads), 0, bs, Q, pack, max_iters + 1);
+                        c0->lm_kernel_name = "lm_solve_small_batch_kernel";
+                        VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, lm_solve_small_batch_kernel, dim3(m), dim3(kEvalThreads), 0, bs, Q, pack, max_iters + 1);
                     }
                     HIP_TRY(hipGetLastError());
                     continue;
                 }
-                hipLaunchKernelGGL(lm_begin_batch_kernel, dim3(n), dim3(64), 0, bs, d_items);
+                VELO_LAUNCH_T(c0, "lm_begin_batch_kernel", 0, lm_begin_batch_kernel, dim3(n), dim3(64), 0, bs, d_items);
+                if (c0->lm_fused) c0->lm_kernel_name = lean ? "eval_step_batch_lean_kernel" : "eval_step_batch_kernel";
                 for (int k = 0; k < K; k++) {
-                    if (c0->lm_fused) { hipLaunchKernelGGL(eval_step_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, d_items, c0->batch_tickets.p); continue; }
+                    if (c0->lm_fused) {
+                        if (lean) VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_lean_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, d_items, c0->batch_tickets.p);
+                        else VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, d_items, c0->batch_tickets.p);
+                        continue;
+                    }
                     hipLaunchKernelGGL(eval_icp_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, d_items);
                     hipLaunchKernelGGL(lm_step_batch_kernel, dim3(n), dim3(256), 0, bs, Q, d_items);
                 }
@@ -2606,6 +2722,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                     note_evals(c, k, L.evals);
                     Si->eval_kernel_launches += L.evals;
                     Si->algorithmic_bytes += (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 224ull);
+                    if (c0->timing >= 2) kacc_add(c0, c0->lm_kernel_name, 0.0, 0, (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 224ull));   // the group's launches are logged on its first context
                     Si->solves[Si->n_solves++] = ss;
                 }
                 c->last_n_valid = h_states[i].n_valid;
@@ -2679,7 +2796,8 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                     }
                     if (fused) {
                         if (nbv_max > 0) hipLaunchKernelGGL(eval_visual_batch_kernel, dim3(nbv_max, n), dim3(kEvalThreads), 0, bs, (const LMBatchItem*)c0->batch_items.p);
-                        hipLaunchKernelGGL(eval_step_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p, c0->batch_tickets.p);
+                        if (lean) hipLaunchKernelGGL(eval_step_batch_lean_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p, c0->batch_tickets.p);
+                        else hipLaunchKernelGGL(eval_step_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p, c0->batch_tickets.p);
                         continue;
                     }
                     if (nb_max > 0) hipLaunchKernelGGL(eval_icp_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, (const LMBatchItem*)c0->batch_items.p);
@@ -2798,7 +2916,7 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
         }
         std::vector<int> gst((size_t)G, VELO_OK);
         std::vector<std::string> gerr((size_t)G);
-        static const bool batch_trace = getenv("VELO_BATCH_TRACE") != nullptr;       // dev aid: host-side timeline of every group to stderr
+        static const bool batch_trace = dev_env("VELO_BATCH_TRACE") != nullptr;       // dev aid: host-side timeline of every group to stderr
         const auto t_call = std::chrono::steady_clock::now();
         auto run_group = [&](int gi) {
             const int b = (int)((int64_t)n * gi / G), e = (int)((int64_t)n * (gi + 1) / G);
@@ -2817,7 +2935,7 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
                 if (st != VELO_OK) { gst[(size_t)gi] = st; gerr[(size_t)gi] = g_err; return; }
             }
             const auto t2 = std::chrono::steady_clock::now();
-            gst[(size_t)gi] = f2f_batch_lockstep(ctxs + b, e - b, x + 6 * (size_t)b, T ? T + 16 * (size_t)b : nullptr, summaries ? summaries + b : nullptr);
+            gst[(size_t)gi] = f2f_batch_lockstep(ctxs + b, e - b, x + 6 * (size_t)b, T ? T + 16 * (size_t)b : nullptr, summaries ? summaries + b : nullptr, true);
             if (gst[(size_t)gi] != VELO_OK) gerr[(size_t)gi] = g_err;
             if (batch_trace) {
                 const auto t3 = std::chrono::steady_clock::now();
@@ -2949,8 +3067,13 @@ int velo_comm_peer_export(velo_ctx* c, char handle[64]) {
             HIP_TRY(hipMalloc(&p, sizeof(PeerSlab)));
         }
         c->peer_slab = (PeerSlab*)p;
-        HIP_TRY(hipMemset(c->peer_slab, 0, sizeof(PeerSlab)));
     }
+    // The slab is cleared HERE, before its handle leaves this call, and never again: a peer may store into it as soon as it has attached,
+    // and nothing orders that against this rank's own attach.  (Every rank exports before any rank can attach -- the host program's
+    // exchange of the handles is that barrier -- so no store of the new epoch can precede this clear.)
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemset(c->peer_slab, 0, sizeof(PeerSlab)));
+    HIP_TRY(hipDeviceSynchronize());
     hipIpcMemHandle_t h;
     HIP_TRY(hipIpcGetMemHandle(&h, c->peer_slab));
     std::memcpy(handle, &h, 64);
@@ -2967,7 +3090,10 @@ int velo_comm_peer_attach(velo_ctx* c, const char* handles, int32_t rank, int32_
     VELO_TRY(c->peer_seq.reserve(1)); VELO_TRY(c->peer_err.reserve(1));
     HIP_TRY(hipMemset(c->peer_seq.p, 0, sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->peer_err.p, 0, sizeof(int)));
-    HIP_TRY(hipMemset(c->peer_slab, 0, sizeof(PeerSlab)));
+    // (the slab itself was cleared by velo_comm_peer_export: a peer that attached earlier may already be storing into it)
+    // Chain mode over peers enqueues a predicted number of LM launches per solve, and every rank must enqueue the SAME number: the
+    // prediction history restarts here, on every rank alike, and from here on all ranks see the same solves.
+    for (int k = 0; k < VELO_MAX_SOLVES; k++) { c->pred_evals[k] = (k == 0) ? 12 : 5; c->eval_hist_n[k] = 0; }
     for (int r = 0; r < world; r++) {
         if (r == rank) { c->peer.slab[r] = c->peer_slab; continue; }
         hipIpcMemHandle_t h;

@@ -2614,12 +2614,14 @@ __device__ __forceinline__ bool eval_point_load(const EvalArgs& A, LMEvalPoint* 
 // The correspondences do not depend on the pose: the first kPre strided rows of a thread are requested at the very start of the
 // kernel, BEFORE the eval point (or, in the one-launch iteration, the whole LM step) is dealt with, so the latencies overlap.
 constexpr int kPre = 4;
-struct RowPrefetch { float4 p[kPre], n[kPre], v[kPre]; };
-__device__ __forceinline__ RowPrefetch prefetch_rows(const EvalArgs& A, const int bx, const int nbx) {
-    RowPrefetch f;
+template <int PRE> struct RowPrefetchT { float4 p[PRE], n[PRE], v[PRE]; };
+using RowPrefetch = RowPrefetchT<kPre>;
+template <int PRE = kPre>
+__device__ __forceinline__ RowPrefetchT<PRE> prefetch_rows(const EvalArgs& A, const int bx, const int nbx) {
+    RowPrefetchT<PRE> f;
     const int tid = bx * blockDim.x + threadIdx.x, nthreads = nbx * blockDim.x;
 #pragma unroll
-    for (int k = 0; k < kPre; k++) {
+    for (int k = 0; k < PRE; k++) {
         const int i = min(A.q_begin + tid + k * nthreads, A.q_end - 1);
         f.p[k] = A.cp[i]; f.n[k] = A.cn[i]; f.v[k] = A.cv0[i];
     }
@@ -2654,8 +2656,8 @@ __device__ __forceinline__ void sweep_row(const EvalArgs& A, const LMEvalPoint& 
 }
 // this workgroup's rows at the eval point in LDS -> the 28 accumulators of every thread (the prefetched rows first, with
 // compile-time indices, then whatever is left)
-template <bool M_FROM_LDS>
-__device__ __forceinline__ void sweep_rows(const EvalArgs& A, const RowPrefetch& f, const LMEvalPoint& s_pt, const int bx, const int nbx, double acc[kNumAcc]) {
+template <bool M_FROM_LDS, int PRE = kPre>
+__device__ __forceinline__ void sweep_rows(const EvalArgs& A, const RowPrefetchT<PRE>& f, const LMEvalPoint& s_pt, const int bx, const int nbx, double acc[kNumAcc]) {
     const int tid = bx * blockDim.x + threadIdx.x, nthreads = nbx * blockDim.x;
     double Mreg[4][9];
     if (!M_FROM_LDS) {
@@ -2671,11 +2673,11 @@ __device__ __forceinline__ void sweep_rows(const EvalArgs& A, const RowPrefetch&
 #pragma unroll
     for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
 #pragma unroll
-    for (int k = 0; k < kPre; k++) {
+    for (int k = 0; k < PRE; k++) {
         const int i = A.q_begin + tid + k * nthreads;
         if (i < A.q_end) sweep_row<M_FROM_LDS>(A, s_pt, Mreg, t, f.p[k], f.n[k], f.v[k], i, acc);
     }
-    for (int i = A.q_begin + tid + kPre * nthreads; i < A.q_end; i += nthreads) sweep_row<M_FROM_LDS>(A, s_pt, Mreg, t, A.cp[i], A.cn[i], A.cv0[i], i, acc);
+    for (int i = A.q_begin + tid + PRE * nthreads; i < A.q_end; i += nthreads) sweep_row<M_FROM_LDS>(A, s_pt, Mreg, t, A.cp[i], A.cn[i], A.cv0[i], i, acc);
 }
 
 __device__ __forceinline__ void eval_icp_body(const EvalArgs& A, const int bx, const int nbx) {
@@ -3028,14 +3030,17 @@ __device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* 
 __device__ __forceinline__ void lm_transition_wave(const LMParams& Q, LMState* sL, const double* E, int lane);
 constexpr int kStepChunk = 128;
 static_assert(kStepChunk * kNumAcc == kScratchDoubles && kStepChunk * kNumAcc % 256 == 0 && kStepChunk % 8 == 0, "chunk geometry");
-template <bool COHERENT = false>
+template <bool COHERENT = false, int CHUNK = kStepChunk>
 __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __restrict__ Sin, const double* __restrict__ partials, int n_blocks, int first,
                                            const double* __restrict__ x_in, const int* __restrict__ n_valid,
                                            double* __restrict__ s_rows, LMState* sL, LMEvalPoint* s_pt, unsigned long long* trace, int trace_eval,
                                            const PeerComm* comm = nullptr, PoseRecord* pose_out = nullptr, SolveLog* log = nullptr, bool writer = true) {
     __shared__ double part[8][kNumAcc];
     __shared__ double E[kNumAcc];
-    constexpr int kPerThread = kStepChunk * kNumAcc / 256;
+    // CHUNK rows of partial sums at a time through s_rows (CHUNK x 28 doubles).  Thread (k, p) adds the rows b = p (mod 8) of its
+    // accumulator k in increasing order whatever the chunk size (a multiple of 64), so every CHUNK gives the same bits.
+    static_assert(CHUNK % 64 == 0 && CHUNK <= kStepChunk, "chunk geometry");
+    constexpr int kPerThread = CHUNK * kNumAcc / 256;
     const int t = threadIdx.x;
     if (t < (int)(sizeof(LMState) / 8)) reinterpret_cast<unsigned long long*>(sL)[t] = reinterpret_cast<const unsigned long long*>(Sin)[t];
     double xin[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -3050,8 +3055,8 @@ __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __r
     const int k_acc = t % kNumAcc, p_acc = t / kNumAcc;
     double v_acc = 0.0;
     if (!first) {
-        for (int c0 = 0; c0 < n_blocks; c0 += kStepChunk) {
-            const int nrows = min(kStepChunk, n_blocks - c0), total = nrows * kNumAcc;
+        for (int c0 = 0; c0 < n_blocks; c0 += CHUNK) {
+            const int nrows = min(CHUNK, n_blocks - c0), total = nrows * kNumAcc;
             const double* __restrict__ src = partials + (size_t)c0 * kNumAcc;
             double a[kPerThread];
 #pragma unroll
@@ -3377,20 +3382,21 @@ lm_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items) {
 // Ordering: the 28 stores of a row are agent-scope write-through stores; their thread waits for them (s_waitcnt vmcnt(0)) ahead of
 // the workgroup barrier behind which thread 0 draws the ticket, so whoever sees ticket n - 1 finds every row where its agent-scope
 // loads look.  tickets[context] is 0 at every launch boundary (the last workgroup resets it).
-__global__ void __launch_bounds__(kEvalThreads)
-eval_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets) {
+template <bool M_LDS, int PRE, int CHUNK>
+__device__ __forceinline__ void eval_step_batch_body(const LMParams& Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets) {
     const LMBatchItem& it = items[blockIdx.y];
     const int bx = blockIdx.x, nbx = it.nb_icp;
     if (bx >= nbx) return;
     const EvalArgs& A = it.A;
-    const RowPrefetch f = prefetch_rows(A, bx, nbx);
+    const RowPrefetchT<PRE> f = prefetch_rows<PRE>(A, bx, nbx);
     __shared__ LMEvalPoint s_pt;
     __shared__ LMState sL;
-    __shared__ double s_scratch[kScratchDoubles];
+    __shared__ double s_scratch[CHUNK * kNumAcc];
     __shared__ int s_last;
+    static_assert(CHUNK * kNumAcc >= kScratchDoubles / 2, "the sweep's reduction needs 64 columns x 28");
     if (!eval_point_load(A, &s_pt)) return;                           // a launch behind the end of the solve: nothing to do, the ticket stays 0
     double acc[kNumAcc];
-    sweep_rows<false>(A, f, s_pt, bx, nbx, acc);                      // matrices in registers: the kernel runs two waves per SIMD either way
+    sweep_rows<M_LDS, PRE>(A, f, s_pt, bx, nbx, acc);
     block_reduce_store<true>(acc, A.partials + (size_t)bx * kNumAcc, s_scratch);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this thread's row entries have been written through
     __syncthreads();
@@ -3398,11 +3404,27 @@ eval_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* _
     __syncthreads();
     if (!s_last) return;
     if (threadIdx.x == 0) __hip_atomic_store(tickets + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    lm_advance<true>(Q, it.S, A.partials, it.n_rows, 0, nullptr, nullptr, s_scratch, &sL, &s_pt, nullptr, 0, nullptr, it.pose_out, it.log);
+    lm_advance<true, CHUNK>(Q, it.S, A.partials, it.n_rows, 0, nullptr, nullptr, s_scratch, &sL, &s_pt, nullptr, 0, nullptr, it.pose_out, it.log);
     const int t = threadIdx.x;
     LMEvalPoint* pt = const_cast<LMEvalPoint*>(A.pt);
     if (t < (int)(sizeof(LMState) / 8)) reinterpret_cast<unsigned long long*>(it.S)[t] = reinterpret_cast<const unsigned long long*>(&sL)[t];
     else if (t >= 64 && t < 64 + (int)(sizeof(LMEvalPoint) / 8)) reinterpret_cast<unsigned long long*>(pt)[t - 64] = reinterpret_cast<const unsigned long long*>(&s_pt)[t - 64];
+}
+// alone on the chip: matrices in registers, four prefetched rows (240 VGPRs, 33 KB of LDS: two waves per SIMD)
+__global__ void __launch_bounds__(kEvalThreads)
+eval_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets) {
+    eval_step_batch_body<false, kPre, kStepChunk>(Q, items, tickets);
+}
+// The LEAN instantiation, for launches that share the chip with other lock-step groups' association kernels: matrices read from LDS,
+// VELO_LEAN_PRE prefetched rows, the step's partial rows 64 at a time -- few enough registers and LDS (<= 152 VGPRs, < 25 KB) that a
+// workgroup fits on a CU beside FIVE association workgroups (5 x 72 VGPRs of 512 per SIMD, 5 x 27 KB of 160 KB with the pad the batch
+// driver gives them), so an LM launch never waits for association workgroups to drain.  Same arithmetic, same order: bit-identical.
+#ifndef VELO_LEAN_PRE
+#define VELO_LEAN_PRE 1
+#endif
+__global__ void __launch_bounds__(kEvalThreads) __attribute__((amdgpu_num_vgpr(152)))
+eval_step_batch_lean_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets) {
+    eval_step_batch_body<true, VELO_LEAN_PRE, 64>(Q, items, tickets);
 }
 // all states of the batch into one contiguous block (one D2H copy per chunk instead of one per context)
 __global__ void lm_gather_states_kernel(const LMBatchItem* __restrict__ items, LMState* __restrict__ out, int which) {

@@ -272,26 +272,52 @@ TRUE_MOTION = dict(yaw=0.02, pitch=0.002, roll=0.002, t=(1.0, 0.02, 0.01))
 INITIAL_GUESS = np.array([0.0, 0.0, 0.0, 0.0, 0.0, 1.0])     # main.cpp:170
 
 
-def scan_pair(n_beams: int = N_BEAMS, n_azimuth: int = N_AZIMUTH, scene_seed: int = 0, sigma: float = 0.02):
+def scan_pair(n_beams: int = N_BEAMS, n_azimuth: int = N_AZIMUTH, scene_seed: int = 0, sigma: float = 0.02,
+              motion=None, noise_seeds=(1, 2), start=(0.0, 0.0, 0.0)):
     """(source=current frame, target=previous frame) ring clouds + true x.
 
+    motion: dict(yaw, pitch, roll, t) of the relative pose (default TRUE_MOTION); noise_seeds: range-noise seeds of the
+    two sweeps; start: sensor position of the previous frame in the scene.  The defaults are the canonical pair of BASELINE configs[1].
     Returns dict(src_xyz, src_off, tgt_xyz, tgt_off, x_true, x0).
     """
     scene = Scene(scene_seed)
-    T_prev = pose_matrix(0.0, 0.0, 0.0, (0.0, 0.0, 0.0))
-    T_rel = pose_matrix(**TRUE_MOTION)
+    T_prev = pose_matrix(0.0, 0.0, 0.0, tuple(start))
+    T_rel = pose_matrix(**(motion or TRUE_MOTION))
     T_cur = T_prev @ T_rel
-    a = hdl64_scan(scene, T_prev, noise_seed=1, sigma=sigma, n_beams=n_beams, n_azimuth=n_azimuth)
-    b = hdl64_scan(scene, T_cur, noise_seed=2, sigma=sigma, n_beams=n_beams, n_azimuth=n_azimuth)
+    a = hdl64_scan(scene, T_prev, noise_seed=noise_seeds[0], sigma=sigma, n_beams=n_beams, n_azimuth=n_azimuth)
+    b = hdl64_scan(scene, T_cur, noise_seed=noise_seeds[1], sigma=sigma, n_beams=n_beams, n_azimuth=n_azimuth)
     tgt_xyz, tgt_off = segment_points(a)
     src_xyz, src_off = segment_points(b)
     return dict(src_xyz=src_xyz, src_off=src_off, tgt_xyz=tgt_xyz, tgt_off=tgt_off,
                 x_true=velo_pose_to_cam_x(T_rel), x0=INITIAL_GUESS.copy())
 
 
+def distinct_pairs(n: int, n_beams: int = N_BEAMS, n_azimuth: int = N_AZIMUTH, sigma: float = 0.02):
+    """n DIFFERENT scan pairs for a batch (bench.py: the pairs in flight must not be copies of one pair): pair 0 is the canonical
+    scan_pair(); pair k > 0 has its own scene (box layout), noise, place on the road and motion -- speeds 0.6 .. 1.4 m per frame, yaw
+    -0.03 .. 0.04 rad, small pitch / roll / lateral drift, all from a counter-based RNG.  Its initial guess is what the reference's
+    drive loop hands frameToFrame (main.cpp:311-331): the PREVIOUS frame's motion, i.e. the true motion up to one frame's
+    acceleration (here up to +-0.1 m along the road, +-0.01 rad of yaw); pair 0 keeps the reference's start-up guess (main.cpp:170)."""
+    out = [scan_pair(n_beams, n_azimuth, sigma=sigma)]
+    for k in range(1, n):
+        u = uniform01(900 + k, 12, stream=3)
+        motion = dict(yaw=-0.03 + 0.07 * u[0], pitch=0.004 * (u[1] - 0.5), roll=0.004 * (u[2] - 0.5),
+                      t=(0.6 + 0.8 * u[3], 0.06 * (u[4] - 0.5), 0.02 * (u[5] - 0.5)))
+        d = scan_pair(n_beams, n_azimuth, scene_seed=k, sigma=sigma, motion=motion, noise_seeds=(1 + 10 * k, 2 + 10 * k),
+                      start=(-20.0 + 40.0 * u[6], 2.0 * (u[7] - 0.5), 0.0))
+        prev = dict(yaw=motion["yaw"] + 0.02 * (u[8] - 0.5), pitch=motion["pitch"] + 0.002 * (u[9] - 0.5), roll=motion["roll"],
+                    t=(motion["t"][0] + 0.2 * (u[10] - 0.5), motion["t"][1] + 0.02 * (u[11] - 0.5), motion["t"][2]))
+        d["x0"] = velo_pose_to_cam_x(pose_matrix(**prev))
+        out.append(d)
+    return out
+
+
 def scan_to_map(n_target: int = 2_000_000, scene_seed: int = 0, sigma: float = 0.02,
-                n_beams: int = N_BEAMS, n_azimuth: int = N_AZIMUTH):
-    """Config 4/5: accumulated map (scans every 1 m along x, all in the newest map pose's frame) as target."""
+                n_beams: int = N_BEAMS, n_azimuth: int = N_AZIMUTH, n_queries: int = 1):
+    """Config 4/5: accumulated map (scans every 1 m along x, all in the newest map pose's frame) as target.
+    n_queries > 1: the returned dict also carries "queries", n_queries DIFFERENT scans to register against the map (query 0 is the
+    canonical one of the top-level keys; the others are taken 0.6 .. 1.4 m further along the road with their own yaw and noise; their
+    initial guess is the previous frame's motion, like distinct_pairs)."""
     scene = Scene(scene_seed)
     per_scan = n_beams * n_azimuth
     n_scans = -(-n_target // per_scan)
@@ -317,8 +343,21 @@ def scan_to_map(n_target: int = 2_000_000, scene_seed: int = 0, sigma: float = 0
     T_cur = T_ref @ T_rel
     b = hdl64_scan(scene, T_cur, noise_seed=2, sigma=sigma, n_beams=n_beams, n_azimuth=n_azimuth)
     src_xyz, src_off = segment_points(b)
-    return dict(src_xyz=src_xyz, src_off=src_off, tgt_xyz=tgt_xyz, tgt_off=tgt_off,
-                x_true=velo_pose_to_cam_x(T_rel), x0=INITIAL_GUESS.copy())
+    out = dict(src_xyz=src_xyz, src_off=src_off, tgt_xyz=tgt_xyz, tgt_off=tgt_off,
+               x_true=velo_pose_to_cam_x(T_rel), x0=INITIAL_GUESS.copy())
+    if n_queries > 1:
+        qs = [dict(src_xyz=src_xyz, src_off=src_off, x_true=out["x_true"], x0=out["x0"])]
+        for k in range(1, n_queries):
+            u = uniform01(700 + k, 8, stream=4)
+            motion = dict(yaw=-0.03 + 0.07 * u[0], pitch=0.004 * (u[1] - 0.5), roll=0.004 * (u[2] - 0.5),
+                          t=(0.6 + 0.8 * u[3], 0.06 * (u[4] - 0.5), 0.02 * (u[5] - 0.5)))
+            Tq = pose_matrix(**motion)
+            pts = hdl64_scan(scene, T_ref @ Tq, noise_seed=2 + 10 * k, sigma=sigma, n_beams=n_beams, n_azimuth=n_azimuth)
+            sx, so = segment_points(pts)
+            prev = dict(motion, yaw=motion["yaw"] + 0.02 * (u[6] - 0.5), t=(motion["t"][0] + 0.2 * (u[7] - 0.5), motion["t"][1], motion["t"][2]))
+            qs.append(dict(src_xyz=sx, src_off=so, x_true=velo_pose_to_cam_x(Tq), x0=velo_pose_to_cam_x(pose_matrix(**prev))))
+        out["queries"] = qs
+    return out
 
 
 def stereo_matches(n_per_cam: int = 1000, seed: int = 3, x_true=None, outlier_frac: float = 0.10,
