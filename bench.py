@@ -372,9 +372,11 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
                 a_n += results[0][2].assoc_kernel_launches
             ctxs[0].synchronize()
             lat = (time.perf_counter() - t1) / n1
+            ktab1 = kernel_table(ctxs[0].kernel_times(reset=True))
+            a_us = next((r["avg_launch_us"] for r in ktab1 if r["kernel"].startswith("assoc")), 1e3 * a_ms / max(a_n, 1))
             single = {"pairs_in_flight": 1, "pairs_walked": min(B, n1), "ms_per_pair": 1e3 * lat, "pairs_per_s": 1.0 / lat,
-                      "assoc_avg_launch_us": 1e3 * a_ms / max(a_n, 1),
-                      "kernels": [{k: r[k] for k in ("kernel", "share", "avg_launch_us", "frac")} for r in kernel_table(ctxs[0].kernel_times(reset=True))[:3]]}
+                      "assoc_avg_launch_us": a_us,
+                      "kernels": [{k: r[k] for k in ("kernel", "share", "avg_launch_us", "frac")} for r in ktab1[:3]]}
             one_pair(0, 0)                                   # context 0 holds its own pair again
 
         shared = None

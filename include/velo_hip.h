@@ -218,17 +218,20 @@ int velo_default_params(velo_params* p);
 int velo_set_params(velo_ctx* ctx, const velo_params* p);
 int velo_get_params(const velo_ctx* ctx, velo_params* p);
 /* Launch timing with HIP events (off by default).  enable = 1: the association launches of a call, summed into
- * velo_summary::assoc_kernel_ms.  enable = 2: every instrumented launch -- association, LM (sweep + step), target index build -- is
- * bracketed by the kernel's own start / stop events (hipExtLaunchKernelGGL); the brackets are read after the call's final
- * synchronisation and accumulated per kernel NAME until velo_get_kernel_times collects them (what bench.py's `kernels` list reports).
- * algorithmic_bytes: SURVEY.md 8(d)'s figure for the launches of that kernel -- B_assoc per association round served, B_eval per LM
- * evaluation -- and, for the index-build kernels, what the kernel must move given the index layout.  Launches shared by the contexts
- * of a lock-step group are logged on the group's first context. */
+ * velo_summary::assoc_kernel_ms.  enable = 2: every instrumented launch -- association, seeds, LM (sweep + step), target index build -- is
+ * COUNTED per kernel name, and every 8th launch of a name is bracketed by the kernel's own start / stop events (hipExtLaunchKernelGGL;
+ * a bracket costs ~5 us of queue time, so bracketing every launch -- enable = 3 -- slows a chain of 20-us launches by a quarter).  The
+ * brackets are read after the call's final synchronisation and accumulated until velo_get_kernel_times collects them: `ms` = bracketed
+ * time scaled by launches / sampled (what bench.py's `kernels` list reports).  algorithmic_bytes: SURVEY.md 8(d)'s figure for the
+ * launches of that kernel -- B_assoc per association round served, B_eval per LM evaluation -- and, for the index-build and seed kernels,
+ * what the kernel must move given the data layout.  Launches shared by the contexts of a lock-step group are logged on the group's
+ * first context.  (At levels 2 and 3 the association launches are bracketed one by one, as at level 1.) */
 int velo_set_timing(velo_ctx* ctx, int enable);
 typedef struct velo_kernel_time {
-    char name[56];
-    double ms;                         /* sum of launch durations */
+    char name[48];
+    double ms;                         /* estimated sum of launch durations: bracketed time x launches / sampled */
     int64_t launches;
+    int64_t sampled;                   /* launches that were bracketed */
     uint64_t algorithmic_bytes;
 } velo_kernel_time;                    /* 80 bytes */
 int velo_get_kernel_times(velo_ctx* ctx, velo_kernel_time* out, int32_t capacity, int32_t* n, int32_t reset);

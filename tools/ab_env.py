@@ -17,9 +17,11 @@ for r in range(rounds):
     for s in settings:
         env = dict(os.environ)
         if lib: env["VELO_LIB_PATH"] = lib
+        extra = []
         for kv in s.split():
-            k, v = kv.split("=", 1); env[k] = v
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-legs", "--no-cpu-baseline", *bench_args.split()], env=env, capture_output=True, text=True)
+            if kv.startswith("--") or not "=" in kv: extra.append(kv); continue      # bench.py arguments of this setting
+            k, v = kv.split("=", 1); env[k] = v                                    # (VELO_LIB_PATH=... selects another build)
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-legs", "--no-cpu-baseline", *bench_args.split(), *extra], env=env, capture_output=True, text=True)
         try:
             line = json.loads(out.stdout.strip().splitlines()[-1])
             res[s].append((line["value"], (line.get("single_pair") or {}).get("ms_per_pair", 0.0), line["roofline"]["avg_launch_us"]))

@@ -49,3 +49,37 @@ q = collections.defaultdict(list)
 for s, e, k, qid in sel:
     q[qid].append((s, e))
 print("per hardware queue: busy share of the stretch: " + ", ".join(f"q{qid}: {100 * union(v) / wall:.0f} %" for qid, v in sorted(q.items())))
+
+# ---- who slows whom: LM launches by how much of them ran under another queue's association kernel; queue gaps -------------------------
+import bisect
+assoc_iv = sorted((s, e, qid) for s, e, k, qid in sel if "assoc_search" in k)
+
+
+def overlap_with_assoc(s, e, qid):
+    tot = 0
+    for a, b, q2 in assoc_iv:
+        if a >= e:
+            break
+        if q2 != qid and b > s:
+            tot += min(e, b) - max(s, a)
+    return tot / max(e - s, 1)
+
+
+for pat in ("eval_step_batch", "lm_iter"):
+    lm = [(s, e, qid) for s, e, k, qid in sel if pat in k]
+    if not lm:
+        continue
+    live = [(s, e, qid) for s, e, qid in lm if e - s > 6000]
+    buckets = {"< 10 % under an association kernel": [], "10-60 %": [], "> 60 %": []}
+    for s, e, qid in live:
+        f_ = overlap_with_assoc(s, e, qid)
+        buckets["< 10 % under an association kernel" if f_ < 0.1 else ("10-60 %" if f_ < 0.6 else "> 60 %")].append((e - s) / 1e3)
+    print(f"{pat}: {len(lm)} launches, {len(live)} live (> 6 us): " + "; ".join(
+        f"{k}: n {len(v)} mean {sum(v) / max(len(v), 1):.1f} us p50 {sorted(v)[len(v) // 2] if v else 0:.1f} p90 {sorted(v)[int(len(v) * 0.9)] if v else 0:.1f}" for k, v in buckets.items()))
+# idle gaps inside each queue's chain (between the end of one kernel and the start of the next on the same queue)
+for qid, iv in sorted(q.items()):
+    iv = sorted(iv)
+    gaps = [(b[0] - a[1]) / 1e3 for a, b in zip(iv, iv[1:]) if b[0] > a[1]]
+    small = [g for g in gaps if g < 50]
+    print(f"q{qid}: {len(iv)} kernels, gaps: n {len(gaps)} sum {sum(gaps) / 1e3:.2f} ms ({100 * sum(gaps) * 1e3 / wall:.0f} % of the stretch), "
+          f"gaps < 50 us: mean {sum(small) / max(len(small), 1):.1f} us, p50 {sorted(small)[len(small) // 2] if small else 0:.1f}")

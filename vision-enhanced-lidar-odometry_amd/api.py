@@ -120,7 +120,7 @@ assert MATCH_DTYPE.itemsize == 68 and GOOD_DTYPE.itemsize == 16 and CORR_DTYPE.i
 assert TRI_OBS_DTYPE.itemsize == 24 and TRI_RESULT_DTYPE.itemsize == 24 and FUNCTOR_DTYPE.itemsize == 80
 
 
-KERNEL_TIME_DTYPE = np.dtype([("name", "S56"), ("ms", "<f8"), ("launches", "<i8"), ("algorithmic_bytes", "<u8")])
+KERNEL_TIME_DTYPE = np.dtype([("name", "S48"), ("ms", "<f8"), ("launches", "<i8"), ("sampled", "<i8"), ("algorithmic_bytes", "<u8")])
 assert KERNEL_TIME_DTYPE.itemsize == 80
 
 
@@ -323,7 +323,8 @@ class Context:
         self._check(self._lib.velo_set_params(self._h, C.byref(p)))
 
     def set_timing(self, enable):
-        """0 / False: off; 1 / True: association launches into the summary; 2: every instrumented launch by kernel name (kernel_times)."""
+        """0 / False: off; 1 / True: association launches into the summary; 2: launches counted by kernel name, every 8th bracketed
+        (kernel_times); 3: every launch bracketed."""
         self._check(self._lib.velo_set_timing(self._h, int(enable)))
 
     def kernel_times(self, reset: bool = True):

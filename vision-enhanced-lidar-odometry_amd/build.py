@@ -45,13 +45,14 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_hip(force: bool = False, verbose: bool = False, extra_flags=(), diagnostics: bool = False) -> str:
+def build_hip(force: bool = False, verbose: bool = False, extra_flags=(), diagnostics: bool = False, out: str | None = None) -> str:
     """The product library; diagnostics=True builds the tools' variant next to it (same source, -DVELO_DIAGNOSTICS: the
     VELO_DEBUG_SKIP hooks exist only there, so a leaked environment variable cannot corrupt a product registration)."""
     hipcc = shutil.which("hipcc") or os.path.join(_rocm(), "bin", "hipcc")
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
-    out = LIB_DIAG if diagnostics else LIB
+    out = out or (LIB_DIAG if diagnostics else LIB)      # out: an A/B build of the same source somewhere else (tools/ab_env.py, VELO_LIB_PATH)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     if diagnostics:
         extra_flags = (*extra_flags, "-DVELO_DIAGNOSTICS")
     if not force and not _stale(out, deps):

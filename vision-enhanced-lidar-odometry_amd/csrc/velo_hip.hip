@@ -155,6 +155,8 @@ struct TargetData {
     std::vector<int> h_tgt_off;
     std::vector<Grid> grids;             // one per distinct gate among iter = 1..f2f_iterations
     float bbox[6] = {0, 0, 0, 0, 0, 0};
+    DevBuf<unsigned long long> dimg;     // direction image (kDimgW x kDimgH nearest-point keys): where the seeds of a round without good predecessors come from
+    bool dimg_built = false;
 };
 
 struct velo_ctx {
@@ -198,6 +200,10 @@ struct velo_ctx {
                                          // CU so that LM workgroups of other pairs in flight find room at once.  Set by the lock-step batch
                                          // driver when several groups share the chip (kAssocPadShared); VELO_ASSOC_LDS_PAD (diagnostics build) fixes it
     bool assoc_lds_pad_fixed = false;
+    int lm_persist = 1;                  // lock-step groups in chain mode: a whole solve is ONE launch (lm_solve_persist_batch_kernel); VELO_LM_PERSIST=0 (diagnostics
+                                         // build): one launch per LM iteration (eval_step_batch_*_kernel)
+    int lm_persist_wgs = 0;              // workgroups per context of that launch (0 = one per virtual block); VELO_LM_PERSIST_WGS (diagnostics build)
+    DevBuf<SolveCtl> solve_ctl;          // its per-context control blocks (owned by the first context of a group; zero between launches)
     int lm_lean = -1;                    // lean fused LM kernel in lock-step groups: -1 = when several groups share the chip; VELO_LM_LEAN (diagnostics build) forces 0 / 1
     // chain mode: a whole frame_to_frame as ONE chain of launches (pose scalars of the next round and the solve summaries stay on the device)
     int patch_order = 1;                 // query list in patch order (VELO_PATCH_ORDER=0: the reference's ring order)
@@ -221,6 +227,10 @@ struct velo_ctx {
     DevBuf<velo_residual_stats> stat_out;
     int assoc_lane = 0;                  // VELO_ASSOC_LANE=1: rounds that start from seeds use the lane kernel (A/B; slower, see assoc_lane_body)
     int seed_rounds = 0;                 // association rounds since the seeds were last cleared
+    int dimg_seeds = 0;                  // VELO_DIMG_SEEDS=1 (diagnostics build): seeds of iteration-1 rounds from the target's direction image (seed_kernel).
+                                         // Measured, exact, NOT a gain: C2 rounds 95 / 80 / 78 -> 90 / 86 / 85 us (the cold round's cost is the true
+                                         // second-ring distance of the far queries, not poor seeds; the seed launch costs 7 us), 8 pairs in flight
+                                         // 3,305 -> 3,354 pairs/s (noise); 2M-point map 1,233 -> 1,050 (0.35-degree buckets are 4 cells wide there)
     int chain_calls = 0;                 // calls that went down the chain
     int chain_margin = 2;                // LM launches enqueued per solve beyond the previous call's count (VELO_CHAIN_MARGIN)
     int chain_misses = 0;                // calls whose chain was too short and were repeated by the host-driven path
@@ -352,7 +362,8 @@ struct velo_ctx {
     struct TimedLaunch { hipEvent_t a = nullptr, b = nullptr; const char* name = nullptr; uint64_t bytes = 0; };
     std::vector<TimedLaunch> klog;
     int klog_used = 0;
-    struct KernelAcc { const char* name; double ms; int64_t launches; uint64_t bytes; };
+    struct KernelAcc { const char* name; double ms; int64_t launches, sampled; uint64_t bytes; };   // ms: of the `sampled` bracketed launches
+    int timing_every = 8;                    // level 2 brackets every n-th launch of a kernel name (a bracket costs ~5 us of queue time); level 3: every launch
     std::vector<KernelAcc> kacc;
     const char* lm_kernel_name = nullptr;    // the LM kernel the last call launched (its evaluations' algorithmic bytes are known only afterwards)
 };
@@ -360,14 +371,34 @@ struct velo_ctx {
 namespace {
 
 // ---- per-kernel launch times (velo_set_timing(ctx, 2)) ----
-void kacc_add(velo_ctx* c, const char* name, double ms, int64_t launches, uint64_t bytes) {
-    if (!name) return;
-    for (auto& a : c->kacc) if (a.name == name || std::strcmp(a.name, name) == 0) { a.ms += ms; a.launches += launches; a.bytes += bytes; return; }
-    c->kacc.push_back({name, ms, launches, bytes});
+velo_ctx::KernelAcc* kacc_find(velo_ctx* c, const char* name) {
+    for (auto& a : c->kacc) if (a.name == name || std::strcmp(a.name, name) == 0) return &a;
+    c->kacc.push_back({name, 0.0, 0, 0, 0});
+    return &c->kacc.back();
 }
-// an event pair for the launch that follows, or null when the context does not time every launch (or the call's log is full)
+void kacc_add(velo_ctx* c, const char* name, double ms, int64_t launches, int64_t sampled, uint64_t bytes) {
+    if (!name) return;
+    velo_ctx::KernelAcc* a = kacc_find(c, name);
+    a->ms += ms; a->launches += launches; a->sampled += sampled; a->bytes += bytes;
+}
+// Association launches keep their own event pool (velo_summary::assoc_kernel_ms): bracketed one by one at levels 1 and 3, sampled like
+// every other kernel at level 2 (where the launch is counted here).  -> bracket this launch?
+bool assoc_bracket(velo_ctx* c, const char* name, uint64_t bytes) {
+    if (c->timing <= 0) return false;
+    if (c->timing == 1) return true;
+    velo_ctx::KernelAcc* a = kacc_find(c, name);
+    a->launches++; a->bytes += bytes;
+    return c->timing >= 3 || (a->launches - 1) % c->timing_every == 0;
+}
+// An event pair for the launch that follows, or null.  Every launch of the kernel is COUNTED (with its bytes); every timing_every-th
+// one is bracketed -- a bracket makes the runtime put two more packets into the queue, ~5 us of a chain whose launches take 20 us --
+// and velo_get_kernel_times scales the bracketed time up by launches / sampled.
 velo_ctx::TimedLaunch* klog_slot(velo_ctx* c, const char* name, uint64_t bytes) {
-    if (c->timing < 2 || c->klog_used >= 1024) return nullptr;
+    if (c->timing < 2 || !name) return nullptr;
+    velo_ctx::KernelAcc* a = kacc_find(c, name);
+    a->launches++; a->bytes += bytes;
+    const int every = c->timing >= 3 ? 1 : c->timing_every;
+    if ((a->launches - 1) % every != 0 || c->klog_used >= 1024) return nullptr;
     if (c->klog_used >= (int)c->klog.size()) {
         velo_ctx::TimedLaunch t;
         if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
@@ -689,19 +720,38 @@ void launch_eval(velo_ctx* c, EvalArgs A, const EvalPlan& E) {
 }
 
 // warm-start seeds of the tube kernel: cleared (index -1) on the first round after a new source or target
-int attach_seeds(velo_ctx* c, AssocOut* out) {
+bool direct_round(const velo_ctx* c, int nq, bool partial);
+// Does this round take its seeds from the target's direction image (seed_kernel ahead of the search)?  The rounds of the first f2f
+// iteration do (wide gate; the pose has just been guessed or moved by a whole solve) and any round without predecessors; the
+// rounds of later iterations move the pose by millimetres and keep the previous winners.  Whole query list, tube kernel only.
+bool seeds_from_image(const velo_ctx* c, int iter, bool partial) {
+    if (!c->dimg_seeds || !c->warm_start || partial || !c->T->dimg_built || c->shard_world != 1) return false;
+    if (c->assoc_variant >= 0 && c->assoc_variant != 5) return false;
+    if (direct_round(c, c->n_q, partial)) return false;
+    return iter == 1 || !c->prev_ready || c->seed_rounds == 0;
+}
+int attach_seeds(velo_ctx* c, AssocOut* out, bool image_seeds = false, int* had_prev = nullptr) {
     out->prev_a = nullptr; out->prev_b = nullptr; out->prev_r = nullptr;
+    if (had_prev) *had_prev = 0;
     if (!c->warm_start) return VELO_OK;
     const size_t nq = (size_t)std::max(c->n_q, 1);
     if (!c->prev_ready) {
         VELO_TRY(c->prev_a.reserve(nq)); VELO_TRY(c->prev_b.reserve(nq)); VELO_TRY(c->prev_r.reserve(nq));
-        HIP_TRY(hipMemsetAsync(c->prev_a.p, 0xff, sizeof(float4) * nq, c->stream));
-        HIP_TRY(hipMemsetAsync(c->prev_b.p, 0xff, sizeof(float4) * nq, c->stream));
+        if (!image_seeds) {                                          // (the seed kernel writes every entry itself)
+            HIP_TRY(hipMemsetAsync(c->prev_a.p, 0xff, sizeof(float4) * nq, c->stream));
+            HIP_TRY(hipMemsetAsync(c->prev_b.p, 0xff, sizeof(float4) * nq, c->stream));
+        }
         c->prev_ready = true;
         c->seed_rounds = 0;
-    }
+    } else if (had_prev) *had_prev = 1;
     out->prev_a = c->prev_a.p; out->prev_b = c->prev_b.p; out->prev_r = c->prev_r.p;
     return VELO_OK;
+}
+void fill_seed_args(const velo_ctx* c, SeedArgs* A, const PoseScalars& S, const PoseRecord* P_dev, const int* chain_fail, int qb, int qe, const AssocOut& out, int had_prev) {
+    A->P = S; A->P_dev = P_dev; A->chain_fail = P_dev ? chain_fail : nullptr;
+    A->qpts = c->qpts; A->q_begin = qb; A->q_end = qe;
+    A->dimg = c->T->dimg.p; A->tgt = c->T->tgt.p; A->ring_of = c->T->tgt_ring_of.p; A->first_point = c->T->tgt_first_point;
+    A->prev_a = out.prev_a; A->prev_b = out.prev_b; A->prev_r = out.prev_r; A->has_prev = had_prev;
 }
 
 // the asker list of a tube launch on a density-shrunk grid (see assoc_asker_kernel); enable = this launch may defer its askers
@@ -757,13 +807,22 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p + c->nv_idx; out.dbg = c->dbg.p; out.wg_times = nullptr;
         out.first_ring = c->T->tgt_first_ring; out.first_point = c->T->tgt_first_point; out.partial = partial ? c->partials_rec.p : nullptr;
         out.n_valid_next = nullptr;
-        VELO_TRY(attach_seeds(c, &out));
+        const bool image_seeds = seeds_from_image(c, iter, partial) && !c->debug_skip && c->tube_map < 0;
+        int had_prev = 0;
+        VELO_TRY(attach_seeds(c, &out, image_seeds, &had_prev));
         VELO_TRY(attach_askers(c, &out, false));
         const bool direct = direct_round(c, qe - qb, partial);
         const bool lane = !direct && lane_round(c, G, partial);
+        if (image_seeds && out.prev_a) {                           // seeds of this round: direction image (+ the previous winners), one thread per query
+            SeedArgs SA;
+            fill_seed_args(c, &SA, S, P_dev, c->chain_fail.p, qb, qe, out, had_prev);
+            VELO_LAUNCH_T(c, "seed_kernel", 132ull * (uint64_t)(qe - qb), seed_kernel, dim3(cdiv(qe - qb, 256)), dim3(256), 0, c->stream, SA);
+        }
         if (c->debug_skip & 32) { VELO_TRY(c->wg_times.reserve((size_t)16 * cdiv(qe - qb, 64) + 2)); HIP_TRY(hipMemsetAsync(c->wg_times.p, 0, sizeof(unsigned long long) * ((size_t)16 * cdiv(qe - qb, 64) + 2), c->stream)); out.wg_times = c->wg_times.p; c->wg_times_n = cdiv(qe - qb, 64); }
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-        if (c->timing) {
+        const char* assoc_name = direct ? "assoc_direct_kernel" : "assoc_search_v5_kernel";
+        const uint64_t assoc_b = 12ull * (uint64_t)(qe - qb) + 12ull * (uint64_t)c->T->n_tgt + 28ull * (uint64_t)(qe - qb);
+        if (assoc_bracket(c, assoc_name, assoc_b)) {
             if (c->assoc_events_used >= 256) c->assoc_events_used = 0;      // standalone velo_associate calls: recycle
             if (c->assoc_events_used >= (int)c->assoc_events.size()) {
                 hipEvent_t a, b;
@@ -771,8 +830,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 c->assoc_events.emplace_back(a, b);
                 c->assoc_event_info.emplace_back(nullptr, 0);
             }
-            c->assoc_event_info[(size_t)c->assoc_events_used] = {direct ? "assoc_direct_kernel" : "assoc_search_v5_kernel",
-                                                                 12ull * (uint64_t)(qe - qb) + 12ull * (uint64_t)c->T->n_tgt + 28ull * (uint64_t)(qe - qb)};
+            c->assoc_event_info[(size_t)c->assoc_events_used] = {assoc_name, assoc_b};
             ev = &c->assoc_events[c->assoc_events_used++];
         }
         // The tube kernel is launched with hipExtLaunchKernelGGL, which stamps the two events with the KERNEL's own start and
@@ -866,7 +924,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 // queries go on a list and are searched by a second launch.  Measured per round on the 2M-point map, list vs in place: cold 399 vs
                 // 688 us; seeded rounds 237 / 326 / 246 / 183 / 160 vs 230 / 272 / 207 / 138 / 116 us (few askers: the second launch only adds its
                 // own ~40 us) -- hence the cold round only.
-                const bool queue = asker_rows < (1 << 30) && variant == 5 && !c->debug_skip && c->seed_rounds == 0;
+                const bool queue = asker_rows < (1 << 30) && variant == 5 && !c->debug_skip && c->seed_rounds == 0 && !image_seeds;
                 VELO_TRY(attach_askers(c, &out, queue));
                 hipEvent_t ev_stop = ev ? ev->second : nullptr;
                 if (out.ask_list && ev) ev_stop = nullptr;              // the bracket closes behind the asker launch
@@ -962,13 +1020,13 @@ int read_assoc_timing(velo_ctx* c, velo_summary* S) {
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, c->assoc_events[k].first, c->assoc_events[k].second));
         ms += t;
-        if (c->timing >= 2 && k < (int)c->assoc_event_info.size()) kacc_add(c, c->assoc_event_info[(size_t)k].first, t, 1, c->assoc_event_info[(size_t)k].second);
+        if (c->timing >= 2 && k < (int)c->assoc_event_info.size()) kacc_add(c, c->assoc_event_info[(size_t)k].first, t, 0, 1, 0);   // (counted when enqueued)
     }
     if (S) S->assoc_kernel_ms = ms;
     for (int k = 0; k < c->klog_used; k++) {
         float t = 0.f;
         HIP_TRY(hipEventElapsedTime(&t, c->klog[(size_t)k].a, c->klog[(size_t)k].b));
-        kacc_add(c, c->klog[(size_t)k].name, t, 1, c->klog[(size_t)k].bytes);
+        kacc_add(c, c->klog[(size_t)k].name, t, 0, 1, 0);       // (the launch and its bytes were counted when it was enqueued)
     }
     c->klog_used = 0;
     return VELO_OK;
@@ -1177,6 +1235,21 @@ int do_solve(velo_ctx* c, const double* x_in, double x_out[6], velo_solve_summar
     return VELO_OK;
 }
 
+// the target's direction image (seed_kernel): one fill + one atomicMin per point, on the context's stream
+int build_direction_image(velo_ctx* c) {
+    c->T->dimg_built = false;
+    if (!c->dimg_seeds || !c->warm_start) return VELO_OK;
+    VELO_TRY(c->T->dimg.reserve((size_t)kDimgW * kDimgH));
+    HIP_TRY(hipMemsetAsync(c->T->dimg.p, 0xff, sizeof(unsigned long long) * (size_t)kDimgW * kDimgH, c->stream));
+    const int n = c->T->n_tgt;
+    if (n > 0) {
+        VELO_LAUNCH_T(c, "dimg_build_kernel", 24ull * (uint64_t)n, dimg_build_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const float4*)c->T->tgt.p, n, c->T->dimg.p);
+        HIP_TRY(hipGetLastError());
+    }
+    c->T->dimg_built = true;
+    return VELO_OK;
+}
+
 // common tail of every way a target enters the context: ring table, ring ids, bounding box, grid
 // target_finalize = target_finalize_begin (everything up to the request for the bounding box, no host wait) + target_finalize_end (the
 // one synchronisation of set_target, then the index).  The batch driver begins all contexts of a group before it ends the first,
@@ -1202,6 +1275,7 @@ int target_finalize_begin(velo_ctx* c) {
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(c->h_int + 8, c->bbox_keys.p, sizeof(init), hipMemcpyDeviceToHost, c->stream));
+    VELO_TRY(build_direction_image(c));
     return VELO_OK;
 }
 int target_finalize_end(velo_ctx* c) {
@@ -1357,6 +1431,7 @@ int velo_create(velo_ctx** out, int device) {
         if (const char* e = dev_env("VELO_XCD_MAP")) c->xcd_map = atoi(e);
         if (const char* e = dev_env("VELO_TUBE_MAP")) c->tube_map = atoi(e);
         if (const char* e = dev_env("VELO_WARM_START")) c->warm_start = atoi(e);
+        if (const char* e = dev_env("VELO_DIMG_SEEDS")) c->dimg_seeds = atoi(e);
         if (const char* e = dev_env("VELO_SMALL_SOLVE")) c->small_solve = atoi(e);
         if (const char* e = dev_env("VELO_LM_MERGED")) c->lm_merged = atoi(e);
         if (const char* e = dev_env("VELO_LM_FUSED")) c->lm_fused = atoi(e);
@@ -1371,6 +1446,8 @@ int velo_create(velo_ctx** out, int device) {
         if (const char* e = getenv("VELO_CHAIN_MARGIN")) { c->chain_margin = std::max(atoi(e), 0); c->chain_margin_fixed = true; }
         if (const char* e = dev_env("VELO_ASSOC_LDS_PAD")) { c->assoc_lds_pad = std::max(atoi(e), 0); c->assoc_lds_pad_fixed = true; }
         if (const char* e = dev_env("VELO_LM_LEAN")) c->lm_lean = atoi(e);
+        if (const char* e = dev_env("VELO_LM_PERSIST")) c->lm_persist = atoi(e);
+        if (const char* e = dev_env("VELO_LM_PERSIST_WGS")) c->lm_persist_wgs = std::max(atoi(e), 0);
         if (const char* e = dev_env("VELO_ASKER_ROWS")) c->asker_rows = atoi(e);
         if (const char* e = dev_env("VELO_PERSISTENT_WGS")) c->persistent_wgs = std::max(atoi(e), 1);
         if (const char* e = getenv("VELO_BATCH_LOCKSTEP")) c->batch_lockstep = atoi(e);
@@ -1455,6 +1532,7 @@ int velo_destroy(velo_ctx* c) {
     if (c->h_batch) (void)hipHostFree(c->h_batch);
     c->batch_items.release(); c->batch_states.release(); c->batch_x.release();
     c->ask_count.release(); c->ask_list.release(); c->ask_keys.release(); c->ask_rings.release();
+    c->solve_ctl.release();
     c->batch_tickets.release(); c->batch_pose.release(); c->batch_logs.release(); c->batch_fail.release(); c->pose_rec.release(); c->solve_log.release(); c->chain_fail.release();
     if (c->h_log) (void)hipHostFree(c->h_log);
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -1495,7 +1573,7 @@ int velo_get_params(const velo_ctx* c, velo_params* p) {
 
 int velo_set_timing(velo_ctx* c, int enable) {
     if (!c) return fail(VELO_ERR_INVALID, "null ctx");
-    c->timing = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
+    c->timing = enable < 0 ? 0 : (enable > 3 ? 3 : enable);
     return VELO_OK;
 }
 
@@ -1780,6 +1858,7 @@ int velo_cache_load(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t as_t
     HIP_TRY(hipMemcpyAsync(G.sring.p, e.grid.sring.p, sizeof(int) * ns, hipMemcpyDeviceToDevice, c->stream));
     G.d = e.grid.d; G.gate = e.grid.gate; G.h = e.grid.h; G.built = true;
     std::memcpy(c->T->bbox, e.bbox, sizeof(c->T->bbox));
+    VELO_TRY(build_direction_image(c));
     HIP_TRY(hipStreamSynchronize(c->stream));                                              // h_tgt_off (pageable) has been read; the entry may be evicted
     c->have_target = true;
     return VELO_OK;
@@ -2322,7 +2401,7 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
         note_evals(c, k, L.evals);
         S->eval_kernel_launches += L.evals;
         S->algorithmic_bytes += (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull);
-        if (c->timing >= 2) kacc_add(c, c->lm_kernel_name, 0.0, 0, (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull));
+        if (c->timing >= 2) kacc_add(c, c->lm_kernel_name, 0.0, 0, 0, (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull));
         if (S->n_solves < VELO_MAX_SOLVES) S->solves[S->n_solves] = ss;
         S->n_solves++;
     }
@@ -2340,7 +2419,9 @@ int velo_get_kernel_times(velo_ctx* c, velo_kernel_time* out, int32_t capacity, 
     for (int i = 0; out && i < capacity && i < (int)c->kacc.size(); i++) {
         std::memset(&out[i], 0, sizeof(out[i]));
         std::snprintf(out[i].name, sizeof(out[i].name), "%s", c->kacc[(size_t)i].name);
-        out[i].ms = c->kacc[(size_t)i].ms; out[i].launches = c->kacc[(size_t)i].launches; out[i].algorithmic_bytes = c->kacc[(size_t)i].bytes;
+        const velo_ctx::KernelAcc& a = c->kacc[(size_t)i];
+        out[i].sampled = a.sampled; out[i].launches = a.launches; out[i].algorithmic_bytes = a.bytes;
+        out[i].ms = a.sampled > 0 ? a.ms * (double)a.launches / (double)a.sampled : 0.0;
     }
     if (reset) c->kacc.clear();
     return VELO_OK;
@@ -2437,7 +2518,7 @@ static bool batch_can_lockstep(velo_ctx** ctxs, int n, bool targets_follow = fal
 // ---- the same association round of several contexts in ONE launch (lock-step batch driver) ---------------------------------------
 // Host-side preparation of one context's round for the tube kernel, exactly what do_associate does before its launch.
 // *groups = 0 when the context has no queries.
-static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs* A, int* groups, bool* asker, bool* lane, bool* direct) {
+static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs* A, int* groups, bool* asker, bool* lane, bool* direct, SeedArgs* SA = nullptr, bool* seeded = nullptr) {
     if (!c->have_target || !c->have_source) return fail(VELO_ERR_STATE, "associate needs set_target and set_source first");
     if (query_list_stale(c)) VELO_TRY(build_query_list(c));
     Grid* G = grid_for_iter(c, iter);
@@ -2461,10 +2542,14 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
     AssocOut& out = A->out;
     out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p + c->nv_idx; out.dbg = c->dbg.p; out.wg_times = nullptr;
     out.first_ring = c->T->tgt_first_ring; out.first_point = c->T->tgt_first_point; out.partial = nullptr;
-    VELO_TRY(attach_seeds(c, &out));
+    const bool image_seeds = SA != nullptr && seeds_from_image(c, iter, false);
+    int had_prev = 0;
+    VELO_TRY(attach_seeds(c, &out, image_seeds, &had_prev));
+    if (seeded) *seeded = image_seeds && out.prev_a != nullptr;
+    if (image_seeds && out.prev_a) fill_seed_args(c, SA, A->P, nullptr, nullptr, qb, qe, out, had_prev);
     *direct = direct_round(c, qe - qb, false);
     *lane = !*direct && lane_round(c, G, false);
-    const bool cold = c->seed_rounds == 0;
+    const bool cold = c->seed_rounds == 0 && !image_seeds;
     if (out.prev_a) c->seed_rounds++;
     {
         const int reach0 = (int)std::ceil(std::sqrt(std::max(gate_of_iter(c->P, 1), 0.0)) / (G->h * 0.999));
@@ -2511,15 +2596,21 @@ static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::arr
         const int m = std::min(kAssocBatchMax, n - b);
         AssocBatch B;
         std::memset(&B, 0, sizeof(B));
-        int gmax = 0, k = 0, first = -1;
+        SeedBatch SB;
+        std::memset(&SB, 0, sizeof(SB));
+        int gmax = 0, k = 0, first = -1, n_seeded = 0;
         bool any_asker = false, all_lane = true, all_direct = true;
         int nq_max = 0;
         for (int i = b; i < b + m; i++) {
-            int groups = 0; bool asker = false, lane = false, direct = false;
-            VELO_TRY(prepare_assoc_v5(ctxs[i], xs[(size_t)i].data(), iter, &B.item[k], &groups, &asker, &lane, &direct));
+            int groups = 0; bool asker = false, lane = false, direct = false, seeded = false;
+            VELO_TRY(prepare_assoc_v5(ctxs[i], xs[(size_t)i].data(), iter, &B.item[k], &groups, &asker, &lane, &direct, &SB.item[n_seeded], &seeded));
             if (groups > 0) { all_lane = all_lane && lane; all_direct = all_direct && direct; nq_max = std::max(nq_max, B.item[k].q_end - B.item[k].q_begin); }
             ctxs[i]->have_corr = true;
             if (pose_dev) { B.item[k].P_dev = pose_dev + i; B.item[k].chain_fail = fail_dev + i; }
+            if (seeded && groups > 0) {
+                if (pose_dev) { SB.item[n_seeded].P_dev = pose_dev + i; SB.item[n_seeded].chain_fail = fail_dev + i; }
+                n_seeded++;
+            }
             if (groups == 0) continue;                                  // no queries: nothing to launch for it
             if (first < 0) first = i;
             gmax = std::max(gmax, groups); any_asker = any_asker || asker; k++;
@@ -2527,7 +2618,11 @@ static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::arr
         if (k == 0) continue;
         velo_ctx* c = ctxs[first];
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-        if (c->timing) {
+        uint64_t bytes = 0;                                           // B_assoc of every context this launch serves
+        for (int j = 0; j < k; j++) bytes += 40ull * (uint64_t)(B.item[j].q_end - B.item[j].q_begin);
+        for (int i = b; i < b + m; i++) { int q0, q1; q_range(ctxs[i], &q0, &q1); if (q1 > q0) bytes += 12ull * (uint64_t)ctxs[i]->T->n_tgt; }
+        const char* assoc_name = all_direct ? "assoc_direct_batch_kernel" : "assoc_search_v5_batch_kernel";
+        if (assoc_bracket(c, assoc_name, bytes)) {
             if (c->assoc_events_used >= 256) c->assoc_events_used = 0;
             if (c->assoc_events_used >= (int)c->assoc_events.size()) {
                 hipEvent_t e0, e1;
@@ -2535,13 +2630,16 @@ static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::arr
                 c->assoc_events.emplace_back(e0, e1);
                 c->assoc_event_info.emplace_back(nullptr, 0);
             }
-            uint64_t bytes = 0;                                       // B_assoc of every context this launch serves
-            for (int j = 0; j < k; j++) bytes += 40ull * (uint64_t)(B.item[j].q_end - B.item[j].q_begin);
-            for (int i = b; i < b + m; i++) { int q0, q1; q_range(ctxs[i], &q0, &q1); if (q1 > q0) bytes += 12ull * (uint64_t)ctxs[i]->T->n_tgt; }
-            c->assoc_event_info[(size_t)c->assoc_events_used] = {all_direct ? "assoc_direct_batch_kernel" : "assoc_search_v5_batch_kernel", bytes};
+            c->assoc_event_info[(size_t)c->assoc_events_used] = {assoc_name, bytes};
             ev = &c->assoc_events[c->assoc_events_used++];
         }
         launched[(size_t)first] = 1;
+        if (n_seeded > 0) {                                          // this round's seeds for the contexts that take them from their target's direction image
+            int nq_seed = 0;
+            uint64_t sbytes = 0;
+            for (int j = 0; j < n_seeded; j++) { nq_seed = std::max(nq_seed, SB.item[j].q_end - SB.item[j].q_begin); sbytes += 132ull * (uint64_t)(SB.item[j].q_end - SB.item[j].q_begin); }
+            VELO_LAUNCH_T(c, "seed_batch_kernel", sbytes, seed_batch_kernel, dim3(cdiv(nq_seed, 256), n_seeded), dim3(256), 0, c->stream, SB);
+        }
         bool all_queue = true;                                       // deferral is compiled in or out: all contexts of the launch or none
         for (int j = 0; j < k; j++) all_queue = all_queue && B.item[j].out.ask_list != nullptr;
         if (!all_queue) {
@@ -2682,6 +2780,17 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                     HIP_TRY(hipGetLastError());
                     continue;
                 }
+                if (c0->lm_persist && c0->lm_fused) {                  // the whole solve of every context of the group: one launch, no prediction
+                    if (c0->solve_ctl.cap < (size_t)n) {
+                        VELO_TRY(c0->solve_ctl.reserve((size_t)n));
+                        HIP_TRY(hipMemsetAsync(c0->solve_ctl.p, 0, sizeof(SolveCtl) * c0->solve_ctl.cap, bs));
+                    }
+                    c0->lm_kernel_name = "lm_solve_persist_batch_kernel";
+                    const int wgs = c0->lm_persist_wgs > 0 ? std::min(c0->lm_persist_wgs, nb_max) : nb_max;
+                    VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, lm_solve_persist_batch_kernel, dim3(wgs, n), dim3(kEvalThreads), 0, bs, Q, d_items, c0->solve_ctl.p, max_iters + 2);
+                    HIP_TRY(hipGetLastError());
+                    continue;
+                }
                 VELO_LAUNCH_T(c0, "lm_begin_batch_kernel", 0, lm_begin_batch_kernel, dim3(n), dim3(64), 0, bs, d_items);
                 if (c0->lm_fused) c0->lm_kernel_name = lean ? "eval_step_batch_lean_kernel" : "eval_step_batch_kernel";
                 for (int k = 0; k < K; k++) {
@@ -2722,7 +2831,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                     note_evals(c, k, L.evals);
                     Si->eval_kernel_launches += L.evals;
                     Si->algorithmic_bytes += (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 224ull);
-                    if (c0->timing >= 2) kacc_add(c0, c0->lm_kernel_name, 0.0, 0, (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 224ull));   // the group's launches are logged on its first context
+                    if (c0->timing >= 2) kacc_add(c0, c0->lm_kernel_name, 0.0, 0, 0, (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 224ull));   // the group's launches are logged on its first context
                     Si->solves[Si->n_solves++] = ss;
                 }
                 c->last_n_valid = h_states[i].n_valid;
@@ -2795,9 +2904,10 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                         continue;
                     }
                     if (fused) {
-                        if (nbv_max > 0) hipLaunchKernelGGL(eval_visual_batch_kernel, dim3(nbv_max, n), dim3(kEvalThreads), 0, bs, (const LMBatchItem*)c0->batch_items.p);
-                        if (lean) hipLaunchKernelGGL(eval_step_batch_lean_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p, c0->batch_tickets.p);
-                        else hipLaunchKernelGGL(eval_step_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p, c0->batch_tickets.p);
+                        c0->lm_kernel_name = lean ? "eval_step_batch_lean_kernel" : "eval_step_batch_kernel";
+                        if (nbv_max > 0) VELO_LAUNCH_T(c0, "eval_visual_batch_kernel", 0, eval_visual_batch_kernel, dim3(nbv_max, n), dim3(kEvalThreads), 0, bs, (const LMBatchItem*)c0->batch_items.p);
+                        if (lean) VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_lean_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p, c0->batch_tickets.p);
+                        else VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p, c0->batch_tickets.p);
                         continue;
                     }
                     if (nb_max > 0) hipLaunchKernelGGL(eval_icp_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, (const LMBatchItem*)c0->batch_items.p);
@@ -2830,6 +2940,10 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                 note_evals(c, solve_idx, ss.evaluations);
                 Si->eval_kernel_launches += st.evals;
                 Si->algorithmic_bytes += (uint64_t)ss.evaluations * (36ull * (uint64_t)ss.n_icp_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull);
+                if (c0->timing >= 2 && fused) {                     // the evaluations' bytes: point-to-plane rows to the fused sweep + step, visual blocks to their sweep
+                    kacc_add(c0, c0->lm_kernel_name, 0.0, 0, 0, (uint64_t)ss.evaluations * (36ull * (uint64_t)ss.n_icp_valid + 224ull));
+                    if (ss.n_visual_blocks > 0) kacc_add(c0, "eval_visual_batch_kernel", 0.0, 0, 0, (uint64_t)ss.evaluations * 32ull * (uint64_t)ss.n_visual_blocks);
+                }
                 if (Si->n_solves < VELO_MAX_SOLVES) Si->solves[Si->n_solves] = ss;
                 Si->n_solves++;
             }

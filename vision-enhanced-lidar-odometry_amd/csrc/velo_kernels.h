@@ -1664,6 +1664,96 @@ assoc_asker_batch_kernel(AssocBatch B) {
     assoc_asker_body(a.P, a.P_dev, a.chain_fail, a.G, a.qpts, a.tgt_pad, a.tgt_off, a.gate_bits, a.norm_cond, a.h_safe, a.out, a.want_aux, (int)blockIdx.x, n_waves);
 }
 
+// ---- seeds from the target's direction image -----------------------------------------------------------------------------------
+// A round's search starts from two candidates per query ("seeds", AssocOut::prev_*): any real target points will do -- the tube kernel
+// recomputes their distances and the result is exact whatever they are -- but the tighter the second-best bound they give, the fewer
+// rows, candidates and asking queries the round has.  The previous round's winners are good seeds while the pose moves by millimetres
+// (rounds 4-6 of a call); the FIRST round has none, and rounds 2-3 follow solves that moved the pose by centimetres to a metre.
+// For those rounds the seeds come from the target itself: a scan (and a map in its newest pose's frame) is a range image around the
+// origin, so the target point seen in (nearly) the direction of the transformed query lies on (nearly) the same surface.  The
+// direction image is a kDimgW x kDimgH table over (azimuth, elevation) holding, per bucket, the NEAREST point that falls into it
+// (64-bit key: range^2 bits << 32 | local index; built with one atomicMin per target point).  seed_kernel looks the query's bucket and
+// its four neighbours up, adds the previous winners when there are any, and leaves the best two of different rings as the seeds.
+// Only a hash: for clouds that are no range images the seeds are merely poor.  Results never depend on it.
+constexpr int kDimgW = 1024, kDimgH = 256;                      // 0.35 deg x 0.35 deg over +-45 deg of elevation: 2 MB
+__device__ __forceinline__ void dimg_bucket(float x, float y, float z, int* a, int* e) {
+    // camera frame (x right, y down, z forward; kitti.h:100-107): azimuth about the y axis, elevation up positive
+    const float az = atan2f(x, z), el = atan2f(-y, sqrtf(x * x + z * z));
+    int ia = (int)((az + 3.14159265f) * ((float)kDimgW / 6.2831853f)), ie = (int)((el + 0.78539816f) * ((float)kDimgH / 1.5707963f));
+    *a = min(max(ia, 0), kDimgW - 1);
+    *e = min(max(ie, 0), kDimgH - 1);
+}
+__global__ void __launch_bounds__(256)
+dimg_build_kernel(const float4* __restrict__ tgt, int n, unsigned long long* __restrict__ dimg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = tgt[i];
+    if (!(isfinite(p.x) && isfinite(p.y) && isfinite(p.z))) return;
+    int a, e;
+    dimg_bucket(p.x, p.y, p.z, &a, &e);
+    const float r2 = p.x * p.x + p.y * p.y + p.z * p.z;
+    atomicMin(&dimg[e * kDimgW + a], ((unsigned long long)__float_as_uint(r2) << 32) | (unsigned)i);
+}
+struct SeedArgs {
+    PoseScalars P; const PoseRecord* P_dev; const int* chain_fail;
+    const float4* qpts; int q_begin, q_end;
+    const unsigned long long* dimg; const float4* tgt; const int* ring_of;    // direction image, ring-major cloud, global ring of each local point
+    int first_point;
+    float4* prev_a; float4* prev_b; int2* prev_r;
+    int has_prev;                                                              // the arrays hold the previous round's winners (else: uninitialised)
+};
+struct SeedBatch { SeedArgs item[kAssocBatchMax]; };
+struct SeedState { unsigned long long b1, b2; int r1, r2; float x1, y1, z1, x2, y2, z2; int i1, i2; };
+__device__ __forceinline__ void seed_enter(SeedState& t, float qx, float qy, float qz, float x, float y, float z, int idx, int ring, int first_point) {
+    const float d = dist2_f(x, y, z, qx, qy, qz);
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(idx + first_point);
+    if (!(key < t.b2)) return;
+    if (key < t.b1) {
+        if (ring != t.r1) { t.b2 = t.b1; t.r2 = t.r1; t.x2 = t.x1; t.y2 = t.y1; t.z2 = t.z1; t.i2 = t.i1; }
+        t.b1 = key; t.r1 = ring; t.x1 = x; t.y1 = y; t.z1 = z; t.i1 = idx;
+    } else if (ring != t.r1) {
+        t.b2 = key; t.r2 = ring; t.x2 = x; t.y2 = y; t.z2 = z; t.i2 = idx;
+    }
+}
+__device__ __forceinline__ void seed_body(const SeedArgs& A, const int i) {
+    if (i >= A.q_end) return;
+    if (A.chain_fail && *A.chain_fail) return;
+    if (A.P_dev && !A.P_dev->ready) return;                                    // the association launch behind this one raises the chain's flag
+    const PoseScalars& P = A.P_dev ? A.P_dev->P : A.P;
+    float qx, qy, qz;
+    transform_query(P, A.qpts[i], &qx, &qy, &qz);
+    SeedState t;
+    t.b1 = ~0ull; t.b2 = ~0ull; t.r1 = -1; t.r2 = -1; t.x1 = t.y1 = t.z1 = t.x2 = t.y2 = t.z2 = 0.f; t.i1 = -1; t.i2 = -1;
+    if (A.has_prev) {
+        const float4 sa = A.prev_a[i], sb = A.prev_b[i];
+        const int2 sr = A.prev_r[i];
+        if (__float_as_int(sa.w) >= 0) seed_enter(t, qx, qy, qz, sa.x, sa.y, sa.z, __float_as_int(sa.w), sr.x, A.first_point);
+        if (__float_as_int(sb.w) >= 0) seed_enter(t, qx, qy, qz, sb.x, sb.y, sb.z, __float_as_int(sb.w), sr.y, A.first_point);
+    }
+    int a, e;
+    dimg_bucket(qx, qy, qz, &a, &e);
+    // the query's bucket and its four neighbours: all look-ups first, then all gathers, then the (rare) updates -- scalars, no arrays
+    const unsigned long long k0 = A.dimg[e * kDimgW + a], k1 = A.dimg[max(e - 1, 0) * kDimgW + a], k2 = A.dimg[min(e + 1, kDimgH - 1) * kDimgW + a];
+    const unsigned long long k3 = A.dimg[e * kDimgW + ((a + 1) & (kDimgW - 1))], k4 = A.dimg[e * kDimgW + ((a + kDimgW - 1) & (kDimgW - 1))];
+    const int j0 = (k0 == ~0ull) ? 0 : (int)(unsigned)(k0 & 0xffffffffull), j1 = (k1 == ~0ull) ? 0 : (int)(unsigned)(k1 & 0xffffffffull);
+    const int j2 = (k2 == ~0ull) ? 0 : (int)(unsigned)(k2 & 0xffffffffull), j3 = (k3 == ~0ull) ? 0 : (int)(unsigned)(k3 & 0xffffffffull);
+    const int j4 = (k4 == ~0ull) ? 0 : (int)(unsigned)(k4 & 0xffffffffull);
+    const float4 p0 = A.tgt[j0], p1 = A.tgt[j1], p2 = A.tgt[j2], p3 = A.tgt[j3], p4 = A.tgt[j4];
+    const int g0 = A.ring_of[j0], g1 = A.ring_of[j1], g2 = A.ring_of[j2], g3 = A.ring_of[j3], g4 = A.ring_of[j4];
+    if (k0 != ~0ull) seed_enter(t, qx, qy, qz, p0.x, p0.y, p0.z, j0, g0, A.first_point);
+    if (k1 != ~0ull) seed_enter(t, qx, qy, qz, p1.x, p1.y, p1.z, j1, g1, A.first_point);
+    if (k2 != ~0ull) seed_enter(t, qx, qy, qz, p2.x, p2.y, p2.z, j2, g2, A.first_point);
+    if (k3 != ~0ull) seed_enter(t, qx, qy, qz, p3.x, p3.y, p3.z, j3, g3, A.first_point);
+    if (k4 != ~0ull) seed_enter(t, qx, qy, qz, p4.x, p4.y, p4.z, j4, g4, A.first_point);
+    A.prev_a[i] = make_float4(t.x1, t.y1, t.z1, __int_as_float(t.i1));
+    A.prev_b[i] = make_float4(t.x2, t.y2, t.z2, __int_as_float(t.i2));
+    A.prev_r[i] = make_int2(t.r1, t.r2);
+}
+__global__ void __launch_bounds__(256)
+seed_kernel(SeedArgs A) { seed_body(A, A.q_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x)); }
+__global__ void __launch_bounds__(256)
+seed_batch_kernel(SeedBatch B) { const SeedArgs& A = B.item[blockIdx.y]; seed_body(A, A.q_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x)); }
+
 // ---- sparse queries: one wave per query -------------------------------------------------------------------------------------
 // With the reference's own constants (icp_skip = 200, kitti.h:8) a round has 640 queries, 6 m apart along their rings: the 64
 // queries of a tube group share nothing, its tube is 64 separate boxes, and ten workgroups walk them one row chunk after the other
@@ -3030,7 +3120,7 @@ __device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* 
 __device__ __forceinline__ void lm_transition_wave(const LMParams& Q, LMState* sL, const double* E, int lane);
 constexpr int kStepChunk = 128;
 static_assert(kStepChunk * kNumAcc == kScratchDoubles && kStepChunk * kNumAcc % 256 == 0 && kStepChunk % 8 == 0, "chunk geometry");
-template <bool COHERENT = false, int CHUNK = kStepChunk>
+template <bool COHERENT = false, int CHUNK = kStepChunk, bool STATE_COHERENT = false>
 __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __restrict__ Sin, const double* __restrict__ partials, int n_blocks, int first,
                                            const double* __restrict__ x_in, const int* __restrict__ n_valid,
                                            double* __restrict__ s_rows, LMState* sL, LMEvalPoint* s_pt, unsigned long long* trace, int trace_eval,
@@ -3042,7 +3132,11 @@ __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __r
     static_assert(CHUNK % 64 == 0 && CHUNK <= kStepChunk, "chunk geometry");
     constexpr int kPerThread = CHUNK * kNumAcc / 256;
     const int t = threadIdx.x;
-    if (t < (int)(sizeof(LMState) / 8)) reinterpret_cast<unsigned long long*>(sL)[t] = reinterpret_cast<const unsigned long long*>(Sin)[t];
+    // STATE_COHERENT (the one-launch solve): the state was written by ANOTHER workgroup of this launch -- agent-scope loads
+    if (t < (int)(sizeof(LMState) / 8))
+        reinterpret_cast<unsigned long long*>(sL)[t] = STATE_COHERENT
+            ? __hip_atomic_load(reinterpret_cast<const unsigned long long*>(Sin) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+            : reinterpret_cast<const unsigned long long*>(Sin)[t];
     double xin[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     int nv = 0;
     if (first && t == 0) {
@@ -3387,6 +3481,9 @@ __device__ __forceinline__ void eval_step_batch_body(const LMParams& Q, const LM
     const LMBatchItem& it = items[blockIdx.y];
     const int bx = blockIdx.x, nbx = it.nb_icp;
     if (bx >= nbx) return;
+#ifdef VELO_LM_SETPRIO
+    __builtin_amdgcn_s_setprio(VELO_LM_SETPRIO);                      // A/B: the LM chain's waves ahead of other groups' association waves in a SIMD's issue arbitration
+#endif
     const EvalArgs& A = it.A;
     const RowPrefetchT<PRE> f = prefetch_rows<PRE>(A, bx, nbx);
     __shared__ LMEvalPoint s_pt;
@@ -3426,6 +3523,123 @@ __global__ void __launch_bounds__(kEvalThreads) __attribute__((amdgpu_num_vgpr(1
 eval_step_batch_lean_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets) {
     eval_step_batch_body<true, VELO_LEAN_PRE, 64>(Q, items, tickets);
 }
+// ---- a whole solve of a lock-step group in ONE launch ---------------------------------------------------------------------------------
+// A solve used to be one launch per LM iteration: ~48 launches per call and group, each paying the queue's hand-over (4-10 us between
+// two kernels of a queue when four queues are busy), the dispatch, the cold loads of eval point and rows, and -- arriving while other
+// groups' association kernels fill the chip -- the wait for CU slots.  Here the workgroups of a context stay for the whole solve.
+// Work is handed out by TICKET: ticket t = (iteration t / nb, virtual block t % nb); a workgroup takes the next ticket, prefetches
+// that block's rows (they do not depend on the pose), waits until the eval point of its iteration is published, sweeps, publishes the
+// block's partial row and counts itself in; the workgroup that completes an iteration does the transition (lm_advance, same order of
+// sums) and publishes the next eval point -- then everybody takes the next ticket.  A workgroup only ever waits for work whose
+// tickets were drawn BEFORE its own, i.e. for workgroups that are running: no deadlock however few workgroups are resident, and no
+// prediction of the iteration count -- the launch ends when the solve does (kmax bounds it).  Virtual blocks, per-thread rows and
+// the reduction are those of the launch-per-iteration kernels, so every partial row and every sum is bit-identical to them.
+// Everything one workgroup hands to another inside the launch goes through agent-scope accesses (partial rows, state, eval point).
+struct SolveCtl { int ticket, arrived, gen, done, exited, pad0, pad1, pad2; };    // one per context; all zero between launches (the last workgroup out resets it)
+__device__ __forceinline__ int ctl_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ctl_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one ticket's work: block bx of iteration k.  -> 0 = swept, 1 = swept and this workgroup completed the iteration, -1 = the solve is over
+template <int PRE>
+__device__ __forceinline__ int persist_sweep(const EvalArgs& A, SolveCtl* __restrict__ ctl, const int k, const int bx, const int nb,
+                                             LMEvalPoint* s_pt, double* s_scratch, int* s_flag) {
+    const int t = threadIdx.x;
+    const LMEvalPoint* pt = A.pt;
+    const RowPrefetchT<PRE> f = prefetch_rows<PRE>(A, bx, nb);
+    // wait for the eval point of iteration k (generation k + 1), or for the end of the solve
+    if (t == 0) {
+        int fl = 0;
+        for (;;) {
+            if (ctl_load(&ctl->done)) { fl = 1; break; }
+            if (ctl_load(&ctl->gen) > k) break;
+            __builtin_amdgcn_s_sleep(2);
+        }
+        *s_flag = fl;
+    }
+    __syncthreads();
+    const int over = *s_flag;
+    __syncthreads();
+    if (over) return -1;
+    if (t < (int)(sizeof(LMEvalPoint) / 8))
+        reinterpret_cast<unsigned long long*>(s_pt)[t] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(pt) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    double acc[kNumAcc];
+#ifndef VELO_T2
+    sweep_rows<true, PRE>(A, f, *s_pt, bx, nb, acc);
+#else
+    for (int q = 0; q < kNumAcc; q++) acc[q] = f.p[0].x;
+#endif
+    block_reduce_store<true>(acc, A.partials + (size_t)bx * kNumAcc, s_scratch);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      // this thread's row entries have been written through
+    __syncthreads();
+    if (t == 0) *s_flag = __hip_atomic_fetch_add(&ctl->arrived, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb - 1 ? 1 : 0;
+    __syncthreads();
+    const int last = *s_flag;
+    __syncthreads();
+    return last;
+}
+// the transition of the one-launch solve as a real function: inlined into the ticket loop it drives the whole kernel over its register
+// budget (the sweep would spill); as a call it costs the launch a stack frame -- once per solve, not once per LM iteration
+__device__ __attribute__((noinline)) void persist_advance(const LMParams* Q, const LMBatchItem* it, int first, double* s_scratch, LMState* sL, LMEvalPoint* s_pt) {
+    lm_advance<true, 64, true>(*Q, it->S, it->A.partials, it->n_rows, first, it->xd, it->n_valid, s_scratch, sL, s_pt, nullptr, 0, nullptr, it->pose_out, it->log);
+}
+template <int PRE>
+__device__ __forceinline__ void lm_solve_persist_body(const LMParams& Q, const LMBatchItem* __restrict__ item, SolveCtl* __restrict__ ctl, const int kmax, const int n_wgs) {
+    __shared__ LMEvalPoint s_pt;
+    __shared__ LMState sL;
+    __shared__ double s_scratch[64 * kNumAcc];
+    __shared__ int s_ticket, s_flag;
+    const int t = threadIdx.x;
+    bool running = true;
+    while (running) {
+        // The item is re-read (scalar loads) in every round of the loop through a pointer the compiler cannot see through: hoisted out of
+        // the loop its ~40 fields stay live across the sweep and the transition, and the kernel spills 100+ registers.
+        const LMBatchItem* itp = item;
+        asm volatile("" : "+s"(itp));
+        const LMBatchItem& it = *itp;
+        const EvalArgs& A = it.A;
+        const int nb = it.nb_icp;
+        LMEvalPoint* pt = const_cast<LMEvalPoint*>(A.pt);
+        if (t == 0) s_ticket = __hip_atomic_fetch_add(&ctl->ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int tk = s_ticket;                                          // ticket 0 starts the solve; ticket 1 + k nb + bx = block bx of iteration k
+        __syncthreads();
+        const int k = (tk - 1) / nb, bx = (tk - 1) - k * nb;
+        int advance = 0;                                                  // this workgroup runs lm_advance: 1 = start of the solve, 2 = it completed iteration k
+        if (tk == 0) advance = 1;
+        else if (k >= kmax) running = false;
+        else {
+            const int r = persist_sweep<PRE>(A, ctl, k, bx, nb, &s_pt, s_scratch, &s_flag);
+            if (r < 0) running = false;
+            else if (r > 0) advance = 2;
+        }
+        if (advance) {                                                    // (workgroup-uniform)
+            if (advance == 2 && t == 0) ctl_store(&ctl->arrived, 0);
+            // start: what lm_begin_kernel does (state reset, eval point 0); else the transition over this iteration's partial rows
+#ifndef VELO_T1
+            persist_advance(&Q, itp, advance == 1 ? 1 : 0, s_scratch, &sL, &s_pt);
+#endif
+            if (t < (int)(sizeof(LMState) / 8)) __hip_atomic_store(reinterpret_cast<unsigned long long*>(it.S) + t, reinterpret_cast<const unsigned long long*>(&sL)[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if (t >= 64 && t < 64 + (int)(sizeof(LMEvalPoint) / 8)) __hip_atomic_store(reinterpret_cast<unsigned long long*>(pt) + (t - 64), reinterpret_cast<const unsigned long long*>(&s_pt)[t - 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0) {
+                if (sL.done) ctl_store(&ctl->done, 1);
+                ctl_store(&ctl->gen, advance == 1 ? 1 : k + 2);
+            }
+            __syncthreads();
+        }
+    }
+    // the last workgroup out leaves the control block as it found it
+    __syncthreads();
+    if (t == 0 && __hip_atomic_fetch_add(&ctl->exited, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_wgs - 1) {
+        ctl_store(&ctl->ticket, 0); ctl_store(&ctl->arrived, 0); ctl_store(&ctl->gen, 0); ctl_store(&ctl->done, 0); ctl_store(&ctl->exited, 0);
+    }
+}
+__global__ void __launch_bounds__(kEvalThreads, 3)                    // <= 168 VGPRs: the workgroups stay for a whole solve, beside other groups' association workgroups
+lm_solve_persist_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, SolveCtl* __restrict__ ctl, int kmax) {
+    lm_solve_persist_body<VELO_LEAN_PRE>(Q, items + blockIdx.y, ctl + blockIdx.y, kmax, (int)gridDim.x);
+}
+
 // all states of the batch into one contiguous block (one D2H copy per chunk instead of one per context)
 __global__ void lm_gather_states_kernel(const LMBatchItem* __restrict__ items, LMState* __restrict__ out, int which) {
     const unsigned* src = reinterpret_cast<const unsigned*>(items[blockIdx.x].S + which);
