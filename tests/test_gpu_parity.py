@@ -521,6 +521,44 @@ def test_chain_mode_lockstep_batch_is_bit_identical(hip_lib, diag_lib, monkeypat
             assert np.array_equal(x0, x1) and np.array_equal(T0, T1) and s0 == s1 and r0 == r1
 
 
+def test_chain_mode_lockstep_batch_with_visual_blocks_is_bit_identical(hip_lib, oracle, monkeypatch):
+    """Lock-step batches whose contexts carry stereo blocks (all four kinds) go down the chain as well: the residual-type choice and the
+    outlier gate of every f2f iteration run on the device at the pose the device holds, the visual sweep rides ahead of every fused
+    sweep + step launch.  Poses, solves, block counts and good_matches equal the host-driven batch bit for bit and the oracle's pose."""
+    pairs = [synth.scan_pair(n_beams=32, n_azimuth=400, scene_seed=30 + k, sigma=0.02 * (k + 1)) for k in range(3)]
+    vis = [api.matches_from_dict(synth.stereo_matches(50, seed=5, mix="all", x_true=pairs[0]["x_true"])), None,
+           api.matches_from_dict(synth.stereo_matches(30, seed=6, x_true=pairs[2]["x_true"]))]
+    res = {}
+    for name, env in (("host", {"VELO_CHAIN": "0"}), ("chain", {"VELO_CHAIN": "1"}), ("tight", {"VELO_CHAIN": "1", "VELO_CHAIN_MARGIN": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctxs = [api.Context(0, icp_skip=1) for _ in pairs]
+        monkeypatch.delenv("VELO_CHAIN_MARGIN", raising=False)
+        for c, v in zip(ctxs, vis):
+            if v is not None:
+                c.set_visual(v)
+        out = []
+        for rep in range(2):
+            for c, d in zip(ctxs, pairs):
+                c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])
+            x, T, S = api.frame_to_frame_batch(ctxs, [d["x0"] for d in pairs])
+            out.append((x.copy(), T.copy(), [_summary_tuple(s) for s in S], [(s.n_assoc_rounds, s.eval_kernel_launches, s.algorithmic_bytes) for s in S],
+                        [c.good_matches().tobytes() for c in ctxs] + [[(s.solves[k].n_visual_blocks, s.solves[k].n_visual_residuals) for k in range(s.n_solves)] for s in S]))
+        res[name] = (out, [c.chain_stats() for c in ctxs])
+        for c in ctxs:
+            c.close()
+    assert all(st == (0, 0) for st in res["host"][1])
+    assert all(st[0] == 2 for st in res["chain"][1])               # (margin 0 may or may not miss here; either way the results must not move)
+    for name in ("chain", "tight"):
+        for (x0, T0, s0, r0, g0), (x1, T1, s1, r1, g1) in zip(res["host"][0], res[name][0]):
+            assert np.array_equal(x0, x1) and np.array_equal(T0, T1) and s0 == s1 and r0 == r1 and g0 == g1
+    assert all(nb > 0 for nb, _ in res["chain"][0][0][4][3]) and all(nb == 0 for nb, _ in res["chain"][0][0][4][4])   # context 0 solved with visual blocks, context 1 without
+    orc = oracle.Oracle(threads=8, icp_skip=1)
+    orc.set_target(pairs[0]["tgt_xyz"], pairs[0]["tgt_off"]); orc.set_source(pairs[0]["src_xyz"], pairs[0]["src_off"]); orc.set_visual(vis[0])
+    xo = orc.frame_to_frame(pairs[0]["x0"])[0]
+    assert H.pose_close(res["chain"][0][0][0][0], xo, 1e-9, 1e-10)
+
+
 def test_lockstep_batch_at_the_reference_constants_uses_single_launch_solves(hip_lib, diag_lib, monkeypatch):
     """icp_skip = 200 (kitti.h:8) in a lock-step batch: every solve of the group is one single-workgroup launch per context
     (lm_solve_small_batch_kernel, the body of the single-pair kernel); poses, solves and counts equal single calls bit for bit, with the

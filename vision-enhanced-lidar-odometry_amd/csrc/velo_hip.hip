@@ -200,8 +200,10 @@ struct velo_ctx {
                                          // CU so that LM workgroups of other pairs in flight find room at once.  Set by the lock-step batch
                                          // driver when several groups share the chip (kAssocPadShared); VELO_ASSOC_LDS_PAD (diagnostics build) fixes it
     bool assoc_lds_pad_fixed = false;
-    int lm_persist = 1;                  // lock-step groups in chain mode: a whole solve is ONE launch (lm_solve_persist_batch_kernel); VELO_LM_PERSIST=0 (diagnostics
-                                         // build): one launch per LM iteration (eval_step_batch_*_kernel)
+    int lm_persist = 0;                  // VELO_LM_PERSIST=1 (diagnostics build): lock-step groups in chain mode run a whole solve as ONE launch
+                                         // (lm_solve_persist_batch_kernel).  Exact (bit-identical), measured, NOT a gain: an iteration inside the launch
+                                         // takes 28 us alone (six agent-scope hand-overs between workgroups) against 19 us for a launch; 8 pairs in
+                                         // flight 2,742 vs 3,376 pairs/s -- the waiting workgroups hold registers the association kernels want
     int lm_persist_wgs = 0;              // workgroups per context of that launch (0 = one per virtual block); VELO_LM_PERSIST_WGS (diagnostics build)
     DevBuf<SolveCtl> solve_ctl;          // its per-context control blocks (owned by the first context of a group; zero between launches)
     int lm_lean = -1;                    // lean fused LM kernel in lock-step groups: -1 = when several groups share the chip; VELO_LM_LEAN (diagnostics build) forces 0 / 1
@@ -924,7 +926,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 // queries go on a list and are searched by a second launch.  Measured per round on the 2M-point map, list vs in place: cold 399 vs
                 // 688 us; seeded rounds 237 / 326 / 246 / 183 / 160 vs 230 / 272 / 207 / 138 / 116 us (few askers: the second launch only adds its
                 // own ~40 us) -- hence the cold round only.
-                const bool queue = asker_rows < (1 << 30) && variant == 5 && !c->debug_skip && c->seed_rounds == 0 && !image_seeds;
+                const bool queue = asker_rows < (1 << 30) && variant == 5 && !c->debug_skip && c->seed_rounds == 0;
                 VELO_TRY(attach_askers(c, &out, queue));
                 hipEvent_t ev_stop = ev ? ev->second : nullptr;
                 if (out.ask_list && ev) ev_stop = nullptr;              // the bracket closes behind the asker launch
@@ -2549,7 +2551,7 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
     if (image_seeds && out.prev_a) fill_seed_args(c, SA, A->P, nullptr, nullptr, qb, qe, out, had_prev);
     *direct = direct_round(c, qe - qb, false);
     *lane = !*direct && lane_round(c, G, false);
-    const bool cold = c->seed_rounds == 0 && !image_seeds;
+    const bool cold = c->seed_rounds == 0;
     if (out.prev_a) c->seed_rounds++;
     {
         const int reach0 = (int)std::ceil(std::sqrt(std::max(gate_of_iter(c->P, 1), 0.0)) / (G->h * 0.999));
@@ -2724,7 +2726,8 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
     bool chain = c0->chain && c0->lm_merged < 2 && rounds >= 1 && rounds <= VELO_MAX_SOLVES;
     for (int i = 0; i < n && chain; i++) {
         velo_ctx* c = ctxs[i];
-        chain = assoc_batchable(c) && c->n_matches == 0 && c->P.enable_icp && !c->lm_trace_on;
+        // (visual blocks: their gate runs on the device at the pose the device holds, like frame_to_frame_chain's; needs the fused sweep + step)
+        chain = assoc_batchable(c) && c->P.enable_icp && !c->lm_trace_on && (c->n_matches == 0 || (c->lm_fused && !c->lm_persist && P.f2f_iterations <= VELO_MAX_STATS));
         if (chain) {
             if (query_list_stale(c)) VELO_TRY(build_query_list(c));
             int qb, qe; q_range(c, &qb, &qe);
@@ -2735,10 +2738,17 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
         const bool fresh = c0->batch_pose.cap < (size_t)n;
         VELO_TRY(c0->batch_pose.reserve((size_t)n)); VELO_TRY(c0->batch_logs.reserve((size_t)n * VELO_MAX_SOLVES)); VELO_TRY(c0->batch_fail.reserve((size_t)n));
         if (fresh) { HIP_TRY(hipMemsetAsync(c0->batch_fail.p, 0, sizeof(int) * (size_t)n, bs)); HIP_TRY(hipMemsetAsync(c0->batch_pose.p, 0, sizeof(PoseRecord) * (size_t)n, bs)); }
+        bool any_matches = false;
         for (int i = 0; i < n; i++) {
-            ctxs[i]->chain_calls++;
-            VELO_TRY(do_build_visual(ctxs[i], xc[(size_t)i].data(), false, 1, nullptr));      // no measurements: clears the host flags
-            ctxs[i]->have_corr = false; ctxs[i]->last_n_valid = 0;
+            velo_ctx* c = ctxs[i];
+            c->chain_calls++;
+            if (c->n_matches > 0) {                                  // block / residual counts per f2f iteration come back at the end
+                any_matches = true;
+                VELO_TRY(c->vis_counts.reserve(2 * VELO_MAX_STATS));
+                HIP_TRY(hipMemsetAsync(c->vis_counts.p, 0, sizeof(int) * 2 * VELO_MAX_STATS, bs));
+                c->vflags_valid = true;
+            } else VELO_TRY(do_build_visual(c, xc[(size_t)i].data(), false, 1, nullptr));      // no measurements: clears the host flags
+            c->have_corr = false; c->last_n_valid = 0;
             for (int k = 0; k < 6; k++) h_x[8 * (size_t)i + k] = xc[(size_t)i][(size_t)k];
         }
         HIP_TRY(hipMemcpyAsync(c0->batch_x.p, h_x, sizeof(double) * 8 * (size_t)n, hipMemcpyHostToDevice, bs));
@@ -2746,10 +2756,16 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
         //  active hardware queues are time-sliced, the same effect as GPU_MAX_HW_QUEUES=8)
         int r = 0;
         for (int iter = 1; iter <= P.f2f_iterations; iter++) {
+            for (int i = 0; i < n && any_matches; i++) {             // residual-type choice + outlier gate of this iteration (velo.h:622-792), on the device
+                velo_ctx* c = ctxs[i];
+                if (c->n_matches <= 0) continue;
+                hipLaunchKernelGGL(visual_gate_kernel, dim3(cdiv(c->n_matches, 128)), dim3(128), 0, bs, (const double*)(iter == 1 ? c0->batch_x.p + 8 * (size_t)i : c->state.p->x),
+                                   visual_params(c->P), c->vm.p, c->n_matches, iter, c->vflags.p, c->vis_counts.p + 2 * (iter - 1));
+            }
             for (int icp_iter = 0; icp_iter < P.icp_iterations; icp_iter++, r++) {
                 VELO_TRY(do_associate_group(ctxs, n, xc, iter, assoc_launched, r == 0 ? nullptr : c0->batch_pose.p, c0->batch_fail.p));
                 LMBatchItem* items_r = h_items + (size_t)r * n;
-                int nb_max = 0, K = 1;
+                int nb_max = 0, nbv_max = 0, K = 1;
                 for (int i = 0; i < n; i++) {
                     velo_ctx* c = ctxs[i];
                     LMBatchItem& it = items_r[i];
@@ -2757,15 +2773,18 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                     const EvalPlan E = eval_plan(it.A);
                     it.S = c->state.p; it.xd = r == 0 ? c0->batch_x.p + 8 * (size_t)i : nullptr;
                     it.n_valid = c->n_valid.p + c->nv_idx;
-                    it.nb_icp = E.nb_icp; it.nb_vis = 0; it.n_rows = E.nb_icp;
+                    it.nb_icp = E.nb_icp; it.nb_vis = E.nb_vis; it.n_rows = E.total();
                     it.A.vis_row0 = E.nb_icp;
                     it.pose_out = c0->batch_pose.p + i; it.log = c0->batch_logs.p + (size_t)i * VELO_MAX_SOLVES + r;
-                    nb_max = std::max(nb_max, E.nb_icp);
+                    nb_max = std::max(nb_max, E.nb_icp); nbv_max = std::max(nbv_max, E.nb_vis);
                     K = std::max(K, std::min(std::max(c->pred_evals[r], 1) + margin_for(c, r), max_iters));
                     S[(size_t)i]->assoc_kernel_launches += assoc_launched[(size_t)i];
                 }
                 const LMBatchItem* d_items = c0->batch_items.p + (size_t)r * n;
-                HIP_TRY(hipMemcpyAsync(c0->batch_items.p + (size_t)r * n, items_r, sizeof(LMBatchItem) * (size_t)n, hipMemcpyHostToDevice, bs));
+                // groups of up to four contexts with the fused sweep + step: the items ride in the kernel arguments; device copies are needed by
+                // the kernels that take a pointer (the visual sweep, the two-launch path, the one-launch solve, the final state gather)
+                const bool by_value = n <= 4 && c0->lm_fused && !c0->lm_persist && nbv_max == 0;
+                if (!by_value || r == 0) HIP_TRY(hipMemcpyAsync(c0->batch_items.p + (size_t)r * n, items_r, sizeof(LMBatchItem) * (size_t)n, hipMemcpyHostToDevice, bs));
                 bool small = c0->small_solve != 0;                      // every solve of the group is ONE single-workgroup launch (lm_solve_small_kernel's body)
                 for (int i = 0; i < n; i++) small = small && items_r[i].n_rows >= 1 && items_r[i].n_rows <= kSmallRows;
                 if (small) {
@@ -2791,12 +2810,27 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                     HIP_TRY(hipGetLastError());
                     continue;
                 }
-                VELO_LAUNCH_T(c0, "lm_begin_batch_kernel", 0, lm_begin_batch_kernel, dim3(n), dim3(64), 0, bs, d_items);
+                // (fused sweep + step: the first launch of a solve starts it as well -- no begin launch; with visual blocks their sweep runs as a
+                //  launch of its own ahead of every fused one and reads the eval point from memory, so the begin launch stays)
+                const int first_fused = nbv_max == 0 ? 1 : 0;
+                if (!c0->lm_fused || nbv_max > 0) VELO_LAUNCH_T(c0, "lm_begin_batch_kernel", 0, lm_begin_batch_kernel, dim3(n), dim3(64), 0, bs, d_items);
                 if (c0->lm_fused) c0->lm_kernel_name = lean ? "eval_step_batch_lean_kernel" : "eval_step_batch_kernel";
+                LMBatchPackV packv;
+                if (by_value) {
+                    std::memset(&packv, 0, sizeof(packv));
+                    for (int i = 0; i < n; i++) packv.item[i] = items_r[i];
+                    c0->lm_kernel_name = lean ? "eval_step_batch_lean_v_kernel" : "eval_step_batch_v_kernel";
+                }
                 for (int k = 0; k < K; k++) {
+                    if (by_value) {
+                        if (lean) VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_lean_v_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, packv, c0->batch_tickets.p, k == 0 ? 1 : 0);
+                        else VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_v_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, packv, c0->batch_tickets.p, k == 0 ? 1 : 0);
+                        continue;
+                    }
                     if (c0->lm_fused) {
-                        if (lean) VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_lean_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, d_items, c0->batch_tickets.p);
-                        else VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, d_items, c0->batch_tickets.p);
+                        if (nbv_max > 0) VELO_LAUNCH_T(c0, "eval_visual_batch_kernel", 0, eval_visual_batch_kernel, dim3(nbv_max, n), dim3(kEvalThreads), 0, bs, d_items);
+                        if (lean) VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_lean_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, d_items, c0->batch_tickets.p, k == 0 ? first_fused : 0);
+                        else VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, d_items, c0->batch_tickets.p, k == 0 ? first_fused : 0);
                         continue;
                     }
                     hipLaunchKernelGGL(eval_icp_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, d_items);
@@ -2811,6 +2845,14 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
         HIP_TRY(hipMemcpyAsync(h_states, c0->batch_states.p, sizeof(LMState) * (size_t)n, hipMemcpyDeviceToHost, bs));
         HIP_TRY(hipMemcpyAsync(h_logs, c0->batch_logs.p, sizeof(SolveLog) * (size_t)n * VELO_MAX_SOLVES, hipMemcpyDeviceToHost, bs));
         HIP_TRY(hipMemcpyAsync(h_fail, c0->batch_fail.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, bs));
+        std::vector<int> h_vis((size_t)n * 2 * VELO_MAX_STATS, 0);
+        for (int i = 0; i < n && any_matches; i++) {
+            velo_ctx* c = ctxs[i];
+            if (c->n_matches <= 0) continue;
+            c->h_vflags.resize((size_t)3 * c->n_matches);
+            HIP_TRY(hipMemcpyAsync(c->h_vflags.data(), c->vflags.p, (size_t)3 * c->n_matches, hipMemcpyDeviceToHost, bs));
+            HIP_TRY(hipMemcpyAsync(h_vis.data() + (size_t)i * 2 * VELO_MAX_STATS, c->vis_counts.p, sizeof(int) * 2 * VELO_MAX_STATS, hipMemcpyDeviceToHost, bs));
+        }
         HIP_TRY(hipStreamSynchronize(bs));
         bool ok = true;
         for (int i = 0; i < n; i++) ok = ok && !h_fail[i] && h_states[i].done != 0;
@@ -2828,10 +2870,17 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                     std::memset(&ss, 0, sizeof(ss));
                     ss.termination = L.termination; ss.lm_iterations = L.iter; ss.evaluations = L.evals; ss.n_icp_valid = L.n_valid;
                     ss.initial_cost = L.initial_cost; ss.final_cost = L.final_cost;
+                    if (c->n_matches > 0) {                          // the blocks of the f2f iteration this solve belongs to
+                        const int it0 = std::min(k / std::max(P.icp_iterations, 1), VELO_MAX_STATS - 1);
+                        ss.n_visual_blocks = h_vis[(size_t)i * 2 * VELO_MAX_STATS + 2 * it0]; ss.n_visual_residuals = h_vis[(size_t)i * 2 * VELO_MAX_STATS + 2 * it0 + 1];
+                    }
                     note_evals(c, k, L.evals);
                     Si->eval_kernel_launches += L.evals;
-                    Si->algorithmic_bytes += (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 224ull);
-                    if (c0->timing >= 2) kacc_add(c0, c0->lm_kernel_name, 0.0, 0, 0, (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 224ull));   // the group's launches are logged on its first context
+                    Si->algorithmic_bytes += (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull);
+                    if (c0->timing >= 2) {                           // the group's launches are logged on its first context
+                        kacc_add(c0, c0->lm_kernel_name, 0.0, 0, 0, (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 224ull));
+                        if (ss.n_visual_blocks > 0) kacc_add(c0, "eval_visual_batch_kernel", 0.0, 0, 0, (uint64_t)L.evals * 32ull * (uint64_t)ss.n_visual_blocks);
+                    }
                     Si->solves[Si->n_solves++] = ss;
                 }
                 c->last_n_valid = h_states[i].n_valid;
@@ -2906,8 +2955,8 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                     if (fused) {
                         c0->lm_kernel_name = lean ? "eval_step_batch_lean_kernel" : "eval_step_batch_kernel";
                         if (nbv_max > 0) VELO_LAUNCH_T(c0, "eval_visual_batch_kernel", 0, eval_visual_batch_kernel, dim3(nbv_max, n), dim3(kEvalThreads), 0, bs, (const LMBatchItem*)c0->batch_items.p);
-                        if (lean) VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_lean_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p, c0->batch_tickets.p);
-                        else VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p, c0->batch_tickets.p);
+                        if (lean) VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_lean_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p, c0->batch_tickets.p, 0);
+                        else VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, (const LMBatchItem*)c0->batch_items.p, c0->batch_tickets.p, 0);
                         continue;
                     }
                     if (nb_max > 0) hipLaunchKernelGGL(eval_icp_batch_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, (const LMBatchItem*)c0->batch_items.p);

@@ -1675,7 +1675,11 @@ assoc_asker_batch_kernel(AssocBatch B) {
 // (64-bit key: range^2 bits << 32 | local index; built with one atomicMin per target point).  seed_kernel looks the query's bucket and
 // its four neighbours up, adds the previous winners when there are any, and leaves the best two of different rings as the seeds.
 // Only a hash: for clouds that are no range images the seeds are merely poor.  Results never depend on it.
-constexpr int kDimgW = 1024, kDimgH = 256;                      // 0.35 deg x 0.35 deg over +-45 deg of elevation: 2 MB
+#ifndef VELO_DIMG_W
+#define VELO_DIMG_W 1024
+#define VELO_DIMG_H 256
+#endif
+constexpr int kDimgW = VELO_DIMG_W, kDimgH = VELO_DIMG_H;       // 1024 x 256: 0.35 deg x 0.35 deg over +-45 deg of elevation, 2 MB (W: a power of two)
 __device__ __forceinline__ void dimg_bucket(float x, float y, float z, int* a, int* e) {
     // camera frame (x right, y down, z forward; kitti.h:100-107): azimuth about the y axis, elevation up positive
     const float az = atan2f(x, z), el = atan2f(-y, sqrtf(x * x + z * z));
@@ -3120,7 +3124,9 @@ __device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* 
 __device__ __forceinline__ void lm_transition_wave(const LMParams& Q, LMState* sL, const double* E, int lane);
 constexpr int kStepChunk = 128;
 static_assert(kStepChunk * kNumAcc == kScratchDoubles && kStepChunk * kNumAcc % 256 == 0 && kStepChunk % 8 == 0, "chunk geometry");
-template <bool COHERENT = false, int CHUNK = kStepChunk, bool STATE_COHERENT = false>
+// first = 2 (instantiations with BEGIN_STEP only): the start of a solve AND the transition over the first sweep's rows in one go -- the
+// launch that carried the solve's first sweep computed its eval point from x itself (eval_step_batch_body), so no begin launch ran
+template <bool COHERENT = false, int CHUNK = kStepChunk, bool STATE_COHERENT = false, bool BEGIN_STEP = false>
 __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __restrict__ Sin, const double* __restrict__ partials, int n_blocks, int first,
                                            const double* __restrict__ x_in, const int* __restrict__ n_valid,
                                            double* __restrict__ s_rows, LMState* sL, LMEvalPoint* s_pt, unsigned long long* trace, int trace_eval,
@@ -3148,7 +3154,8 @@ __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __r
     }
     const int k_acc = t % kNumAcc, p_acc = t / kNumAcc;
     double v_acc = 0.0;
-    if (!first) {
+    const bool step = BEGIN_STEP ? first != 1 : !first;
+    if (step) {
         for (int c0 = 0; c0 < n_blocks; c0 += CHUNK) {
             const int nrows = min(CHUNK, n_blocks - c0), total = nrows * kNumAcc;
             const double* __restrict__ src = partials + (size_t)c0 * kNumAcc;
@@ -3172,7 +3179,9 @@ __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __r
             sL->phase = PHASE_INIT; sL->done = 0; sL->termination = 1; sL->iter = 0; sL->evals = 0; sL->invalid = 0; sL->reuse_diag = 0;
             if (pose_out && writer) pose_out->ready = 0;     // chain mode: the next round's association must wait for THIS solve
         }
-    } else if (!sL->done) {                                  // uniform: a step behind a finished solve changes nothing
+    }
+    if (BEGIN_STEP && first == 2) __syncthreads();           // the reset state is what the transition starts from
+    if (step && !sL->done) {                                 // uniform: a step behind a finished solve changes nothing
         if (t < kNumAcc) { double v = 0.0; for (int p = 0; p < 8; p++) v += part[p][t]; E[t] = v; }
         __syncthreads();
         if (comm) peer_allreduce28(*comm, E);                // query-sharded: every rank continues with the same 28 sums
@@ -3476,9 +3485,10 @@ lm_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items) {
 // Ordering: the 28 stores of a row are agent-scope write-through stores; their thread waits for them (s_waitcnt vmcnt(0)) ahead of
 // the workgroup barrier behind which thread 0 draws the ticket, so whoever sees ticket n - 1 finds every row where its agent-scope
 // loads look.  tickets[context] is 0 at every launch boundary (the last workgroup resets it).
+// first != 0: this launch carries the FIRST sweep of a solve: every workgroup builds the start's eval point from x itself (what
+// lm_begin_batch_kernel used to leave in memory one launch earlier), and the stepping workgroup starts the solve before it steps.
 template <bool M_LDS, int PRE, int CHUNK>
-__device__ __forceinline__ void eval_step_batch_body(const LMParams& Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets) {
-    const LMBatchItem& it = items[blockIdx.y];
+__device__ __forceinline__ void eval_step_batch_body(const LMParams& Q, const LMBatchItem& it, int* __restrict__ tickets, const int first) {
     const int bx = blockIdx.x, nbx = it.nb_icp;
     if (bx >= nbx) return;
 #ifdef VELO_LM_SETPRIO
@@ -3491,6 +3501,15 @@ __device__ __forceinline__ void eval_step_batch_body(const LMParams& Q, const LM
     __shared__ double s_scratch[CHUNK * kNumAcc];
     __shared__ int s_last;
     static_assert(CHUNK * kNumAcc >= kScratchDoubles / 2, "the sweep's reduction needs 64 columns x 28");
+    if (first) {
+        if (threadIdx.x < 4) {
+            double x[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) x[k] = it.xd ? it.xd[k] : it.S->x[k];
+            eval_point_column(x, 0, threadIdx.x, &s_pt);
+        }
+        __syncthreads();
+    } else
     if (!eval_point_load(A, &s_pt)) return;                           // a launch behind the end of the solve: nothing to do, the ticket stays 0
     double acc[kNumAcc];
     sweep_rows<M_LDS, PRE>(A, f, s_pt, bx, nbx, acc);
@@ -3501,7 +3520,7 @@ __device__ __forceinline__ void eval_step_batch_body(const LMParams& Q, const LM
     __syncthreads();
     if (!s_last) return;
     if (threadIdx.x == 0) __hip_atomic_store(tickets + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    lm_advance<true, CHUNK>(Q, it.S, A.partials, it.n_rows, 0, nullptr, nullptr, s_scratch, &sL, &s_pt, nullptr, 0, nullptr, it.pose_out, it.log);
+    lm_advance<true, CHUNK, false, true>(Q, it.S, A.partials, it.n_rows, first ? 2 : 0, it.xd, it.n_valid, s_scratch, &sL, &s_pt, nullptr, 0, nullptr, it.pose_out, it.log);
     const int t = threadIdx.x;
     LMEvalPoint* pt = const_cast<LMEvalPoint*>(A.pt);
     if (t < (int)(sizeof(LMState) / 8)) reinterpret_cast<unsigned long long*>(it.S)[t] = reinterpret_cast<const unsigned long long*>(&sL)[t];
@@ -3509,8 +3528,8 @@ __device__ __forceinline__ void eval_step_batch_body(const LMParams& Q, const LM
 }
 // alone on the chip: matrices in registers, four prefetched rows (240 VGPRs, 33 KB of LDS: two waves per SIMD)
 __global__ void __launch_bounds__(kEvalThreads)
-eval_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets) {
-    eval_step_batch_body<false, kPre, kStepChunk>(Q, items, tickets);
+eval_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets, int first) {
+    eval_step_batch_body<false, kPre, kStepChunk>(Q, items[blockIdx.y], tickets, first);
 }
 // The LEAN instantiation, for launches that share the chip with other lock-step groups' association kernels: matrices read from LDS,
 // VELO_LEAN_PRE prefetched rows, the step's partial rows 64 at a time -- few enough registers and LDS (<= 152 VGPRs, < 25 KB) that a
@@ -3520,8 +3539,19 @@ eval_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* _
 #define VELO_LEAN_PRE 1
 #endif
 __global__ void __launch_bounds__(kEvalThreads) __attribute__((amdgpu_num_vgpr(152)))
-eval_step_batch_lean_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets) {
-    eval_step_batch_body<true, VELO_LEAN_PRE, 64>(Q, items, tickets);
+eval_step_batch_lean_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets, int first) {
+    eval_step_batch_body<true, VELO_LEAN_PRE, 64>(Q, items[blockIdx.y], tickets, first);
+}
+// The same two with the group's items BY VALUE in the kernel arguments (groups of up to four contexts): no copy of the items into
+// device memory ahead of every round of a chained call -- six copy operations, and the queue hand-overs around them, per call.
+struct LMBatchPackV { LMBatchItem item[4]; };
+__global__ void __launch_bounds__(kEvalThreads)
+eval_step_batch_v_kernel(LMParams Q, LMBatchPackV P, int* __restrict__ tickets, int first) {
+    eval_step_batch_body<false, kPre, kStepChunk>(Q, P.item[blockIdx.y], tickets, first);
+}
+__global__ void __launch_bounds__(kEvalThreads) __attribute__((amdgpu_num_vgpr(152)))
+eval_step_batch_lean_v_kernel(LMParams Q, LMBatchPackV P, int* __restrict__ tickets, int first) {
+    eval_step_batch_body<true, VELO_LEAN_PRE, 64>(Q, P.item[blockIdx.y], tickets, first);
 }
 // ---- a whole solve of a lock-step group in ONE launch ---------------------------------------------------------------------------------
 // A solve used to be one launch per LM iteration: ~48 launches per call and group, each paying the queue's hand-over (4-10 us between
@@ -3535,7 +3565,11 @@ eval_step_batch_lean_kernel(LMParams Q, const LMBatchItem* __restrict__ items, i
 // prediction of the iteration count -- the launch ends when the solve does (kmax bounds it).  Virtual blocks, per-thread rows and
 // the reduction are those of the launch-per-iteration kernels, so every partial row and every sum is bit-identical to them.
 // Everything one workgroup hands to another inside the launch goes through agent-scope accesses (partial rows, state, eval point).
-struct SolveCtl { int ticket, arrived, gen, done, exited, pad0, pad1, pad2; };    // one per context; all zero between launches (the last workgroup out resets it)
+// One per context; all zero between launches (the last workgroup out resets it).  Every word on a 128-byte line of its own: the
+// generation word is polled by every waiting workgroup, and a ticket or arrival counter on the same line would queue behind the polls.
+// gen = eval points published so far, | kSolveDone once the solve has ended.
+struct SolveCtl { int ticket, pad0[31]; int arrived, pad1[31]; int gen, pad2[31]; int exited, pad3[31]; };
+constexpr int kSolveDone = 1 << 30;
 __device__ __forceinline__ int ctl_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ctl_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // one ticket's work: block bx of iteration k.  -> 0 = swept, 1 = swept and this workgroup completed the iteration, -1 = the solve is over
@@ -3549,9 +3583,10 @@ __device__ __forceinline__ int persist_sweep(const EvalArgs& A, SolveCtl* __rest
     if (t == 0) {
         int fl = 0;
         for (;;) {
-            if (ctl_load(&ctl->done)) { fl = 1; break; }
-            if (ctl_load(&ctl->gen) > k) break;
-            __builtin_amdgcn_s_sleep(2);
+            const int g = ctl_load(&ctl->gen);
+            if (g & kSolveDone) { fl = 1; break; }
+            if (g > k) break;
+            __builtin_amdgcn_s_sleep(8);
         }
         *s_flag = fl;
     }
@@ -3622,17 +3657,14 @@ __device__ __forceinline__ void lm_solve_persist_body(const LMParams& Q, const L
             else if (t >= 64 && t < 64 + (int)(sizeof(LMEvalPoint) / 8)) __hip_atomic_store(reinterpret_cast<unsigned long long*>(pt) + (t - 64), reinterpret_cast<const unsigned long long*>(&s_pt)[t - 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (t == 0) {
-                if (sL.done) ctl_store(&ctl->done, 1);
-                ctl_store(&ctl->gen, advance == 1 ? 1 : k + 2);
-            }
+            if (t == 0) ctl_store(&ctl->gen, (advance == 1 ? 1 : k + 2) | (sL.done ? kSolveDone : 0));
             __syncthreads();
         }
     }
     // the last workgroup out leaves the control block as it found it
     __syncthreads();
     if (t == 0 && __hip_atomic_fetch_add(&ctl->exited, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == n_wgs - 1) {
-        ctl_store(&ctl->ticket, 0); ctl_store(&ctl->arrived, 0); ctl_store(&ctl->gen, 0); ctl_store(&ctl->done, 0); ctl_store(&ctl->exited, 0);
+        ctl_store(&ctl->ticket, 0); ctl_store(&ctl->arrived, 0); ctl_store(&ctl->gen, 0); ctl_store(&ctl->exited, 0);
     }
 }
 __global__ void __launch_bounds__(kEvalThreads, 3)                    // <= 168 VGPRs: the workgroups stay for a whole solve, beside other groups' association workgroups
