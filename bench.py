@@ -487,11 +487,15 @@ def main():
             try:
                 tj = json.load(open(tf[-1]))
                 by = tj.get("traffic_by_kernel") or {}
-                base = rf["kernel"].replace("_batch", "").replace("_lean", "")
-                rf["traffic"] = by.get(rf["kernel"], by.get(base, tj["traffic_bytes_per_launch"] if "assoc" in rf["kernel"] else None))
+
+                def traffic_of(name):      # the committed pass measured the kernel alone: the lean / by-value instantiations move the same bytes
+                    for cand in (name, name.replace("_lean", ""), name.replace("_lean", "").replace("_v_kernel", "_kernel")):
+                        if cand in by:
+                            return by[cand]
+                    return tj["traffic_bytes_per_launch"] if "assoc" in name else None
+                rf["traffic"] = traffic_of(rf["kernel"])
                 for kr in main_leg["kernels"]:
-                    kb = kr["kernel"].replace("_batch", "").replace("_lean", "")
-                    kr["traffic"] = by.get(kr["kernel"], by.get(kb, tj["traffic_bytes_per_launch"] if "assoc" in kr["kernel"] else None))
+                    kr["traffic"] = traffic_of(kr["kernel"])
                 sq = tj.get("sq_per_launch")
                 rf["traffic_source"] = os.path.basename(tf[-1])
             except Exception:       # noqa: BLE001
@@ -540,8 +544,8 @@ def main():
                     t4 = json.load(open(tf4[-1]))
                     r4 = line["configs"]["c4"]["roofline"]
                     by4 = t4.get("traffic_by_kernel") or {}
-                    r4["traffic"] = by4.get(r4["kernel"], by4.get(r4["kernel"].replace("_batch", "").replace("_lean", ""),
-                                                                  t4["traffic_bytes_per_launch"] if "assoc" in r4["kernel"] else None))
+                    r4["traffic"] = next((by4[c_] for c_ in (r4["kernel"], r4["kernel"].replace("_lean", ""), r4["kernel"].replace("_lean", "").replace("_v_kernel", "_kernel")) if c_ in by4),
+                                         t4["traffic_bytes_per_launch"] if "assoc" in r4["kernel"] else None)
                     r4["traffic_note"] = "HBM-side bytes per launch of ONE context's launch alone (committed PMC passes)"
                 except Exception:       # noqa: BLE001
                     pass

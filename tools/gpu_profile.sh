@@ -11,5 +11,8 @@ STEPS=${STEPS:-10}
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-legs --workload $WL > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --batch 1 --no-cpu-baseline --no-legs --workload $WL > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --batch 1 --no-cpu-baseline --no-legs --workload $WL > /dev/null 2>&1
+# the kernels of a lock-step group alone on the chip (one group of two contexts): HBM-side bytes per launch of the batched kernels
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_b2 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --batch 2 --no-cpu-baseline --no-legs --workload $WL > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_b2 -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --batch 2 --no-cpu-baseline --no-legs --workload $WL > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --batch 1 --no-cpu-baseline --no-legs --workload $WL > /dev/null 2>&1
 ls $OUT

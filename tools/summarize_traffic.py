@@ -27,5 +27,27 @@ if out["FETCH_SIZE"] is not None and out["WRITE_SIZE"] is not None:
             if "assoc_search" in r["Kernel_Name"]:
                 per[r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
         res["sq_per_launch"] = {k: sum(v.values()) / len(v) for k, v in per.items()}
+    # every kernel of the PMC passes (one pair in flight; "_b2": one lock-step group of two contexts alone on the chip): mean HBM-side bytes
+    # per LIVE launch (launches behind the end of a solve move nothing: those below a quarter of the kernel's largest launch are left out)
+    by = {}
+    for suffix in ("", "_b2"):
+        tot = collections.defaultdict(lambda: collections.defaultdict(float))
+        for name, counter, mul in (("pmc_fetch" + suffix, "FETCH_SIZE", 2.0), ("pmc_write" + suffix, "WRITE_SIZE", 1.0)):
+            g = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag, name, "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)
+            if not g:
+                continue
+            per = collections.defaultdict(lambda: collections.defaultdict(float))
+            for r in csv.DictReader(open(g[0])):
+                if r["Counter_Name"] == counter:
+                    per[r["Kernel_Name"].split("(")[0].replace("void ", "").replace("velo::", "").split("<")[0]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+            for k, d in per.items():
+                v = list(d.values())
+                live = [x for x in v if x >= 0.25 * max(v)] or v
+                tot[k][counter] = mul * 1024.0 * sum(live) / len(live)
+        for k, d in tot.items():
+            if k.startswith("__amd") or k in by:
+                continue
+            by[k] = d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)
+    res["traffic_by_kernel"] = by
     json.dump(res, open(os.path.join(ROOT, "profiles", f"{tag}_traffic.json"), "w"), indent=1)
     print(res)

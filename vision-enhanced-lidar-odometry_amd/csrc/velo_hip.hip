@@ -214,6 +214,14 @@ struct velo_ctx {
     bool ring_order_forced = false;      // this context exchanges per-query records with others (target-sharded workflow): the list stays in the reference's order
     int direct_max = 12288;              // sparse rounds (icp_skip >= direct_skip) of at most this many queries search one wave per query
     int direct_skip = 4;                 // (VELO_ASSOC_DIRECT_MAX, 0 = never; VELO_ASSOC_DIRECT_SKIP)
+    // Density-shrunk grids (scan-to-map), single calls: a group whose phase-1 boxes span more than dense_rows grid rows -- queries strung
+    // along a wall that thirty scans have sampled: 12,000-17,000 staged candidates -- is searched query by query as a whole, provided at
+    // most dense_far of its members have a bound beyond four cells (see assoc_search_v5_body).  Measured on the 2M-point map, us per round
+    // of a call: 450 / 402 / 305 / 231 / 230 / 137 -> 435 / 396 / 215 / 149 / 165 / 102, single registration 2.56 -> 2.35 ms.  A launch
+    // ends with its slowest group, and these are the slowest; with 8 pairs in flight other groups' kernels fill that tail anyway and the
+    // step does not move (1,242 vs 1,235 pairs/s), so lock-step batches keep the tile path (dense_batch).  VELO_DENSE_ROWS / VELO_DENSE_FAR /
+    // VELO_DENSE_BATCH (diagnostics build) override.
+    int dense_rows = 384, dense_far = 2, dense_batch = 0;
     int asker_queue = 1;                 // shrunk grid: asking queries go to assoc_asker_kernel (VELO_ASKER_QUEUE=0: searched inside their group's workgroup)
     DevBuf<int> ask_count, ask_list;
     DevBuf<unsigned long long> ask_keys;
@@ -933,7 +941,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
 #define VELO_LAUNCH_V5(NW, MINW, DBG, PPT, ASKER)                                                                                         \
                 hipExtLaunchKernelGGL((assoc_search_v5_kernel<NW, MINW, DBG, PPT, ASKER>), dim3(groups), dim3(NW * 64), c->assoc_lds_pad, c->stream,                    \
                                       ev ? ev->first : nullptr, ev_stop, 0, S, P_dev, P_dev ? c->chain_fail.p : (int*)nullptr, V, c->qpts, qb, qe,                      \
-                                   (const float4*)c->T->tgt_pad.p, (const int*)c->T->tgt_off.p, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux, perm, c->debug_skip, asker_rows)
+                                   (const float4*)c->T->tgt_pad.p, (const int*)c->T->tgt_off.p, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux, perm, c->debug_skip ? c->debug_skip : (asker_rows < (1 << 30) ? (c->dense_rows | (c->dense_far << 20)) : 0), asker_rows)
                 // default: 5 waves/SIMD (96 VGPRs, no spills, no scratch traffic), 2 candidate pairs per trip.  Measured on C2:
                 // 62 us; 6 waves + 2 pairs (5 spilled VGPRs) 65; 7 waves + 2 pairs 64; 5 waves + 4 pairs 66; 6 waves + 4 pairs 71
 #ifdef VELO_DIAGNOSTICS
@@ -956,7 +964,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                     AssocArgs& a = B1.item[0];
                     a.P = S; a.P_dev = P_dev; a.chain_fail = P_dev ? c->chain_fail.p : nullptr; a.G = V; a.qpts = c->qpts; a.q_begin = qb; a.q_end = qe;
                     a.tgt_pad = c->T->tgt_pad.p; a.tgt_off = c->T->tgt_off.p; a.gate_bits = gbits; a.norm_cond = c->P.icp_norm_condition; a.cluster_w = cw;
-                    a.h_safe = h_safe; a.out = out; a.want_aux = aux; a.group_perm = perm; a.dbg = 0; a.asker_rows = asker_rows;
+                    a.h_safe = h_safe; a.out = out; a.want_aux = aux; a.group_perm = perm; a.dbg = c->dense_rows | (c->dense_far << 20); a.asker_rows = asker_rows;
                     hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, 2>), dim3(groups, 1), dim3(256), c->assoc_lds_pad, c->stream,
                                           ev ? ev->first : nullptr, ev_stop, 0, B1);
                     hipExtLaunchKernelGGL(assoc_asker_kernel, dim3(cdiv(qe - qb, kAskChunk)), dim3(64), 0, c->stream, nullptr, ev ? ev->second : nullptr, 0,
@@ -1440,6 +1448,9 @@ int velo_create(velo_ctx** out, int device) {
         if (const char* e = dev_env("VELO_ASSOC_LANE")) c->assoc_lane = atoi(e);
         if (const char* e = dev_env("VELO_LM_MERGED_VIS")) c->lm_trace_vis_off = atoi(e) == 0;
         if (const char* e = dev_env("VELO_ASKER_QUEUE")) c->asker_queue = atoi(e);
+        if (const char* e = dev_env("VELO_DENSE_ROWS")) c->dense_rows = std::min(std::max(atoi(e), 0), 0xfffff);
+        if (const char* e = dev_env("VELO_DENSE_FAR")) c->dense_far = std::min(std::max(atoi(e), 0), 64);
+        if (const char* e = dev_env("VELO_DENSE_BATCH")) c->dense_batch = atoi(e);
         if (const char* e = dev_env("VELO_ASSOC_DIRECT_MAX")) c->direct_max = std::max(atoi(e), 0);
         if (const char* e = dev_env("VELO_PATCH_ORDER")) c->patch_order = atoi(e);
         if (const char* e = dev_env("VELO_PATCH_SHAPE")) { int a = 0, b = 0; if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && b >= 1) { c->patch_rings = a; c->patch_len = b; } }
@@ -2566,6 +2577,7 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
     const int reach_cells = (int)std::ceil(std::sqrt(std::max(gate_of_iter(c->P, 1), 0.0)) / (G->h * 0.999));
     A->asker_rows = c->asker_rows >= 0 ? c->asker_rows : (reach_cells > 5 ? 0 : (1 << 30));
     *asker = A->asker_rows < (1 << 30);
+    if (*asker && c->dense_batch) A->dbg = c->dense_rows | (c->dense_far << 20);                       // (see assoc_search_v5_body: groups that go query by query as a whole)
     *groups = cdiv(qe - qb, 64);
     return VELO_OK;
 }

@@ -1043,7 +1043,7 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
     __shared__ int s_wave_tot[NW];
     __shared__ int s_lo[NT], s_hi[NT], s_plo[NT], s_phi[NT];   // per-row x-interval of this phase / of what phase 1 visited
     __shared__ int s_box[2][6][64];                            // per-query cell box of phase 1 / phase 2 (x0, x1, y0, y1, z0, z1)
-    __shared__ int s_phase[8];                                 // Y0, Y1, Z0, Z1, asking-lane mask (lo, hi), total rows asked for, any bound beyond one cell
+    __shared__ int s_phase[9];                                 // Y0, Y1, Z0, Z1, asking-lane mask (lo, hi), total rows asked for, bounds beyond one cell, bounds beyond four cells
     // The transformed queries live HERE, not in registers: lane i of every wave re-reads query i where it needs it (cell boxes, the
     // rare exact-distance path of the sweep, the finish).  Three registers less across the sweep is what keeps the kernel at
     // 96 VGPRs -- five waves per SIMD -- without a single spilled register (a kernel that touches scratch pays ~11 us per launch).
@@ -1146,6 +1146,15 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
         // visited for it; the others ask phase 2 for the box of their current bound.
         const float r1 = sqrtf(t.b2d) * 1.0001f + 1e-6f;               // bound radius phase 1 works with (padded against rounding)
         bool asker_phase = false;
+        // Dense targets only (ASKER instantiations): a group whose phase-1 boxes span more than `dense_rows` grid rows -- queries strung
+        // along a wall that thirty scans have sampled -- would stage the union of 64 nearly disjoint little boxes (12,000-17,000 candidates)
+        // and make every lane test all of them.  Such a group skips the tile machinery: every member goes query by query (all 64 lanes
+        // of a wave on one query's own bound sphere), the path the asking queries of phase 2 take anyway.  Exact: a query searched that
+        // way sees its whole bound sphere.  (dense_rows rides in the `dbg` argument, which the product instantiations do not use.)
+        // ... and only when at most `dense_far` members have a bound that reaches beyond FOUR cells (a cold round, or one behind a solve that
+        // moved the pose by decimetres, has big spheres: there the union tube is the cheaper way).  dbg = dense_rows | dense_far << 20.
+        const int dense_rows = (ASKER && !DBG) ? (dbg & 0xfffff) : 0, dense_far = (ASKER && !DBG) ? (dbg >> 20) : 0;
+        bool asker_all = false;
         for (int ph = 0; ph < 2; ph++) {
             // No second phase at all when no member's bound reaches beyond one cell: the box of a radius <= h lies inside the query's own
             // cell +- 1, which is what phase 1 visited -- nobody can ask (s_phase[7] was published with phase 1's boxes).
@@ -1173,15 +1182,21 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
                 s_box[ph][3][lane] = bb.y1; s_box[ph][4][lane] = bb.z0; s_box[ph][5][lane] = bb.z1;
                 const unsigned long long am0 = __ballot(asks0);
                 const unsigned long long far0 = (ph == 0) ? __ballot(member && r1 > h_safe) : 1ull;
+                const unsigned long long far4 = (ASKER && ph == 0) ? __ballot(member && r1 > 4.0f * h_safe) : 0ull;
                 const int y0 = wave_min_i(asks0 ? bb.y0 : big), y1 = wave_max_i(asks0 ? bb.y1 : -big);
                 const int z0 = wave_min_i(asks0 ? bb.z0 : big), z1 = wave_max_i(asks0 ? bb.z1 : -big);
                 if (lane == 0) {
                     s_phase[0] = max(y0, 0); s_phase[1] = min(y1, g.ny - 1); s_phase[2] = max(z0, 0); s_phase[3] = min(z1, g.nz - 1);
                     s_phase[4] = (int)(unsigned)(am0 & 0xffffffffull); s_phase[5] = (int)(unsigned)(am0 >> 32); s_phase[6] = rows_all;
-                    if (ph == 0) s_phase[7] = far0 != 0ull ? 1 : 0;
+                    if (ph == 0) s_phase[7] = (int)__popcll(far0);            // members whose bound reaches beyond one cell
+                    if (ASKER && ph == 0) s_phase[8] = (int)__popcll(far4);   // ... beyond four cells (what the query-by-query search takes in its first stage)
                 }
             }
             __syncthreads();
+            if (ASKER && ph == 0 && dense_rows > 0) {
+                const int ny0 = s_phase[1] - s_phase[0] + 1, nz0 = s_phase[3] - s_phase[2] + 1;
+                if (ny0 > 0 && nz0 > 0 && ny0 * nz0 > dense_rows && s_phase[8] <= dense_far) { asker_all = true; asker_phase = true; break; }
+            }
             const unsigned long long am_ph = ((unsigned long long)(unsigned)s_phase[5] << 32) | (unsigned long long)(unsigned)s_phase[4];
             const bool asks = ((am_ph >> lane) & 1ull) != 0ull;
             if (ph == 1) {
@@ -1371,8 +1386,8 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
             const int cx = cell_coord(qx, g.ox, g.inv_h, g.nx), cy = cell_coord(qy, g.oy, g.inv_h, g.ny), cz = cell_coord(qz, g.oz, g.inv_h, g.nz);
             const float rq0 = sqrtf(t.b2d) * 1.0001f + 1e-6f;
             const CellBox b2 = query_box(g, qx, qy, qz, cx, cy, cz, rq0, false);       // against the phase-1 box wave 0 left in s_box[0]
-            const bool asks = member && !(b2.x0 >= s_box[0][0][lane] && b2.x1 <= s_box[0][1][lane] && b2.y0 >= s_box[0][2][lane] &&
-                                          b2.y1 <= s_box[0][3][lane] && b2.z0 >= s_box[0][4][lane] && b2.z1 <= s_box[0][5][lane]);
+            const bool asks = member && (asker_all || !(b2.x0 >= s_box[0][0][lane] && b2.x1 <= s_box[0][1][lane] && b2.y0 >= s_box[0][2][lane] &&
+                                                        b2.y1 <= s_box[0][3][lane] && b2.z0 >= s_box[0][4][lane] && b2.z1 <= s_box[0][5][lane]));
             if (wid == 0) {                                            // every wave holds the same states: one of them writes
                 const unsigned long long am = __ballot(asks);
                 int base = 0;
@@ -1405,7 +1420,7 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
             {
                 const float rq0 = sqrtf(t.b2d) * 1.0001f + 1e-6f;
                 const CellBox b2 = query_box(g, qx, qy, qz, cx, cy, cz, rq0, false), b1 = query_box(g, qx, qy, qz, cx, cy, cz, r1, true);
-                asks = member && !(b2.x0 >= b1.x0 && b2.x1 <= b1.x1 && b2.y0 >= b1.y0 && b2.y1 <= b1.y1 && b2.z0 >= b1.z0 && b2.z1 <= b1.z1);
+                asks = member && (asker_all || !(b2.x0 >= b1.x0 && b2.x1 <= b1.x1 && b2.y0 >= b1.y0 && b2.y1 <= b1.y1 && b2.z0 >= b1.z0 && b2.z1 <= b1.z1));
             }
             for (int stage = 0; stage < 2; stage++) {
             const float rnow = sqrtf(t.b2d) * 1.0001f + 1e-6f;
@@ -3155,7 +3170,27 @@ __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __r
     const int k_acc = t % kNumAcc, p_acc = t / kNumAcc;
     double v_acc = 0.0;
     const bool step = BEGIN_STEP ? first != 1 : !first;
-    if (step) {
+    if (step && CHUNK < kStepChunk && n_blocks > CHUNK && n_blocks <= 2 * CHUNK) {
+        // two chunks (the lean instantiations: 64-row chunks, 118 rows): BOTH chunks' loads are issued before the first is consumed -- one
+        // memory round trip instead of two on the path every other workgroup's next launch waits for.  Same rows, same order of sums.
+        const int n0 = CHUNK * kNumAcc, n1 = (n_blocks - CHUNK) * kNumAcc;
+        const double* __restrict__ src1 = partials + (size_t)CHUNK * kNumAcc;
+        double a[kPerThread], b[kPerThread];
+#pragma unroll
+        for (int u = 0; u < kPerThread; u++) { const int i = t + 256 * u; a[u] = COHERENT ? load_agent(partials + i) : partials[i]; }
+#pragma unroll
+        for (int u = 0; u < kPerThread; u++) { const int i = t + 256 * u; b[u] = (i < n1) ? (COHERENT ? load_agent(src1 + i) : src1[i]) : 0.0; }
+#pragma unroll
+        for (int u = 0; u < kPerThread; u++) s_rows[t + 256 * u] = a[u];
+        __syncthreads();
+        if (t < 8 * kNumAcc) for (int r = p_acc; r < CHUNK; r += 8) v_acc += s_rows[r * kNumAcc + k_acc];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kPerThread; u++) { const int i = t + 256 * u; if (i < n1) s_rows[i] = b[u]; }
+        __syncthreads();
+        if (t < 8 * kNumAcc) { for (int r = p_acc; r < n_blocks - CHUNK; r += 8) v_acc += s_rows[r * kNumAcc + k_acc]; part[p_acc][k_acc] = v_acc; }
+        (void)n0;
+    } else if (step) {
         for (int c0 = 0; c0 < n_blocks; c0 += CHUNK) {
             const int nrows = min(CHUNK, n_blocks - c0), total = nrows * kNumAcc;
             const double* __restrict__ src = partials + (size_t)c0 * kNumAcc;
