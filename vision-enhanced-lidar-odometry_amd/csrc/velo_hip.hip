@@ -12,6 +12,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <array>
 #include <cfloat>
 #include <cmath>
@@ -237,6 +238,9 @@ struct velo_ctx {
     DevBuf<velo_residual_stats> stat_out;
     int assoc_lane = 0;                  // VELO_ASSOC_LANE=1: rounds that start from seeds use the lane kernel (A/B; slower, see assoc_lane_body)
     int seed_rounds = 0;                 // association rounds since the seeds were last cleared
+    int xcd_chunks = 0;                  // VELO_XCD_CHUNKS=1 (diagnostics build): XCD k searches the k-th eighth of the query list (see assoc_search_v5_body)
+    int cu_mask_mode = 0;                // VELO_CU_MASK=1|2 (diagnostics build): this context's stream is confined to a quarter of the CUs (1: bits 64 q .. 64 q + 63,
+                                         // 2: the bits i with (i % 8) / 2 == q), q = (creation order / 2) % 4 -- the experiment of giving every lock-step group its own CUs
     int dimg_seeds = 0;                  // VELO_DIMG_SEEDS=1 (diagnostics build): seeds of iteration-1 rounds from the target's direction image (seed_kernel).
                                          // Measured, exact, NOT a gain: C2 rounds 95 / 80 / 78 -> 90 / 86 / 85 us (the cold round's cost is the true
                                          // second-ring distance of the far queries, not poor seeds; the seed launch costs 7 us), 8 pairs in flight
@@ -930,6 +934,8 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 const int asker_rows = c->asker_rows >= 0 ? c->asker_rows : (reach_cells > 5 ? 0 : (1 << 30));
                 const int* perm = nullptr;
                 if (c->tube_map >= 0) { VELO_TRY(build_group_perm(c, qb, qe, c->tube_map)); perm = c->group_perm.p; }
+                else if (c->xcd_chunks) perm = kXcdChunks;
+                const int grid_groups = perm == kXcdChunks ? 8 * cdiv(groups, 8) : groups;
                 // density-shrunk grid, default instantiation, COLD round (no seeds yet: half of the queries ask, the heavy ones in clumps): the asking
                 // queries go on a list and are searched by a second launch.  Measured per round on the 2M-point map, list vs in place: cold 399 vs
                 // 688 us; seeded rounds 237 / 326 / 246 / 183 / 160 vs 230 / 272 / 207 / 138 / 116 us (few askers: the second launch only adds its
@@ -939,7 +945,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 hipEvent_t ev_stop = ev ? ev->second : nullptr;
                 if (out.ask_list && ev) ev_stop = nullptr;              // the bracket closes behind the asker launch
 #define VELO_LAUNCH_V5(NW, MINW, DBG, PPT, ASKER)                                                                                         \
-                hipExtLaunchKernelGGL((assoc_search_v5_kernel<NW, MINW, DBG, PPT, ASKER>), dim3(groups), dim3(NW * 64), c->assoc_lds_pad, c->stream,                    \
+                hipExtLaunchKernelGGL((assoc_search_v5_kernel<NW, MINW, DBG, PPT, ASKER>), dim3(grid_groups), dim3(NW * 64), c->assoc_lds_pad, c->stream,                    \
                                       ev ? ev->first : nullptr, ev_stop, 0, S, P_dev, P_dev ? c->chain_fail.p : (int*)nullptr, V, c->qpts, qb, qe,                      \
                                    (const float4*)c->T->tgt_pad.p, (const int*)c->T->tgt_off.p, gbits, c->P.icp_norm_condition, cw, h_safe, out, aux, perm, c->debug_skip ? c->debug_skip : (asker_rows < (1 << 30) ? (c->dense_rows | (c->dense_far << 20)) : 0), asker_rows)
                 // default: 5 waves/SIMD (96 VGPRs, no spills, no scratch traffic), 2 candidate pairs per trip.  Measured on C2:
@@ -965,7 +971,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                     a.P = S; a.P_dev = P_dev; a.chain_fail = P_dev ? c->chain_fail.p : nullptr; a.G = V; a.qpts = c->qpts; a.q_begin = qb; a.q_end = qe;
                     a.tgt_pad = c->T->tgt_pad.p; a.tgt_off = c->T->tgt_off.p; a.gate_bits = gbits; a.norm_cond = c->P.icp_norm_condition; a.cluster_w = cw;
                     a.h_safe = h_safe; a.out = out; a.want_aux = aux; a.group_perm = perm; a.dbg = c->dense_rows | (c->dense_far << 20); a.asker_rows = asker_rows;
-                    hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, 2>), dim3(groups, 1), dim3(256), c->assoc_lds_pad, c->stream,
+                    hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, 2>), dim3(grid_groups, 1), dim3(256), c->assoc_lds_pad, c->stream,
                                           ev ? ev->first : nullptr, ev_stop, 0, B1);
                     hipExtLaunchKernelGGL(assoc_asker_kernel, dim3(cdiv(qe - qb, kAskChunk)), dim3(64), 0, c->stream, nullptr, ev ? ev->second : nullptr, 0,
                                           S, P_dev, (const int*)(P_dev ? c->chain_fail.p : nullptr), V, c->qpts, (const float4*)c->T->tgt_pad.p, (const int*)c->T->tgt_off.p,
@@ -1442,6 +1448,8 @@ int velo_create(velo_ctx** out, int device) {
         if (const char* e = dev_env("VELO_TUBE_MAP")) c->tube_map = atoi(e);
         if (const char* e = dev_env("VELO_WARM_START")) c->warm_start = atoi(e);
         if (const char* e = dev_env("VELO_DIMG_SEEDS")) c->dimg_seeds = atoi(e);
+        if (const char* e = dev_env("VELO_XCD_CHUNKS")) c->xcd_chunks = atoi(e);
+        if (const char* e = dev_env("VELO_CU_MASK")) c->cu_mask_mode = atoi(e);
         if (const char* e = dev_env("VELO_SMALL_SOLVE")) c->small_solve = atoi(e);
         if (const char* e = dev_env("VELO_LM_MERGED")) c->lm_merged = atoi(e);
         if (const char* e = dev_env("VELO_LM_FUSED")) c->lm_fused = atoi(e);
@@ -1464,6 +1472,16 @@ int velo_create(velo_ctx** out, int device) {
         if (const char* e = dev_env("VELO_ASKER_ROWS")) c->asker_rows = atoi(e);
         if (const char* e = dev_env("VELO_PERSISTENT_WGS")) c->persistent_wgs = std::max(atoi(e), 1);
         if (const char* e = getenv("VELO_BATCH_LOCKSTEP")) c->batch_lockstep = atoi(e);
+        if (c->cu_mask_mode > 0) {
+            static std::atomic<int> seq{0};
+            const int q = (seq.fetch_add(1) / 2) % 4;
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < 256; i++) {
+                const bool mine = c->cu_mask_mode == 1 ? (i / 64 == q) : ((i % 8) / 2 == q);
+                if (mine) mask[i / 32] |= 1u << (i % 32);
+            }
+            HIP_TRY(hipExtStreamCreateWithCUMask(&c->stream, 8, mask));
+        } else
         HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_TRY(hipHostMalloc((void**)&c->h_status, sizeof(HostStatus), hipHostMallocDefault));
         HIP_TRY(hipHostMalloc((void**)&c->h_x, sizeof(double) * 64, hipHostMallocDefault));
@@ -2573,7 +2591,7 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
     }
     out.n_valid_next = c->n_valid.p + (c->nv_idx ^ 1);
     c->nv_clean[c->nv_idx ^ 1] = true;
-    A->want_aux = 0; A->group_perm = nullptr; A->dbg = 0;
+    A->want_aux = 0; A->group_perm = c->xcd_chunks ? kXcdChunks : nullptr; A->dbg = 0;
     const int reach_cells = (int)std::ceil(std::sqrt(std::max(gate_of_iter(c->P, 1), 0.0)) / (G->h * 0.999));
     A->asker_rows = c->asker_rows >= 0 ? c->asker_rows : (reach_cells > 5 ? 0 : (1 << 30));
     *asker = A->asker_rows < (1 << 30);
@@ -2630,6 +2648,7 @@ static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::arr
             gmax = std::max(gmax, groups); any_asker = any_asker || asker; k++;
         }
         if (k == 0) continue;
+        if (ctxs[first]->xcd_chunks) gmax = 8 * cdiv(gmax, 8);
         velo_ctx* c = ctxs[first];
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
         uint64_t bytes = 0;                                           // B_assoc of every context this launch serves

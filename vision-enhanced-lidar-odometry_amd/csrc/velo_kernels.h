@@ -1026,6 +1026,7 @@ __device__ __forceinline__ void top2_merge_xor(Top2& t, int mask) {
 //     is never a third phase.
 // Tubes do not blow up with the length of the segment, so the cluster radius can be large (one cluster per group).
 //   * rounds after the first are warm-started from the previous round's winners (AssocOut::prev).
+#define kXcdChunks (reinterpret_cast<const int*>(8))
 template <int NW, int MINW, bool DBG, int PPT, int ASKER>
 __device__ __forceinline__ void
 assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_dev, int* __restrict__ chain_fail, const GridView& G, const float4* __restrict__ qpts, int q_begin, int q_end,
@@ -1069,8 +1070,16 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = (DBG && (dbg & 8)) ? (long long)__builtin_readcyclecounter() : 0;
 #define VELO_STAMP(k) do { if (DBG && (dbg & 8)) { const long long now__ = (long long)__builtin_readcyclecounter(); tacc[k] += now__ - tlast; tlast = now__; } } while (0)
-    // workgroup -> group through the host-built table (XCD-aware wedges, see build_group_perm); placement affects speed only
-    const int group = group_perm ? group_perm[block_x] : (int)block_x;
+    // workgroup -> group through the host-built table (XCD-aware wedges, see build_group_perm); placement affects speed only.
+    // group_perm == kXcdChunks (a tag, not a pointer): workgroups are dealt round-robin over the 8 XCDs, so block 8 j + k goes to the j-th
+    // group of the k-th EIGHTH of the list -- every XCD's L2 then sees one contiguous eighth of the queries (in patch order: one band of
+    // rings) and the part of the target they look at, instead of the whole scene.  The grid has 8 * ceil(groups / 8) blocks.
+    int group = (int)block_x;
+    if (group_perm == kXcdChunks) {
+        const int n_groups = (q_end - q_begin + 63) / 64, per = (n_groups + 7) / 8;
+        group = (block_x & 7) * per + (block_x >> 3);
+        if (group >= n_groups) return;
+    } else if (group_perm) group = group_perm[block_x];
     if (out.n_valid_next && block_x == 0 && tid == 0) *out.n_valid_next = 0;   // its last reader ran before this launch (same stream)
     if (ASKER == 2 && block_x == 0 && tid == 0) *out.ask_count_next = 0;
     if (DBG && out.wg_times && tid == 0) out.wg_times[2 * group] = __builtin_amdgcn_s_memrealtime();
@@ -1558,7 +1567,7 @@ template <int NW, int MINW, bool DBG, int PPT, int ASKER>
 __global__ void __launch_bounds__(NW * 64, MINW)
 assoc_search_v5_batch_kernel(AssocBatch B) {
     const AssocArgs& a = B.item[blockIdx.y];
-    if ((int)blockIdx.x * 64 >= a.q_end - a.q_begin) return;
+    if (a.group_perm != kXcdChunks && (int)blockIdx.x * 64 >= a.q_end - a.q_begin) return;
     assoc_search_v5_body<NW, MINW, DBG, PPT, ASKER>(a.P, a.P_dev, a.chain_fail, a.G, a.qpts, a.q_begin, a.q_end, a.tgt_pad, a.tgt_off, a.gate_bits, a.norm_cond,
                                                     a.cluster_w, a.h_safe, a.out, a.want_aux, a.group_perm, a.dbg, a.asker_rows, (int)blockIdx.x);
 }
