@@ -193,7 +193,7 @@ struct velo_ctx {
     int src_skip = 0;                    // icp_skip the query list was built with
     DevBuf<float4> qpts_buf;             // query points by query index when icp_skip > 1 (with icp_skip == 1 the source cloud is the list)
     const float4* qpts = nullptr;
-    DevBuf<float4> prev_a, prev_b;       // tube kernel warm start: last round's winners per query with their coordinates (index -1 = none),
+    DevBuf<float4> prev_a;               // tube kernel warm start: last round's two winners per query with their coordinates (index -1 = none; [0, nq) best, [nq, 2 nq) second),
     DevBuf<int2> prev_r;                 // and their rings; reset with every new source / target
     bool prev_ready = false;             // the seed arrays hold n_q initialised entries for the current source and target
     int warm_start = 1;                  // VELO_WARM_START=0 turns the seeds off (A/B; results are identical either way)
@@ -750,15 +750,12 @@ int attach_seeds(velo_ctx* c, AssocOut* out, bool image_seeds = false, int* had_
     if (!c->warm_start) return VELO_OK;
     const size_t nq = (size_t)std::max(c->n_q, 1);
     if (!c->prev_ready) {
-        VELO_TRY(c->prev_a.reserve(nq)); VELO_TRY(c->prev_b.reserve(nq)); VELO_TRY(c->prev_r.reserve(nq));
-        if (!image_seeds) {                                          // (the seed kernel writes every entry itself)
-            HIP_TRY(hipMemsetAsync(c->prev_a.p, 0xff, sizeof(float4) * nq, c->stream));
-            HIP_TRY(hipMemsetAsync(c->prev_b.p, 0xff, sizeof(float4) * nq, c->stream));
-        }
+        VELO_TRY(c->prev_a.reserve(2 * nq)); VELO_TRY(c->prev_r.reserve(nq));   // both winners' arrays in one allocation: one fill
+        if (!image_seeds) HIP_TRY(hipMemsetAsync(c->prev_a.p, 0xff, sizeof(float4) * 2 * nq, c->stream));   // (the seed kernel writes every entry itself)
         c->prev_ready = true;
         c->seed_rounds = 0;
     } else if (had_prev) *had_prev = 1;
-    out->prev_a = c->prev_a.p; out->prev_b = c->prev_b.p; out->prev_r = c->prev_r.p;
+    out->prev_a = c->prev_a.p; out->prev_b = c->prev_a.p + nq; out->prev_r = c->prev_r.p;
     return VELO_OK;
 }
 void fill_seed_args(const velo_ctx* c, SeedArgs* A, const PoseScalars& S, const PoseRecord* P_dev, const int* chain_fail, int qb, int qe, const AssocOut& out, int had_prev) {
@@ -1281,10 +1278,12 @@ int target_finalize_begin(velo_ctx* c) {
     HIP_TRY(hipMemcpyAsync(c->T->tgt_off.p, c->T->h_tgt_off.data(), sizeof(int) * ((size_t)n_rings + 1), hipMemcpyHostToDevice, c->stream));
     // bbox of the finite points -> host (the only sync of set_target; the grid dimensions are sized from it)
     unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
-    std::memcpy(c->h_int, init, sizeof(init));
-    HIP_TRY(hipMemcpyAsync(c->bbox_keys.p, c->h_int, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    if (n == 0) {                                                     // (with points the ring_of launch initialises the keys)
+        std::memcpy(c->h_int, init, sizeof(init));
+        HIP_TRY(hipMemcpyAsync(c->bbox_keys.p, c->h_int, sizeof(init), hipMemcpyHostToDevice, c->stream));
+    }
     if (n > 0) {
-        hipLaunchKernelGGL(ring_of_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->T->tgt_off.p, n_rings, n, c->T->tgt_first_ring, c->T->tgt_ring_of.p);
+        hipLaunchKernelGGL(ring_of_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->T->tgt_off.p, n_rings, n, c->T->tgt_first_ring, c->T->tgt_ring_of.p, c->bbox_keys.p);
         hipLaunchKernelGGL(pad_rings_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const float4*)c->T->tgt.p, (const int*)c->T->tgt_off.p, (const int*)c->T->tgt_ring_of.p, n,
                            c->T->tgt_first_ring, c->T->tgt_pad.p);
         hipLaunchKernelGGL(bbox_kernel, dim3(std::min(cdiv(n, 256 * 8), 256)), dim3(256), 0, c->stream, c->T->tgt.p, n, c->bbox_keys.p);

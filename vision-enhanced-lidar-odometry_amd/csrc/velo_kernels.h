@@ -104,8 +104,11 @@ __global__ void pack_points_kernel(const char* __restrict__ src, int64_t stride,
 // ring id per point (binary search in ring_offsets) -- the target's gidx -> ring map
 // (a context may hold only a block of whole rings of the target -- target-sharded mode -- so ring ids and point
 //  indices that leave the kernels are GLOBAL: local ring + first_ring, local index + first_point)
-__global__ void ring_of_kernel(const int* __restrict__ off, int n_rings, int n, int first_ring, int* __restrict__ ring_of) {
+// (bbox_init: the six keys bbox_kernel folds into -- min keys all ones, max keys zero -- are initialised here, one launch ahead of it,
+//  instead of by a copy operation of their own)
+__global__ void ring_of_kernel(const int* __restrict__ off, int n_rings, int n, int first_ring, int* __restrict__ ring_of, unsigned* __restrict__ bbox_init) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bbox_init && i < 6) bbox_init[i] = i < 3 ? 0xffffffffu : 0u;
     if (i >= n) return;
     int lo = 0, hi = n_rings;   // find r with off[r] <= i < off[r+1]
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= i) lo = mid; else hi = mid; }
