@@ -706,3 +706,43 @@ def test_chain_mode_with_visual_blocks_is_bit_identical(hip_lib, oracle, monkeyp
         xo, To, so = orc.frame_to_frame(d["x0"])
         assert H.pose_close(res["chain"][0][0][0], xo)
         assert [(so.solves[k].n_visual_blocks, so.solves[k].n_visual_residuals) for k in range(so.n_solves)] == res["chain"][0][0][3]
+
+
+def test_kernel_times_count_every_launch_and_bracket_a_sample(hip_lib):
+    """velo_set_timing(ctx, 2) / velo_get_kernel_times (what bench.py's `kernels` list is made of): every instrumented launch is counted
+    by kernel name with its algorithmic bytes, every 8th is bracketed with HIP events and the time scaled up; level 3 brackets all of
+    them; timing never changes a result."""
+    d = synth.scan_pair(n_beams=32, n_azimuth=400)
+    ref = api.Context(0, icp_skip=1)
+    ref.set_target(d["tgt_xyz"], d["tgt_off"]); ref.set_source(d["src_xyz"], d["src_off"])
+    x0, T0, s0 = ref.frame_to_frame(d["x0"])
+    ref.close()
+    evals = sum(s0.solves[k].evaluations for k in range(s0.n_solves))
+    for level in (2, 3):
+        c = api.Context(0, icp_skip=1)
+        c.set_timing(level)
+        for rep in range(3):
+            c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])
+            x, T, s = c.frame_to_frame(d["x0"])
+            assert np.array_equal(x, x0) and np.array_equal(T, T0)
+        kt = c.kernel_times(reset=True)
+        assert c.kernel_times() == {}                                   # reset
+        assert kt["assoc_search_v5_kernel"][1] == 18 and kt["grid_scatter_kernel"][1] == 3      # 3 calls x 6 rounds; one index build per load
+        ms, n, b = kt["lm_iter_kernel"]
+        assert n >= 3 * (evals + 6) and ms > 0.0                        # every solve takes its evaluations + 1 launches (+ the chain's margin)
+        nq, nt = 32 * 400, 32 * 400
+        assert kt["assoc_search_v5_kernel"][2] == 18 * (40 * nq + 12 * nt)                      # B_assoc per round served
+        assert b == 3 * sum(s0.solves[k].evaluations * (36 * s0.solves[k].n_icp_valid + 224) for k in range(s0.n_solves))   # B_eval per evaluation
+        assert all(v[0] >= 0.0 and v[1] > 0 for v in kt.values())
+        c.close()
+    # a lock-step batch logs its shared launches on the group's first context
+    ctxs = [api.Context(0, icp_skip=1) for _ in range(4)]
+    for c in ctxs:
+        c.set_timing(2)
+    xs, Ts, Ss = api.register_batch(ctxs, [(d["tgt_xyz"], d["tgt_off"])] * 4, [(d["src_xyz"], d["src_off"])] * 4, np.tile(d["x0"], (4, 1)))
+    assert all(np.array_equal(xs[i], x0) for i in range(4))
+    names = set()
+    for c in ctxs:
+        names |= set(c.kernel_times())
+        c.close()
+    assert "assoc_search_v5_batch_kernel" in names and any(nm.startswith("eval_step_batch") for nm in names)

@@ -79,3 +79,27 @@ def test_map_and_stereo_generators():
     M = v["p3_1"].astype(np.float64) @ R.T + t + v["t_cam"]
     err = np.linalg.norm(M[:, :2] / M[:, 2:3] - v["p2_2"], axis=1)
     assert np.median(err[inl]) < 5e-3
+
+
+def test_distinct_pairs_are_distinct_and_keep_the_ring_layout():
+    """bench.py's step registers B DIFFERENT pairs: own scene, noise, place and motion each; pair 0 is the canonical pair."""
+    ps = synth.distinct_pairs(3, n_beams=16, n_azimuth=200)
+    canon = synth.scan_pair(n_beams=16, n_azimuth=200)
+    assert np.array_equal(ps[0]["src_xyz"], canon["src_xyz"]) and np.array_equal(ps[0]["x0"], canon["x0"])
+    for d in ps:
+        assert len(d["src_off"]) - 1 == 16 and len(d["tgt_off"]) - 1 == 16          # the segmenter finds every ring again
+        assert d["src_xyz"].shape == (3200, 3) and d["src_xyz"].dtype == np.float32
+    assert not np.array_equal(ps[1]["tgt_xyz"], ps[2]["tgt_xyz"]) and not np.allclose(ps[1]["x_true"], ps[2]["x_true"])
+    for d in ps[1:]:                                                                    # the guess is the previous frame's motion: near the truth, not equal
+        e = np.abs(np.asarray(d["x0"]) - np.asarray(d["x_true"]))
+        assert 0 < e[3:].max() <= 0.12 and e[:3].max() <= 0.012
+    again = synth.distinct_pairs(3, n_beams=16, n_azimuth=200)
+    assert all(np.array_equal(a["src_xyz"], b["src_xyz"]) and np.array_equal(a["x0"], b["x0"]) for a, b in zip(ps, again))   # counter-based RNG: reproducible
+
+
+def test_scan_to_map_with_several_query_scans():
+    m = synth.scan_to_map(3 * 16 * 100, n_beams=16, n_azimuth=100, n_queries=3)
+    qs = m["queries"]
+    assert len(qs) == 3 and np.array_equal(qs[0]["src_xyz"], m["src_xyz"])
+    assert all(len(q["src_off"]) - 1 == 16 for q in qs) and not np.array_equal(qs[1]["src_xyz"], qs[2]["src_xyz"])
+    assert "queries" not in synth.scan_to_map(3 * 16 * 100, n_beams=16, n_azimuth=100)
