@@ -254,6 +254,7 @@ struct velo_ctx {
     DevBuf<int> chain_fail;
     SolveLog* h_log = nullptr;           // pinned: VELO_MAX_SOLVES logs + the failure flag behind them
     int lm_fused = 1;                    // VELO_LM_FUSED=0: the lock-step batch driver launches sweep and LM step separately (A/B, identical results)
+    int lm_iter = 0;                     // VELO_LM_ITER=1: chained batch solves launch the lean one-launch iteration (every workgroup advances the state itself) instead of the fused sweep + step (A/B, identical results; measured slower: 3,204 vs 3,418 pairs/s)
     int lm_merged = 1;                   // VELO_LM_MERGED=0: sweep and LM step as two launches per iteration also where one would do (A/B, identical results)
     int small_solve = 1;                 // VELO_SMALL_SOLVE=0: small problems go through the launch-per-iteration path too (A/B, identical results)
     int asker_rows = -1;                 // tube kernel (VELO_ASKER_ROWS): phase 2 goes query by query when the asking queries' boxes have more
@@ -460,7 +461,7 @@ int upload_cloud(velo_ctx* c, const float* xyz, int64_t stride, int n, int on_de
         HIP_TRY(hipMemcpyAsync(c->staging.p, xyz, bytes, hipMemcpyHostToDevice, c->stream));
         dsrc = c->staging.p;
     }
-    hipLaunchKernelGGL(pack_points_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, dsrc, stride, n, dst.p);
+    VELO_LAUNCH_T(c, "pack_points_kernel", 28ull * (uint64_t)n, pack_points_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, dsrc, stride, n, dst.p);
     HIP_TRY(hipGetLastError());
     return VELO_OK;
 }
@@ -1283,10 +1284,10 @@ int target_finalize_begin(velo_ctx* c) {
         HIP_TRY(hipMemcpyAsync(c->bbox_keys.p, c->h_int, sizeof(init), hipMemcpyHostToDevice, c->stream));
     }
     if (n > 0) {
-        hipLaunchKernelGGL(ring_of_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->T->tgt_off.p, n_rings, n, c->T->tgt_first_ring, c->T->tgt_ring_of.p, c->bbox_keys.p);
-        hipLaunchKernelGGL(pad_rings_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const float4*)c->T->tgt.p, (const int*)c->T->tgt_off.p, (const int*)c->T->tgt_ring_of.p, n,
-                           c->T->tgt_first_ring, c->T->tgt_pad.p);
-        hipLaunchKernelGGL(bbox_kernel, dim3(std::min(cdiv(n, 256 * 8), 256)), dim3(256), 0, c->stream, c->T->tgt.p, n, c->bbox_keys.p);
+        VELO_LAUNCH_T(c, "ring_of_kernel", 4ull * (uint64_t)n, ring_of_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, c->T->tgt_off.p, n_rings, n, c->T->tgt_first_ring, c->T->tgt_ring_of.p, c->bbox_keys.p);
+        VELO_LAUNCH_T(c, "pad_rings_kernel", 36ull * (uint64_t)n, pad_rings_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, (const float4*)c->T->tgt.p, (const int*)c->T->tgt_off.p, (const int*)c->T->tgt_ring_of.p, n,
+                      c->T->tgt_first_ring, c->T->tgt_pad.p);
+        VELO_LAUNCH_T(c, "bbox_kernel", 16ull * (uint64_t)n, bbox_kernel, dim3(std::min(cdiv(n, 256 * 8), 256)), dim3(256), 0, c->stream, c->T->tgt.p, n, c->bbox_keys.p);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipMemcpyAsync(c->h_int + 8, c->bbox_keys.p, sizeof(init), hipMemcpyDeviceToHost, c->stream));
@@ -1452,6 +1453,7 @@ int velo_create(velo_ctx** out, int device) {
         if (const char* e = dev_env("VELO_SMALL_SOLVE")) c->small_solve = atoi(e);
         if (const char* e = dev_env("VELO_LM_MERGED")) c->lm_merged = atoi(e);
         if (const char* e = dev_env("VELO_LM_FUSED")) c->lm_fused = atoi(e);
+        if (const char* e = dev_env("VELO_LM_ITER")) c->lm_iter = atoi(e);
         if (const char* e = dev_env("VELO_ASSOC_LANE")) c->assoc_lane = atoi(e);
         if (const char* e = dev_env("VELO_LM_MERGED_VIS")) c->lm_trace_vis_off = atoi(e) == 0;
         if (const char* e = dev_env("VELO_ASKER_QUEUE")) c->asker_queue = atoi(e);
@@ -2785,6 +2787,8 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
         // (A/B, measured: the LM launches on a high-priority stream of their own halve the throughput -- 1,530 vs 3,020 pairs/s: more than four
         //  active hardware queues are time-sliced, the same effect as GPU_MAX_HW_QUEUES=8)
         int r = 0;
+        const bool iter_mode = c0->lm_iter && n <= 4 && !any_matches && c0->lm_fused && !c0->lm_persist;
+        int iter_launches = 0;                                       // iter_mode: parity of every context's state / partial-row double buffer
         for (int iter = 1; iter <= P.f2f_iterations; iter++) {
             for (int i = 0; i < n && any_matches; i++) {             // residual-type choice + outlier gate of this iteration (velo.h:622-792), on the device
                 velo_ctx* c = ctxs[i];
@@ -2815,8 +2819,19 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                 // the kernels that take a pointer (the visual sweep, the two-launch path, the one-launch solve, the final state gather)
                 const bool by_value = n <= 4 && c0->lm_fused && !c0->lm_persist && nbv_max == 0;
                 if (!by_value || r == 0) HIP_TRY(hipMemcpyAsync(c0->batch_items.p + (size_t)r * n, items_r, sizeof(LMBatchItem) * (size_t)n, hipMemcpyHostToDevice, bs));
-                bool small = c0->small_solve != 0;                      // every solve of the group is ONE single-workgroup launch (lm_solve_small_kernel's body)
+                bool small = c0->small_solve != 0 && !iter_mode;        // every solve of the group is ONE single-workgroup launch (lm_solve_small_kernel's body)
                 for (int i = 0; i < n; i++) small = small && items_r[i].n_rows >= 1 && items_r[i].n_rows <= kSmallRows;
+                if (iter_mode) {                                        // K + 1 launches: the last one only advances the state over the K-th sweep's rows
+                    LMBatchPackV pk;
+                    std::memset(&pk, 0, sizeof(pk));
+                    for (int i = 0; i < n; i++) pk.item[i] = items_r[i];
+                    c0->lm_kernel_name = "lm_iter_batch_lean_kernel";
+                    const size_t half = (size_t)(kMaxEvalBlocks + kMaxVisBlocks) * kNumAcc;
+                    for (int k = 0; k <= K; k++, iter_launches++)
+                        VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, lm_iter_batch_lean_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, pk, iter_launches & 1, k == 0 ? 1 : 0, half);
+                    HIP_TRY(hipGetLastError());
+                    continue;
+                }
                 if (small) {
                     for (int b0 = 0; b0 < n; b0 += kItemsByValue) {     // (the items copied above serve lm_gather_states_kernel)
                         LMBatchPack pack;
@@ -2870,7 +2885,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
 
             }
         }
-        hipLaunchKernelGGL(lm_gather_states_kernel, dim3(n), dim3(128), 0, bs, (const LMBatchItem*)c0->batch_items.p, c0->batch_states.p, 0);
+        hipLaunchKernelGGL(lm_gather_states_kernel, dim3(n), dim3(128), 0, bs, (const LMBatchItem*)c0->batch_items.p, c0->batch_states.p, iter_launches & 1);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h_states, c0->batch_states.p, sizeof(LMState) * (size_t)n, hipMemcpyDeviceToHost, bs));
         HIP_TRY(hipMemcpyAsync(h_logs, c0->batch_logs.p, sizeof(SolveLog) * (size_t)n * VELO_MAX_SOLVES, hipMemcpyDeviceToHost, bs));
@@ -3399,6 +3414,13 @@ int velo_synchronize(velo_ctx* c) {
     if (!c) return fail(VELO_ERR_INVALID, "null ctx");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->timing >= 2 && c->klog_used > 0) {                            // brackets of launches outside a registration (index builds)
+        const int used = c->assoc_events_used;
+        c->assoc_events_used = 0;
+        const int st = read_assoc_timing(c, nullptr);
+        c->assoc_events_used = used;
+        VELO_TRY(st);
+    }
     return VELO_OK;
 }
 

@@ -268,13 +268,33 @@ __device__ __forceinline__ int cell_of_point(const GridDesc& g, const float4& p)
 // table[c + 1] = start(c); the scatter takes its slots with atomicAdd(&table[c + 1], 1), which leaves table[c + 1] = start(c + 1).
 // table[0] stays 0, so in the end table[k] = start(k) for k = 0..ncells -- no cursor copy of the table (a 134 MB write per build
 // of the 2M-point map's 33 M cells), no second pass over it.
+// Consecutive points of a ring are neighbours in space, on an accumulated map often several per cell: the lanes of a wave that hold a RUN
+// of equal cell ids send ONE atomic for the run (count) / take one block of slots for it (scatter).  The atomics on a cell's word come
+// from workgroups on different XCDs -- every one moves the line to another L2 -- so fewer of them is what shortens both kernels.
+// run_of_lane: `head` lanes start a run; returns the run's first lane and its length (valid on every lane with c >= 0).
+__device__ __forceinline__ void run_of_lane(int c, int lane, bool* head, int* first, int* len) {
+    const int prev = __shfl_up(c, 1);
+    const bool h = c >= 0 && (lane == 0 || prev != c);
+    const unsigned long long hm = __ballot(h), vm = __ballot(c >= 0);
+    const unsigned long long upto = (2ull << lane) - 1ull;                       // lanes 0..lane
+    const int f = 63 - __clzll((long long)((hm & upto) | 1ull));                 // (| 1: keeps clz defined on lanes before the first run)
+    const unsigned long long stop = (hm | ~vm) & ~upto;                          // the next run or the next lane without a cell
+    *head = h; *first = f; *len = (stop ? (int)__ffsll((long long)stop) - 1 : 64) - f;
+#ifdef VELO_NO_RUN_AGG                                                   // A/B build: one atomic per point, as before round 3
+    *head = c >= 0; *first = lane; *len = 1;
+#endif
+}
 __global__ void grid_count_kernel(GridDesc g, const float4* __restrict__ pts, int n, int* __restrict__ cell_of, int* __restrict__ table) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float4 p = pts[i];
     int c = -1;
-    if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) { c = cell_of_point(g, p); atomicAdd(&table[c + 1], 1); }
-    cell_of[i] = c;
+    if (i < n) {
+        const float4 p = pts[i];
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) c = cell_of_point(g, p);
+        cell_of[i] = c;
+    }
+    bool head; int first, len;
+    run_of_lane(c, threadIdx.x & 63, &head, &first, &len);
+    if (head) atomicAdd(&table[c + 1], len);
 }
 
 constexpr int kScanThreads = 256;
@@ -411,10 +431,13 @@ __global__ void grid_scatter_kernel(const float4* __restrict__ pts, const int* _
         sorted[j] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __int_as_float(0x7fffffff));
         sring[j] = 0x7fffffff;
     }
-    if (i >= n) return;
-    const int c = cell_of[i];
+    const int c = i < n ? cell_of[i] : -1;
+    bool head; int first, len;
+    const int lane = threadIdx.x & 63;
+    run_of_lane(c, lane, &head, &first, &len);
+    int slot = head ? atomicAdd(&cursor[c], len) : 0;                  // cursor = table + 1 (see grid_count_kernel); one block of slots per run
+    slot = __shfl(slot, first) + (lane - first);
     if (c < 0) return;
-    const int slot = atomicAdd(&cursor[c], 1);                         // cursor = table + 1 (see grid_count_kernel)
     const float4 p = pts[i];
     sorted[slot] = make_float4(p.x, p.y, p.z, __int_as_float(i + first_point));
     sring[slot] = ring_of[i];
@@ -3599,6 +3622,36 @@ eval_step_batch_v_kernel(LMParams Q, LMBatchPackV P, int* __restrict__ tickets, 
 __global__ void __launch_bounds__(kEvalThreads) __attribute__((amdgpu_num_vgpr(152)))
 eval_step_batch_lean_v_kernel(LMParams Q, LMBatchPackV P, int* __restrict__ tickets, int first) {
     eval_step_batch_body<true, VELO_LEAN_PRE, 64>(Q, P.item[blockIdx.y], tickets, first);
+}
+// The one-launch iteration of the single-pair path (every workgroup runs the transition itself, then sweeps: no last-workgroup hand-over
+// inside the launch) for the contexts of a lock-step group, in the LEAN shape of eval_step_batch_lean_kernel (matrices from LDS, one
+// prefetched row, 64-row chunks), items by value.  parity selects the halves of every context's state / partial-row double buffer (a
+// running launch count across the call's rounds).  Same virtual blocks, same order of sums: bit-identical to every other path.
+// VELO_LM_ITER=1 (diagnostics build).  Measured (round 3, 8 different pairs in flight): 24.4 us per launch against 26.6 us for the
+// fused sweep + step, but a solve needs one launch more and every workgroup re-reads all 118 partial rows: 3,204 vs 3,418 pairs/s.
+template <bool M_LDS, int PRE, int CHUNK>
+__device__ __forceinline__ void lm_iter_lean_body(const EvalArgs& A, const LMParams& Q, const LMState* __restrict__ Sin, LMState* __restrict__ Sout,
+                                                  const double* __restrict__ pin, int n_in, double* __restrict__ pout, int first,
+                                                  const double* __restrict__ x_in, const int* __restrict__ n_valid, const int bx, const int nbx,
+                                                  PoseRecord* pose_out, SolveLog* log) {
+    __shared__ LMState sL;
+    __shared__ LMEvalPoint s_pt;
+    __shared__ double s_scratch[CHUNK * kNumAcc];
+    const RowPrefetchT<PRE> f = prefetch_rows<PRE>(A, bx, nbx);
+    lm_advance<false, CHUNK>(Q, Sin, pin, n_in, first, x_in, n_valid, s_scratch, &sL, &s_pt, nullptr, 0, nullptr, pose_out, log, bx == 0);
+    const int t = threadIdx.x;
+    if (bx == 0 && t < (int)(sizeof(LMState) / 8)) reinterpret_cast<unsigned long long*>(Sout)[t] = reinterpret_cast<const unsigned long long*>(&sL)[t];
+    if (sL.done) return;
+    double acc[kNumAcc];
+    sweep_rows<M_LDS, PRE>(A, f, s_pt, bx, nbx, acc);
+    block_reduce_store(acc, pout + (size_t)bx * kNumAcc, s_scratch);
+}
+__global__ void __launch_bounds__(kEvalThreads) __attribute__((amdgpu_num_vgpr(152)))
+lm_iter_batch_lean_kernel(LMParams Q, LMBatchPackV P, int parity, int first, size_t half) {
+    const LMBatchItem& it = P.item[blockIdx.y];
+    if ((int)blockIdx.x >= it.nb_icp) return;
+    lm_iter_lean_body<true, VELO_LEAN_PRE, 64>(it.A, Q, it.S + parity, it.S + (parity ^ 1), it.A.partials + (size_t)parity * half, it.nb_icp,
+                                               it.A.partials + (size_t)(parity ^ 1) * half, first, it.xd, it.n_valid, blockIdx.x, it.nb_icp, it.pose_out, it.log);
 }
 // ---- a whole solve of a lock-step group in ONE launch ---------------------------------------------------------------------------------
 // A solve used to be one launch per LM iteration: ~48 launches per call and group, each paying the queue's hand-over (4-10 us between
