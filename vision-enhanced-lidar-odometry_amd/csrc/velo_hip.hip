@@ -181,6 +181,7 @@ struct velo_ctx {
     std::shared_ptr<TargetData> T = std::make_shared<TargetData>();
     DevBuf<int> vis_counts;                       // chain mode: [f2f iteration][blocks, residuals] selected by the device-side gate
     DevBuf<int> scan_tiles, cursor, scan_total;   // scratch of an index build / of the segmenter's scans
+    bool batch_load = false;                      // set while velo_register_batch loads this context's scans for a batch of two or more (see build_grid)
     DevBuf<unsigned long long> lb_status;         // one-pass scan: tile status words + ticket
     DevBuf<unsigned> bbox_keys;
     bool have_target = false;
@@ -503,7 +504,12 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
             dims[k] = (int)std::min(dk, 8192.0);
             total *= dk;
         }
-        static const double cell_cap = dev_env("VELO_GRID_CAP") ? std::max(atof(dev_env("VELO_GRID_CAP")), 4096.0) : 33554432.0;
+        // (a target loaded by velo_register_batch for one of several registrations in flight: 2^24 cells.  Measured on the 2M-point map,
+        //  where the cap decides -- 23 M cells of 6.2 cm or 11.5 M of 7.8 cm: one pair 2.29 vs 2.36 ms, eight pairs in flight 1,340-1,370
+        //  vs 1,450-1,465 pairs/s: the bigger cells cost the lone search 3 %, the half-size table -- build, and the lines every other
+        //  queue's kernels compete with -- is worth 8 % to the batch.  Any cell size is exact.)
+        static const double cap_env = dev_env("VELO_GRID_CAP") ? std::max(atof(dev_env("VELO_GRID_CAP")), 4096.0) : 0.0;
+        const double cell_cap = cap_env > 0.0 ? cap_env : (c->batch_load ? 16777216.0 : 33554432.0);
         if (ok && total <= cell_cap) break;
         h *= 1.26;
     }
@@ -3078,6 +3084,11 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
         if (!ctxs[i]) return fail(VELO_ERR_INVALID, "batch entry %d is null", i);
         for (int j = 0; j < i; j++) if (ctxs[j] == ctxs[i]) return fail(VELO_ERR_INVALID, "batch entries %d and %d are the same context", j, i);
     }
+    struct BatchLoad {                                               // marks the contexts while their scans are loaded (index sizing, build_grid)
+        velo_ctx** c; int n;
+        BatchLoad(velo_ctx** c_, int n_) : c(c_), n(n_) { for (int i = 0; i < n; i++) c[i]->batch_load = n >= 2; }
+        ~BatchLoad() { for (int i = 0; i < n; i++) c[i]->batch_load = false; }
+    } batch_load(ctxs, n);
     // Targets flagged VELO_SCAN_SHARED with identical descriptors (scan-to-map: many scans against one map) are loaded and indexed
     // ONCE, by the first job that names them; the other jobs' contexts take that target by reference (velo_share_target).
     std::vector<velo_scan_ref> tgt_local;
