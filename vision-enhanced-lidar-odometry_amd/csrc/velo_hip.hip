@@ -181,6 +181,8 @@ struct velo_ctx {
     std::shared_ptr<TargetData> T = std::make_shared<TargetData>();
     DevBuf<int> vis_counts;                       // chain mode: [f2f iteration][blocks, residuals] selected by the device-side gate
     DevBuf<int> scan_tiles, cursor, scan_total;   // scratch of an index build / of the segmenter's scans
+    struct { const char* dsrc = nullptr; int64_t stride = 0; bool on = false; } src_raw;   // set_source: the records the fused ingest launch still has to read (source_finalize)
+    int lb_zeroed = 0;                            // status words of the one-pass scan that target_ingest_kernel cleared for the next build (0: build_grid clears them)
     bool batch_load = false;                      // set while velo_register_batch loads this context's scans for a batch of two or more (see build_grid)
     DevBuf<unsigned long long> lb_status;         // one-pass scan: tile status words + ticket
     DevBuf<unsigned> bbox_keys;
@@ -319,7 +321,7 @@ struct velo_ctx {
     // pinned staging for the small host tables a load sends to the device (source ring offsets, query offsets): the copy is asynchronous
     // and the slot's event says when the host may write the slot again -- no stream synchronisation at the end of a load
     struct PinSlot { int* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };
-    PinSlot pin[2];
+    PinSlot pin[3];                               // 0: source ring offsets (+ query offsets), 1: query offsets, 2: target ring offsets + bounding-box keys
     DevBuf<int> row_off_vis, row_off_icp;
     DevBuf<double> rows_r, rows_J;
 
@@ -527,7 +529,8 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
     VELO_TRY(c->lb_status.reserve((size_t)n_tiles + 1));               // tile status words + the ticket counter behind them
     VELO_TRY(c->scan_total.reserve(1));
     HIP_TRY(hipMemsetAsync(G.cell_start.p, 0, sizeof(int) * ((size_t)nc + 4), c->stream));
-    HIP_TRY(hipMemsetAsync(c->lb_status.p, 0, sizeof(unsigned long long) * ((size_t)n_tiles + 1), c->stream));
+    if (c->lb_zeroed < n_tiles + 1) HIP_TRY(hipMemsetAsync(c->lb_status.p, 0, sizeof(unsigned long long) * ((size_t)n_tiles + 1), c->stream));
+    c->lb_zeroed = 0;                                                  // (about to be used)
     // (bytes: what each kernel must move given this index layout -- count: cloud in, cell ids out; scan: table in + out; scatter: cloud + ids in, sorted copy out)
     if (n > 0) VELO_LAUNCH_T(c, "grid_count_kernel", 20ull * (uint64_t)n, grid_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, G.d, c->T->tgt.p, n, c->T->tgt_cell_of.p, G.table());
     VELO_LAUNCH_T(c, "scan_lookback_kernel", 8ull * (uint64_t)nc, scan_lookback_kernel, dim3(n_tiles), dim3(kScanThreads), 0, c->stream, G.table() + 1, nc, c->lb_status.p,
@@ -1300,6 +1303,44 @@ int target_finalize_begin(velo_ctx* c) {
     VELO_TRY(build_direction_image(c));
     return VELO_OK;
 }
+// velo_set_target's own way in: the caller's records -> packed cloud, ring ids, padded rings, bounding-box request in ONE copy (ring
+// offsets + the box's start keys, through a pinned slot) and ONE launch (target_ingest_kernel), instead of upload_cloud + target_finalize_begin
+constexpr int kLbWordsCleared = (1 << 25) / kLbTile + 2;                 // status words of the largest default table (+ ticket)
+int target_ingest(velo_ctx* c, const float* xyz, int64_t stride, int on_device) {
+    const int n = c->T->n_tgt, n_rings = c->T->n_tgt_rings;
+    c->prev_ready = false;                                            // seeds refer to points of the old target
+    VELO_TRY(c->T->tgt.reserve((size_t)std::max(n, 1)));
+    VELO_TRY(c->T->tgt_off.reserve((size_t)n_rings + 1 + 8));         // the six box keys ride behind the offsets
+    VELO_TRY(c->T->tgt_ring_of.reserve((size_t)std::max(n, 1)));
+    VELO_TRY(c->T->tgt_cell_of.reserve((size_t)std::max(n, 1)));
+    VELO_TRY(c->T->tgt_pad.reserve((size_t)n + 2 * (size_t)n_rings + 2));
+    VELO_TRY(c->lb_status.reserve((size_t)kLbWordsCleared));
+    const char* dsrc = (const char*)xyz;
+    if (!on_device && n > 0) {
+        const size_t bytes = (size_t)(n - 1) * (size_t)stride + 12;
+        VELO_TRY(c->staging.reserve(bytes));
+        HIP_TRY(hipMemcpyAsync(c->staging.p, xyz, bytes, hipMemcpyHostToDevice, c->stream));
+        dsrc = c->staging.p;
+    }
+    unsigned* keys = reinterpret_cast<unsigned*>(c->T->tgt_off.p + n_rings + 1);
+    {
+        int* pin = nullptr;
+        VELO_TRY(pin_acquire(c, 2, (size_t)n_rings + 1 + 8, &pin));
+        std::memcpy(pin, c->T->h_tgt_off.data(), sizeof(int) * ((size_t)n_rings + 1));
+        for (int k = 0; k < 6; k++) pin[n_rings + 1 + k] = k < 3 ? -1 : 0;   // min keys all ones, max keys zero
+        HIP_TRY(hipMemcpyAsync(c->T->tgt_off.p, pin, sizeof(int) * ((size_t)n_rings + 1 + 6), hipMemcpyHostToDevice, c->stream));
+        VELO_TRY(pin_release(c, 2));
+    }
+    if (n > 0) {
+        VELO_LAUNCH_T(c, "target_ingest_kernel", 64ull * (uint64_t)n, target_ingest_kernel, dim3(cdiv(n, 256 * kIngestPerThread)), dim3(256), 0, c->stream, dsrc, stride, n,
+                      (const int*)c->T->tgt_off.p, n_rings, c->T->tgt_first_ring, c->T->tgt.p, c->T->tgt_ring_of.p, c->T->tgt_pad.p, keys, c->lb_status.p, kLbWordsCleared);
+        HIP_TRY(hipGetLastError());
+        c->lb_zeroed = kLbWordsCleared;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_int + 8, keys, sizeof(unsigned) * 6, hipMemcpyDeviceToHost, c->stream));
+    VELO_TRY(build_direction_image(c));
+    return VELO_OK;
+}
 int target_finalize_end(velo_ctx* c) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     unsigned keys[6];
@@ -1320,7 +1361,48 @@ int target_finalize(velo_ctx* c) {
     return target_finalize_end(c);
 }
 
+// velo_set_source's own way in (set_source_begin left the records to be read): ring offsets + query offsets in ONE copy, packed cloud +
+// query list + query points in ONE launch (source_ingest_kernel) -- what upload_cloud + source_finalize + build_query_list do in five
+int source_ingest(velo_ctx* c) {
+    const int R = c->n_src_rings, skip = std::max(c->P.icp_skip, 1);
+    c->prev_ready = false;                                            // seeds are indexed by query
+    c->h_q_off.assign((size_t)R + 1, 0);
+    for (int r = 0; r < R; r++) {
+        const int n = c->h_src_off[r + 1] - c->h_src_off[r];
+        c->h_q_off[r + 1] = c->h_q_off[r] + (n + skip - 1) / skip;        // smi = 0, skip, 2 skip, ... < n  (velo.h:807)
+    }
+    c->n_q = c->P.enable_icp ? c->h_q_off[R] : 0;                         // velo.h:806 `* enable_icp`
+    c->src_skip = skip;
+    const bool patch = want_patch(c);
+    const size_t nq = (size_t)std::max(c->n_q, 1);
+    VELO_TRY(c->src_off.reserve(2 * ((size_t)R + 1)));                    // [ring offsets | query offsets]
+    VELO_TRY(c->q_src.reserve(nq));
+    const bool own_list = !(skip == 1 && !patch);                         // else q_src[i] == i and the source cloud itself is the list
+    if (own_list) VELO_TRY(c->qpts_buf.reserve(nq));
+    {
+        int* pin = nullptr;
+        VELO_TRY(pin_acquire(c, 0, 2 * ((size_t)R + 1), &pin));
+        std::memcpy(pin, c->h_src_off.data(), sizeof(int) * ((size_t)R + 1));
+        std::memcpy(pin + R + 1, c->h_q_off.data(), sizeof(int) * ((size_t)R + 1));
+        HIP_TRY(hipMemcpyAsync(c->src_off.p, pin, sizeof(int) * 2 * ((size_t)R + 1), hipMemcpyHostToDevice, c->stream));
+        VELO_TRY(pin_release(c, 0));
+    }
+    const int nb_pack = cdiv(c->n_src, 256), nb_q = c->n_q > 0 ? cdiv(c->n_q, 256) : 0;
+    VELO_LAUNCH_T(c, "source_ingest_kernel", 28ull * (uint64_t)c->n_src + 32ull * (uint64_t)c->n_q, source_ingest_kernel, dim3(nb_pack + nb_q), dim3(256), 0, c->stream,
+                  c->src_raw.dsrc, c->src_raw.stride, c->n_src, c->src.p, nb_pack, (const int*)c->src_off.p, (const int*)(c->src_off.p + R + 1), R, skip, c->n_q,
+                  patch ? 1 : 0, c->patch_rings, c->patch_len, c->q_src.p, own_list ? c->qpts_buf.p : (float4*)nullptr);
+    HIP_TRY(hipGetLastError());
+    c->src_raw.on = false;
+    c->q_patch = patch;
+    c->qpts = own_list ? c->qpts_buf.p : c->src.p;
+    VELO_TRY(c->cp.reserve(nq)); VELO_TRY(c->cn.reserve(nq)); VELO_TRY(c->cv0.reserve(nq));
+    VELO_TRY(c->aux0.reserve(nq)); VELO_TRY(c->aux1.reserve(nq));
+    c->have_corr = false;
+    c->have_source = true;
+    return VELO_OK;
+}
 int source_finalize(velo_ctx* c) {
+    if (c->src_raw.on) return source_ingest(c);
     VELO_TRY(c->src_off.reserve((size_t)c->n_src_rings + 1));
     {
         int* pin = nullptr;
@@ -1641,8 +1723,7 @@ static int set_target_begin(velo_ctx* c, const float* xyz, int64_t stride, const
     c->T->n_tgt = n; c->T->n_tgt_rings = n_rings;
     c->T->tgt_first_ring = first_ring; c->T->tgt_first_point = first_point;
     c->T->h_tgt_off.assign(off, off + n_rings + 1);
-    VELO_TRY(upload_cloud(c, xyz, stride, n, on_device, c->T->tgt));
-    return target_finalize_begin(c);
+    return target_ingest(c, xyz, stride, on_device);
 }
 int velo_set_target_part(velo_ctx* c, const float* xyz, int64_t stride, const int32_t* off, int32_t n_rings, int32_t first_ring, int32_t first_point, int on_device) {
     VELO_TRY(set_target_begin(c, xyz, stride, off, n_rings, first_ring, first_point, on_device));
@@ -1660,7 +1741,17 @@ static int set_source_begin(velo_ctx* c, const float* xyz, int64_t stride, const
     c->have_source = false; c->have_corr = false;
     c->n_src = n; c->n_src_rings = n_rings;
     c->h_src_off.assign(off, off + n_rings + 1);
-    return upload_cloud(c, xyz, stride, n, on_device, c->src);
+    // (the packed copy is written by the launch that also lays out the query list: source_finalize -> source_ingest)
+    VELO_TRY(c->src.reserve((size_t)std::max(n, 1)));
+    const char* dsrc = (const char*)xyz;
+    if (!on_device && n > 0) {
+        const size_t bytes = (size_t)(n - 1) * (size_t)stride + 12;
+        VELO_TRY(c->staging.reserve(bytes));
+        HIP_TRY(hipMemcpyAsync(c->staging.p, xyz, bytes, hipMemcpyHostToDevice, c->stream));
+        dsrc = c->staging.p;
+    }
+    c->src_raw.dsrc = dsrc; c->src_raw.stride = stride; c->src_raw.on = n > 0;
+    return VELO_OK;
 }
 int velo_set_source(velo_ctx* c, const float* xyz, int64_t stride, const int32_t* off, int32_t n_rings, int on_device) {
     VELO_TRY(set_source_begin(c, xyz, stride, off, n_rings, on_device));
@@ -1716,7 +1807,7 @@ int velo_set_scan_velodyne(velo_ctx* c, int32_t as_target, const float* xyzr, in
     }
     if (as_target) { c->T->n_tgt = n; c->T->n_tgt_rings = n_rings; return target_finalize(c); }
     c->n_src = n; c->n_src_rings = n_rings;
-    return source_finalize(c);
+    c->src_raw.on = false; return source_finalize(c);          // (the cloud is packed already)
 }
 
 int velo_share_target(velo_ctx* dst, velo_ctx* src) {
@@ -1861,7 +1952,7 @@ int velo_cache_load(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t as_t
         c->h_src_off = e.h_off;
         c->n_src = e.n; c->n_src_rings = e.n_rings;
         c->have_source = false;
-        return source_finalize(c);
+        c->src_raw.on = false; return source_finalize(c);          // (the cloud is packed already)
     }
     for (int r = 0; r < e.n_rings; r++) if (e.h_off[(size_t)r + 1] <= e.h_off[(size_t)r]) return fail(VELO_ERR_INVALID, "target ring %d is empty", r);
     own_target(c);

@@ -258,6 +258,79 @@ bbox_kernel(const float4* __restrict__ pts, int n, unsigned* __restrict__ mnmx /
     }
 }
 
+// ---- a scan enters a context in ONE launch per side -----------------------------------------------------------------------------------
+// With several registrations in flight a queue operation costs 5-10 us of hand-over whatever it does, and loading a pair used to take
+// sixteen of them (pack, ring ids, padded rings, bounding box, two clears, ... each a launch or a copy of its own) against ~30 for the
+// registration itself.  target_ingest_kernel is pack_points + ring_of + pad_rings + bbox (and clears the scan's status words);
+// source_ingest_kernel is pack_points + query_list + gather_queries (the query blocks read the caller's records themselves, so they
+// do not wait for the packed copy).  Same arithmetic, same tables as the separate kernels, which the other entries keep using.
+constexpr int kIngestPerThread = 4;                                    // points per thread: 1,024 per workgroup, 6 bounding-box atomics per workgroup at most
+__global__ void __launch_bounds__(256)
+target_ingest_kernel(const char* __restrict__ src, int64_t stride, int n, const int* __restrict__ off, int n_rings, int first_ring,
+                     float4* __restrict__ tgt, int* __restrict__ ring_of, float4* __restrict__ pad, unsigned* __restrict__ mnmx,
+                     unsigned long long* __restrict__ lb_status, int lb_words) {
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < lb_words; j += gridDim.x * 256) lb_status[j] = 0ull;
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+#pragma unroll
+    for (int u = 0; u < kIngestPerThread; u++) {
+        const int i = (blockIdx.x * kIngestPerThread + u) * 256 + threadIdx.x;
+        if (i >= n) continue;
+        const float* q = (const float*)(src + (int64_t)i * stride);
+        const float4 p = make_float4(q[0], q[1], q[2], 0.0f);
+        tgt[i] = p;
+        int lo = 0, hi = n_rings;   // find r with off[r] <= i < off[r+1]
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= i) lo = mid; else hi = mid; }
+        ring_of[i] = lo + first_ring;
+        const int base = off[lo], end = off[lo + 1];
+        pad[i + 2 * lo + 1] = p;
+        if (i == base) pad[end + 2 * lo + 1] = p;          // trailing sentinel = first point
+        if (i == end - 1) pad[base + 2 * lo] = p;          // leading sentinel = last point
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) {
+            mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+            mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[k] = fminf(mn[k], __shfl_xor(mn[k], o));
+            mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o));
+        }
+    }
+    __shared__ float red[4][6];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) { for (int k = 0; k < 3; k++) { red[wid][k] = mn[k]; red[wid][3 + k] = mx[k]; } }
+    __syncthreads();
+    if (threadIdx.x < 6) {     // one atomic per workgroup and component, and only where this workgroup moves the box (a stale look is harmless)
+        const int k = threadIdx.x;
+        float v = red[0][k];
+        for (int w = 1; w < 4; w++) v = (k < 3) ? fminf(v, red[w][k]) : fmaxf(v, red[w][k]);
+        const unsigned key = f2key(v), cur = mnmx[k];
+        if (k < 3) { if (v < 3.0e38f && key < cur) atomicMin(&mnmx[k], key); } else { if (v > -3.0e38f && key > cur) atomicMax(&mnmx[k], key); }
+    }
+}
+__global__ void __launch_bounds__(256)
+source_ingest_kernel(const char* __restrict__ raw, int64_t stride, int n, float4* __restrict__ src, int nb_pack,
+                     const int* __restrict__ src_off, const int* __restrict__ q_off, int n_rings, int skip, int nq, int patch, int patch_rings, int patch_len,
+                     int* __restrict__ q_src, float4* __restrict__ qpts) {
+    if ((int)blockIdx.x < nb_pack) {
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= n) return;
+        const float* p = (const float*)(raw + (int64_t)i * stride);
+        src[i] = make_float4(p[0], p[1], p[2], 0.0f);
+        return;
+    }
+    const int i = ((int)blockIdx.x - nb_pack) * 256 + threadIdx.x;
+    if (i >= nq) return;
+    int lo = 0, hi = n_rings;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (q_off[mid] <= i) lo = mid; else hi = mid; }
+    const int k = i - q_off[lo];
+    const int pos = patch ? patch_position(q_off, n_rings, lo, k, patch_rings, patch_len) : i, si = src_off[lo] + k * skip;
+    q_src[pos] = si;
+    if (qpts) { const float* p = (const float*)(raw + (int64_t)si * stride); qpts[pos] = make_float4(p[0], p[1], p[2], 0.0f); }
+}
+
 // ---- grid build: count, exclusive scan (3 kernels), scatter ----------------------------------------------------
 __device__ __forceinline__ int cell_of_point(const GridDesc& g, const float4& p) {
     int cx = cell_coord(p.x, g.ox, g.inv_h, g.nx), cy = cell_coord(p.y, g.oy, g.inv_h, g.ny), cz = cell_coord(p.z, g.oz, g.inv_h, g.nz);
