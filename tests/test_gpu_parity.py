@@ -527,7 +527,7 @@ def test_chain_mode_lockstep_batch_is_bit_identical(hip_lib, diag_lib, monkeypat
             assert np.array_equal(x0, x1) and np.array_equal(T0, T1) and s0 == s1 and r0 == r1
 
 
-def test_chain_mode_lockstep_batch_with_visual_blocks_is_bit_identical(hip_lib, oracle, monkeypatch):
+def test_chain_mode_lockstep_batch_with_visual_blocks_is_bit_identical(hip_lib, diag_lib, oracle, monkeypatch):
     """Lock-step batches whose contexts carry stereo blocks (all four kinds) go down the chain as well: the residual-type choice and the
     outlier gate of every f2f iteration run on the device at the pose the device holds, the visual sweep rides ahead of every fused
     sweep + step launch.  Poses, solves, block counts and good_matches equal the host-driven batch bit for bit and the oracle's pose."""
@@ -535,11 +535,13 @@ def test_chain_mode_lockstep_batch_with_visual_blocks_is_bit_identical(hip_lib, 
     vis = [api.matches_from_dict(synth.stereo_matches(50, seed=5, mix="all", x_true=pairs[0]["x_true"])), None,
            api.matches_from_dict(synth.stereo_matches(30, seed=6, x_true=pairs[2]["x_true"]))]
     res = {}
-    for name, env in (("host", {"VELO_CHAIN": "0"}), ("chain", {"VELO_CHAIN": "1"}), ("tight", {"VELO_CHAIN": "1", "VELO_CHAIN_MARGIN": "0"})):
+    for name, env in (("host", {"VELO_CHAIN": "0"}), ("chain", {"VELO_CHAIN": "1"}), ("tight", {"VELO_CHAIN": "1", "VELO_CHAIN_MARGIN": "0"}),
+                      # the visual sweep as a launch of its own ahead of every fused sweep + step launch (diagnostics build; the product rides them in one)
+                      ("separate", {"VELO_CHAIN": "1", "VELO_LM_VIS_MERGED": "0"}), ("separate_tight", {"VELO_CHAIN": "1", "VELO_CHAIN_MARGIN": "0", "VELO_LM_VIS_MERGED": "0"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        ctxs = [api.Context(0, icp_skip=1) for _ in pairs]
-        monkeypatch.delenv("VELO_CHAIN_MARGIN", raising=False)
+        ctxs = [api.Context(0, lib=diag_lib if "VELO_LM_VIS_MERGED" in env else None, icp_skip=1) for _ in pairs]
+        monkeypatch.delenv("VELO_CHAIN_MARGIN", raising=False); monkeypatch.delenv("VELO_LM_VIS_MERGED", raising=False)
         for c, v in zip(ctxs, vis):
             if v is not None:
                 c.set_visual(v)
@@ -555,7 +557,7 @@ def test_chain_mode_lockstep_batch_with_visual_blocks_is_bit_identical(hip_lib, 
             c.close()
     assert all(st == (0, 0) for st in res["host"][1])
     assert all(st[0] == 2 for st in res["chain"][1])               # (margin 0 may or may not miss here; either way the results must not move)
-    for name in ("chain", "tight"):
+    for name in ("chain", "tight", "separate", "separate_tight"):
         for (x0, T0, s0, r0, g0), (x1, T1, s1, r1, g1) in zip(res["host"][0], res[name][0]):
             assert np.array_equal(x0, x1) and np.array_equal(T0, T1) and s0 == s1 and r0 == r1 and g0 == g1
     assert all(nb > 0 for nb, _ in res["chain"][0][0][4][3]) and all(nb == 0 for nb, _ in res["chain"][0][0][4][4])   # context 0 solved with visual blocks, context 1 without

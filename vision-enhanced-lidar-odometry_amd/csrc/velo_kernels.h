@@ -3630,15 +3630,18 @@ lm_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items) {
 // loads look.  tickets[context] is 0 at every launch boundary (the last workgroup resets it).
 // first != 0: this launch carries the FIRST sweep of a solve: every workgroup builds the start's eval point from x itself (what
 // lm_begin_batch_kernel used to leave in memory one launch earlier), and the stepping workgroup starts the solve before it steps.
-template <bool M_LDS, int PRE, int CHUNK>
+// VIS: the contexts' visual blocks ride in the same launch -- workgroups nb_icp .. nb_icp + nb_vis - 1 of a context run the visual sweep
+// (visual_sweep_acc, the arithmetic of eval_visual_kernel) into the partial rows behind the point-to-plane ones and draw tickets like
+// the others, instead of a launch of their own ahead of every iteration (21.7 us each, 48 per call).
+template <bool M_LDS, int PRE, int CHUNK, bool VIS = false>
 __device__ __forceinline__ void eval_step_batch_body(const LMParams& Q, const LMBatchItem& it, int* __restrict__ tickets, const int first) {
-    const int bx = blockIdx.x, nbx = it.nb_icp;
-    if (bx >= nbx) return;
+    const int bx = blockIdx.x, nbx = it.nb_icp, nb_all = VIS ? it.nb_icp + it.nb_vis : it.nb_icp;
+    if (bx >= nb_all) return;
 #ifdef VELO_LM_SETPRIO
     __builtin_amdgcn_s_setprio(VELO_LM_SETPRIO);                      // A/B: the LM chain's waves ahead of other groups' association waves in a SIMD's issue arbitration
 #endif
     const EvalArgs& A = it.A;
-    const RowPrefetchT<PRE> f = prefetch_rows<PRE>(A, bx, nbx);
+    const RowPrefetchT<PRE> f = prefetch_rows<PRE>(A, (VIS && bx >= nbx) ? 0 : bx, nbx);   // (a visual workgroup: block 0's rows, unused)
     __shared__ LMEvalPoint s_pt;
     __shared__ LMState sL;
     __shared__ double s_scratch[CHUNK * kNumAcc];
@@ -3655,11 +3658,16 @@ __device__ __forceinline__ void eval_step_batch_body(const LMParams& Q, const LM
     } else
     if (!eval_point_load(A, &s_pt)) return;                           // a launch behind the end of the solve: nothing to do, the ticket stays 0
     double acc[kNumAcc];
-    sweep_rows<M_LDS, PRE>(A, f, s_pt, bx, nbx, acc);
-    block_reduce_store<true>(acc, A.partials + (size_t)bx * kNumAcc, s_scratch);
+    if (VIS && bx >= nbx) {
+        visual_sweep_acc(A, s_pt, bx - nbx, it.nb_vis, acc);
+        block_reduce_store<true>(acc, A.partials + (size_t)(A.vis_row0 + bx - nbx) * kNumAcc, s_scratch);
+    } else {
+        sweep_rows<M_LDS, PRE>(A, f, s_pt, bx, nbx, acc);
+        block_reduce_store<true>(acc, A.partials + (size_t)bx * kNumAcc, s_scratch);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this thread's row entries have been written through
     __syncthreads();
-    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(tickets + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nbx - 1 ? 1 : 0;
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(tickets + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nb_all - 1 ? 1 : 0;
     __syncthreads();
     if (!s_last) return;
     if (threadIdx.x == 0) __hip_atomic_store(tickets + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3684,6 +3692,10 @@ eval_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* _
 __global__ void __launch_bounds__(kEvalThreads) __attribute__((amdgpu_num_vgpr(152)))
 eval_step_batch_lean_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets, int first) {
     eval_step_batch_body<true, VELO_LEAN_PRE, 64>(Q, items[blockIdx.y], tickets, first);
+}
+__global__ void __launch_bounds__(kEvalThreads)
+eval_step_batch_vis_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets, int first) {
+    eval_step_batch_body<false, kPre, kStepChunk, true>(Q, items[blockIdx.y], tickets, first);
 }
 // The same two with the group's items BY VALUE in the kernel arguments (groups of up to four contexts): no copy of the items into
 // device memory ahead of every round of a chained call -- six copy operations, and the queue hand-overs around them, per call.
