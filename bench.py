@@ -30,6 +30,7 @@ The same JSON line also carries
 from __future__ import annotations
 
 import argparse
+import gc
 import glob
 import json
 import os
@@ -331,6 +332,12 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
 
         for _ in range(warmup):
             step()
+        # The harness's own interpreter must not stall the timed region: with torch imported a full pass of Python's cyclic garbage
+        # collector takes ~55 ms, and when its allocation counter happened to trip inside a 12-step leg the leg read 860 instead of 1,450
+        # pairs/s (kernel trace: all four queues idle for 56 ms in the middle of the region).  Collect now, keep it off until the leg ends
+        # (what timeit does); nothing the library does is affected.
+        gc.collect()
+        gc.disable()
         for c in ctxs:
             c.kernel_times(reset=True)                       # the per-kernel log starts with the timed region
         chain0 = [c.chain_stats() for c in ctxs]
@@ -434,6 +441,7 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
             leg["communicator"] = comm_info
         return leg
     finally:
+        gc.enable()
         if rig.dist is not None:
             rig.dist.barrier()
         for c in ctxs:

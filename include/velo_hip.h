@@ -367,7 +367,8 @@ int velo_frame_to_frame_batch(velo_ctx** ctxs, int32_t n, double* x /* n*6 */, d
  * target and source go into context i exactly as velo_set_target / velo_set_source would put them, on the thread that then
  * drives that context's group -- a group starts registering as soon as ITS scans are indexed, no barrier across the batch.
  * targets / sources may be NULL (keep what the contexts hold).  n == 1 is velo_set_target + velo_set_source + velo_frame_to_frame
- * in one call (the single-pair path: one chain of launches, one host synchronisation). */
+ * in one call (the single-pair path: one chain of launches, one host synchronisation).  A target loaded here for n >= 2 is indexed
+ * with at most 2^24 cells instead of 2^25 (only a 2M-point map reaches either; any cell size gives the same results). */
 #define VELO_SCAN_ON_DEVICE 1   /* xyz is a device pointer */
 #define VELO_SCAN_SHARED 2      /* targets only: jobs with IDENTICAL descriptors carrying this flag share one device copy and one
                                  * index (scan-to-map: many scans against one map) -- built once, held by reference */

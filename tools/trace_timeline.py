@@ -76,6 +76,28 @@ for pat in ("eval_step_batch", "lm_iter"):
         buckets["< 10 % under an association kernel" if f_ < 0.1 else ("10-60 %" if f_ < 0.6 else "> 60 %")].append((e - s) / 1e3)
     print(f"{pat}: {len(lm)} launches, {len(live)} live (> 6 us): " + "; ".join(
         f"{k}: n {len(v)} mean {sum(v) / max(len(v), 1):.1f} us p50 {sorted(v)[len(v) // 2] if v else 0:.1f} p90 {sorted(v)[int(len(v) * 0.9)] if v else 0:.1f}" for k, v in buckets.items()))
+# ... and the same launches by what ELSE ran under them: another queue's LM launch (they share the one LM slot per CU the association
+# workgroups leave) and/or another queue's association kernel
+lm_iv = sorted((s, e, qid) for s, e, k, qid in sel if "eval_step_batch" in k and e - s > 6000)
+
+
+def overlap_with(iv, s, e, qid):
+    tot = 0
+    for a, b, q2 in iv:
+        if a >= e:
+            break
+        if q2 != qid and b > s:
+            tot += min(e, b) - max(s, a)
+    return tot / max(e - s, 1)
+
+
+cells = collections.defaultdict(list)
+for s, e, qid in lm_iv:
+    fa, fl = overlap_with(assoc_iv, s, e, qid), overlap_with(lm_iv, s, e, qid)
+    cells[("assoc" if fa > 0.5 else "no assoc", "other LM" if fl > 0.5 else "no other LM")].append((e - s) / 1e3)
+if cells:
+    print("live eval_step_batch launches by what ran under more than half of them: " + "; ".join(
+        f"{a} / {b}: n {len(v)} mean {sum(v) / len(v):.1f} us" for (a, b), v in sorted(cells.items())))
 # idle gaps inside each queue's chain (between the end of one kernel and the start of the next on the same queue)
 for qid, iv in sorted(q.items()):
     iv = sorted(iv)
