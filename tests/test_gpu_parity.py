@@ -527,6 +527,44 @@ def test_chain_mode_lockstep_batch_is_bit_identical(hip_lib, diag_lib, monkeypat
             assert np.array_equal(x0, x1) and np.array_equal(T0, T1) and s0 == s1 and r0 == r1
 
 
+def test_lean_visual_sweep_in_shared_chip_groups_equals_single_calls(hip_lib):
+    """Four contexts = two lock-step groups sharing the chip, so the groups' LM launches are the LEAN ones: a group whose contexts hold at
+    most one visual block slot per thread runs the blocks inside the lean sweep + step launch (visual_sweep_one: block evaluated ahead of
+    the accumulators, the epipolar block in three passes of two pose parameters); a group with more matches than that (6,000 > 5,461)
+    keeps the visual sweep as a launch of its own.  Either way every pose, solve summary, block count and good_matches list equals the
+    single-pair call's (one-launch iteration, 6-wide duals) bit for bit."""
+    pairs = [synth.scan_pair(n_beams=32, n_azimuth=400, scene_seed=50 + k, sigma=0.02) for k in range(4)]
+    vis = [api.matches_from_dict(synth.stereo_matches(6000, seed=11, mix="all", x_true=pairs[0]["x_true"])),
+           api.matches_from_dict(synth.stereo_matches(100, seed=12, x_true=pairs[1]["x_true"])), None,
+           api.matches_from_dict(synth.stereo_matches(700, seed=13, mix="all", x_true=pairs[3]["x_true"]))]
+
+    def loaded():
+        cs = [api.Context(0, icp_skip=1) for _ in pairs]
+        for c, d, v in zip(cs, pairs, vis):
+            c.set_target(d["tgt_xyz"], d["tgt_off"]); c.set_source(d["src_xyz"], d["src_off"])
+            if v is not None:
+                c.set_visual(v)
+        return cs
+
+    singles = loaded()
+    ref = []
+    for c, d in zip(singles, pairs):
+        x, T, S = c.frame_to_frame(d["x0"])
+        ref.append((x.copy(), T.copy(), _summary_tuple(S), [(S.solves[k].n_visual_blocks, S.solves[k].n_visual_residuals) for k in range(S.n_solves)], c.good_matches().tobytes()))
+    batch = loaded()
+    for rep in range(2):                                   # the second call chains from real history
+        xs, Ts, Ss = api.frame_to_frame_batch(batch, [d["x0"] for d in pairs])
+        for i, (x, T, st, vb, gm) in enumerate(ref):
+            assert np.array_equal(xs[i], x) and np.array_equal(Ts[i], T) and _summary_tuple(Ss[i]) == st
+            assert [(Ss[i].solves[k].n_visual_blocks, Ss[i].solves[k].n_visual_residuals) for k in range(Ss[i].n_solves)] == vb
+            assert batch[i].good_matches().tobytes() == gm
+        for c, d in zip(batch, pairs):
+            c.set_source(d["src_xyz"], d["src_off"])
+    assert all(nb > 0 for nb, _ in ref[0][3]) and all(nb == 0 for nb, _ in ref[2][3])
+    for c in singles + batch:
+        c.close()
+
+
 def test_chain_mode_lockstep_batch_with_visual_blocks_is_bit_identical(hip_lib, diag_lib, oracle, monkeypatch):
     """Lock-step batches whose contexts carry stereo blocks (all four kinds) go down the chain as well: the residual-type choice and the
     outlier gate of every f2f iteration run on the device at the pose the device holds, the visual sweep rides ahead of every fused

@@ -270,6 +270,45 @@ __device__ __forceinline__ void res_2d2d(const PoseRot& R, const double t[3], co
     for (int j = 0; j < 6; j++) J[j] = res.v[j];
 }
 
+// The same residual with the pose parameters J0 .. J0 + W - 1 only: every partial of a dual number is computed from the values and
+// the SAME partial of its operands, so a window of the six gives the bits the 6-wide evaluation gives for those columns (and the same
+// value).  Three passes of width 2 need a third of the registers of one pass of width 6 -- what lets the visual sweep ride in the lean
+// sweep + step kernel (velo_kernels.h, visual_sweep_one).
+template <int W, int J0> __device__ __forceinline__ Dual<W> widen_win(const D3& f) {
+    Dual<W> h; h.a = f.a;
+#pragma unroll
+    for (int i = 0; i < W; i++) h.v[i] = (J0 + i < 3) ? f.v[(J0 + i < 3) ? J0 + i : 0] : 0.0;
+    return h;
+}
+template <int W, int J0> __device__ __forceinline__ Dual<W> dvar_win(double s, int param) {
+    Dual<W> h; h.a = s;
+#pragma unroll
+    for (int i = 0; i < W; i++) h.v[i] = (J0 + i == param) ? 1.0 : 0.0;
+    return h;
+}
+template <int W, int J0>
+__device__ __forceinline__ void res_2d2d_win(const PoseRot& R, const double t[3], const double mm[2], const double s[2], const double tc[3],
+                                             double* r, double* Jw /* [W] */) {
+    typedef Dual<W> DW;
+    const double p[3] = {mm[0], mm[1], 1.0};
+    D3 m3[3], rt3[3];
+    rotate_point(R, p, m3);
+    rotate_point(R, tc, rt3);
+    const DW m0 = widen_win<W, J0>(m3[0]), m1 = widen_win<W, J0>(m3[1]), m2 = widen_win<W, J0>(m3[2]);
+    DW tx = -widen_win<W, J0>(rt3[0]) + dvar_win<W, J0>(t[0], 3) + tc[0];
+    DW ty = -widen_win<W, J0>(rt3[1]) + dvar_win<W, J0>(t[1], 4) + tc[1];
+    DW tz = -widen_win<W, J0>(rt3[2]) + dvar_win<W, J0>(t[2], 5) + tc[2];
+    const DW tn = dsqrt(tx * tx + ty * ty + tz * tz);
+    tx = tx / tn;
+    ty = ty / tn;
+    tz = tz / tn;
+    const double sx = s[0], sy = s[1];
+    const DW res = m0 * (tz * (-sy) + ty) + m1 * (tz * sx - tx) + m2 * (ty * (-sx) + tx * sy);
+    *r = res.a;
+#pragma unroll
+    for (int j = 0; j < W; j++) Jw[j] = res.v[j];
+}
+
 // ---- loss functions [3P loss_function.cc] ---------------------------------------------------
 // Cauchy(a) scaled by w: rho = w b ln(1 + s/b), rho' = w / (1 + s/b), b = a^2
 __device__ __forceinline__ void loss_cauchy(double a, double w, double s, double* rho0, double* rho1) {

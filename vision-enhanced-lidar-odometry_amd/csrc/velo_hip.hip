@@ -257,9 +257,8 @@ struct velo_ctx {
     DevBuf<int> chain_fail;
     SolveLog* h_log = nullptr;           // pinned: VELO_MAX_SOLVES logs + the failure flag behind them
     int lm_fused = 1;                    // VELO_LM_FUSED=0: the lock-step batch driver launches sweep and LM step separately (A/B, identical results)
-    int lm_vis_merged = 1;               // chained batch solves with visual blocks run them INSIDE the fused sweep + step launch (extra workgroups, eval_step_batch_vis_kernel);
-                                         // VELO_LM_VIS_MERGED=0: a launch of their own ahead of it (A/B, identical results).  Measured on C3, 8 pairs in flight:
-                                         // separate 2,826, merged with the lean sweep 2,776 (the visual code takes 256 registers either way), merged as below 2,930 pairs/s
+    int lm_vis_merged = 1;               // chained batch solves with visual blocks run them INSIDE the fused sweep + step launch (extra workgroups, eval_step_batch_(lean_)vis_kernel);
+                                         // VELO_LM_VIS_MERGED=0: a launch of their own ahead of it (A/B, identical results)
     int lm_iter = 0;                     // VELO_LM_ITER=1: chained batch solves launch the lean one-launch iteration (every workgroup advances the state itself) instead of the fused sweep + step (A/B, identical results; measured slower: 3,204 vs 3,418 pairs/s)
     int lm_merged = 1;                   // VELO_LM_MERGED=0: sweep and LM step as two launches per iteration also where one would do (A/B, identical results)
     int small_solve = 1;                 // VELO_SMALL_SOLVE=0: small problems go through the launch-per-iteration path too (A/B, identical results)
@@ -2812,13 +2811,18 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
     HIP_TRY(hipSetDevice(c0->device));
     const bool lean = c0->lm_lean >= 0 ? c0->lm_lean != 0 : shared_chip;
     struct PadRestore { velo_ctx** c; int n; std::vector<int> old; ~PadRestore() { for (int i = 0; i < n; i++) c[i]->assoc_lds_pad = old[(size_t)i]; } } pad_restore{ctxs, n, {}};
-    // (a group with visual blocks: its LM launches carry the visual sweep -- 256 VGPRs per lane, they wait for a drained SIMD whatever the
-    //  association workgroups leave -- and batches are alike, so no pad: C3, 8 pairs in flight, 2,845 with the pad, 2,930 without)
-    bool group_visual = false;
-    for (int i = 0; i < n; i++) group_visual = group_visual || (ctxs[i]->n_matches > 0 && c0->lm_vis_merged && c0->lm_fused);
+    // A group with visual blocks: its LM launches carry the visual sweep.  With at most one block slot per thread (3 n_matches <= 64 x 256:
+    // 5,461 matches) the LEAN kernel takes them (visual_sweep_one: 126 VGPRs like the plain lean kernel), pad as usual; with more, and
+    // lean wanted, the visual sweep stays a launch of its own ahead of the lean one (its kernel carries the slot loop: 256 VGPRs).
+    bool group_visual = false, one_slot = true;
+    for (int i = 0; i < n; i++) {
+        group_visual = group_visual || ctxs[i]->n_matches > 0;
+        one_slot = one_slot && (int64_t)3 * ctxs[i]->n_matches <= (int64_t)kMaxVisBlocks * kEvalThreads;
+    }
+    const bool vis_in_launch = group_visual && c0->lm_vis_merged && c0->lm_fused && (!lean || one_slot);
     for (int i = 0; i < n; i++) {
         pad_restore.old.push_back(ctxs[i]->assoc_lds_pad);
-        if (!ctxs[i]->assoc_lds_pad_fixed) ctxs[i]->assoc_lds_pad = (lean && shared_chip && !group_visual) ? kAssocPadShared : 0;
+        if (!ctxs[i]->assoc_lds_pad_fixed) ctxs[i]->assoc_lds_pad = (lean && shared_chip) ? kAssocPadShared : 0;
     }
     const velo_params P = c0->P;
     const LMParams Q = lm_params(P);
@@ -2962,7 +2966,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                 }
                 // (fused sweep + step: the first launch of a solve starts it as well -- no begin launch; with visual blocks their sweep runs as a
                 //  launch of its own ahead of every fused one and reads the eval point from memory, so the begin launch stays)
-                const bool vis_merged = c0->lm_fused && nbv_max > 0 && c0->lm_vis_merged;
+                const bool vis_merged = nbv_max > 0 && vis_in_launch;
                 const int first_fused = (nbv_max == 0 || vis_merged) ? 1 : 0;
                 if (!c0->lm_fused || (nbv_max > 0 && !vis_merged)) VELO_LAUNCH_T(c0, "lm_begin_batch_kernel", 0, lm_begin_batch_kernel, dim3(n), dim3(64), 0, bs, d_items);
                 if (c0->lm_fused) c0->lm_kernel_name = lean ? "eval_step_batch_lean_kernel" : "eval_step_batch_kernel";
@@ -2981,10 +2985,9 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                     if (vis_merged) {
                         int nb_all = 0;
                         for (int i = 0; i < n; i++) nb_all = std::max(nb_all, items_r[i].nb_icp + items_r[i].nb_vis);
-                        // (always the instantiation with the matrices in registers: the visual code needs the 256 registers anyway, so the lean
-                        //  sweep would only be slower here)
-                        c0->lm_kernel_name = "eval_step_batch_vis_kernel";
-                        VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_vis_kernel, dim3(nb_all, n), dim3(kEvalThreads), 0, bs, Q, d_items, c0->batch_tickets.p, k == 0 ? 1 : 0);
+                        c0->lm_kernel_name = lean ? "eval_step_batch_lean_vis_kernel" : "eval_step_batch_vis_kernel";
+                        if (lean) VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_lean_vis_kernel, dim3(nb_all, n), dim3(kEvalThreads), 0, bs, Q, d_items, c0->batch_tickets.p, k == 0 ? 1 : 0);
+                        else VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_vis_kernel, dim3(nb_all, n), dim3(kEvalThreads), 0, bs, Q, d_items, c0->batch_tickets.p, k == 0 ? 1 : 0);
                         continue;
                     }
                     if (c0->lm_fused) {
@@ -3039,7 +3042,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                     Si->algorithmic_bytes += (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull);
                     if (c0->timing >= 2) {                           // the group's launches are logged on its first context
                         kacc_add(c0, c0->lm_kernel_name, 0.0, 0, 0, (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 224ull));
-                        if (ss.n_visual_blocks > 0) kacc_add(c0, c0->lm_vis_merged ? c0->lm_kernel_name : "eval_visual_batch_kernel", 0.0, 0, 0, (uint64_t)L.evals * 32ull * (uint64_t)ss.n_visual_blocks);
+                        if (ss.n_visual_blocks > 0) kacc_add(c0, vis_in_launch ? c0->lm_kernel_name : "eval_visual_batch_kernel", 0.0, 0, 0, (uint64_t)L.evals * 32ull * (uint64_t)ss.n_visual_blocks);
                     }
                     Si->solves[Si->n_solves++] = ss;
                 }

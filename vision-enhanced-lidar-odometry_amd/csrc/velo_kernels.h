@@ -2409,12 +2409,15 @@ __device__ __forceinline__ void pose_eval_init(const double x[6], PoseEval* P, b
 }
 
 // residuals r[<=3] and row-major Jacobian J[<=3][6] of one visual block; returns the residual dimension
+// (WITH_2D2D = false: the caller evaluates the epipolar block itself -- visual_sweep_one, in three narrow passes -- and this function
+//  must not carry the 6-wide code for it)
+template <bool WITH_2D2D = true>
 __device__ __forceinline__ int visual_block_eval3(const PoseEval& P, const VisualMatch& m, int slot, double& r0, double& r1, double& r2, double J[18]) {
     // one exit, residuals carried as scalars: written as an array on several branches they end up on the stack
     r0 = 0.0; r1 = 0.0; r2 = 0.0;
     int d;
     if (slot == 0) {
-        if (m.d1 && m.d2) {
+        if (!WITH_2D2D || (m.d1 && m.d2)) {
             const double a[3] = {m.p3_1[0], m.p3_1[1], m.p3_1[2]}, s[3] = {m.p3_2[0], m.p3_2[1], m.p3_2[2]};
             double rl[3];
             res_3d3d(P.fwd, P.t, a, s, rl, J);
@@ -2972,6 +2975,63 @@ __device__ __forceinline__ void visual_sweep_acc(const EvalArgs& A, const LMEval
         else loss_arctan(A.V.th_3d2d, A.V.w_3d2d, sq, &rho0, &rho1);
         acc[27] += 0.5 * rho0;
         const double sr = sqrt(rho1);
+        accumulate_row(acc, r0, J, sr);
+        if (d > 1) accumulate_row(acc, r1, J + 6, sr);
+        if (d > 2) accumulate_row(acc, r2, J + 12, sr);
+        if (A.rows_r) {
+            const int row = A.row_offset_vis[s];
+            A.rows_r[row] = r0 * sr;
+            if (d > 1) A.rows_r[row + 1] = r1 * sr;
+            if (d > 2) A.rows_r[row + 2] = r2 * sr;
+#pragma unroll
+            for (int c = 0; c < 18; c++) if (c < 6 * d) A.rows_J[(size_t)row * 6 + c] = J[c] * sr;
+        }
+    }
+}
+// The same sweep for launches in which every thread holds AT MOST ONE block slot (nbx x 256 >= 3 n_matches: up to 5,461 matches with
+// kMaxVisBlocks workgroups) and registers are short -- the visual workgroups of the lean sweep + step kernel.  The block is evaluated
+// BEFORE the 28 accumulators exist (56 registers that visual_sweep_acc carries through its loop), the epipolar block in three passes
+// of two pose parameters (res_2d2d_win: a third of the 6-wide duals' registers); then the accumulators are zeroed and take the
+// block's rows in visual_sweep_acc's order -- the same additions on the same values: the partial row is bit-identical.
+__device__ __forceinline__ void visual_sweep_one(const EvalArgs& A, const LMEvalPoint& pt, const int bx, const int nbx, double acc[kNumAcc]) {
+    __shared__ PoseEval s_P;
+    if (threadIdx.x == 0) {
+        double x[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) x[k] = pt.x[k];
+        pose_eval_init(x, &s_P, true);
+    }
+    __syncthreads();
+    const PoseEval& P = s_P;
+    const int s = bx * blockDim.x + threadIdx.x;
+    const unsigned char f = s < 3 * A.n_matches ? A.vflags[s] : (unsigned char)0;
+    double r0 = 0.0, r1 = 0.0, r2 = 0.0, J[18], sr = 0.0, rho0 = 0.0;
+    int d = 0;
+#pragma unroll
+    for (int c = 0; c < 18; c++) J[c] = 0.0;
+    if (f) {
+        const int mi = s / 3, slot = s - 3 * mi;
+        const VisualMatch m = A.vm[mi];
+        if (slot == 0 && !(m.d1 && m.d2)) {                            // the epipolar block, two columns of the Jacobian at a time
+            const double a[2] = {m.p2_1[0], m.p2_1[1]}, q[2] = {m.p2_2[0], m.p2_2[1]}, tc[3] = {m.t_cam[0], m.t_cam[1], m.t_cam[2]};
+            double rr;
+            res_2d2d_win<2, 0>(P.fwd, P.t, a, q, tc, &r0, J);
+            res_2d2d_win<2, 2>(P.fwd, P.t, a, q, tc, &rr, J + 2);
+            res_2d2d_win<2, 4>(P.fwd, P.t, a, q, tc, &rr, J + 4);
+            d = 1;
+        } else d = visual_block_eval3<false>(P, m, slot, r0, r1, r2, J);
+        const double sq = r0 * r0 + (d > 1 ? r1 * r1 : 0.0) + (d > 2 ? r2 * r2 : 0.0);
+        double rho1;
+        const int type = f - 1;
+        if (type == 0) loss_arctan(A.V.th_3d3d, 1.0, sq, &rho0, &rho1);
+        else if (type == 3) loss_arctan(A.V.th_2d2d, A.V.w_2d2d, sq, &rho0, &rho1);
+        else loss_arctan(A.V.th_3d2d, A.V.w_3d2d, sq, &rho0, &rho1);
+        sr = sqrt(rho1);
+    }
+#pragma unroll
+    for (int k = 0; k < kNumAcc; k++) acc[k] = 0.0;
+    if (f) {
+        acc[27] += 0.5 * rho0;
         accumulate_row(acc, r0, J, sr);
         if (d > 1) accumulate_row(acc, r1, J + 6, sr);
         if (d > 2) accumulate_row(acc, r2, J + 12, sr);
@@ -3659,7 +3719,8 @@ __device__ __forceinline__ void eval_step_batch_body(const LMParams& Q, const LM
     if (!eval_point_load(A, &s_pt)) return;                           // a launch behind the end of the solve: nothing to do, the ticket stays 0
     double acc[kNumAcc];
     if (VIS && bx >= nbx) {
-        visual_sweep_acc(A, s_pt, bx - nbx, it.nb_vis, acc);
+        if (M_LDS) visual_sweep_one(A, s_pt, bx - nbx, it.nb_vis, acc);      // (the host sends a group here only when every thread holds at most one slot)
+        else visual_sweep_acc(A, s_pt, bx - nbx, it.nb_vis, acc);
         block_reduce_store<true>(acc, A.partials + (size_t)(A.vis_row0 + bx - nbx) * kNumAcc, s_scratch);
     } else {
         sweep_rows<M_LDS, PRE>(A, f, s_pt, bx, nbx, acc);
@@ -3692,6 +3753,10 @@ eval_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* _
 __global__ void __launch_bounds__(kEvalThreads) __attribute__((amdgpu_num_vgpr(152)))
 eval_step_batch_lean_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets, int first) {
     eval_step_batch_body<true, VELO_LEAN_PRE, 64>(Q, items[blockIdx.y], tickets, first);
+}
+__global__ void __launch_bounds__(kEvalThreads) __attribute__((amdgpu_num_vgpr(152)))
+eval_step_batch_lean_vis_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets, int first) {
+    eval_step_batch_body<true, VELO_LEAN_PRE, 64, true>(Q, items[blockIdx.y], tickets, first);
 }
 __global__ void __launch_bounds__(kEvalThreads)
 eval_step_batch_vis_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets, int first) {
