@@ -402,7 +402,10 @@ int velo_comm_destroy(velo_ctx* ctx);
  * A peer that never arrives makes the wait time out (5 s): the call in flight (velo_frame_to_frame, velo_solve, velo_evaluate,
  * velo_associate in target-sharded mode) returns VELO_ERR_COMM, and the communicator must be exported and attached again on every rank
  * (the slabs' sequence numbers are out of step).  velo_comm_peer_export clears the slab: every rank must have exported before any rank
- * attaches -- gathering the handles is that barrier -- and no barrier is needed between attach and the first call. */
+ * attaches -- gathering the handles is that barrier -- and no barrier is needed between attach and the first call.
+ * A chained call enqueues a predicted number of LM launches per solve, and over peers that number must be the same on every rank: it is
+ * derived from the context's call history, which velo_comm_peer_attach resets -- so after attaching, every rank makes the same sequence
+ * of registration calls (they do: every rank registers the same pairs) under the same VELO_CHAIN_MARGIN. */
 int velo_comm_peer_export(velo_ctx* ctx, char handle[64]);
 int velo_comm_peer_attach(velo_ctx* ctx, const char* handles /* world * 64 bytes, rank order */, int32_t rank, int32_t world);
 /* Target-sharded mode over the same peers (instead of RCCL send/recv): the receive area for the per-query records of up to
