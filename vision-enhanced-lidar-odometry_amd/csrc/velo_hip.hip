@@ -527,7 +527,8 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
     const size_t ns = (size_t)n + kGridPad;
     VELO_TRY(G.sorted.reserve(ns)); VELO_TRY(G.sring.reserve(ns));
     // count -> one-pass exclusive scan -> scatter, all in the table itself with an offset of one (grid_count_kernel, scan_lookback_kernel)
-    const int n_tiles = cdiv(nc, kLbTile);
+    const bool large_tiles = nc >= kLbLargeFrom;
+    const int n_tiles = cdiv(nc, lb_tile(large_tiles ? kLbItemsLarge : kLbItemsSmall));
     VELO_TRY(c->lb_status.reserve((size_t)n_tiles + 1));               // tile status words + the ticket counter behind them
     VELO_TRY(c->scan_total.reserve(1));
     HIP_TRY(hipMemsetAsync(G.cell_start.p, 0, sizeof(int) * ((size_t)nc + 4), c->stream));
@@ -535,8 +536,10 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
     c->lb_zeroed = 0;                                                  // (about to be used)
     // (bytes: what each kernel must move given this index layout -- count: cloud in, cell ids out; scan: table in + out; scatter: cloud + ids in, sorted copy out)
     if (n > 0) VELO_LAUNCH_T(c, "grid_count_kernel", 20ull * (uint64_t)n, grid_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, G.d, c->T->tgt.p, n, c->T->tgt_cell_of.p, G.table());
-    VELO_LAUNCH_T(c, "scan_lookback_kernel", 8ull * (uint64_t)nc, scan_lookback_kernel, dim3(n_tiles), dim3(kScanThreads), 0, c->stream, G.table() + 1, nc, c->lb_status.p,
-                  reinterpret_cast<int*>(c->lb_status.p + n_tiles), c->scan_total.p);
+    if (large_tiles) VELO_LAUNCH_T(c, "scan_lookback_kernel", 8ull * (uint64_t)nc, scan_lookback_kernel<kLbItemsLarge>, dim3(n_tiles), dim3(kScanThreads), 0, c->stream, G.table() + 1, nc, c->lb_status.p,
+                                   reinterpret_cast<int*>(c->lb_status.p + n_tiles), c->scan_total.p);
+    else VELO_LAUNCH_T(c, "scan_lookback_kernel", 8ull * (uint64_t)nc, scan_lookback_kernel<kLbItemsSmall>, dim3(n_tiles), dim3(kScanThreads), 0, c->stream, G.table() + 1, nc, c->lb_status.p,
+                       reinterpret_cast<int*>(c->lb_status.p + n_tiles), c->scan_total.p);
     VELO_LAUNCH_T(c, "grid_scatter_kernel", 44ull * (uint64_t)n, grid_scatter_kernel, dim3(cdiv(std::max(n, kGridPad), 256)), dim3(256), 0, c->stream, c->T->tgt.p, c->T->tgt_cell_of.p, c->T->tgt_ring_of.p, n,
                   G.table() + 1, (const int*)c->scan_total.p, c->T->tgt_first_point, G.sorted.p, G.sring.p);
     HIP_TRY(hipGetLastError());
@@ -1307,7 +1310,7 @@ int target_finalize_begin(velo_ctx* c) {
 }
 // velo_set_target's own way in: the caller's records -> packed cloud, ring ids, padded rings, bounding-box request in ONE copy (ring
 // offsets + the box's start keys, through a pinned slot) and ONE launch (target_ingest_kernel), instead of upload_cloud + target_finalize_begin
-constexpr int kLbWordsCleared = (1 << 25) / kLbTile + 2;                 // status words of the largest default table (+ ticket)
+constexpr int kLbWordsCleared = (1 << 25) / lb_tile(kLbItemsLarge) + 2 > kLbLargeFrom / lb_tile(kLbItemsSmall) + 2 ? (1 << 25) / lb_tile(kLbItemsLarge) + 2 : kLbLargeFrom / lb_tile(kLbItemsSmall) + 2;                 // status words of the largest default table (+ ticket)
 int target_ingest(velo_ctx* c, const float* xyz, int64_t stride, int on_device) {
     const int n = c->T->n_tgt, n_rings = c->T->n_tgt_rings;
     c->prev_ready = false;                                            // seeds refer to points of the old target

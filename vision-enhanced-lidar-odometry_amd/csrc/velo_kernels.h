@@ -394,36 +394,63 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int* total) {
 // words at a time, each {flag, value} in one 64-bit word read with a device-scope atomic -- adding totals until it meets a tile
 // whose whole prefix is known.  The atomics are RELAXED on purpose: a status word carries everything its reader needs, and an
 // acquire / release at device scope costs an L2 invalidate / write-back per spin (measured: the whole chip slows down 2x).  Read once, write once: 2 x 134 MB for the map's table instead of 5 x (three-kernel scan + cursor).
-constexpr int kLbItems = 16;                       // four 16-byte loads per thread (data is 16-byte aligned); 1,024-element tiles measured 272 vs 186 us on 33 M cells: per-tile cost
-constexpr int kLbTile = kScanThreads * kLbItems;
+// Elements per thread and tile: 16 (4,096-element tiles) for a scan's table, 64 (16,384) for a map's -- the one-pass scan is bound by its
+// NUMBER of tiles (ticket, status word, look-back per tile), not by bytes: on the 23 M cells of the 2M-point map 1,024-element tiles take
+// 272 us, 4,096: 96 us, 8,192: 67 us, 16,384: 56 us (185 MB: 3.3 TB/s); on the 0.87 M cells of a scan 16,384-element tiles leave 53
+// workgroups for the chip (11.0 against 7.9 us).
+constexpr int kLbItemsSmall = 16, kLbItemsLarge = 64;
+constexpr int kLbLargeFrom = 1 << 22;              // table entries from which the large tiles are used
+__host__ __device__ constexpr int lb_tile(int items) { return kScanThreads * items; }
 constexpr unsigned long long kLbAgg = 1ull << 62, kLbPrefix = 2ull << 62, kLbFlags = 3ull << 62;
+template <int kLbItems>
 __global__ void __launch_bounds__(kScanThreads)
 scan_lookback_kernel(int* __restrict__ data, int n, unsigned long long* __restrict__ status, int* __restrict__ ticket, int* __restrict__ grand_total) {
+    // A tile = kLbItems / 4 sub-tiles of kScanThreads x 4 ints; thread t holds the int4 number t of EVERY sub-tile, so a wave's loads and
+    // stores are 1 KB of consecutive memory.  The sub-tiles' prefixes come out of ONE round of wave scans (all sub-tiles at once) and
+    // one barrier.
+    constexpr int kSub = kLbItems / 4, kWaves = kScanThreads / kWave, kLbTile = lb_tile(kLbItems);
+    static_assert(kLbItems % 4 == 0, "int4 loads");
     __shared__ int s_tile, s_prefix;
+    __shared__ int s_wsum[kSub][kWaves];
     if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1);
     __syncthreads();
     const int tile = s_tile;
-    const int base = tile * kLbTile + threadIdx.x * kLbItems;
-    static_assert(kLbItems % 4 == 0, "int4 loads");
-    int v[kLbItems], s = 0;
-    if (base + kLbItems - 1 < n) {
+    const int tbase = tile * kLbTile, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int4 v[kSub];
+    int inc[kSub];
 #pragma unroll
-        for (int k = 0; k < kLbItems; k += 4) { const int4 q = *reinterpret_cast<const int4*>(data + base + k); v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w; }
-    } else {
-#pragma unroll
-        for (int k = 0; k < kLbItems; k++) v[k] = (base + k < n) ? data[base + k] : 0;
+    for (int k = 0; k < kSub; k++) {
+        const int i = tbase + k * (kScanThreads * 4) + threadIdx.x * 4;
+        if (i + 3 < n) v[k] = *reinterpret_cast<const int4*>(data + i);
+        else { v[k].x = i < n ? data[i] : 0; v[k].y = i + 1 < n ? data[i + 1] : 0; v[k].z = i + 2 < n ? data[i + 2] : 0; v[k].w = 0; }
+        inc[k] = (v[k].x + v[k].y) + (v[k].z + v[k].w);
     }
 #pragma unroll
-    for (int k = 0; k < kLbItems; k++) s += v[k];
-    int total;
-    int ex = block_exclusive_scan(s, &total);
+    for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+        for (int k = 0; k < kSub; k++) { const int t = __shfl_up(inc[k], off); if (lane >= off) inc[k] += t; }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < kSub; k++) s_wsum[k][wid] = inc[k];
+    }
+    __syncthreads();
+    int ex[kSub], run = 0;                                              // exclusive prefix of this thread's int4 inside the tile
+#pragma unroll
+    for (int k = 0; k < kSub; k++) {
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) { const int sw = s_wsum[k][w]; if (w < wid) before += sw; all += sw; }
+        ex[k] = run + before + inc[k] - ((v[k].x + v[k].y) + (v[k].z + v[k].w));
+        run += all;
+    }
+    const int total = run;
     if (threadIdx.x == 0) {
         s_prefix = 0;
         __hip_atomic_store(&status[tile], (tile == 0 ? kLbPrefix : kLbAgg) | (unsigned long long)(unsigned)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (tile > 0 && threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        int run = 0;
+        int acc = 0;
         for (int idx = tile - 1;; idx -= 64) {
             const int j = idx - lane;                                  // lane 0 = the nearest tile before this one
             unsigned long long w = kLbPrefix;                          // tiles before the first: prefix 0
@@ -433,29 +460,25 @@ scan_lookback_kernel(int* __restrict__ data, int n, unsigned long long* __restri
             int val = (pm == 0ull || lane <= first) ? (int)(unsigned)(w & 0xffffffffull) : 0;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) val += __shfl_xor(val, off);
-            run += val;
+            acc += val;
             if (pm != 0ull) break;
         }
         if (lane == 0) {
-            s_prefix = run;
-            __hip_atomic_store(&status[tile], kLbPrefix | (unsigned long long)(unsigned)(run + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_prefix = acc;
+            __hip_atomic_store(&status[tile], kLbPrefix | (unsigned long long)(unsigned)(acc + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     __syncthreads();
-    ex += s_prefix;
-    if (base + kLbItems - 1 < n) {
+    const int pre = s_prefix;
 #pragma unroll
-        for (int k = 0; k < kLbItems; k += 4) {
-            int4 q;
-            q.x = ex; q.y = ex + v[k]; q.z = q.y + v[k + 1]; q.w = q.z + v[k + 2];
-            *reinterpret_cast<int4*>(data + base + k) = q;
-            ex = q.w + v[k + 3];
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < kLbItems; k++) { if (base + k < n) data[base + k] = ex; ex += v[k]; }
+    for (int k = 0; k < kSub; k++) {
+        const int i = tbase + k * (kScanThreads * 4) + threadIdx.x * 4;
+        int4 q;
+        q.x = pre + ex[k]; q.y = q.x + v[k].x; q.z = q.y + v[k].y; q.w = q.z + v[k].z;
+        if (i + 3 < n) *reinterpret_cast<int4*>(data + i) = q;
+        else { if (i < n) data[i] = q.x; if (i + 1 < n) data[i + 1] = q.y; if (i + 2 < n) data[i + 2] = q.z; }
+        if (i <= n - 1 && n - 1 < i + 4) *grand_total = q.w + v[k].w;  // the thread that holds the last element: its running sum is the total (elements beyond n are zero)
     }
-    if (base <= n - 1 && n - 1 < base + kLbItems) *grand_total = ex;   // the thread that holds the last element: its running sum is the total
 }
 // (three-kernel scan, kept for the device ring segmenter's small arrays)
 // pass 1: tile-local exclusive scan in place (counts -> local offsets), tile totals out
