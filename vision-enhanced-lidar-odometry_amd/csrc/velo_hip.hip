@@ -2462,9 +2462,13 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
             SolveLog* logp = c->solve_log.p + std::min(r, VELO_MAX_SOLVES - 1);
             const bool peer = c->peer_on;
             if (small && !peer && (!visual || E.total() <= kSmallRows)) {     // no prediction needed: the launch runs the solve to its end
-                c->lm_kernel_name = "lm_solve_small_kernel";
-                VELO_LAUNCH_T(c, c->lm_kernel_name, 0, lm_solve_small_kernel, dim3(1), dim3(kEvalThreads), 0, c->stream, A, Q, c->state.p, (const double*)(r == 0 ? c->xdev.p : nullptr),
-                              nvp, E.nb_icp, E.nb_vis, c->P.max_num_iterations + 3, c->pose_rec.p, logp);
+                c->lm_kernel_name = E.nb_vis > 0 ? "lm_solve_small_kernel" : "lm_solve_small_icp_kernel";
+                if (E.nb_vis > 0)
+                    VELO_LAUNCH_T(c, c->lm_kernel_name, 0, lm_solve_small_kernel, dim3(1), dim3(kEvalThreads), 0, c->stream, A, Q, c->state.p, (const double*)(r == 0 ? c->xdev.p : nullptr),
+                                  nvp, E.nb_icp, E.nb_vis, c->P.max_num_iterations + 3, c->pose_rec.p, logp);
+                else                                                  // no visual blocks: the instantiation without their code
+                    VELO_LAUNCH_T(c, c->lm_kernel_name, 0, lm_solve_small_icp_kernel, dim3(1), dim3(kEvalThreads), 0, c->stream, A, Q, c->state.p, (const double*)(r == 0 ? c->xdev.p : nullptr),
+                                  nvp, E.nb_icp, c->P.max_num_iterations + 3, c->pose_rec.p, logp);
                 HIP_TRY(hipGetLastError());
                 continue;
             }
@@ -2950,8 +2954,9 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                         std::memset(&pack, 0, sizeof(pack));
                         const int m = std::min(kItemsByValue, n - b0);
                         for (int i = 0; i < m; i++) pack.item[i] = items_r[b0 + i];
-                        c0->lm_kernel_name = "lm_solve_small_batch_kernel";
-                        VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, lm_solve_small_batch_kernel, dim3(m), dim3(kEvalThreads), 0, bs, Q, pack, max_iters + 1);
+                        c0->lm_kernel_name = nbv_max > 0 ? "lm_solve_small_batch_kernel" : "lm_solve_small_icp_batch_kernel";
+                        if (nbv_max > 0) VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, lm_solve_small_batch_kernel, dim3(m), dim3(kEvalThreads), 0, bs, Q, pack, max_iters + 1);
+                        else VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, lm_solve_small_icp_batch_kernel, dim3(m), dim3(kEvalThreads), 0, bs, Q, pack, max_iters + 1);
                     }
                     HIP_TRY(hipGetLastError());
                     continue;

@@ -3959,6 +3959,7 @@ __global__ void lm_gather_states_kernel(const LMBatchItem* __restrict__ items, L
 // index and block count, so every partial row is bit-identical to the multi-launch path -- reduces them in the same order,
 // thread 0 does the transition, and the loop continues on the device.  State and partial rows live in LDS for the duration.
 constexpr int kSmallRows = 4;
+template <bool VIS = true>                                             // VIS = false: no visual blocks -- the instantiation without their code (and its registers)
 __device__ __forceinline__ void
 lm_solve_small_body(const EvalArgs& A, const LMParams& Q, LMState* Sg, const double* __restrict__ x_in, const int* __restrict__ n_valid,
                     int nb_icp, int nb_vis, int max_sweeps, PoseRecord* __restrict__ pose_out, SolveLog* __restrict__ log) {
@@ -3988,7 +3989,7 @@ lm_solve_small_body(const EvalArgs& A, const LMParams& Q, LMState* Sg, const dou
     for (int sweep = 0; sweep < max_sweeps; sweep++) {
         if (s_done) break;
         for (int bx = 0; bx < nb_icp; bx++) eval_icp_body(B, bx, nb_icp);
-        for (int bx = 0; bx < nb_vis; bx++) eval_visual_body(B, bx, nb_vis);
+        if (VIS) for (int bx = 0; bx < nb_vis; bx++) eval_visual_body(B, bx, nb_vis);
         __syncthreads();
         if (t < 8 * kNumAcc) {                               // the reduction of lm_transition, same order
             const int k = t % kNumAcc, p = t / kNumAcc;
@@ -4044,6 +4045,16 @@ __global__ void __launch_bounds__(kEvalThreads)
 lm_solve_small_batch_kernel(LMParams Q, LMBatchPack P, int max_sweeps) {
     const LMBatchItem& it = P.item[blockIdx.x];
     lm_solve_small_body(it.A, Q, it.S, it.xd, it.n_valid, it.nb_icp, it.nb_vis, max_sweeps, it.pose_out, it.log);
+}
+__global__ void __launch_bounds__(kEvalThreads)
+lm_solve_small_icp_batch_kernel(LMParams Q, LMBatchPack P, int max_sweeps) {
+    const LMBatchItem& it = P.item[blockIdx.x];
+    lm_solve_small_body<false>(it.A, Q, it.S, it.xd, it.n_valid, it.nb_icp, 0, max_sweeps, it.pose_out, it.log);
+}
+__global__ void __launch_bounds__(kEvalThreads)
+lm_solve_small_icp_kernel(EvalArgs A, LMParams Q, LMState* Sg, const double* __restrict__ x_in, const int* __restrict__ n_valid,
+                          int nb_icp, int max_sweeps, PoseRecord* __restrict__ pose_out, SolveLog* __restrict__ log) {
+    lm_solve_small_body<false>(A, Q, Sg, x_in, n_valid, nb_icp, 0, max_sweeps, pose_out, log);
 }
 
 // ---- seam 2 by value: a batch of residual functors (costfunctions.h:17-220) at one pose -----------------------------------
