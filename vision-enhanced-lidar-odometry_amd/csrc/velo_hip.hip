@@ -3217,6 +3217,26 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
         for (int i = 0; i < n; i++) any = any || (targets[i].on_device & VELO_SCAN_SHARED) != 0;
         if (any) {
             tgt_local.assign(targets, targets + n);
+            auto owner_of = [&](int i) {
+                for (int j = 0; j < i; j++) {
+                    const velo_scan_ref &a = targets[i], &b = targets[j];
+                    if ((b.on_device & VELO_SCAN_SHARED) && a.xyz == b.xyz && a.stride_bytes == b.stride_bytes && a.ring_offsets == b.ring_offsets &&
+                        a.n_rings == b.n_rings && a.on_device == b.on_device && ctxs[i]->device == ctxs[j]->device) return j;
+                }
+                return -1;
+            };
+            // The sharers let go of what they hold from their owner BEFORE it loads: a target other contexts still hold is left to them
+            // (own_target), so the owner of a map shared in the last call would allocate a whole new index every call -- seven buffers
+            // of up to 90 MB, and as many frees when the last sharer moves on -- instead of rebuilding in place.
+            for (int i = 0; i < n; i++) {
+                if (!(targets[i].on_device & VELO_SCAN_SHARED)) continue;
+                const int owner = owner_of(i);
+                if (owner >= 0 && ctxs[i]->T && ctxs[i]->T == ctxs[owner]->T) {
+                    HIP_TRY(hipSetDevice(ctxs[i]->device));
+                    HIP_TRY(hipStreamSynchronize(ctxs[i]->stream));
+                    ctxs[i]->T.reset(); ctxs[i]->have_target = false; ctxs[i]->have_corr = false; ctxs[i]->have_partials = false;
+                }
+            }
             for (int i = 0; i < n; i++) {
                 if (!(targets[i].on_device & VELO_SCAN_SHARED)) continue;
                 int owner = -1;
