@@ -344,17 +344,20 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
         rig.barrier(ctxs)
         t0 = time.perf_counter()
         assoc_ms, assoc_n, alg_bytes, assoc_bytes, evals = 0.0, 0, 0, 0, 0
+        kept = []                                            # the steps' summaries: added up behind the timed region (150 ctypes reads per step)
         for _ in range(steps):
             step()
-            for r in results:
-                s = r[2]
+            kept.append([r[2] for r in results])
+        rig.barrier(ctxs)
+        dt = rig.max_over_ranks(time.perf_counter() - t0)
+        for step_summaries in kept:
+            for s in step_summaries:
                 assoc_ms += s.assoc_kernel_ms
                 assoc_n += s.assoc_kernel_launches
                 alg_bytes += s.algorithmic_bytes
                 assoc_bytes += s.assoc_bytes
                 evals += sum(s.solves[k].evaluations for k in range(s.n_solves))
-        rig.barrier(ctxs)
-        dt = rig.max_over_ranks(time.perf_counter() - t0)
+        del kept
         chain1 = [c.chain_stats() for c in ctxs]
         kacc = {}
         for c in ctxs:
