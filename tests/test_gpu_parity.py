@@ -449,7 +449,26 @@ def test_shared_target_equals_own_copy_and_outlives_its_owner(hip_lib, oracle):
     orc.set_target(d["tgt_xyz"], d["tgt_off"]); orc.set_source(d2["src_xyz"], d2["src_off"])
     xo, _, _ = orc.frame_to_frame(d["x0"])
     assert H.pose_close(xs1[1], xo, 1e-9, 1e-10)
-    for c in ctxs + [own_copy, borrower]:
+    # repeated shared calls rebuild the index IN PLACE: the sharers of the last call let go of it before their owner reloads (a target
+    # others still hold is left to them and a new one allocated) -- no device memory is taken from call to call; a context OUTSIDE the batch
+    # that borrowed the map keeps the old one when the batch moves on to another map, and still registers against it
+    import torch
+    outsider = api.Context(0, icp_skip=1)
+    outsider.share_target(ctxs[0]); outsider.set_source(d2["src_xyz"], d2["src_off"])
+    x_out, _, _ = outsider.frame_to_frame(d["x0"])
+    for _ in range(2):
+        api.register_batch(ctxs, None, None, x0s, refs=refs_sh)
+    torch.cuda.synchronize(); free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(6):
+        xs3, _, _ = api.register_batch(ctxs, None, None, x0s, refs=refs_sh)
+    torch.cuda.synchronize(); free1 = torch.cuda.mem_get_info()[0]
+    assert np.array_equal(xs3, xs1) and free1 >= free0 - (1 << 20)
+    tgt2 = (d2["tgt_xyz"], d2["tgt_off"])
+    refs_sh2 = (api.scan_refs([tgt2] * 4, 0, shared=True), api.scan_refs(srcs, 0))
+    xs4, _, _ = api.register_batch(ctxs, None, None, x0s, refs=refs_sh2)            # another map for the batch
+    x_out2, _, _ = outsider.frame_to_frame(d["x0"])                                 # the outsider still holds the first one
+    assert np.array_equal(x_out2, x_out) and not np.array_equal(xs4, xs1)
+    for c in ctxs + [own_copy, borrower, outsider]:
         c.close()
 
 
