@@ -268,6 +268,7 @@ struct KdTree {
     const float* pts = nullptr;  // n x 3 packed
     int n = 0;
     static const int kLeaf = 15;
+    bool tie_high = false;       // parity-budget variant: exact-distance ties go to the HIGHEST index instead of the lowest
 
     // pcl::KdTreeFLANN::setInputCloud [3P] copies only the FINITE points into the index and keeps a map back to the
     // cloud's own indices, so non-finite target points simply can never be returned.
@@ -303,7 +304,7 @@ struct KdTree {
             for (int i = nd.lo; i < nd.hi; i++) {
                 const int k = perm[i];
                 const float d = dist2f(q, pts + 3 * k);
-                if (d < best || (d == best && k < bi)) { best = d; bi = k; }
+                if (d < best || (d == best && (tie_high ? k > bi : k < bi))) { best = d; bi = k; }
             }
             return;
         }
@@ -315,10 +316,19 @@ struct KdTree {
         // pruning on a strict ">" keeps exactness AND equal-distance candidates (lowest-index tie rule).
         if (!(diff * diff > best)) search_rec(far_c, q, best, bi);
     }
+    // how many indexed points lie at EXACTLY float distance d from q (tie census, tests only)
+    void count_rec(int id, const float* q, float d, int& cnt) const {
+        const Node& nd = nodes[id];
+        if (nd.left < 0) { for (int i = nd.lo; i < nd.hi; i++) if (dist2f(q, pts + 3 * perm[i]) == d) cnt++; return; }
+        const float diff = q[nd.dim] - nd.split;
+        count_rec(diff < 0.f ? nd.left : nd.right, q, d, cnt);
+        if (!(diff * diff > d)) count_rec(diff < 0.f ? nd.right : nd.left, q, d, cnt);
+    }
+    int count_equal(const float* q, float d) const { int c = 0; if (n > 0) count_rec(0, q, d, c); return c; }
     // returns number found (0 for an empty ring; PCL would throw -- the reference never guards)
     int nearest(const float* q, int* idx, float* d2) const {
         if (n == 0) return 0;
-        float best = FLT_MAX; int bi = 0x7fffffff;
+        float best = FLT_MAX; int bi = tie_high ? -1 : 0x7fffffff;
         search_rec(0, q, best, bi);
         *idx = bi; *d2 = best;
         return 1;
@@ -326,6 +336,21 @@ struct KdTree {
 };
 
 struct Block { int kind; double c[9]; Loss loss; };
+
+// one LM iteration as solve() saw it (test hook vo_solve_trace)
+struct vo_trace_row {
+    int32_t iteration;          // 1-based, as Ceres counts them
+    int32_t status;             // 1 accepted, 0 rejected, -1 invalid step, 2 parameter tolerance, 3 function tolerance, 4 gradient tolerance after acceptance
+    double cost;                // cost at x when the iteration began
+    double candidate_cost;      // cost at x + delta (NaN for an invalid step)
+    double radius;              // trust-region radius the step was computed with
+    double model_change;        // model cost change of the step
+    double step_norm;           // ||delta|| in parameter space (Jacobi scaling undone)
+    double relative_decrease;   // cost change / model change (NaN when not reached)
+    double gradient_max;        // max |g| at x when the iteration began
+};
+// a block as the solver sees it (test hook vo_get_blocks)
+struct vo_block { int32_t kind; int32_t loss_type; double c[9]; double loss_a; double loss_w; };
 
 struct Oracle {
     velo_params P;
@@ -342,6 +367,11 @@ struct Oracle {
     int threads = 1;
     int shard_rank = 0, shard_world = 1;
     bool want_stats = false;           // residualStats after every f2f iteration into the summary (velo.h:909)
+    // --- parity-budget switches (tests/test_parity_budget.py): alternatives for [3P] choices the reference does not pin ---
+    bool variant_qr = false;           // solve the LM step in row space by Householder QR of [J; D] (Ceres' DENSE_QR path)
+    bool variant_ftol_apply = false;   // a successful step that meets the function tolerance is applied before terminating
+    bool variant_tie_high = false;     // exact in-ring distance ties go to the highest point index (FLANN's order is unpinned)
+    std::vector<vo_trace_row>* trace = nullptr;   // when set, solve() appends one row per LM iteration
 };
 
 void default_params(velo_params* p) {
@@ -592,6 +622,41 @@ bool chol_solve6(const double A[36], const double b[6], double y[6]) {
     return true;
 }
 
+// Parity-budget variant (Oracle::variant_qr): the step as Ceres' DENSE_QR computes it [3P dense_qr_solver.cc] -- least squares of the
+// augmented system [J; D] y = [r; 0] by unpivoted Householder QR (Eigen::HouseholderQR's algorithm), no normal equations.
+// A: m x 6 column-major (destroyed), b: m (destroyed).
+bool qr_solve6(std::vector<double>& A, std::vector<double>& b, size_t m, double y[6]) {
+    for (int k = 0; k < 6; k++) {
+        double* ak = &A[(size_t)k * m];
+        double nrm = 0.0;
+        for (size_t i = k; i < m; i++) nrm += ak[i] * ak[i];
+        nrm = std::sqrt(nrm);
+        if (!(nrm > 0.0) || !std::isfinite(nrm)) return false;
+        const double alpha = ak[k] > 0.0 ? -nrm : nrm;
+        const double v0 = ak[k] - alpha;                 // v = (v0, a[k+1..]) ; H = I - 2 v v^T / (v^T v)
+        double vtv = v0 * v0;
+        for (size_t i = k + 1; i < m; i++) vtv += ak[i] * ak[i];
+        if (vtv > 0.0) {
+            for (int j = k + 1; j <= 6; j++) {
+                double* c = j < 6 ? &A[(size_t)j * m] : b.data();
+                double dot = v0 * c[k];
+                for (size_t i = k + 1; i < m; i++) dot += ak[i] * c[i];
+                const double f = 2.0 * dot / vtv;
+                c[k] -= f * v0;
+                for (size_t i = k + 1; i < m; i++) c[i] -= f * ak[i];
+            }
+        }
+        ak[k] = alpha;
+    }
+    for (int i = 5; i >= 0; i--) {
+        double s = b[i];
+        for (int k = i + 1; k < 6; k++) s -= A[(size_t)k * m + i] * y[k];
+        y[i] = s / A[(size_t)i * m + i];
+        if (!std::isfinite(y[i])) return false;
+    }
+    return true;
+}
+
 // ceres::Solve with trust-region Levenberg-Marquardt, all defaults (row S1) [3P].
 void solve(Oracle& o, double x[6], velo_solve_summary* S) {
     const velo_params& P = o.P;
@@ -599,8 +664,12 @@ void solve(Oracle& o, double x[6], velo_solve_summary* S) {
     S->n_icp_valid = (int)o.icp_blocks.size();
     S->n_visual_blocks = (int)o.vis_blocks.size();
     for (const Block& b : o.vis_blocks) S->n_visual_residuals += kind_dim(b.kind);
+    const size_t n_rows = (size_t)S->n_icp_valid + (size_t)S->n_visual_residuals;
+    // row storage only for the QR variant (the default works on the 6x6 normal equations)
+    std::vector<double> rows_r, rows_J, rows_rc, rows_Jc;
+    if (o.variant_qr) { rows_r.resize(n_rows); rows_J.resize(n_rows * 6); rows_rc.resize(n_rows); rows_Jc.resize(n_rows * 6); }
     EvalOut E;
-    evaluate(o, x, true, &E, nullptr, nullptr);
+    evaluate(o, x, true, &E, o.variant_qr ? rows_r.data() : nullptr, o.variant_qr ? rows_J.data() : nullptr);
     S->evaluations = 1;
     double cost = E.cost;
     S->initial_cost = cost; S->final_cost = cost;
@@ -613,6 +682,10 @@ void solve(Oracle& o, double x[6], velo_solve_summary* S) {
     bool reuse_diag = false;
     double diag[6];
     int invalid = 0;
+    const double kNaN = std::numeric_limits<double>::quiet_NaN();
+    auto trace = [&](int it, int status, double cand, double rad, double mc, double sn, double q) {
+        if (o.trace) o.trace->push_back(vo_trace_row{it, status, cost, cand, rad, mc, sn, q, gmax(E)});
+    };
     S->termination = VELO_NO_CONVERGENCE;
     for (int it = 1;; it++) {
         if (it > P.max_num_iterations) { S->termination = VELO_NO_CONVERGENCE; break; }
@@ -621,21 +694,43 @@ void solve(Oracle& o, double x[6], velo_solve_summary* S) {
         double Hs[36], gs[6];
         for (int i = 0; i < 6; i++) { gs[i] = E.g[i] * scale[i]; for (int j = 0; j < 6; j++) Hs[i * 6 + j] = E.H[i * 6 + j] * scale[i] * scale[j]; }
         if (!reuse_diag) for (int j = 0; j < 6; j++) diag[j] = std::min(std::max(Hs[j * 6 + j], P.min_lm_diagonal), P.max_lm_diagonal);
-        double A[36];
-        std::memcpy(A, Hs, sizeof(A));
-        for (int j = 0; j < 6; j++) { const double l = std::sqrt(diag[j] / radius); A[j * 6 + j] += l * l; }
+        const double radius_used = radius;
         double y[6], step[6];
-        bool ok = chol_solve6(A, gs, y);
-        reuse_diag = true;
+        bool ok;
         double model_change = 0.0;
-        if (ok) {
-            for (int i = 0; i < 6; i++) step[i] = -y[i];
-            double gd = 0, dHd = 0;
-            for (int i = 0; i < 6; i++) { gd += gs[i] * step[i]; for (int j = 0; j < 6; j++) dHd += step[i] * Hs[i * 6 + j] * step[j]; }
-            model_change = -(gd + 0.5 * dHd);
-            if (!(model_change > 0.0)) ok = false;
+        if (!o.variant_qr) {
+            double A[36];
+            std::memcpy(A, Hs, sizeof(A));
+            for (int j = 0; j < 6; j++) { const double l = std::sqrt(diag[j] / radius); A[j * 6 + j] += l * l; }
+            ok = chol_solve6(A, gs, y);
+            if (ok) {
+                for (int i = 0; i < 6; i++) step[i] = -y[i];
+                double gd = 0, dHd = 0;
+                for (int i = 0; i < 6; i++) { gd += gs[i] * step[i]; for (int j = 0; j < 6; j++) dHd += step[i] * Hs[i * 6 + j] * step[j]; }
+                model_change = -(gd + 0.5 * dHd);
+            }
+        } else {
+            // row space: lhs = [J diag(scale); diag(sqrt(diag / radius))], rhs = [r; 0]; model change = -(Js).(r + Js/2) row by row
+            const size_t m = n_rows + 6;
+            std::vector<double> A(m * 6, 0.0), rhs(m, 0.0);
+            for (size_t r = 0; r < n_rows; r++) { rhs[r] = rows_r[r]; for (int j = 0; j < 6; j++) A[(size_t)j * m + r] = rows_J[r * 6 + j] * scale[j]; }
+            for (int j = 0; j < 6; j++) A[(size_t)j * m + n_rows + j] = std::sqrt(diag[j] / radius);
+            ok = qr_solve6(A, rhs, m, y);
+            if (ok) {
+                for (int i = 0; i < 6; i++) step[i] = -y[i];
+                double acc = 0.0;
+                for (size_t r = 0; r < n_rows; r++) {
+                    double js = 0.0;
+                    for (int j = 0; j < 6; j++) js += rows_J[r * 6 + j] * scale[j] * step[j];
+                    acc += js * (rows_r[r] + js / 2.0);
+                }
+                model_change = -acc;
+            }
         }
+        reuse_diag = true;
+        if (ok && !(model_change > 0.0)) ok = false;
         if (!ok) {  // invalid step
+            trace(it, -1, kNaN, radius_used, model_change, kNaN, kNaN);
             if (++invalid >= P.max_consecutive_invalid_steps) { S->termination = VELO_FAILURE; break; }
             radius = radius / decrease; decrease *= 2.0; reuse_diag = true;
             continue;
@@ -645,22 +740,39 @@ void solve(Oracle& o, double x[6], velo_solve_summary* S) {
         for (int i = 0; i < 6; i++) { const double d = step[i] * scale[i]; xc[i] = x[i] + d; dn += d * d; }
         dn = std::sqrt(dn);
         EvalOut Ec;
-        evaluate(o, xc, true, &Ec, nullptr, nullptr);   // Ceres evaluates the cost only here and J after acceptance; same numbers
+        // Ceres evaluates the cost only here and J after acceptance; same numbers
+        evaluate(o, xc, true, &Ec, o.variant_qr ? rows_rc.data() : nullptr, o.variant_qr ? rows_Jc.data() : nullptr);
         S->evaluations++;
-        if (dn <= P.parameter_tolerance * (x_norm + P.parameter_tolerance)) { S->termination = VELO_CONVERGENCE; break; }
+        if (dn <= P.parameter_tolerance * (x_norm + P.parameter_tolerance)) {
+            trace(it, 2, Ec.cost, radius_used, model_change, dn, kNaN);
+            S->termination = VELO_CONVERGENCE; break;
+        }
         const double cost_change = cost - Ec.cost;
-        if (std::fabs(cost_change) <= P.function_tolerance * cost) { S->termination = VELO_CONVERGENCE; break; }
         const double q = cost_change / model_change;
+        if (std::fabs(cost_change) <= P.function_tolerance * cost) {
+            trace(it, 3, Ec.cost, radius_used, model_change, dn, q);
+            if (o.variant_ftol_apply && q > P.min_relative_decrease) {   // budget variant: the converging step is taken
+                for (int i = 0; i < 6; i++) x[i] = xc[i];
+                cost = Ec.cost;
+            }
+            S->termination = VELO_CONVERGENCE; break;
+        }
         if (q > P.min_relative_decrease) {
+            trace(it, 1, Ec.cost, radius_used, model_change, dn, q);
             for (int i = 0; i < 6; i++) x[i] = xc[i];
             cost = Ec.cost; E = Ec;
+            if (o.variant_qr) { rows_r.swap(rows_rc); rows_J.swap(rows_Jc); }
             x_norm = 0; for (int i = 0; i < 6; i++) x_norm += x[i] * x[i]; x_norm = std::sqrt(x_norm);
-            if (gmax(E) <= P.gradient_tolerance) { S->termination = VELO_CONVERGENCE; break; }
+            if (gmax(E) <= P.gradient_tolerance) {
+                if (o.trace) o.trace->back().status = 4;
+                S->termination = VELO_CONVERGENCE; break;
+            }
             const double t = 2.0 * q - 1.0;
             radius = radius / std::max(1.0 / 3.0, 1.0 - t * t * t);
             radius = std::min(P.max_trust_region_radius, radius);
             decrease = 2.0; reuse_diag = false;
         } else {
+            trace(it, 0, Ec.cost, radius_used, model_change, dn, q);
             radius = radius / decrease; decrease *= 2.0; reuse_diag = true;
         }
     }
@@ -986,7 +1098,7 @@ int vo_set_target(void* h, const float* xyz, int64_t stride, const int32_t* off,
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1) num_threads(o->threads)
 #endif
-    for (int r = 0; r < nr; r++) o->trees[r].build(&o->tgt[3 * (size_t)off[r]], off[r + 1] - off[r]);  // lru.h:17-20
+    for (int r = 0; r < nr; r++) { o->trees[r].build(&o->tgt[3 * (size_t)off[r]], off[r + 1] - off[r]); o->trees[r].tie_high = o->variant_tie_high; }  // lru.h:17-20
     return 0;
 }
 int vo_set_source(void* h, const float* xyz, int64_t stride, const int32_t* off, int32_t nr) {
@@ -1046,6 +1158,89 @@ int vo_solve(void* h, double* x, velo_solve_summary* s) {
     solve(*(Oracle*)h, x, s ? s : &tmp);
     return 0;
 }
+// --- parity-budget hooks (tests/test_parity_budget.py, tools/parity_budget.py) ------------------------------------------------
+// qr / ftol_apply: see Oracle::variant_*.  Both off = the restatement every parity test compares the HIP path with.
+int vo_set_variant(void* h, int qr, int ftol_apply, int tie_high) {
+    Oracle* o = (Oracle*)h; o->variant_qr = qr != 0; o->variant_ftol_apply = ftol_apply != 0; o->variant_tie_high = tie_high != 0;
+    for (KdTree& t : o->trees) t.tie_high = o->variant_tie_high;
+    return 0;
+}
+// solve() with one trace row per LM iteration; returns the number of rows (the first `cap` are copied)
+int vo_solve_trace(void* h, double* x, velo_solve_summary* s, vo_trace_row* rows, int32_t cap) {
+    Oracle* o = (Oracle*)h;
+    std::vector<vo_trace_row> tr;
+    velo_solve_summary tmp;
+    o->trace = &tr;
+    solve(*o, x, s ? s : &tmp);
+    o->trace = nullptr;
+    const int n = (int)tr.size();
+    if (rows) std::memcpy(rows, tr.data(), sizeof(vo_trace_row) * (size_t)std::min(n, (int)cap));
+    return n;
+}
+// the residual blocks of the current problem in the order the solver sums them (visual first, then point-to-plane)
+int vo_get_blocks(void* h, vo_block* out, int32_t cap) {
+    Oracle* o = (Oracle*)h;
+    int n = 0;
+    auto put = [&](const std::vector<Block>& v) {
+        for (const Block& b : v) {
+            if (out && n < cap) {
+                vo_block& d = out[n];
+                d.kind = b.kind; d.loss_type = b.loss.type; d.loss_a = b.loss.a; d.loss_w = b.loss.w;
+                std::memcpy(d.c, b.c, sizeof(d.c));
+            }
+            n++;
+        }
+    };
+    put(o->vis_blocks); put(o->icp_blocks);
+    return n;
+}
+// Census of EXACT distance ties in one association round at pose x (velo.h:825-848): where FLANN's unpinned traversal order
+// (in-ring ties) could matter.  The strict '<' of velo.h:836,843 decides cross-ring ties itself (pinned by the reference); they are
+// counted because the HIP path's 64-bit key has to reproduce that rule.  out[0] queries, out[1] (query, ring) pairs inside the gate,
+// out[2] of those: pairs whose ring holds >= 2 points at exactly the minimal float distance, out[3] queries where such a ring is
+// the best or the second-best ring (the only place the tie rule is observable), out[4] queries whose two best rings are at exactly
+// equal distance, out[5] queries where another ring ties the second-best distance, out[6] queries with both rings found.
+int vo_tie_census(void* h, const double* x, int32_t iter, int64_t* out) {
+    Oracle& o = *(Oracle*)h;
+    std::vector<std::pair<int, int>> q;
+    query_list(o, q);
+    const int nq = (int)q.size();
+    const double it = (double)iter;
+    const double gate = o.P.correspondence_thresh_icp / it / it / it / it;
+    const int Rs = (int)o.trees.size();
+    int64_t c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 64) num_threads(o.threads) reduction(+ : c1, c2, c3, c4, c5, c6)
+#endif
+    for (int i = 0; i < nq; i++) {
+        const float* pM0 = &o.src[3 * (size_t)(o.src_off[q[i].first] + q[i].second)];
+        float pM[3];
+        transform_point(pM0, x, pM);
+        int s_i = -1, s_j = -1; double d_i = kInf, d_j = kInf; bool tie_i = false, tie_j = false;
+        std::vector<double> ds;
+        for (int ss = 0; ss < Rs; ss++) {
+            int id; float d2;
+            if (o.trees[ss].nearest(pM, &id, &d2) <= 0 || (double)d2 > gate) continue;
+            c1++;
+            const bool tied = o.trees[ss].count_equal(pM, d2) > 1;
+            if (tied) c2++;
+            const double d = sub_norm2(&o.tgt[3 * (size_t)(o.tgt_off[ss] + id)], pM);
+            ds.push_back(d);
+            if (d < d_i) { d_j = d_i; s_j = s_i; tie_j = tie_i; d_i = d; s_i = ss; tie_i = tied; }
+            else if (d < d_j) { d_j = d; s_j = ss; tie_j = tied; }
+        }
+        if (s_i < 0 || s_j < 0) continue;
+        c6++;
+        if (tie_i || tie_j) c3++;
+        if (d_i == d_j) c4++;
+        int at_dj = 0;
+        for (double d : ds) if (d == d_j) at_dj++;
+        if (at_dj > (d_i == d_j ? 2 : 1)) c5++;
+    }
+    out[0] = nq; out[1] = c1; out[2] = c2; out[3] = c3; out[4] = c4; out[5] = c5; out[6] = c6;
+    return 0;
+}
+
 int vo_frame_to_frame(void* h, double* x, double* T, velo_summary* s) {
     frame_to_frame(*(Oracle*)h, x, T, s);
     return 0;

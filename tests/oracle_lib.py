@@ -19,6 +19,11 @@ ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "libvelo_oracle.so")
 ORACLE_SO_OVERRIDE = os.environ.get("VELO_ORACLE_SO")
 
 _dp = C.POINTER(C.c_double)
+# layouts of the oracle's test hooks (oracle/velo_oracle.cpp: vo_trace_row, vo_block)
+TRACE_DTYPE = np.dtype([("iteration", "<i4"), ("status", "<i4"), ("cost", "<f8"), ("candidate_cost", "<f8"), ("radius", "<f8"),
+                        ("model_change", "<f8"), ("step_norm", "<f8"), ("relative_decrease", "<f8"), ("gradient_max", "<f8")])
+BLOCK_DTYPE = np.dtype([("kind", "<i4"), ("loss_type", "<i4"), ("c", "<f8", (9,)), ("loss_a", "<f8"), ("loss_w", "<f8")])
+TRACE_ACCEPTED, TRACE_REJECTED, TRACE_INVALID, TRACE_PARAMETER_TOL, TRACE_FUNCTION_TOL, TRACE_GRADIENT_TOL = 1, 0, -1, 2, 3, 4
 ORACLE_SO_LIBM = os.path.join(ORACLE_DIR, "_build", "libvelo_oracle_libm.so")   # -DVELO_ORACLE_LIBM: the host libm's sin / cos
 _libs = {}
 
@@ -44,7 +49,8 @@ def lib(libm: bool = False) -> C.CDLL:
         for name in ("vo_destroy", "vo_set_params", "vo_set_threads", "vo_set_target", "vo_set_source",
                      "vo_set_visual", "vo_associate", "vo_get_correspondences", "vo_build_visual",
                      "vo_get_good_matches", "vo_evaluate", "vo_evaluate_rows", "vo_solve", "vo_frame_to_frame",
-                     "vo_ring_nn", "vo_set_query_shard", "vo_max_threads", "vo_uses_libm", "vo_sincos"):
+                     "vo_ring_nn", "vo_set_query_shard", "vo_max_threads", "vo_uses_libm", "vo_sincos",
+                     "vo_set_variant", "vo_solve_trace", "vo_get_blocks", "vo_tie_census"):
             getattr(l, name).restype = C.c_int
         assert l.vo_uses_libm() == (1 if libm else 0)
         _libs[libm] = l
@@ -170,6 +176,38 @@ class Oracle:
         s = VeloSolveSummary()
         self._l.vo_solve(self._h, xv.ctypes.data_as(_dp), C.byref(s))
         return xv, s
+
+    # --- parity-budget hooks (tests/test_parity_budget.py) ---
+    def set_variant(self, qr=False, ftol_apply=False, tie_high=False):
+        """Alternatives for un-pinned third-party behaviour: the LM step by Householder QR of [J; D] (Ceres' DENSE_QR) instead of
+        the 6x6 Cholesky; a successful step that meets the function tolerance applied before terminating; exact in-ring distance
+        ties to the HIGHEST index (FLANN's traversal order is unpinned) instead of the lowest."""
+        self._l.vo_set_variant(self._h, C.c_int(1 if qr else 0), C.c_int(1 if ftol_apply else 0), C.c_int(1 if tie_high else 0))
+
+    def solve_trace(self, x):
+        """solve() plus one TRACE_DTYPE row per LM iteration."""
+        xv = _d(x, 6).copy()
+        s = VeloSolveSummary()
+        rows = np.zeros(64, dtype=TRACE_DTYPE)
+        n = self._l.vo_solve_trace(self._h, xv.ctypes.data_as(_dp), C.byref(s), C.c_void_p(rows.ctypes.data), C.c_int32(len(rows)))
+        assert 0 <= n <= len(rows)
+        return xv, s, rows[:n]
+
+    def blocks(self):
+        """The residual blocks of the current problem in solver order (visual first, then point-to-plane)."""
+        n = self._l.vo_get_blocks(self._h, None, C.c_int32(0))
+        out = np.zeros(n, dtype=BLOCK_DTYPE)
+        self._l.vo_get_blocks(self._h, C.c_void_p(out.ctypes.data), C.c_int32(n))
+        return out
+
+    def tie_census(self, x, it):
+        """Exact-distance ties of one association round at pose x: dict of counts (see vo_tie_census)."""
+        xv = _d(x, 6)
+        out = np.zeros(8, dtype=np.int64)
+        self._l.vo_tie_census(self._h, xv.ctypes.data_as(_dp), C.c_int32(it), C.c_void_p(out.ctypes.data))
+        keys = ("queries", "gated_ring_pairs", "in_ring_ties", "in_ring_ties_on_a_winner", "cross_ring_tie_first",
+                "cross_ring_tie_second", "queries_with_two_rings")
+        return {k: int(v) for k, v in zip(keys, out)}
 
     def set_residual_stats(self, enable=True):
         self._l.vo_set_residual_stats(self._h, C.c_int(1 if enable else 0))
