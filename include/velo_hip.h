@@ -401,11 +401,12 @@ int velo_comm_destroy(velo_ctx* ctx);
  * collective launch.  world <= 8.  Ranks may be processes on different GPUs of one node or -- for tests -- on the same GPU.
  * A peer that never arrives makes the wait time out (5 s): the call in flight (velo_frame_to_frame, velo_solve, velo_evaluate,
  * velo_associate in target-sharded mode) returns VELO_ERR_COMM, and the communicator must be exported and attached again on every rank
- * (the slabs' sequence numbers are out of step).  velo_comm_peer_export clears the slab: every rank must have exported before any rank
+ * (the slabs' sequence numbers are out of step).  Every velo_comm_peer_export hands out a NEW, cleared slab (the previous one is
+ * retired, not re-used: a slow peer's timed-out call may still be storing into it): every rank must have exported before any rank
  * attaches -- gathering the handles is that barrier -- and no barrier is needed between attach and the first call.
- * A chained call enqueues a predicted number of LM launches per solve, and over peers that number must be the same on every rank: it is
- * derived from the context's call history, which velo_comm_peer_attach resets -- so after attaching, every rank makes the same sequence
- * of registration calls (they do: every rank registers the same pairs) under the same VELO_CHAIN_MARGIN. */
+ * A chained call enqueues a predicted number of LM launches per solve, and over peers that number must be the same on every rank: the
+ * ranks agree on it at the start of every chained call (the maximum over the ranks' own predictions, exchanged through the slabs),
+ * so contexts with different call histories or VELO_CHAIN_MARGIN settings may share a communicator. */
 int velo_comm_peer_export(velo_ctx* ctx, char handle[64]);
 int velo_comm_peer_attach(velo_ctx* ctx, const char* handles /* world * 64 bytes, rank order */, int32_t rank, int32_t world);
 /* Target-sharded mode over the same peers (instead of RCCL send/recv): the receive area for the per-query records of up to

@@ -808,3 +808,42 @@ def test_kernel_times_count_every_launch_and_bracket_a_sample(hip_lib):
         names |= set(c.kernel_times())
         c.close()
     assert "assoc_search_v5_batch_kernel" in names and any(nm.startswith("eval_step_batch") for nm in names)
+
+
+def test_failed_shared_batch_leaves_sharers_in_a_defined_state(hip_lib):
+    """A shared-map batch releases the sharers' hold on the old map before the owner reloads.  If the owner's load then fails (here: a
+    ring table that decreases), the sharers must be left WITHOUT a target but in a defined state: the getters and the registration
+    entry points report a status -- the C-ABI promises codes, never a crash -- and the contexts work again after the next good load."""
+    d = H.small_pair(16, 128)
+    ctxs = [api.Context(0, icp_skip=1) for _ in range(4)]
+    srcs = [(d["src_xyz"], d["src_off"])] * 4
+    x0s = np.tile(d["x0"], (4, 1))
+    tgt = (d["tgt_xyz"], d["tgt_off"])
+    good = (api.scan_refs([tgt] * 4, 0, shared=True), api.scan_refs(srcs, 0))
+    xs, _, _ = api.register_batch(ctxs, None, None, x0s, refs=good)
+    assert np.array_equal(ctxs[1].ring_offsets(True), d["tgt_off"])
+    bad_off = np.array(d["tgt_off"], dtype=np.int32).copy()
+    bad_off[3] = bad_off[2] - 1                                           # offsets decrease: velo_set_target rejects the owner's job
+    bad = (api.scan_refs([(d["tgt_xyz"], bad_off)] * 4, 0, shared=True), api.scan_refs(srcs, 0))
+    # (the descriptor differs from the last call's, so the sharers are only released when it matches; run the failing call twice with the
+    #  SAME descriptor as a good first call by patching the offsets in place)
+    with pytest.raises(api.VeloError):
+        api.register_batch(ctxs, None, None, x0s, refs=bad)
+    off_live = np.array(d["tgt_off"], dtype=np.int32).copy()
+    live = (api.scan_refs([(d["tgt_xyz"], off_live)] * 4, 0, shared=True), api.scan_refs(srcs, 0))
+    xs_live, _, _ = api.register_batch(ctxs, None, None, x0s, refs=live)   # a good call: ctxs 1..3 share ctx 0's map
+    assert np.array_equal(xs_live, xs)
+    off_live[3] = off_live[2] - 1                                          # the SAME descriptor turns bad: sharers are released, then the owner fails
+    with pytest.raises(api.VeloError):
+        api.register_batch(ctxs, None, None, x0s, refs=live)
+    for c in ctxs[1:]:
+        with pytest.raises(api.VeloError):
+            c.ring_offsets(True)
+        with pytest.raises(api.VeloError):
+            c.cloud(True)
+        with pytest.raises(api.VeloError):
+            c.frame_to_frame(d["x0"])
+    xs2, _, _ = api.register_batch(ctxs, None, None, x0s, refs=good)
+    assert np.array_equal(xs2, xs)
+    for c in ctxs:
+        c.close()

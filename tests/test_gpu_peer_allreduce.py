@@ -173,3 +173,59 @@ def test_target_sharded_ranks_on_one_gpu_match_the_oracle(hip_lib, oracle, tmp_p
     want = np.array([[so.solves[k].termination, so.solves[k].lm_iterations, so.solves[k].evaluations] for k in range(so.n_solves)])
     assert np.array_equal(ranks[0]["counts"][:, :3], want)
     assert sum(int(r["counts"][-1, 3]) for r in ranks) == so.solves[so.n_solves - 1].n_icp_valid
+
+
+# ---- chained calls over peers: the ranks agree on the launch counts, whatever their own predictions are -------------------------------
+def _uneven_rank_main(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    # rank 1 predicts with a different (fixed) margin: without the agreement it would enqueue more LM launches per solve than rank 0,
+    # its last all-reduces would wait for a partner that never comes, and the call would fail with VELO_ERR_COMM after 5 s
+    if rank == 1:
+        os.environ["VELO_CHAIN_MARGIN"] = "3"
+    import torch.distributed as dist
+    import velo_amd  # noqa: F401
+    from velo_amd import api, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = synth.scan_pair(n_beams=32, n_azimuth=400)
+    ctx = api.Context(0, icp_skip=1)
+    out = {}
+    for epoch in range(2):                                   # the second pass exports and attaches AGAIN: new slabs, same results
+        handles = [None] * world
+        dist.all_gather_object(handles, ctx.comm_peer_export())
+        ctx.comm_peer_attach(handles, rank, world)
+        ctx.set_target(d["tgt_xyz"], d["tgt_off"])
+        ctx.set_source(d["src_xyz"], d["src_off"])
+        for rep in range(3):
+            x, T, s = ctx.frame_to_frame(d["x0"])
+        out[f"x{epoch}"] = x
+        out[f"counts{epoch}"] = np.array([[s.solves[k].termination, s.solves[k].lm_iterations, s.solves[k].evaluations] for k in range(s.n_solves)])
+    out["chain"] = np.array(ctx.chain_stats())
+    np.savez(os.path.join(out_dir, f"uneven_{rank}.npz"), **out)
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_chained_peer_calls_agree_on_launch_counts_when_the_ranks_predict_differently(hip_lib, tmp_path):
+    import torch.multiprocessing as mp
+    from velo_amd import api, synth
+    mp.spawn(_uneven_rank_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = (np.load(tmp_path / f"uneven_{r}.npz") for r in range(2))
+    for e in range(2):
+        assert np.array_equal(a[f"x{e}"], b[f"x{e}"]) and np.array_equal(a[f"counts{e}"], b[f"counts{e}"])
+    assert np.array_equal(a["x0"], a["x1"])
+    assert a["chain"][0] >= 6 and b["chain"][0] >= 6                       # the calls really were chained ...
+    assert a["chain"][1] == b["chain"][1]                                   # ... and a miss, if any, is every rank's miss
+    d = synth.scan_pair(n_beams=32, n_azimuth=400)
+    one = api.Context(0, icp_skip=1)
+    one.set_target(d["tgt_xyz"], d["tgt_off"]); one.set_source(d["src_xyz"], d["src_off"])
+    x1, _T, s1 = one.frame_to_frame(d["x0"])
+    one.close()
+    import helpers as H
+    assert H.pose_close(a["x0"], x1, 1e-11, 1e-12)
+    assert np.array_equal(a["counts0"], np.array([[s1.solves[k].termination, s1.solves[k].lm_iterations, s1.solves[k].evaluations] for k in range(s1.n_solves)]))

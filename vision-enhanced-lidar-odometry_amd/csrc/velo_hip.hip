@@ -365,6 +365,9 @@ struct velo_ctx {
     PeerComm peer{};
     void* peer_mapped[kMaxPeers] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     DevBuf<unsigned long long> peer_seq;
+    DevBuf<unsigned long long> peer_kseq;           // counter of the launch-count agreements (peer_agree_kernel)
+    int* h_agree = nullptr;                         // pinned: the agreed launch counts of a chained peer call
+    std::vector<void*> peer_retired;                // slabs of earlier exports: a peer's timed-out call may still store into them; freed with the context
     DevBuf<int> peer_err;
     PartialRec* peer_area = nullptr;     // my receive area of the record exchange (fine-grained, exported)
     int peer_area_queries = 0;           // max_queries it was sized for
@@ -1645,6 +1648,9 @@ int velo_destroy(velo_ctx* c) {
     for (int r = 0; r < kMaxPeers; r++) if (c->peer_mapped[r]) { (void)hipIpcCloseMemHandle(c->peer_mapped[r]); c->peer_mapped[r] = nullptr; }
     for (int r = 0; r < kMaxPeers; r++) if (c->peer_area_mapped[r]) { (void)hipIpcCloseMemHandle(c->peer_area_mapped[r]); c->peer_area_mapped[r] = nullptr; }
     if (c->peer_slab) { (void)hipFree(c->peer_slab); c->peer_slab = nullptr; }
+    for (void* p : c->peer_retired) (void)hipFree(p);
+    c->peer_retired.clear();
+    if (c->h_agree) { (void)hipHostFree(c->h_agree); c->h_agree = nullptr; }
     if (c->peer_area) { (void)hipFree(c->peer_area); c->peer_area = nullptr; }
     c->T.reset();                                            // the target goes with its last holder
     c->vis_counts.release(); c->lb_status.release(); c->scan_tiles.release(); c->cursor.release(); c->scan_total.release(); c->bbox_keys.release();
@@ -1737,6 +1743,7 @@ int velo_set_target_part(velo_ctx* c, const float* xyz, int64_t stride, const in
 }
 
 static int set_source_begin(velo_ctx* c, const float* xyz, int64_t stride, const int32_t* off, int32_t n_rings, int on_device) {
+    if (c) c->src_raw.on = false;
     if (!c || !off || n_rings < 0) return fail(VELO_ERR_INVALID, "null/negative argument");
     if (stride < 12) return fail(VELO_ERR_INVALID, "stride_bytes must be >= 12");
     if (off[0] != 0) return fail(VELO_ERR_INVALID, "ring_offsets[0] must be 0");
@@ -1761,7 +1768,7 @@ static int set_source_begin(velo_ctx* c, const float* xyz, int64_t stride, const
 }
 int velo_set_source(velo_ctx* c, const float* xyz, int64_t stride, const int32_t* off, int32_t n_rings, int on_device) {
     VELO_TRY(set_source_begin(c, xyz, stride, off, n_rings, on_device));
-    VELO_TRY(source_finalize(c));
+    { const int st = source_finalize(c); c->src_raw.on = false; if (st != VELO_OK) return st; }
     HIP_TRY(hipStreamSynchronize(c->stream));                             // the caller's buffer has been read when the call returns
     return VELO_OK;
 }
@@ -2001,6 +2008,7 @@ int velo_cache_load(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t as_t
 
 int velo_get_ring_offsets(velo_ctx* c, int32_t of_target, int32_t* out, int32_t capacity, int32_t* n_rings) {
     if (!c) return fail(VELO_ERR_INVALID, "null ctx");
+    if (of_target ? !(c->have_target && c->T) : !c->have_source) { if (n_rings) *n_rings = 0; return fail(VELO_ERR_STATE, "the context holds no %s scan", of_target ? "target" : "source"); }
     const std::vector<int>& h = of_target ? c->T->h_tgt_off : c->h_src_off;
     const int nr = h.empty() ? 0 : (int)h.size() - 1;
     if (n_rings) *n_rings = nr;
@@ -2011,6 +2019,7 @@ int velo_get_ring_offsets(velo_ctx* c, int32_t of_target, int32_t* out, int32_t 
 // copies the context's camera-frame cloud back (tests): n points, 3 floats each
 int velo_get_cloud(velo_ctx* c, int32_t of_target, float* xyz_out, int32_t capacity_points, int32_t* n_points) {
     if (!c) return fail(VELO_ERR_INVALID, "null ctx");
+    if (of_target ? !(c->have_target && c->T) : !c->have_source) { if (n_points) *n_points = 0; return fail(VELO_ERR_STATE, "the context holds no %s scan", of_target ? "target" : "source"); }
     const int n = of_target ? c->T->n_tgt : c->n_src;
     if (n_points) *n_points = n;
     if (!xyz_out || capacity_points <= 0 || n == 0) return VELO_OK;
@@ -2445,6 +2454,20 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
     c->chain_calls++;
     int j = 0, r = 0;                                                // launch counter (its parity selects the double-buffer halves), round
     const int rounds = c->P.f2f_iterations * c->P.icp_iterations;
+    // Over peers every rank must enqueue the same number of LM launches per solve (the all-reduce sits inside the step kernel): the
+    // ranks agree on the maximum of their predictions before anything else is enqueued -- one tiny launch and one synchronisation.
+    int k_agreed[VELO_MAX_SOLVES];
+    if (c->peer_on) {
+        static_assert(VELO_MAX_SOLVES <= 64, "AgreeCounts holds 64 counts (one lane each)");
+        AgreeCounts mine;
+        std::memset(&mine, 0, sizeof(mine));
+        for (int k = 0; k < VELO_MAX_SOLVES; k++) mine.v[k] = std::min(std::max(c->pred_evals[k], 1) + margin_for(c, k), max_launches);
+        hipLaunchKernelGGL(peer_agree_kernel, dim3(1), dim3(64), 0, c->stream, c->peer, mine, (int)VELO_MAX_SOLVES, c->h_agree);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        VELO_TRY(peer_check(c));
+        for (int k = 0; k < VELO_MAX_SOLVES; k++) k_agreed[k] = std::min(std::max(c->h_agree[k], 1), max_launches);
+    }
     for (int iter = 1; iter <= c->P.f2f_iterations; iter++) {
         if (visual) {
             // (x of a later iteration: the state buffer the last launch wrote -- index j & 1 with one-launch iterations, else buffer 0)
@@ -2473,7 +2496,8 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
                 continue;
             }
             if (peer || (visual && c->lm_trace_vis_off)) {           // sweep (+ visual sweep) + step per LM iteration, state single-buffered
-                const int Kv = std::min(std::max(c->pred_evals[std::min(r, VELO_MAX_SOLVES - 1)], 1) + margin_for(c, r), max_launches);
+                const int Kv = peer ? k_agreed[std::min(r, VELO_MAX_SOLVES - 1)]
+                                    : std::min(std::max(c->pred_evals[std::min(r, VELO_MAX_SOLVES - 1)], 1) + margin_for(c, r), max_launches);
                 hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->state.p, c->eval_pt.p, (const double*)(r == 0 ? c->xdev.p : nullptr), nvp, c->pose_rec.p);
                 for (int k = 0; k < Kv; k++) {
                     launch_eval(c, A, E);
@@ -3207,7 +3231,8 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
     struct BatchLoad {                                               // marks the contexts while their scans are loaded (index sizing, build_grid)
         velo_ctx** c; int n;
         BatchLoad(velo_ctx** c_, int n_) : c(c_), n(n_) { for (int i = 0; i < n; i++) c[i]->batch_load = n >= 2; }
-        ~BatchLoad() { for (int i = 0; i < n; i++) c[i]->batch_load = false; }
+        // (src_raw points into the caller's buffer or the staging area and is only good inside this call: a failed load must not leave it armed)
+        ~BatchLoad() { for (int i = 0; i < n; i++) { c[i]->batch_load = false; c[i]->src_raw.on = false; } }
     } batch_load(ctxs, n);
     // Targets flagged VELO_SCAN_SHARED with identical descriptors (scan-to-map: many scans against one map) are loaded and indexed
     // ONCE, by the first job that names them; the other jobs' contexts take that target by reference (velo_share_target).
@@ -3234,7 +3259,8 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
                 if (owner >= 0 && ctxs[i]->T && ctxs[i]->T == ctxs[owner]->T) {
                     HIP_TRY(hipSetDevice(ctxs[i]->device));
                     HIP_TRY(hipStreamSynchronize(ctxs[i]->stream));
-                    ctxs[i]->T.reset(); ctxs[i]->have_target = false; ctxs[i]->have_corr = false; ctxs[i]->have_partials = false;
+                    // never a null T (every other path assumes one): an empty target of its own has the same effect on the owner's use_count
+                    ctxs[i]->T = std::make_shared<TargetData>(); ctxs[i]->have_target = false; ctxs[i]->have_corr = false; ctxs[i]->have_partials = false;
                 }
             }
             for (int i = 0; i < n; i++) {
@@ -3418,7 +3444,12 @@ int velo_comm_peer_export(velo_ctx* c, char handle[64]) {
     if (!c || !handle) return fail(VELO_ERR_INVALID, "null argument");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes in the ABI");
     HIP_TRY(hipSetDevice(c->device));
-    if (!c->peer_slab) {
+    // Every export hands out a NEW slab.  On the recovery path (a VELO_ERR_COMM timeout, then export + attach again on every rank) a
+    // slow peer's timed-out call may still be storing old-epoch blocks while a fast rank is already here; with sequence numbers
+    // restarting at attach, such a block written into a re-used slab could be taken for a new one.  The old slab is therefore
+    // retired, not cleared and re-used: stale stores land in memory nobody reads any more (4.5 KB per recovery, freed with the context).
+    if (c->peer_slab) { c->peer_retired.push_back(c->peer_slab); c->peer_slab = nullptr; }
+    {
         // fine-grained device memory: stores of a peer on another GPU become visible while the kernels run
         void* p = nullptr;
         if (hipExtMallocWithFlags(&p, sizeof(PeerSlab), hipDeviceMallocFinegrained) != hipSuccess) {
@@ -3446,12 +3477,15 @@ int velo_comm_peer_attach(velo_ctx* c, const char* handles, int32_t rank, int32_
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     peer_release(c);
-    VELO_TRY(c->peer_seq.reserve(1)); VELO_TRY(c->peer_err.reserve(1));
+    VELO_TRY(c->peer_seq.reserve(1)); VELO_TRY(c->peer_err.reserve(1)); VELO_TRY(c->peer_kseq.reserve(1));
+    if (!c->h_agree) HIP_TRY(hipHostMalloc((void**)&c->h_agree, sizeof(int) * 64, hipHostMallocDefault));
     HIP_TRY(hipMemset(c->peer_seq.p, 0, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(c->peer_kseq.p, 0, sizeof(unsigned long long)));
     HIP_TRY(hipMemset(c->peer_err.p, 0, sizeof(int)));
     // (the slab itself was cleared by velo_comm_peer_export: a peer that attached earlier may already be storing into it)
     // Chain mode over peers enqueues a predicted number of LM launches per solve, and every rank must enqueue the SAME number: the
-    // prediction history restarts here, on every rank alike, and from here on all ranks see the same solves.
+    // ranks agree on the counts at the start of every chained call (peer_agree_kernel, the maximum over ranks), whatever their
+    // histories are.  The history still restarts here so that the first calls of a fresh communicator predict alike.
     for (int k = 0; k < VELO_MAX_SOLVES; k++) { c->pred_evals[k] = (k == 0) ? 12 : 5; c->eval_hist_n[k] = 0; }
     for (int r = 0; r < world; r++) {
         if (r == rank) { c->peer.slab[r] = c->peer_slab; continue; }
@@ -3462,7 +3496,7 @@ int velo_comm_peer_attach(velo_ctx* c, const char* handles, int32_t rank, int32_
         c->peer_mapped[r] = p;
         c->peer.slab[r] = (PeerSlab*)p;
     }
-    c->peer.seq = c->peer_seq.p; c->peer.error = c->peer_err.p; c->peer.rank = rank; c->peer.world = world;
+    c->peer.seq = c->peer_seq.p; c->peer.kseq = c->peer_kseq.p; c->peer.error = c->peer_err.p; c->peer.rank = rank; c->peer.world = world;
     c->peer_on = true;
     c->shard_rank = rank; c->shard_world = world;
     c->have_corr = false;

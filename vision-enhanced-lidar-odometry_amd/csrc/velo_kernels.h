@@ -3104,10 +3104,13 @@ struct PeerSlab {
     double data[2][kMaxPeers][32];             // [parity][writer rank][value]
     unsigned long long flag[2][kMaxPeers];     // sequence number the writer's block belongs to
     unsigned long long xflag[2][kMaxPeers];    // the same for the record exchange of the target-sharded mode
+    int kval[2][kMaxPeers][64];                // launch-count agreement of a chained call (peer_agree_kernel): [parity][writer rank][solve]
+    unsigned long long kflag[2][kMaxPeers];    // its sequence numbers
 };
 struct PeerComm {
     PeerSlab* slab[kMaxPeers];                 // slab[r]: rank r's slab as mapped into this process (slab[rank]: my own)
     unsigned long long* seq;                   // my all-reduce counter (device memory, starts at 0)
+    unsigned long long* kseq;                  // my agreement counter (device memory, starts at 0)
     int* error;                                // set to 1 when a wait ran into its time limit
     int rank, world;
 };
@@ -3145,6 +3148,35 @@ __device__ __forceinline__ void peer_allreduce28(const PeerComm& C, double* __re
     }
     if (t == 0) *C.seq = seq;
     __syncthreads();
+}
+
+// A chained call over peers enqueues a PREDICTED number of LM launches per solve, and the all-reduce inside the step kernel only
+// completes when every rank has enqueued the same number.  The ranks therefore agree on the counts before anything is enqueued:
+// every rank pushes its own prediction (from its own call history) into every peer's slab and takes the maximum over ranks --
+// uniform by construction, whatever the ranks' histories are.  One wave; `out` is host-pinned memory the host reads after a sync.
+struct AgreeCounts { int v[64]; };
+__global__ void __launch_bounds__(64) peer_agree_kernel(PeerComm C, AgreeCounts mine, int n, int* __restrict__ out) {
+    const int t = threadIdx.x;
+    const unsigned long long seq = *C.kseq + 1ull;
+    const int par = (int)(seq & 1ull);
+    if (t < C.world) {
+        for (int k = 0; k < n; k++) __hip_atomic_store(&C.slab[t]->kval[par][C.rank][k], mine.v[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        __hip_atomic_store(&C.slab[t]->kflag[par][C.rank], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(&C.slab[C.rank]->kflag[par][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 500000000ull) { *C.error = 1; break; }   // 5 s at 100 MHz: a peer is gone
+        }
+        __threadfence_system();
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (t < n) {
+        int m = 0;
+        for (int r = 0; r < C.world; r++) m = max(m, __hip_atomic_load(&C.slab[C.rank]->kval[par][r][t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        __hip_atomic_store(&out[t], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    if (t == 0) *C.kseq = seq;
 }
 
 // ---- target-sharded mode over the same peers (BASELINE config 5): the per-round exchange of the per-query top-2 records -------------
