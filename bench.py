@@ -4,11 +4,15 @@
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one batch of B complete scan-pair registrations: from the raw ring clouds already resident in HBM to the solved
-poses -- target index build, query list and frame_to_frame (6 association rounds + 6 Levenberg-Marquardt solves to Ceres-default
-tolerances) of every pair, through ONE library call (velo_register_batch).  The B pairs of a step are DIFFERENT pairs
-(synth.distinct_pairs: own scene, noise, place on the road, motion and initial guess), so the lock-step groups of the batch
-driver diverge and the chain's launch prediction works from real history; `chain` reports its calls and misses.
+One "step" = B DRIVES advancing one frame each (the reference's loop, main.cpp:305-413, B sequences at a time): context i registers
+frame k+1 of drive i against frame k -- the previous frame, registered as source in the last step, is promoted to target ON THE DEVICE
+(velo_source_to_target through VELO_SCAN_PROMOTE: sd_prev, main.cpp:233,380 -- buffer swap + index build), the new frame comes from
+the ring clouds already resident in HBM, the initial guess is the constant-velocity prediction from the drive's last two poses
+(main.cpp:311-331; the start-up guess {0,0,0,0,0,1} for a drive's first pair, main.cpp:170) -- target index build, query list and
+frame_to_frame (6 association rounds + 6 Levenberg-Marquardt solves to Ceres-default tolerances) of every pair, through ONE library
+call (velo_register_batch).  Every timed registration is a pair its context has never seen (steps x B different pairs; synth.drive:
+own scene, noise and speed / yaw profile per drive), so the lock-step groups diverge and the chain's launch prediction is a real
+prediction; `chain` reports its calls and misses.  `--same-pairs` re-registers B fixed pairs every step (what round 3 measured).
 The headline (`value`) is workload configs[1] of BASELINE.json: synthetic HDL-64E pairs, 64 x 1875 = 120,000 points each,
 icp_skip = 1; at N > 1 every rank registers its own pairs (replicas, no data-path collective -> "scaling": "weak").
 
@@ -52,13 +56,15 @@ METRIC = "scan-pairs/sec + achieved HBM GB/s, 120k-pt HDL-64E frame-to-frame ICP
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--mode", choices=["replicas", "sharded", "target-sharded"], default="replicas")
     ap.add_argument("--workload", choices=["c1", "c2", "c3", "c4"], default="c2",
                     help="c2: 120k pairs; c3: + 2000 stereo blocks; c4: 120k scans vs 2M-point map; c1: reference constants (icp_skip=200)")
     ap.add_argument("--batch", type=int, default=8, help="independent pairs in flight per GPU (one context + stream each)")
+    ap.add_argument("--same-pairs", action="store_true", help="A/B: B fixed, different pairs re-registered every step instead of B drives (what round 3 measured)")
     ap.add_argument("--same-pair", action="store_true", help="A/B: every context registers the canonical pair (what rounds 1-2 measured)")
+    ap.add_argument("--gen-procs", type=int, default=0, help="worker processes that synthesise the drives' frames (0: min(16, host cores))")
     ap.add_argument("--threads-per-pair", dest="batch_api", action="store_false",
                     help="drive every pair from its own host thread (frame_to_frame) instead of velo_register_batch")
     ap.add_argument("--separate-loads", action="store_true",
@@ -103,6 +109,44 @@ def kitti_pairs(root, n):
     x0 = synth.INITIAL_GUESS.copy()                          # main.cpp:170; later frames would use the previous motion
     return [dict(tgt_xyz=scans[k][0], tgt_off=scans[k][1], src_xyz=scans[k + 1][0], src_off=scans[k + 1][1], x0=x0, x_true=None)
             for k in range(min(n, len(scans) - 1))]
+
+
+_drives = {}
+
+
+def _drive_frame_job(job):
+    from velo_amd import synth
+    plan, k = job
+    return synth.drive_frame(plan, k)
+
+
+def make_drives(B, n_frames, procs=0):
+    """B planned drives of n_frames frames each (synth.drive_plan / drive_frame), the frames synthesised by a pool of worker PROCESSES
+    (0.3 s of numpy ray casting per 120k-point frame).  Called BEFORE anything touches the GPU (fork).  Cached: the c1 / c3 legs run on
+    the same drives as the headline."""
+    key = (B, n_frames)
+    if key in _drives:
+        return _drives[key]
+    from velo_amd import synth
+    plans = [synth.drive_plan(n_frames, seed) for seed in range(B)]
+    jobs = [(plans[i], k) for i in range(B) for k in range(n_frames)]
+    procs = procs or max(1, min(16, (os.cpu_count() or 1) // max(1, int(os.environ.get("WORLD_SIZE", "1")))))
+    t0 = time.perf_counter()
+    frames = None
+    if procs > 1:
+        try:
+            import multiprocessing as mp
+            with mp.get_context("fork").Pool(procs) as pool:
+                frames = pool.map(_drive_frame_job, jobs, chunksize=1)
+        except Exception as e:       # noqa: BLE001
+            print(f"[bench] frame pool unavailable ({e}); generating in-process", file=sys.stderr, flush=True)
+    if frames is None:
+        frames = [_drive_frame_job(j) for j in jobs]
+    for i in range(B):
+        plans[i]["frames"] = frames[i * n_frames:(i + 1) * n_frames]
+    print(f"[bench] {B} drives x {n_frames} frames synthesised in {time.perf_counter() - t0:.1f} s ({procs} processes)", file=sys.stderr, flush=True)
+    _drives[key] = plans
+    return plans
 
 
 def make_workload(name, B, same_pair=False):
@@ -161,7 +205,7 @@ def cpu_baseline(d, vis, icp_skip=1):
     t_one, _ = one(1)
     return {
         "value": 1.0 / t_all, "unit": "scan-pairs/s", "cores": cores, "kind": "port",
-        "sample": f"the canonical pair of the workload (icp_skip={icp_skip}), whole: {cores} OpenMP threads = {t_all:.2f} s; "
+        "sample": f"the first pair of the workload (icp_skip={icp_skip}), whole: {cores} OpenMP threads = {t_all:.2f} s; "
                   f"1 thread (the reference's configuration, velo.h:900) = {t_one:.2f} s",
         "single_thread_pairs_per_s": 1.0 / t_one, "single_thread_s_per_pair": t_one, "single_thread_extrapolated": False,
         "x": [float(v) for v in x],
@@ -223,14 +267,68 @@ def kernel_table(acc):
     return rows
 
 
-def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="peer"):
-    """One timed leg: `steps` steps of B registrations (B = 1 in the sharded modes) bracketed by barrier + synchronize, max over ranks."""
+class DriveWalker:
+    """B drives advancing in step (main.cpp:305-413 for B sequences at a time): context i holds frame k of drive i as its source; a step
+    promotes it to target on the device, registers frame k+1 against it and hands the pose over -- T[k+1] = T[k] * dpose (main.cpp:408),
+    next guess = pose_vec2mat(T[k]^-1 T[k+1]) (main.cpp:311-331).  One library call per step (velo_register_batch)."""
+
+    def __init__(self, api, ctxs, frames, local_rank, vis=None):
+        self.api, self.ctxs, self.frames, self.vis = api, ctxs, frames, vis
+        self.B = len(ctxs)
+        self.n_frames = min(len(f) for f in frames)
+        self.promote = api.promote_refs(self.B)
+        self.src_refs = [api.scan_refs([frames[i][k] for i in range(self.B)], local_rank) for k in range(self.n_frames)]
+        # the front-end's matches of every frame pair, handed over with the scans in the same call (velo_register_batch_visual)
+        self.vis_refs = [api.visual_refs([vis[i][k] for i in range(self.B)]) for k in range(self.n_frames - 1)] if vis is not None else None
+        self.restart()
+
+    def restart(self):
+        from velo_amd import synth
+        for i, c in enumerate(self.ctxs):
+            c.set_source(*self.frames[i][0])                 # frame 0 waits on the device as "source"
+        self.k = 0
+        self.P_prev = np.ascontiguousarray(np.tile(np.eye(4), (self.B, 1, 1)))
+        self.x0 = np.tile(synth.INITIAL_GUESS, (self.B, 1))  # main.cpp:170
+        self.first = None
+
+    def step(self):
+        k = self.k + 1
+        xs, Ts, Ss = self.api.register_batch(self.ctxs, None, None, self.x0, refs=(self.promote, self.src_refs[k]),
+                                             visual=self.vis_refs[k - 1] if self.vis_refs is not None else None)
+        # T[k] = T[k-1] dpose (main.cpp:408); next guess = pose_vec2mat(T[k-1]^-1 T[k]) (main.cpp:315-317,331) -- one native call for the B drives
+        self.x0 = self.api.pose_handoff(self.P_prev, Ts)
+        self.k = k
+        if k == 1:
+            self.first = xs.copy()
+        return xs, Ts, Ss
+
+
+def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="peer", drives=None):
+    """One timed leg: `steps` steps of B registrations (B = 1 in the sharded modes) bracketed by barrier + synchronize, max over ranks.
+    drives (replicas, c1 / c2 / c3): B planned drives with their frames -- every step registers the next frame of every drive."""
     import velo_amd  # noqa: F401
     from velo_amd import api
     torch = rig.torch
     world, rank = rig.world, rig.rank
     B = 1 if mode != "replicas" else max(1, B)
-    W = make_workload(workload, B, a.same_pair or mode != "replicas")
+    drive = drives is not None and mode == "replicas" and workload in ("c1", "c2", "c3") and len(drives) >= B
+    if drive:
+        from velo_amd import synth
+        n_frames = min(len(p["frames"]) for p in drives[:B])
+        steps = max(1, min(steps, n_frames - 1 - warmup))
+        label, icp_skip = {
+            "c1": ("configs[0] stand-in: synthetic 120k-pt drives in the KITTI ring layout, reference constants (icp_skip=200)", 200),
+            "c2": ("synthetic HDL-64E 64x1875=120k-pt drives (configs[1]): frame k+1 -> frame k, icp_skip=1, point-to-plane ICP", 1),
+            "c3": ("configs[2]: 120k-pt drives + 2000 stereo reprojection blocks per pair, icp_skip=1", 1)}[workload]
+        label += f"; {B} drives advancing one frame per step, the previous frame promoted to target on the device, constant-velocity initial guess"
+        vis_all = None
+        if workload == "c3":
+            vis_all = [[synth.stereo_matches(1000, seed=3 + 1000 * i + k, x_true=drives[i]["x_true"][k]) for k in range(n_frames - 1)] for i in range(B)]
+        first_pairs = [dict(tgt_xyz=p["frames"][0][0], tgt_off=p["frames"][0][1], src_xyz=p["frames"][1][0], src_off=p["frames"][1][1],
+                            x0=synth.INITIAL_GUESS.copy(), x_true=p["x_true"][0], vis=(vis_all[i][0] if vis_all else None)) for i, p in enumerate(drives[:B])]
+        W = dict(label=label, icp_skip=icp_skip, pairs=first_pairs, shared_map=False, distinct=steps * B)
+    else:
+        W = make_workload(workload, B, a.same_pair or mode != "replicas")
     pairs, icp_skip, label = W["pairs"], W["icp_skip"], W["label"]
     d0 = pairs[0]
     tgt_off0, tgt_first_ring, tgt_first_point = d0["tgt_off"], 0, 0
@@ -253,6 +351,7 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
     else:
         tgts = [(resident(d["tgt_xyz"]), d["tgt_off"]) for d in pairs]
     srcs = [(resident(d["src_xyz"]), d["src_off"]) for d in pairs]
+    frames_dev = [[(resident(f[0]), f[1]) for f in p["frames"]] for p in drives[:B]] if drive else None
     torch.cuda.synchronize()
     ctxs = [api.Context(rig.local_rank, icp_skip=icp_skip) for _ in range(B)]
     comm_info = None
@@ -311,8 +410,14 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
         batch_refs = (api.scan_refs(tgts, rig.local_rank), api.scan_refs(srcs, rig.local_rank)) if (B > 1 or one_call) else None
         x0s = np.stack([np.asarray(d["x0"], dtype=np.float64) for d in pairs])
 
+        walker = DriveWalker(api, ctxs, frames_dev, rig.local_rank, vis_all) if drive else None
+
         def step():
-            if pool is None and one_call:
+            if walker is not None:
+                xs, Ts, Ss = walker.step()
+                for i in range(B):
+                    results[i] = (xs[i], Ts[i], Ss[i])
+            elif pool is None and one_call:
                 xs, Ts, Ss = api.register_batch(ctxs, None, None, x0s, refs=batch_refs)
                 results[0] = (xs[0], Ts[0], Ss[0])
             elif pool is None:
@@ -365,9 +470,33 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
                 e = kacc.setdefault(name, [0.0, 0, 0])
                 e[0] += ms; e[1] += n; e[2] += b
         solutions = [[float(v) for v in r[0]] for r in results]
+        first_pair_solutions = [[float(v) for v in x] for x in walker.first] if (walker is not None and walker.first is not None) else None
 
         single = None
-        if single_leg and world == 1 and mode == "replicas" and B > 1:
+        if single_leg and world == 1 and walker is not None and B > 1 and walker.n_frames >= 8:
+            # the single-pair latency next to the throughput -- ONE drive in flight (context 0 walks drive 0 again from its
+            # first frame: a pair per call through the single-pair path, promotion and hand-off included), after the timed region
+            w1 = DriveWalker(api, ctxs[:1], frames_dev[:1], rig.local_rank, vis_all[:1] if vis_all else None)
+            n_warm = 3
+            n1 = min(24, w1.n_frames - 1 - n_warm)
+            for _ in range(n_warm):
+                w1.step()
+            ctxs[0].synchronize()
+            ctxs[0].kernel_times(reset=True)
+            t1 = time.perf_counter()
+            a_ms, a_n = 0.0, 0
+            for _ in range(n1):
+                _xs, _Ts, Ss1 = w1.step()
+                a_ms += Ss1[0].assoc_kernel_ms
+                a_n += Ss1[0].assoc_kernel_launches
+            ctxs[0].synchronize()
+            lat = (time.perf_counter() - t1) / n1
+            ktab1 = kernel_table(ctxs[0].kernel_times(reset=True))
+            a_us = next((r["avg_launch_us"] for r in ktab1 if r["kernel"].startswith("assoc")), 1e3 * a_ms / max(a_n, 1))
+            single = {"pairs_in_flight": 1, "pairs_walked": n1, "ms_per_pair": 1e3 * lat, "pairs_per_s": 1.0 / lat,
+                      "assoc_avg_launch_us": a_us,
+                      "kernels": [{k: r[k] for k in ("kernel", "share", "avg_launch_us", "frac")} for r in ktab1[:3]]}
+        elif single_leg and world == 1 and mode == "replicas" and B > 1:
             # SURVEY 8(d) asks for the single-pair latency next to the throughput: ONE pair in flight, a sequence that walks through
             # the step's different pairs (a drive is a sequence, main.cpp:305-413), after the timed region
             for k in range(3):
@@ -436,6 +565,9 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
             "kernels": ktab[:3],
             "solution_x": solutions[0], "solutions": solutions,
         }
+        if first_pair_solutions is not None:                 # a drive's last pair is not its first: the pose the CPU baseline is compared with
+            leg["first_pair_solution_x"] = first_pair_solutions[0]
+            leg["frames_per_drive"] = walker.n_frames
         if single is not None:
             leg["single_pair"] = single
         if shared is not None:
@@ -455,16 +587,35 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
 
 def main():
     a = parse()
+    # the drives' frames are synthesised by worker processes BEFORE this process initialises the GPU (fork)
+    drives = None
+    if a.mode == "replicas" and not (a.same_pairs or a.same_pair) and a.workload in ("c1", "c2", "c3") and a.batch_api and not a.separate_loads \
+            and not (a.workload == "c1" and os.environ.get("VELO_KITTI_ROOT")):
+        import velo_amd  # noqa: F401
+        drives = make_drives(max(1, a.batch), a.warmup + a.steps + 1, a.gen_procs)
     rig = Rig(a)
     world, rank = rig.world, rig.rank
-    main_leg = run_leg(rig, a, a.workload, a.mode, a.batch, a.steps, a.warmup, comm=a.comm)
+    main_leg = run_leg(rig, a, a.workload, a.mode, a.batch, a.steps, a.warmup, comm=a.comm, drives=drives)
     legs, modes = {}, {}
     if not a.no_legs:
         if world == 1 and a.mode == "replicas":
-            # short legs of the other single-GPU configs (each a complete bench of its own: warm-up, barrier-bracketed timed region)
+            # short legs of the other single-GPU configs (each a complete bench of its own: warm-up, barrier-bracketed timed region);
+            # c1 / c3 walk the SAME drives as the headline (as many steps as their frames allow), c4 registers B scans against the 2M-point map
             for name, steps in (("c1", 100), ("c3", 40), ("c4", 12)):
                 if name != a.workload:
-                    legs[name] = run_leg(rig, a, name, "replicas", a.batch, steps, 3)
+                    kitti_c1 = name == "c1" and os.environ.get("VELO_KITTI_ROOT")
+                    legs[name] = run_leg(rig, a, name, "replicas", a.batch, steps, 3, drives=None if kitti_c1 else drives)
+                    if name == "c1" and not a.no_cpu_baseline:
+                        # the reference's own constants on its own kind of host: icp_skip = 200, one thread (velo.h:900) and all cores
+                        W1 = make_workload("c1", a.batch, a.same_pair) if (drives is None or kitti_c1) else None
+                        d1 = W1["pairs"][0] if W1 is not None else dict(tgt_xyz=drives[0]["frames"][0][0], tgt_off=drives[0]["frames"][0][1],
+                                                                           src_xyz=drives[0]["frames"][1][0], src_off=drives[0]["frames"][1][1],
+                                                                           x0=np.array([0.0, 0.0, 0.0, 0.0, 0.0, 1.0]))
+                        cb1 = cpu_baseline(d1, None, 200)
+                        xo1 = np.array(cb1.pop("x"))
+                        xg1 = np.array(legs[name].get("first_pair_solution_x", legs[name]["solution_x"]))
+                        cb1["pose_diff_vs_gpu"] = {"dt_m": float(np.linalg.norm(xo1[3:] - xg1[3:])), "dw_rad": float(np.linalg.norm(xo1[:3] - xg1[:3]))}
+                        legs[name]["cpu_baseline"] = cb1
         if world > 1 and a.mode == "replicas" and os.environ.get("VELO_BENCH_MODES", "1") != "0":
             # the north_star's multi-GPU modes, next to the replicas: one pair per step, strong scaling.  Never fatal for the headline:
             # a leg that fails on any rank is reported as an error by all of them (the ranks agree after every attempt), and a failed
@@ -528,9 +679,10 @@ def main():
             "metric": METRIC, "value": main_leg["pairs_per_s"], "unit": "scan-pairs/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": main_leg["ms_per_step"], "higher_is_better": True,
             "scaling": "weak" if a.mode == "replicas" else "strong", "vs_baseline": None,
-            "dtype": "f32 association / f64 residuals+solve", "data": "synthetic",
+            "dtype": "f32 association / f64 residuals+solve",
+            "data": "kitti" if (a.workload == "c1" and "KITTI seq 00" in main_leg["workload"]) else "synthetic",
             "config": {"workload": main_leg["workload"], "pairs_in_flight_per_gpu": main_leg["pairs_in_flight_per_gpu"],
-                       "distinct_pairs": main_leg["distinct_pairs"], "mode": a.mode,
+                       "distinct_pairs": main_leg["distinct_pairs"], "frames_per_drive": main_leg.get("frames_per_drive"), "mode": a.mode,
                        "Nq": main_leg["Nq"], "Nt": main_leg["Nt"], "lm_evaluations_per_pair": main_leg["lm_evaluations_per_pair"],
                        "valid_correspondences_last_round": main_leg["valid_correspondences_last_round"],
                        "algorithmic_bytes_per_pair": main_leg["algorithmic_bytes_per_pair"]},
@@ -563,11 +715,18 @@ def main():
         if modes:
             line["modes"] = {k: {kk: vv for kk, vv in v.items() if kk not in ("roofline", "kernels", "solutions")} for k, v in modes.items()}   # solution_x stays: tests compare it with a single-rank call
         if not a.no_cpu_baseline and world == 1:             # rank 0 at N = 1 only: the other runs just report the GPU side
-            W = make_workload(a.workload, a.batch, a.same_pair)
-            d = W["pairs"][0]
-            cb = cpu_baseline(d, d["vis"], W["icp_skip"])
+            if drives is not None:                           # the first pair of drive 0 (start-up guess), with the matches the c3 walk gave it
+                from velo_amd import synth
+                f0, f1 = drives[0]["frames"][0], drives[0]["frames"][1]
+                d = dict(tgt_xyz=f0[0], tgt_off=f0[1], src_xyz=f1[0], src_off=f1[1], x0=synth.INITIAL_GUESS.copy(),
+                         vis=synth.stereo_matches(1000, seed=3, x_true=drives[0]["x_true"][0]) if a.workload == "c3" else None)
+                skip = 200 if a.workload == "c1" else 1
+            else:
+                W = make_workload(a.workload, a.batch, a.same_pair)
+                d, skip = W["pairs"][0], W["icp_skip"]
+            cb = cpu_baseline(d, d["vis"], skip)
             xo = np.array(cb.pop("x"))
-            xg = np.array(main_leg["solution_x"])
+            xg = np.array(main_leg.get("first_pair_solution_x", main_leg["solution_x"]))
             cb["pose_diff_vs_gpu"] = {"dt_m": float(np.linalg.norm(xo[3:] - xg[3:])), "dw_rad": float(np.linalg.norm(xo[:3] - xg[:3]))}
             line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)

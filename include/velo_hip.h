@@ -372,6 +372,10 @@ int velo_frame_to_frame_batch(velo_ctx** ctxs, int32_t n, double* x /* n*6 */, d
 #define VELO_SCAN_ON_DEVICE 1   /* xyz is a device pointer */
 #define VELO_SCAN_SHARED 2      /* targets only: jobs with IDENTICAL descriptors carrying this flag share one device copy and one
                                  * index (scan-to-map: many scans against one map) -- built once, held by reference */
+#define VELO_SCAN_PROMOTE 4     /* targets only: this job's target is the scan the context holds as its SOURCE (velo_source_to_target:
+                                 * the previous frame of a drive becomes sd_prev, main.cpp:233,380 -- buffer swap + index build, no
+                                 * upload, no second segmentation); xyz / ring_offsets of the descriptor are ignored.  The job's source
+                                 * descriptor then brings the new frame. */
 typedef struct velo_scan_ref {
     const float* xyz;
     int64_t stride_bytes;
@@ -381,10 +385,20 @@ typedef struct velo_scan_ref {
 } velo_scan_ref;   /* 32 bytes */
 int velo_register_batch(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, const velo_scan_ref* sources,
                         double* x /* n*6 */, double* T /* n*16 */, velo_summary* summaries /* n */);
+/* The same with the jobs' visual matches handed over in the call as well (seam 1 takes `matches` / `keypoints` per call, velo.h:599-605):
+ * job i's n_matches[i] records go into context i as velo_set_visual would put them (0: the context registers LiDAR-only), without a
+ * host synchronisation per context -- the step of a tightly-coupled drive (BASELINE configs[2]) is ONE call. */
+int velo_register_batch_visual(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, const velo_scan_ref* sources,
+                               const velo_match* const* matches /* n pointers */, const int32_t* n_matches /* n */,
+                               double* x /* n*6 */, double* T /* n*16 */, velo_summary* summaries /* n or NULL */);
 
 /* --- pose helpers (utility.h:67-96; note the reference's swapped names) ---------------- */
 int velo_pose_vec_to_mat(const double x[6], double T[16]);  /* util::pose_mat2vec */
 int velo_pose_mat_to_vec(const double T[16], double x[6]);  /* util::pose_vec2mat */
+/* The pose hand-off of the drive loop (main.cpp:311-331,408) for n sequences at once, host arithmetic only: poses[i] (row-major 4x4,
+ * in/out) <- poses[i] * dpose[i] (ceres_poses_mat[frame] = ceres_poses_mat[frame-1] * dpose), and x_next[i] <- the 6-vector of
+ * poses_old[i]^-1 * poses_new[i] -- the constant-velocity guess the next frame's frameToFrame starts from.  x_next may be NULL. */
+int velo_pose_handoff(int32_t n, double* poses /* n*16 */, const double* dpose /* n*16 */, double* x_next /* n*6 or NULL */);
 
 /* --- multi-GPU: one process per GPU, RCCL over xGMI ---------------------------------- */
 /* Query-sharded mode: every rank holds the whole target and a contiguous 1/world share of the query list;

@@ -24,7 +24,8 @@ def test_kitti_root_pairs_are_the_reference_segmenters_rings(hip_lib, tmp_path):
     (tmp_path / "sequences" / "00" / "calib.txt").write_text("P0: 1 0 0 0 0 1 0 0 0 0 1 0\nTr: " + " ".join(f"{v:.9e}" for v in M[:3].reshape(-1)) + "\n")
     pairs = bench.kitti_pairs(str(tmp_path), 2)
     assert pairs is not None and len(pairs) == 2
-    want = [synth.segment_points(f[:, :3], np.vstack([M[:3], [0, 0, 0, 1]])) for f in frames]
+    import segmenter_ref
+    want = [segmenter_ref.segment_points(f[:, :3], np.vstack([M[:3], [0, 0, 0, 1]])) for f in frames]
     for k, d in enumerate(pairs):                              # pair k registers frame k+1 (source) against frame k (target), main.cpp:388-405
         assert np.array_equal(d["tgt_off"], want[k][1]) and np.array_equal(d["src_off"], want[k + 1][1])
         assert np.array_equal(d["tgt_xyz"].view(np.uint32), want[k][0].view(np.uint32))

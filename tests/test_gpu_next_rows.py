@@ -1,5 +1,5 @@
 """-m gpu: the rows SURVEY.md 8(f) marks "next", each to the same bar as the path:
-  row 1  device-side scan ingestion  (kitti.h:121-185)  -- bit-exact against the numpy restatement of the ring segmenter;
+  row 1  device-side scan ingestion  (kitti.h:121-185)  -- bit-exact against the restatements of the ring segmenter in tests/segmenter_ref.py;
   row 2  pose hand-off / odometry loop (main.cpp:305-331,407-437, kitti.h:202-216) -- same chain as the oracle driven on the CPU;
   row 3  projectLidarToCamera + featureDepthAssociation (velo.h:329-497) -- bit-exact (float) against the oracle's restatement;
   row 4  batched triangulatePoint (velo.h:1027-1130) -- float32 points within 1e-4 (relative to max(1, |p|)) of the oracle's, solver
@@ -9,6 +9,7 @@ import pytest
 
 import helpers as H
 import oracle_lib as O
+import segmenter_ref                     # the CHECKER of the device segmenter lives under tests/ (pinned by tests/test_segmenter_ref.py)
 from velo_amd import api, odometry, synth
 
 pytestmark = pytest.mark.gpu
@@ -28,7 +29,10 @@ def test_device_segmenter_matches_numpy_bit_exact(hip_lib, shape):
     if shape[0] == 16:                          # ragged rings: drop 10 % of the returns (file order preserved)
         keep = synth.uniform01(9, len(pts)) > 0.1
         pts = pts[keep]
-    want_xyz, want_off = synth.segment_points(pts)
+    want_xyz, want_off = segmenter_ref.segment_points(pts, synth.VELO_TO_CAM)
+    if shape[0] == 16:                          # small enough for the literal scalar transcription of kitti.h:158-183 as well
+        sc_xyz, sc_off = segmenter_ref.segment_points_scalar(pts, synth.VELO_TO_CAM)
+        assert np.array_equal(sc_off, want_off) and np.array_equal(sc_xyz.view(np.uint32), want_xyz.view(np.uint32))
     c = api.Context(0)
     for as_target in (True, False):
         c.set_scan_velodyne(as_target, records_of(pts), synth.VELO_TO_CAM)
@@ -44,8 +48,8 @@ def test_device_segmenter_feeds_the_path_like_host_rings(hip_lib):
     c1, c2 = api.Context(0, icp_skip=1), api.Context(0, icp_skip=1)
     c1.set_scan_velodyne(True, records_of(a), synth.VELO_TO_CAM)
     c1.set_scan_velodyne(False, records_of(b), synth.VELO_TO_CAM)
-    ta, oa = synth.segment_points(a)
-    tb, ob = synth.segment_points(b)
+    ta, oa = segmenter_ref.segment_points(a, synth.VELO_TO_CAM)
+    tb, ob = segmenter_ref.segment_points(b, synth.VELO_TO_CAM)
     c2.set_target(ta, oa)
     c2.set_source(tb, ob)
     x1, _, _ = c1.frame_to_frame(synth.INITIAL_GUESS)
@@ -469,7 +473,29 @@ def test_odometry_with_diagonal_edges_from_the_scan_cache(hip_lib):
         c.close()
         assert np.array_equal(dpose, want)
         assert np.linalg.norm((dpose @ np.linalg.inv(dT))[:3, 3]) < 0.05
+    assert diag.rejected_edges == []
     plain.close(); diag.close()
+
+    # main.cpp:426-437: an edge over dframe > 1 frames whose registration disagrees with the chained poses is skipped (`continue`) and
+    # never reaches the graph.  Inject two bad registrations: 0.5 m off over 2 frames (limit 0.2 m), 0.08 rad off over 3 (limit 0.05).
+    class Faulty(odometry.LidarOdometer):
+        def _register_edge(self, a, b, x0):
+            x, dpose, s = super()._register_edge(a, b, x0)
+            if (a, b) == (1, 3):
+                dpose = dpose.copy(); dpose[0, 3] += 0.5
+            if (a, b) == (1, 4):
+                R = np.eye(4); R[:3, :3] = synth.rotvec_to_matrix([0.0, 0.08, 0.0])
+                dpose = R @ dpose
+            return x, dpose, s
+
+    bad = Faulty(0, icp_skip=1, ndiagonal=3, cache_capacity=3)
+    for rec in frames:
+        bad.push(rec)
+    assert all(np.array_equal(a, b) for a, b in zip(plain.poses, bad.poses))            # the chain itself never skips (dframe == 1)
+    assert [(a, b) for a, b, _ in bad.edges] == [(0, 2), (0, 3), (2, 4)]
+    assert [(a, b, why) for a, b, _, _, why in bad.rejected_edges] == [(1, 3, "poor t agreement"), (1, 4, "poor r agreement")]
+    assert abs(np.linalg.norm(bad.rejected_edges[0][3][3:]) - 0.5) < 0.05 and abs(np.linalg.norm(bad.rejected_edges[1][3][:3]) - 0.08) < 0.01
+    bad.close()
 
 
 @pytest.mark.gpu
@@ -501,3 +527,51 @@ def test_randomized_next_rows_sweep(hip_lib):
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     assert m.run(8, first_seed=900) == 48
+
+
+def test_bench_drive_step_promotes_on_the_device_and_matches_the_oracle_pair_by_pair(hip_lib, oracle):
+    """bench.py's default step (DriveWalker): B drives advance one frame through ONE velo_register_batch call -- targets flagged
+    VELO_SCAN_PROMOTE (the previous frame, held as source, becomes the target on the device), sources = the new frames, guesses from the
+    constant-velocity hand-off (main.cpp:311-331,408).  Every registration must be the oracle's on the same two frames and the same guess,
+    and the same as the explicit calls velo_source_to_target + velo_set_source + velo_frame_to_frame."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    B, n_frames = 4, 5
+    drives = [synth.drive(n_frames, seed=s, n_beams=16, n_azimuth=128) for s in range(B)]
+    ctxs = [api.Context(0, icp_skip=1) for _ in range(B)]
+    w = bench.DriveWalker(api, ctxs, [d["frames"] for d in drives], 0)
+    solo = api.Context(0, icp_skip=1)
+    solo.set_source(*drives[1]["frames"][0])
+    P = np.tile(np.eye(4), (B, 1, 1))
+    for k in range(1, n_frames):
+        x0 = w.x0.copy()
+        if k == 1:
+            assert np.array_equal(x0, np.tile(synth.INITIAL_GUESS, (B, 1)))
+        xs, Ts, Ss = w.step()
+        for i in range(B):
+            orc = oracle.Oracle(threads=4, icp_skip=1)
+            orc.set_target(*drives[i]["frames"][k - 1])
+            orc.set_source(*drives[i]["frames"][k])
+            xo, To, so = orc.frame_to_frame(x0[i])
+            assert H.pose_close(xs[i], xo, 1e-9, 1e-10), (k, i, xs[i], xo)
+            assert [Ss[i].solves[j].evaluations for j in range(6)] == [so.solves[j].evaluations for j in range(6)]
+            # the hand-off itself against hand-written matrix arithmetic: T[k] = T[k-1] dpose; next guess = vec(T[k-1]^-1 T[k])
+            P_new = P[i] @ To
+            assert np.allclose(w.P_prev[i], P_new, atol=1e-9)
+            assert H.pose_close(w.x0[i], api.pose_mat_to_vec(np.linalg.inv(P[i]) @ P_new), 1e-9, 1e-10)
+            assert H.pose_close(w.x0[i], xs[i], 1e-9, 1e-9)              # ... which is the pair's own motion: constant velocity
+            P[i] = P_new
+        # drive 1 once more, with the explicit calls
+        solo.source_to_target()
+        solo.set_source(*drives[1]["frames"][k])
+        x1, _T1, s1 = solo.frame_to_frame(x0[1])
+        assert np.array_equal(x1, xs[1]) and [s1.solves[j].evaluations for j in range(6)] == [Ss[1].solves[j].evaluations for j in range(6)]
+        assert np.array_equal(solo.ring_offsets(True), drives[1]["frames"][k - 1][1])
+        assert np.array_equal(solo.cloud(True).view(np.uint32), np.asarray(drives[1]["frames"][k - 1][0]).view(np.uint32))
+    # the estimated motion follows the simulated one at the noise level of these 2,048-point sweeps
+    for i in range(B):
+        assert np.linalg.norm(xs[i][3:] - drives[i]["x_true"][-1][3:]) < 0.15 and np.linalg.norm(xs[i][:3] - drives[i]["x_true"][-1][:3]) < 3e-2
+    for c in ctxs + [solo]:
+        c.close()

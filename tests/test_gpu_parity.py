@@ -825,15 +825,17 @@ def test_failed_shared_batch_leaves_sharers_in_a_defined_state(hip_lib):
     bad_off = np.array(d["tgt_off"], dtype=np.int32).copy()
     bad_off[3] = bad_off[2] - 1                                           # offsets decrease: velo_set_target rejects the owner's job
     bad = (api.scan_refs([(d["tgt_xyz"], bad_off)] * 4, 0, shared=True), api.scan_refs(srcs, 0))
-    # (the descriptor differs from the last call's, so the sharers are only released when it matches; run the failing call twice with the
-    #  SAME descriptor as a good first call by patching the offsets in place)
+    # (first with a fresh descriptor; further down with the SAME descriptor as the preceding good call, patched in place -- the case in
+    #  which the sharers have let go of their map before the owner's load fails)
     with pytest.raises(api.VeloError):
         api.register_batch(ctxs, None, None, x0s, refs=bad)
     off_live = np.array(d["tgt_off"], dtype=np.int32).copy()
     live = (api.scan_refs([(d["tgt_xyz"], off_live)] * 4, 0, shared=True), api.scan_refs(srcs, 0))
     xs_live, _, _ = api.register_batch(ctxs, None, None, x0s, refs=live)   # a good call: ctxs 1..3 share ctx 0's map
     assert np.array_equal(xs_live, xs)
-    off_live[3] = off_live[2] - 1                                          # the SAME descriptor turns bad: sharers are released, then the owner fails
+    off_a = live[0][1][0][1]                                               # the offsets array the descriptors point at
+    assert np.shares_memory(off_a, off_live)
+    off_a[3] = off_a[2] - 1                                                # the SAME descriptor turns bad: sharers are released, then the owner fails
     with pytest.raises(api.VeloError):
         api.register_batch(ctxs, None, None, x0s, refs=live)
     for c in ctxs[1:]:
@@ -846,4 +848,40 @@ def test_failed_shared_batch_leaves_sharers_in_a_defined_state(hip_lib):
     xs2, _, _ = api.register_batch(ctxs, None, None, x0s, refs=good)
     assert np.array_equal(xs2, xs)
     for c in ctxs:
+        c.close()
+
+
+def test_register_batch_visual_hands_matches_over_with_the_scans(hip_lib, oracle):
+    """velo_register_batch_visual: job i's matches go into context i inside the call (seam 1 takes them per call, velo.h:599-605).  Same
+    poses, solves and good-match lists as velo_set_visual per context followed by velo_register_batch; a job with zero matches registers
+    LiDAR-only; the one-job form takes the single-pair path."""
+    d = H.small_pair(24, 200)
+    d2 = H.small_pair(24, 200, scene_seed=5)
+    pairs = [d, d2, d, d2]
+    vis = [synth.stereo_matches(80, seed=3 + k, mix="all", x_true=p["x_true"]) for k, p in enumerate(pairs)]
+    vis[2] = None                                                                # this job: no matches
+    tg = [(p["tgt_xyz"], p["tgt_off"]) for p in pairs]
+    sr = [(p["src_xyz"], p["src_off"]) for p in pairs]
+    x0s = np.stack([p["x0"] for p in pairs])
+    a = [api.Context(0, icp_skip=1) for _ in range(4)]
+    b = [api.Context(0, icp_skip=1) for _ in range(4)]
+    b[2].set_visual(vis[0])                                                      # stale matches from an earlier frame: the call must replace them with none
+    xa, Ta, Sa = api.register_batch(a, tg, sr, x0s, visual=api.visual_refs(vis))
+    for c, m in zip(b, vis):
+        c.set_visual(m)
+    xb, Tb, Sb = api.register_batch(b, tg, sr, x0s)
+    assert np.array_equal(xa, xb) and np.array_equal(Ta, Tb)
+    for i in range(4):
+        assert _summary_tuple(Sa[i]) == _summary_tuple(Sb[i])
+        assert np.array_equal(a[i].good_matches(), b[i].good_matches())
+        assert Sa[i].solves[0].n_visual_blocks == (0 if vis[i] is None else Sb[i].solves[0].n_visual_blocks)
+    assert Sa[0].solves[0].n_visual_blocks > 0 and Sa[2].solves[0].n_visual_blocks == 0
+    orc = oracle.Oracle(threads=4, icp_skip=1)
+    H.load_both(api.Context(0, icp_skip=1), orc, d2, visual=vis[1])
+    xo, _, so = orc.frame_to_frame(d2["x0"])
+    assert H.pose_close(xa[1], xo, 1e-9, 1e-10) and so.solves[0].n_visual_blocks == Sa[1].solves[0].n_visual_blocks
+    # one job
+    x1, _, S1 = api.register_batch(a[:1], tg[1:2], sr[1:2], x0s[1:2], visual=api.visual_refs(vis[1:2]))
+    assert H.pose_close(x1[0], xo, 1e-9, 1e-10)
+    for c in a + b:
         c.close()

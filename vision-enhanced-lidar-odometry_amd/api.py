@@ -207,8 +207,10 @@ SIGNATURES = {
     "velo_frame_to_frame": (C.c_int, [_ctx, _dp, _dp, _P(VeloSummary)]),
     "velo_frame_to_frame_batch": (C.c_int, [_P(_ctx), C.c_int32, _dp, _dp, _P(VeloSummary)]),
     "velo_register_batch": (C.c_int, [_P(_ctx), C.c_int32, C.c_void_p, C.c_void_p, _dp, _dp, _P(VeloSummary)]),
+    "velo_register_batch_visual": (C.c_int, [_P(_ctx), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _dp, _dp, _P(VeloSummary)]),
     "velo_pose_vec_to_mat": (C.c_int, [_dp, _dp]),
     "velo_pose_mat_to_vec": (C.c_int, [_dp, _dp]),
+    "velo_pose_handoff": (C.c_int, [C.c_int32, _dp, _dp, _dp]),
     "velo_comm_unique_id": (C.c_int, [C.c_char_p]),
     "velo_comm_init": (C.c_int, [_ctx, C.c_char_p, C.c_int32, C.c_int32]),
     "velo_comm_destroy": (C.c_int, [_ctx]),
@@ -703,7 +705,7 @@ def frame_to_frame_batch(ctxs, x0s):
     return x, T.reshape(n, 4, 4), list(S)
 
 
-SCAN_ON_DEVICE, SCAN_SHARED = 1, 2
+SCAN_ON_DEVICE, SCAN_SHARED, SCAN_PROMOTE = 1, 2, 4
 
 
 def scan_refs(scans, device=None, shared=False):
@@ -728,10 +730,41 @@ def scan_refs(scans, device=None, shared=False):
     return arr, keep
 
 
-def register_batch(ctxs, targets, sources, x0s, refs=None):
+def promote_refs(n: int):
+    """n target descriptors that say "this job's target is the scan the context holds as its source" (VELO_SCAN_PROMOTE): the step of a
+    drive, where frame k -- registered as source in the last call -- is the target of frame k+1 (main.cpp:233,380)."""
+    arr = (VeloScanRef * n)()
+    for i in range(n):
+        arr[i].xyz = None
+        arr[i].stride_bytes = 16
+        arr[i].ring_offsets = None
+        arr[i].n_rings = 0
+        arr[i].on_device = SCAN_ON_DEVICE | SCAN_PROMOTE
+    return arr, []
+
+
+def visual_refs(matches_per_job):
+    """[matches of job 0, ...] (structured arrays / dicts / None) -> (pointer array, count array, objects to keep alive) for
+    register_batch(..., visual=...)."""
+    n = len(matches_per_job)
+    ptrs = (C.c_void_p * n)()
+    cnt = (C.c_int32 * n)()
+    keep = []
+    for i, m in enumerate(matches_per_job):
+        if isinstance(m, dict):
+            m = matches_from_dict(m)
+        a = np.ascontiguousarray(m, dtype=MATCH_DTYPE) if m is not None else np.zeros(0, MATCH_DTYPE)
+        ptrs[i] = a.ctypes.data if len(a) else None
+        cnt[i] = len(a)
+        keep.append(a)
+    return ptrs, cnt, keep
+
+
+def register_batch(ctxs, targets, sources, x0s, refs=None, visual=None):
     """velo_register_batch: job i's target / source scans go into context i and the batch is registered, all inside the library
     (the index builds run on the threads that drive the groups).  targets / sources: lists of (xyz, ring_offsets) or None to keep
-    what the contexts hold; refs = (target_refs, source_refs) from scan_refs() to reuse prepared descriptors across calls."""
+    what the contexts hold; refs = (target_refs, source_refs) from scan_refs() to reuse prepared descriptors across calls;
+    visual = visual_refs(...) hands the jobs' matches over in the same call (velo_register_batch_visual)."""
     lib = ctxs[0]._lib if len(ctxs) else load_library()      # the build the contexts were created on
     n = len(ctxs)
     arr = (_ctx * n)(*[c.handle for c in ctxs])
@@ -744,12 +777,31 @@ def register_batch(ctxs, targets, sources, x0s, refs=None):
     x = np.ascontiguousarray(np.asarray(x0s, dtype=np.float64).reshape(n, 6)).copy()
     T = np.zeros((n, 16))
     S = (VeloSummary * n)()
-    st = lib.velo_register_batch(arr, n, C.cast(tr[0], C.c_void_p) if tr[0] is not None else None,
-                                 C.cast(sr[0], C.c_void_p) if sr[0] is not None else None, _ptr(x), _ptr(T), S)
+    tp = C.cast(tr[0], C.c_void_p) if tr[0] is not None else None
+    sp = C.cast(sr[0], C.c_void_p) if sr[0] is not None else None
+    if visual is not None:
+        st = lib.velo_register_batch_visual(arr, n, tp, sp, C.cast(visual[0], C.c_void_p), C.cast(visual[1], C.c_void_p), _ptr(x), _ptr(T), S)
+    else:
+        st = lib.velo_register_batch(arr, n, tp, sp, _ptr(x), _ptr(T), S)
     if st != 0:
         msg = lib.velo_last_error()
         raise VeloError(f"velo status {st}: {msg.decode() if msg else ''}")
     return x, T.reshape(n, 4, 4), list(S)
+
+
+def pose_handoff(poses: np.ndarray, dpose: np.ndarray):
+    """velo_pose_handoff: poses (n,4,4) float64 C-contiguous, UPDATED IN PLACE to poses @ dpose (main.cpp:408); returns the (n,6) guesses
+    of the next frame, the 6-vectors of poses_old^-1 poses_new (main.cpp:311-331)."""
+    lib = load_library()
+    assert poses.dtype == np.float64 and poses.flags.c_contiguous and poses.shape[1:] == (4, 4)
+    n = poses.shape[0]
+    d = np.ascontiguousarray(np.asarray(dpose, dtype=np.float64).reshape(n, 16))
+    x = np.zeros((n, 6))
+    st = lib.velo_pose_handoff(n, _ptr(poses), _ptr(d), _ptr(x))
+    if st != 0:
+        msg = lib.velo_last_error()
+        raise VeloError(f"velo status {st}: {msg.decode() if msg else ''}")
+    return x
 
 
 def pose_vec_to_mat(x) -> np.ndarray:

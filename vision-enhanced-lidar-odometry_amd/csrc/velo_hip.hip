@@ -1841,7 +1841,9 @@ int velo_share_target(velo_ctx* dst, velo_ctx* src) {
     return VELO_OK;
 }
 
-int velo_source_to_target(velo_ctx* c) {
+// the promotion in two halves (like a target load): swap + the fused ingest launch on the packed records, IN PLACE (record i -> tgt[i],
+// every thread reads its own record before it writes it; pack of a packed record is the identity), then the index once the box is known
+static int promote_begin(velo_ctx* c) {
     if (!c) return fail(VELO_ERR_INVALID, "null ctx");
     if (!c->have_source) return fail(VELO_ERR_STATE, "no source cloud to promote");
     HIP_TRY(hipSetDevice(c->device));
@@ -1852,7 +1854,12 @@ int velo_source_to_target(velo_ctx* c) {
     c->T->tgt_first_ring = 0; c->T->tgt_first_point = 0;
     c->have_source = false; c->have_target = false; c->have_corr = false; c->have_partials = false;
     c->n_src = 0; c->n_src_rings = 0; c->n_q = 0; c->h_src_off.assign(1, 0); c->h_q_off.assign(1, 0);
-    return target_finalize(c);
+    for (int r = 0; r < c->T->n_tgt_rings; r++) if (c->T->h_tgt_off[r + 1] <= c->T->h_tgt_off[r]) return fail(VELO_ERR_INVALID, "target ring %d is empty", r);
+    return target_ingest(c, reinterpret_cast<const float*>(c->T->tgt.p), (int64_t)sizeof(float4), 1);
+}
+int velo_source_to_target(velo_ctx* c) {
+    VELO_TRY(promote_begin(c));
+    return target_finalize_end(c);
 }
 
 // ---- device-resident scan cache (lru.h:31-61) -------------------------------------------------------------------------------
@@ -2031,7 +2038,11 @@ int velo_get_cloud(velo_ctx* c, int32_t of_target, float* xyz_out, int32_t capac
     return VELO_OK;
 }
 
-int velo_set_visual(velo_ctx* c, const velo_match* m, int32_t n) {
+static int set_visual_impl(velo_ctx* c, const velo_match* m, int32_t n, bool wait);
+int velo_set_visual(velo_ctx* c, const velo_match* m, int32_t n) { return set_visual_impl(c, m, n, true); }
+// wait = false: the copy stays queued on the context's stream (the records were copied into the context first), for callers that
+// order the stream against their launches themselves (velo_register_batch_visual: the group driver synchronises the contexts' streams)
+static int set_visual_impl(velo_ctx* c, const velo_match* m, int32_t n, bool wait) {
     if (!c || n < 0 || (n > 0 && !m)) return fail(VELO_ERR_INVALID, "bad visual arguments");
     static_assert(sizeof(VisualMatch) == sizeof(velo_match), "device/host match layout");
     HIP_TRY(hipSetDevice(c->device));
@@ -2044,7 +2055,7 @@ int velo_set_visual(velo_ctx* c, const velo_match* m, int32_t n) {
         VELO_TRY(c->vflags.reserve((size_t)3 * n));
         HIP_TRY(hipMemcpyAsync(c->vm.p, c->h_matches.data(), sizeof(velo_match) * (size_t)n, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemsetAsync(c->vflags.p, 0, (size_t)3 * n, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (wait) HIP_TRY(hipStreamSynchronize(c->stream));
     }
     return VELO_OK;
 }
@@ -3205,14 +3216,22 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
 }
 
 // upload (optional) + register: the scans of job i go into context i (velo_set_target / velo_set_source semantics), then the batch runs
+struct JobVisual { const velo_match* const* m = nullptr; const int32_t* n = nullptr; };   // per-job matches of velo_register_batch_visual (or none)
+static int load_job_visual(velo_ctx* c, const JobVisual& V, int i) {
+    if (!V.n) return VELO_OK;
+    if (V.n[i] < 0 || (V.n[i] > 0 && (!V.m || !V.m[i]))) return fail(VELO_ERR_INVALID, "job %d: bad visual arguments", i);
+    return set_visual_impl(c, V.n[i] > 0 ? V.m[i] : nullptr, V.n[i], false);
+}
 static int load_job(velo_ctx* c, const velo_scan_ref* tg, const velo_scan_ref* sr) {
-    if (tg) VELO_TRY(velo_set_target(c, tg->xyz, tg->stride_bytes, tg->ring_offsets, tg->n_rings, tg->on_device & 1));
+    if (tg && (tg->on_device & VELO_SCAN_PROMOTE)) VELO_TRY(velo_source_to_target(c));
+    else if (tg) VELO_TRY(velo_set_target(c, tg->xyz, tg->stride_bytes, tg->ring_offsets, tg->n_rings, tg->on_device & 1));
     if (sr) VELO_TRY(velo_set_source(c, sr->xyz, sr->stride_bytes, sr->ring_offsets, sr->n_rings, sr->on_device & 1));
     return VELO_OK;
 }
 // the same in two halves: everything that needs no answer from the device (uploads, ring tables, the bounding-box request), then the rest
 static int load_job_begin(velo_ctx* c, const velo_scan_ref* tg, const velo_scan_ref* sr) {
-    if (tg) VELO_TRY(set_target_begin(c, tg->xyz, tg->stride_bytes, tg->ring_offsets, tg->n_rings, 0, 0, tg->on_device & 1));
+    if (tg && (tg->on_device & VELO_SCAN_PROMOTE)) VELO_TRY(promote_begin(c));
+    else if (tg) VELO_TRY(set_target_begin(c, tg->xyz, tg->stride_bytes, tg->ring_offsets, tg->n_rings, 0, 0, tg->on_device & 1));
     if (sr) VELO_TRY(set_source_begin(c, sr->xyz, sr->stride_bytes, sr->ring_offsets, sr->n_rings, sr->on_device & 1));
     return VELO_OK;
 }
@@ -3222,7 +3241,8 @@ static int load_job_end(velo_ctx* c, bool tg, bool sr) {
     return VELO_OK;
 }
 
-static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, const velo_scan_ref* sources, double* x, double* T, velo_summary* summaries) {
+static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, const velo_scan_ref* sources, double* x, double* T, velo_summary* summaries,
+                      JobVisual V = JobVisual()) {
     if (!ctxs || n < 0 || (n > 0 && !x)) return fail(VELO_ERR_INVALID, "bad batch arguments");
     for (int i = 0; i < n; i++) {                                    // one registration per context: a context listed twice would race with itself
         if (!ctxs[i]) return fail(VELO_ERR_INVALID, "batch entry %d is null", i);
@@ -3283,9 +3303,13 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
         return targets + i;
     };
     if (n == 1) {                                                     // one job: the single-pair path (one chain of launches, one-launch LM iterations)
+        VELO_TRY(load_job_visual(ctxs[0], V, 0));
         VELO_TRY(load_job(ctxs[0], target_of(0), sources));
         return velo_frame_to_frame(ctxs[0], x, T, summaries);
     }
+    // the jobs' matches go in BEFORE the path is chosen (groups with visual blocks take their own launch shapes); the copies stay queued on
+    // the contexts' streams, which every path below synchronises or continues on
+    for (int i = 0; i < n && V.n; i++) VELO_TRY(load_job_visual(ctxs[i], V, i));
     if (batch_can_lockstep(ctxs, n, targets != nullptr, sources != nullptr)) {
         // G lock-step groups, one host thread and one stream each: while one group is in its (chip-filling) association
         // launches or waits for a status copy, another group's LM launches run -- the groups hide each other's bubbles
@@ -3351,6 +3375,13 @@ int velo_register_batch(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets
     return batch_impl(ctxs, n, targets, sources, x, T, summaries);
 }
 
+int velo_register_batch_visual(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, const velo_scan_ref* sources, const velo_match* const* matches,
+                               const int32_t* n_matches, double* x, double* T, velo_summary* summaries) {
+    if (n > 0 && !n_matches) return fail(VELO_ERR_INVALID, "n_matches is null");
+    JobVisual V; V.m = matches; V.n = n_matches;
+    return batch_impl(ctxs, n, targets, sources, x, T, summaries, V);
+}
+
 // util::pose_mat2vec (utility.h:67-82): 6-vector -> 4x4, row-major out.  Column j of R is R(omega) e_j, which is what
 // ceres::AngleAxisToRotationMatrix [3P] writes column-major and utility.h:73-77 transposes back.
 int velo_pose_vec_to_mat(const double x[6], double T[16]) {
@@ -3403,6 +3434,55 @@ int velo_pose_mat_to_vec(const double T[16], double x[6]) {
         x[0] = q[1] * 2.0; x[1] = q[2] * 2.0; x[2] = q[3] * 2.0;
     }
     x[3] = T[3]; x[4] = T[7]; x[5] = T[11];
+    return VELO_OK;
+}
+
+// The pose hand-off of the drive loop for n sequences at once (main.cpp:311-331,408): pose[k] = pose[k-1] * dpose (main.cpp:408), then the
+// next frame's constant-velocity guess pose_vec2mat(pose[k-1]^-1 * pose[k]) (main.cpp:315-317,331).  Row-major 4x4s; plain double
+// arithmetic in the order Eigen's fixed-size products take (sum over k = 0..3); the inverse is the general 4x4 inverse Eigen's
+// Matrix4d::inverse() computes by cofactors -- for a rigid pose it equals [R^T | -R^T t] to rounding, and the guess only seeds the solve.
+static void mat4_mul(const double* A, const double* B, double* Cm) {
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) {
+        double v = 0.0;
+        for (int k = 0; k < 4; k++) v += A[4 * i + k] * B[4 * k + j];
+        Cm[4 * i + j] = v;
+    }
+}
+static bool mat4_inv(const double* m, double* inv) {
+    double a[16];
+    a[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+    a[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+    a[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+    a[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+    a[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+    a[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+    a[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+    a[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+    a[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+    a[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+    a[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+    a[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+    a[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+    a[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+    a[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+    a[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+    const double det = m[0] * a[0] + m[1] * a[4] + m[2] * a[8] + m[3] * a[12];
+    if (det == 0.0 || !std::isfinite(det)) return false;
+    const double r = 1.0 / det;
+    for (int i = 0; i < 16; i++) inv[i] = a[i] * r;
+    return true;
+}
+int velo_pose_handoff(int32_t n, double* poses, const double* dpose, double* x_next) {
+    if (n < 0 || (n > 0 && (!poses || !dpose))) return fail(VELO_ERR_INVALID, "null/negative argument");
+    for (int i = 0; i < n; i++) {
+        double* P = poses + 16 * (size_t)i;
+        double Pn[16], Pi[16], dT[16];
+        mat4_mul(P, dpose + 16 * (size_t)i, Pn);                     // main.cpp:408
+        if (!mat4_inv(P, Pi)) return fail(VELO_ERR_INVALID, "pose %d is singular", i);
+        mat4_mul(Pi, Pn, dT);                                        // main.cpp:315-317 (one frame later)
+        if (x_next) VELO_TRY(velo_pose_mat_to_vec(dT, x_next + 6 * (size_t)i));   // main.cpp:331
+        std::memcpy(P, Pn, sizeof(Pn));
+    }
     return VELO_OK;
 }
 

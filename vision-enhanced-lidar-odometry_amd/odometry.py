@@ -16,6 +16,29 @@ from . import api
 
 AGREEMENT_T_THRESH = 0.1      # kitti.h:33
 AGREEMENT_R_THRESH = 0.05     # kitti.h:34
+LOOP_CLOSE_THRESH = 10.0      # kitti.h:35
+
+
+def agreement_of(dpose: np.ndarray, dT: np.ndarray) -> np.ndarray:
+    """main.cpp:416-417: pose_vec2mat(dpose * dT^-1) -- how far the registration moved away from its prediction, as a 6-vector."""
+    return api.pose_mat_to_vec(np.asarray(dpose) @ np.linalg.inv(np.asarray(dT)))
+
+
+def edge_is_rejected(agreement: np.ndarray, dframe: int):
+    """main.cpp:426-437 for the odometry pass (ba == 0): an edge over dframe > 1 frames is skipped (`continue`: it never reaches the
+    pose graph) when its translation disagrees with the prediction by more than min(agreement_t_thresh * dframe, loop_close_thresh)
+    or its rotation by more than agreement_r_thresh.  dframe == 1 edges are never skipped (the value is only printed).
+    Returns None or the reason."""
+    if dframe <= 1:
+        return None
+    t, r = float(np.linalg.norm(agreement[3:])), float(np.linalg.norm(agreement[:3]))
+    if t > min(AGREEMENT_T_THRESH * dframe, LOOP_CLOSE_THRESH):
+        return "poor t agreement"
+    if r > AGREEMENT_R_THRESH:
+        return "poor r agreement"
+    return None
+
+
 FIRST_GUESS = np.array([0.0, 0.0, 0.0, 0.0, 0.0, 1.0])     # main.cpp:170
 
 
@@ -36,7 +59,8 @@ class LidarOdometer:
         self.ctx = api.Context(device, **params)
         self.ndiagonal = int(ndiagonal)
         self.cache = api.ScanCache(device, max(cache_capacity, self.ndiagonal + 1)) if self.ndiagonal > 1 else None   # the window must fit
-        self.edges = []          # (frame_from, frame_to, 4x4 relative pose) of the extra registrations
+        self.edges = []          # (frame_from, frame_to, 4x4 relative pose) of the extra registrations that passed the agreement check
+        self.rejected_edges = [] # (frame_from, frame_to, 4x4 relative pose, agreement 6-vector, reason): skipped like main.cpp:426-437
         self.velo_to_cam = np.asarray(velo_to_cam if velo_to_cam is not None else synth.VELO_TO_CAM, dtype=np.float32)
         self.poses = []          # ceres_poses_mat (main.cpp:179), camera-0 frame
         self.prev_records = None
@@ -61,7 +85,7 @@ class LidarOdometer:
         self.ctx.set_scan_velodyne(False, records, self.velo_to_cam)           # source = current frame (sd)
         x, dpose, s = self.ctx.frame_to_frame(x0)
         self.poses.append(self.poses[k - 1] @ dpose)                           # main.cpp:408
-        self.agreements.append(api.pose_mat_to_vec(dpose @ np.linalg.inv(dT)))  # main.cpp:417
+        self.agreements.append(agreement_of(dpose, dT))                        # main.cpp:417 (dframe == 1: printed, never acted on)
         self.summaries.append(s)
         self.prev_records = records
         if self.cache is not None:
@@ -71,10 +95,19 @@ class LidarOdometer:
                     break
                 dT = np.linalg.inv(self.poses[k - d]) @ self.poses[k]          # main.cpp:324-326
                 self.cache.load(k - d, self.ctx, True)                         # sd_prev = lru.get(dataset, frame - dframe), main.cpp:350
-                _, dpose_d, _ = self.ctx.frame_to_frame(api.pose_mat_to_vec(dT))
-                self.edges.append((k - d, k, dpose_d))
+                _, dpose_d, _ = self._register_edge(k - d, k, api.pose_mat_to_vec(dT))
+                ag = agreement_of(dpose_d, dT)                                 # main.cpp:416-424
+                why = edge_is_rejected(ag, d)                                  # main.cpp:426-437
+                if why is None:
+                    self.edges.append((k - d, k, dpose_d))
+                else:
+                    self.rejected_edges.append((k - d, k, dpose_d, ag, why))
             # the context still holds frame k as its source, which is all the next push needs
         return self.poses[-1]
+
+    def _register_edge(self, frame_from: int, frame_to: int, x0):
+        """One extra registration of the current source against the loaded older target (a seam for tests that inject a bad edge)."""
+        return self.ctx.frame_to_frame(x0)
 
     def write_kitti(self, path: str):
         with open(path, "w") as f:                                             # main.cpp:758-763

@@ -158,8 +158,9 @@ def velo_pose_to_cam_x(T_velo: np.ndarray) -> np.ndarray:
 class Scene:
     """Closed street canyon: ground, two side walls, two end walls and seeded car-sized boxes."""
 
-    def __init__(self, seed: int = 0, n_boxes: int = 24, half_width: float = 8.0, half_length: float = 45.0):
+    def __init__(self, seed: int = 0, n_boxes: int = 24, half_width: float = 8.0, half_length: float = 45.0, box_horizon=None):
         self.ground_z = -SENSOR_HEIGHT
+        self.box_horizon = box_horizon
         self.half_width = half_width
         self.half_length = half_length
         u = uniform01(seed, 4 * n_boxes, stream=7).reshape(n_boxes, 4)
@@ -191,6 +192,8 @@ class Scene:
         t_best = np.minimum(t_best, plane(0, self.half_length))
         t_best = np.minimum(t_best, plane(0, -self.half_length))
         for bmin, bmax in zip(self.box_min, self.box_max):
+            if self.box_horizon is not None and (bmin[0] - o[0] > self.box_horizon or o[0] - bmax[0] > self.box_horizon):
+                continue                                      # long roads (drives): boxes beyond the horizon are not drawn
             t0 = (bmin - o) * inv
             t1 = (bmax - o) * inv
             tn = np.nanmax(np.minimum(t0, t1), axis=1)
@@ -310,6 +313,52 @@ def distinct_pairs(n: int, n_beams: int = N_BEAMS, n_azimuth: int = N_AZIMUTH, s
         d["x0"] = velo_pose_to_cam_x(pose_matrix(**prev))
         out.append(d)
     return out
+
+
+def drive_plan(n_frames: int, seed: int = 0):
+    """The trajectory of one DRIVE (bench.py's default workload): scene parameters + the sensor pose of every frame.  The motion changes
+    from frame to frame like a car's: speed 0.6 .. 1.4 m per frame with up to +-0.1 m of acceleration per frame, a smooth yaw rate of up to
+    +-0.03 rad per frame (the car follows a gently winding lane line inside the free lane), small pitch / roll / vertical jitter -- so the constant-velocity prediction the reference's loop hands frameToFrame (main.cpp:311-331) is off by one frame's
+    acceleration.  The road is as long as the drive needs (90 m for up to ~55 frames; boxes farther than 80 m along it are not drawn)."""
+    u = uniform01(7000 + seed, 8 * (n_frames + 1), stream=5).reshape(n_frames + 1, 8)
+    half_length = max(45.0, 0.5 * 1.4 * n_frames + 15.0)
+    scene_kw = dict(seed=seed, n_boxes=int(round(24 * half_length / 45.0)), half_length=half_length, box_horizon=80.0 if half_length > 45.0 else None)
+    # the lane line: two sinusoids of the travelled distance (|y| <= 1.2 m: the boxes start 1.7 m from the centre line); the heading follows it
+    A1, L1, P1 = 0.3 + 0.3 * u[0, 3], 35.0 + 15.0 * u[0, 4], 2.0 * np.pi * u[0, 5]
+    A2, L2, P2 = 0.2 + 0.4 * u[0, 6], 80.0 + 60.0 * u[0, 7], 2.0 * np.pi * u[0, 1]
+
+    def lane(s):
+        a1, a2 = 2.0 * np.pi * s / L1 + P1, 2.0 * np.pi * s / L2 + P2
+        return A1 * np.sin(a1) + A2 * np.sin(a2), A1 * (2.0 * np.pi / L1) * np.cos(a1) + A2 * (2.0 * np.pi / L2) * np.cos(a2)
+
+    x_start = -half_length + 12.0 + 6.0 * u[0, 0]
+    v, dist = 0.6 + 0.8 * u[0, 2], 0.0
+    poses = []
+    for k in range(n_frames):
+        if k > 0:
+            v = float(np.clip(v + 0.2 * (u[k, 0] - 0.5), 0.6, 1.4))
+            dist += v
+        y, slope = lane(dist)
+        poses.append(pose_matrix(float(np.arctan(slope)), 0.004 * (u[k, 2] - 0.5), 0.004 * (u[k, 3] - 0.5),
+                                 (x_start + dist, float(y), 0.02 * (u[k, 5] - 0.5))))
+    x_true = [velo_pose_to_cam_x(np.linalg.inv(poses[k]) @ poses[k + 1]) for k in range(n_frames - 1)]
+    return dict(seed=seed, scene_kw=scene_kw, poses_velo=poses, x_true=x_true)
+
+
+def drive_frame(plan, k: int, n_beams: int = N_BEAMS, n_azimuth: int = N_AZIMUTH, sigma: float = 0.02):
+    """Frame k of a planned drive as camera-frame rings (xyz, ring_offsets) -- frames are independent of each other (own noise seed),
+    so a pool may produce them in any order."""
+    scene = Scene(**plan["scene_kw"])
+    pts = hdl64_scan(scene, plan["poses_velo"][k], noise_seed=100_000 * (plan["seed"] + 1) + k, sigma=sigma, n_beams=n_beams, n_azimuth=n_azimuth)
+    return segment_points(pts)
+
+
+def drive(n_frames: int, seed: int = 0, n_beams: int = N_BEAMS, n_azimuth: int = N_AZIMUTH, sigma: float = 0.02):
+    """drive_plan + every frame: dict(frames=[(xyz, ring_offsets)] * n_frames, x_true=[relative pose of frame k+1 -> k as the solver's
+    6-vector] * (n_frames - 1), poses_velo).  Frame k+1 is registered against frame k, every pair once."""
+    plan = drive_plan(n_frames, seed)
+    plan["frames"] = [drive_frame(plan, k, n_beams, n_azimuth, sigma) for k in range(n_frames)]
+    return plan
 
 
 def scan_to_map(n_target: int = 2_000_000, scene_seed: int = 0, sigma: float = 0.02,
