@@ -323,7 +323,8 @@ struct velo_ctx {
     // pinned staging for the small host tables a load sends to the device (source ring offsets, query offsets): the copy is asynchronous
     // and the slot's event says when the host may write the slot again -- no stream synchronisation at the end of a load
     struct PinSlot { int* p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };
-    PinSlot pin[3];                               // 0: source ring offsets (+ query offsets), 1: query offsets, 2: target ring offsets + bounding-box keys
+    PinSlot pin[4];                               // 0: source ring offsets (+ query offsets), 1: query offsets, 2: target ring offsets + bounding-box keys,
+                                                  // 3: the visual matches on their way to the device (set_visual_impl without a wait)
     DevBuf<int> row_off_vis, row_off_icp;
     DevBuf<double> rows_r, rows_J;
 
@@ -2053,7 +2054,15 @@ static int set_visual_impl(velo_ctx* c, const velo_match* m, int32_t n, bool wai
     if (n > 0) {
         VELO_TRY(c->vm.reserve((size_t)n));
         VELO_TRY(c->vflags.reserve((size_t)3 * n));
-        HIP_TRY(hipMemcpyAsync(c->vm.p, c->h_matches.data(), sizeof(velo_match) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        if (wait) {
+            HIP_TRY(hipMemcpyAsync(c->vm.p, c->h_matches.data(), sizeof(velo_match) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+        } else {                                                      // through a pinned slot: the copy is really asynchronous
+            int* pin = nullptr;
+            VELO_TRY(pin_acquire(c, 3, (sizeof(velo_match) * (size_t)n + sizeof(int) - 1) / sizeof(int), &pin));
+            std::memcpy(pin, m, sizeof(velo_match) * (size_t)n);
+            HIP_TRY(hipMemcpyAsync(c->vm.p, pin, sizeof(velo_match) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+            VELO_TRY(pin_release(c, 3));
+        }
         HIP_TRY(hipMemsetAsync(c->vflags.p, 0, (size_t)3 * n, c->stream));
         if (wait) HIP_TRY(hipStreamSynchronize(c->stream));
     }
@@ -3307,9 +3316,8 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
         VELO_TRY(load_job(ctxs[0], target_of(0), sources));
         return velo_frame_to_frame(ctxs[0], x, T, summaries);
     }
-    // the jobs' matches go in BEFORE the path is chosen (groups with visual blocks take their own launch shapes); the copies stay queued on
-    // the contexts' streams, which every path below synchronises or continues on
-    for (int i = 0; i < n && V.n; i++) VELO_TRY(load_job_visual(ctxs[i], V, i));
+    // (the jobs' matches are loaded next to their scans, on the thread that drives the context; the copies stay queued on the contexts'
+    //  streams, which every path below synchronises or continues on)
     if (batch_can_lockstep(ctxs, n, targets != nullptr, sources != nullptr)) {
         // G lock-step groups, one host thread and one stream each: while one group is in its (chip-filling) association
         // launches or waits for a status copy, another group's LM launches run -- the groups hide each other's bubbles
@@ -3320,7 +3328,7 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
         //  11: 3 groups 2,490, 4 groups 2,700 -- a launch serves up to four contexts, so groups of five split theirs 4 + 1)
         const int G = groups_env > 0 ? std::min(groups_env, n / 2) : (n >= 12 ? 2 : ((n == 9 || n == 10) ? 3 : std::min(4, n / 2)));
         if (G <= 1) {
-            for (int i = 0; i < n; i++) VELO_TRY(load_job(ctxs[i], target_of(i), sources ? sources + i : nullptr));
+            for (int i = 0; i < n; i++) { VELO_TRY(load_job_visual(ctxs[i], V, i)); VELO_TRY(load_job(ctxs[i], target_of(i), sources ? sources + i : nullptr)); }
             return f2f_batch_lockstep(ctxs, n, x, T, summaries);
         }
         std::vector<int> gst((size_t)G, VELO_OK);
@@ -3335,7 +3343,8 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
             // slower, 2.32-2.34 k vs 2.42-2.47 k pairs/s: more host threads contending for the runtime's submission path.)
             // (in two passes: all contexts' uploads and bounding-box requests are in flight before the first context waits for its answer)
             for (int i = b; i < e; i++) {
-                const int st = load_job_begin(ctxs[i], target_of(i), sources ? sources + i : nullptr);
+                int st = load_job_visual(ctxs[i], V, i);
+                if (st == VELO_OK) st = load_job_begin(ctxs[i], target_of(i), sources ? sources + i : nullptr);
                 if (st != VELO_OK) { gst[(size_t)gi] = st; gerr[(size_t)gi] = g_err; return; }
             }
             const auto t1 = std::chrono::steady_clock::now();
@@ -3359,7 +3368,8 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
     std::vector<int> status((size_t)n, VELO_OK);
     std::vector<std::string> errs((size_t)n);
     WorkerPool::instance().run(n, [&](int i) {
-        status[i] = load_job(ctxs[i], target_of(i), sources ? sources + i : nullptr);
+        status[i] = load_job_visual(ctxs[i], V, i);
+        if (status[i] == VELO_OK) status[i] = load_job(ctxs[i], target_of(i), sources ? sources + i : nullptr);
         if (status[i] == VELO_OK) status[i] = velo_frame_to_frame(ctxs[i], x + 6 * (size_t)i, T ? T + 16 * (size_t)i : nullptr, summaries ? summaries + i : nullptr);
         if (status[i] != VELO_OK) errs[i] = g_err;
     });
