@@ -342,7 +342,8 @@ def test_small_problem_single_launch_solve_is_bit_identical(hip_lib, diag_lib, m
                                  {"VELO_DENSE_REF": "300", "VELO_ASKER_QUEUE": "0"}, {"VELO_DENSE_REF": "300", "VELO_ASKER_ROWS": "0", "VELO_ASKER_QUEUE": "0"},
                                  {"VELO_DENSE_REF": "300", "VELO_DENSE_ROWS": "4"}, {"VELO_DENSE_REF": "300", "VELO_DENSE_ROWS": "40", "VELO_ASKER_QUEUE": "0"},
                                  {"VELO_DENSE_REF": "300", "VELO_DENSE_ROWS": "1", "VELO_WARM_START": "0"}, {"VELO_XCD_CHUNKS": "1"},
-                                 {"VELO_XCD_CHUNKS": "1", "VELO_DENSE_REF": "300"}])
+                                 {"VELO_XCD_CHUNKS": "1", "VELO_DENSE_REF": "300"}, {"VELO_GRID_COMPRESS": "1"},
+                                 {"VELO_GRID_COMPRESS": "1", "VELO_DENSE_REF": "300"}, {"VELO_GRID_COMPRESS": "1", "VELO_DENSE_REF": "300", "VELO_ASKER_QUEUE": "0"}])
 def test_association_random_geometry_all_paths(hip_lib, diag_lib, oracle, monkeypatch, env):
     """Every way through the tube kernel (tile pass / query-by-query second phase, one or many clusters, regular or
     density-shrunk grid, with or without seeds) against the oracle on clouds that look nothing like a street scan: ragged

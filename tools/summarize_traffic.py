@@ -49,5 +49,52 @@ if out["FETCH_SIZE"] is not None and out["WRITE_SIZE"] is not None:
                 continue
             by[k] = d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)
     res["traffic_by_kernel"] = by
+
+    # round 4: the passes taken on the bench's own command shape (8 pairs in flight): bytes and SQ / busy counters per launch, keyed by
+    # the kernel instantiation that actually ran.  Launches behind the end of a solve (the chain's margin) move nothing and are left out
+    # of the byte figures like above; the SQ / busy counters are means over ALL launches of the name.
+    def short(name):
+        return name.split("(")[0].replace("void ", "").replace("velo::", "").split("<")[0]
+
+    def newest(name):
+        g = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", tag, name, "*", "*counter_collection.csv")), key=os.path.getmtime, reverse=True)
+        return g[0] if g else None
+
+    load = {}
+    tot = collections.defaultdict(dict)
+    for name, counter, mul in (("pmc_fetch_b8", "FETCH_SIZE", 2.0), ("pmc_write_b8", "WRITE_SIZE", 1.0)):
+        f8 = newest(name)
+        if not f8:
+            continue
+        per = collections.defaultdict(lambda: collections.defaultdict(float))
+        for r in csv.DictReader(open(f8)):
+            if r["Counter_Name"] == counter:
+                per[short(r["Kernel_Name"])][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        for k, d in per.items():
+            v = list(d.values())
+            live = [x for x in v if x >= 0.25 * max(v)] or v
+            tot[k][counter] = mul * 1024.0 * sum(live) / len(live)
+    for k, d in tot.items():
+        if not k.startswith("__amd") and "FETCH_SIZE" in d and "WRITE_SIZE" in d:
+            load[k] = d["FETCH_SIZE"] + d["WRITE_SIZE"]
+    if load:
+        res["traffic_by_kernel_in_flight"] = load
+        res["in_flight_source"] = f"gpurun_out/{tag}/pmc_fetch_b8 + pmc_write_b8: bench.py's default batch (8 pairs in flight), separate passes"
+    counters = {}
+    for name in ("pmc_sq_b8", "pmc_busy_b8"):
+        f8 = newest(name)
+        if not f8:
+            continue
+        per = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
+        for r in csv.DictReader(open(f8)):
+            per[short(r["Kernel_Name"])][r["Counter_Name"]][r["Dispatch_Id"]] += float(r["Counter_Value"])
+        for k, cs in per.items():
+            if k.startswith("__amd"):
+                continue
+            counters.setdefault(k, {}).update({cn: sum(d.values()) / len(d) for cn, d in cs.items()})
+            counters[k]["launches"] = max(len(d) for d in cs.values())
+    if counters:
+        keep = {k: v for k, v in counters.items() if any(t in k for t in ("assoc_search", "eval_step", "lm_iter", "lm_solve", "assoc_direct", "target_ingest", "scan_lookback", "grid_"))}
+        res["counters_by_kernel_in_flight"] = keep
     json.dump(res, open(os.path.join(ROOT, "profiles", f"{tag}_traffic.json"), "w"), indent=1)
     print(res)

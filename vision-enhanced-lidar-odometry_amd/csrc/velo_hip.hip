@@ -102,7 +102,19 @@ struct Grid {
     int* table() const { return cell_start.p + 3; }
     DevBuf<float4> sorted;      // cell-sorted copy {x,y,z,bits(gidx)} (+ kGridPad sentinels)
     DevBuf<int> sring;
+    // compressed table (VELO_GRID_COMPRESS=1 in the diagnostics build, see GridView and build_grid): occupancy bits + occupied cells before every word;
+    // cell_start then holds the start of every OCCUPIED cell (at most n + 1 entries)
+    DevBuf<unsigned long long> wmask;
+    DevBuf<int> wprefix;
+    int wpr = 0;                // words per grid row; 0 = dense table
+    size_t table_len() const { return wpr > 0 ? (size_t)n_points_cap + 1 : (size_t)d.ncells + 1; }   // entries of table() in use
+    size_t n_words() const { return (size_t)wpr * (size_t)d.ny * (size_t)d.nz; }
+    int n_points_cap = 0;       // compressed: the target's point count when the table was built
     bool built = false;
+    void view(GridView* V) const {
+        V->d = d; V->cell_start = table(); V->sorted = sorted.p; V->sring = sring.p;
+        V->wmask = wpr > 0 ? wmask.p : nullptr; V->wprefix = wpr > 0 ? wprefix.p : nullptr; V->wpr = wpr;
+    }
 };
 
 struct HostStatus {   // pinned; one D2H copy per LM chunk
@@ -227,6 +239,7 @@ struct velo_ctx {
     // VELO_DENSE_BATCH (diagnostics build) override.
     int dense_rows = 384, dense_far = 2, dense_batch = 0;
     int asker_queue = 1;                 // shrunk grid: asking queries go to assoc_asker_kernel (VELO_ASKER_QUEUE=0: searched inside their group's workgroup)
+    int ask_map = 0;                     // VELO_ASK_MAP: which list entries a wave of the asker kernel takes (0 strided, 1 contiguous + XCD-chunked)
     DevBuf<int> ask_count, ask_list;
     DevBuf<unsigned long long> ask_keys;
     DevBuf<int2> ask_rings;
@@ -390,6 +403,11 @@ struct velo_ctx {
     int timing_every = 8;                    // level 2 brackets every n-th launch of a kernel name (a bracket costs ~5 us of queue time); level 3: every launch
     std::vector<KernelAcc> kacc;
     const char* lm_kernel_name = nullptr;    // the LM kernel the last call launched (its evaluations' algorithmic bytes are known only afterwards)
+    const char* lm_round_name[VELO_MAX_SOLVES] = {};   // ... per solve of a chained call: rounds may take different kernels (small solve / sweep + step)
+    // a chained call that misses is repeated host-driven: what the abandoned chain logged (counted launches, brackets) is dropped with it
+    struct TimingMark { std::vector<KernelAcc> kacc; int klog_used = 0, assoc_events_used = 0; };
+    void timing_mark(TimingMark* m) const { if (timing >= 2) { m->kacc = kacc; m->klog_used = klog_used; m->assoc_events_used = assoc_events_used; } }
+    void timing_rewind(const TimingMark& m) { if (timing >= 2) { kacc = m.kacc; klog_used = m.klog_used; assoc_events_used = m.assoc_events_used; } }
 };
 
 namespace {
@@ -527,14 +545,59 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
     G.d.nx = dims[0]; G.d.ny = dims[1]; G.d.nz = dims[2];
     G.d.ncells = dims[0] * dims[1] * dims[2];
     const int nc = G.d.ncells, n = c->T->n_tgt;
-    VELO_TRY(G.cell_start.reserve((size_t)nc + 4));
     const size_t ns = (size_t)n + kGridPad;
     VELO_TRY(G.sorted.reserve(ns)); VELO_TRY(G.sring.reserve(ns));
+    VELO_TRY(c->scan_total.reserve(1));
+    // Measured on the 2M-point map (round 4, tools/build_times.py, tools/ab_env.py): the compressed table moves 175 MB per build instead of
+    // 466 MB, yet the build takes 218 us instead of 191 (grid_mark 64 us: the atomicOr's of neighbouring points meet on the same 8-byte word;
+    // grid_ccount 41 us) and the search pays the dependent load of every look-up with 8 % (association launch 522 vs 466-485 us; 8 pairs in
+    // flight 1,428 vs 1,475 pairs/s).  Exact (every full-size parity test passes on it), NOT kept: the dense table stays the default,
+    // VELO_GRID_COMPRESS=1 (diagnostics build) switches it on.
+    const int compress_env = dev_env("VELO_GRID_COMPRESS") ? atoi(dev_env("VELO_GRID_COMPRESS")) : 0;
+    const bool compressed = compress_env != 0;
+    if (compressed) {
+        // occupancy bits -> occupied cells before every word (one-pass scan over the words) -> points per occupied cell -> their starts
+        // (one-pass scan over at most n + 1 entries) -> scatter.  The compact table is sized by the point count: its length on the device
+        // (the number of occupied cells) is never needed on the host.
+        G.wpr = (G.d.nx + 63) / 64;
+        G.n_points_cap = n;
+        const size_t nw = G.n_words();
+        if (nw + 1 > (size_t)0x7fffffff) return fail(VELO_ERR_INVALID, "grid too large for the compressed table");
+        VELO_TRY(G.wmask.reserve(nw + 1)); VELO_TRY(G.wprefix.reserve(nw + 4));
+        VELO_TRY(G.cell_start.reserve((size_t)n + 8));
+        const int nwi = (int)nw + 1;                                       // scanned entries: every word + the sentinel
+        const int tiles_w = cdiv(nwi, lb_tile(kLbItemsSmall));
+        const bool large_c = n + 1 >= kLbLargeFrom;
+        const int tiles_c = cdiv(n + 1, lb_tile(large_c ? kLbItemsLarge : kLbItemsSmall));
+        VELO_TRY(c->lb_status.reserve((size_t)tiles_w + 1 + (size_t)tiles_c + 1));   // two scans, a status region (+ ticket) each
+        HIP_TRY(hipMemsetAsync(G.wmask.p, 0, sizeof(unsigned long long) * (nw + 1), c->stream));
+        HIP_TRY(hipMemsetAsync(G.cell_start.p, 0, sizeof(int) * ((size_t)n + 8), c->stream));
+        HIP_TRY(hipMemsetAsync(c->lb_status.p, 0, sizeof(unsigned long long) * ((size_t)tiles_w + 1 + (size_t)tiles_c + 1), c->stream));
+        c->lb_zeroed = 0;
+        unsigned long long* st_w = c->lb_status.p;
+        unsigned long long* st_c = c->lb_status.p + tiles_w + 1;
+        if (n > 0) VELO_LAUNCH_T(c, "grid_mark_kernel", 20ull * (uint64_t)n, grid_mark_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, G.d, c->T->tgt.p, n, c->T->tgt_cell_of.p, G.wmask.p, G.wpr);
+        VELO_LAUNCH_T(c, "word_popc_kernel", 12ull * (uint64_t)nw, word_popc_kernel, dim3(cdiv(nwi, 256)), dim3(256), 0, c->stream, (const unsigned long long*)G.wmask.p, (int)nw, G.wprefix.p);
+        VELO_LAUNCH_T(c, "scan_lookback_kernel", 8ull * (uint64_t)nwi, scan_lookback_kernel<kLbItemsSmall>, dim3(tiles_w), dim3(kScanThreads), 0, c->stream, G.wprefix.p, nwi, st_w,
+                      reinterpret_cast<int*>(st_w + tiles_w), c->scan_total.p);
+        if (n > 0) VELO_LAUNCH_T(c, "grid_ccount_kernel", 8ull * (uint64_t)n, grid_ccount_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, G.d, c->T->tgt_cell_of.p, n,
+                                 (const unsigned long long*)G.wmask.p, (const int*)G.wprefix.p, G.wpr, G.table());
+        if (large_c) VELO_LAUNCH_T(c, "scan_lookback_kernel", 8ull * (uint64_t)(n + 1), scan_lookback_kernel<kLbItemsLarge>, dim3(tiles_c), dim3(kScanThreads), 0, c->stream, G.table() + 1, n, st_c,
+                                   reinterpret_cast<int*>(st_c + tiles_c), c->scan_total.p);
+        else VELO_LAUNCH_T(c, "scan_lookback_kernel", 8ull * (uint64_t)(n + 1), scan_lookback_kernel<kLbItemsSmall>, dim3(tiles_c), dim3(kScanThreads), 0, c->stream, G.table() + 1, n, st_c,
+                           reinterpret_cast<int*>(st_c + tiles_c), c->scan_total.p);
+        VELO_LAUNCH_T(c, "grid_scatter_kernel", 44ull * (uint64_t)n, grid_scatter_kernel, dim3(cdiv(std::max(n, kGridPad), 256)), dim3(256), 0, c->stream, c->T->tgt.p, c->T->tgt_cell_of.p, c->T->tgt_ring_of.p, n,
+                      G.table() + 1, (const int*)c->scan_total.p, c->T->tgt_first_point, G.sorted.p, G.sring.p);
+        HIP_TRY(hipGetLastError());
+        G.built = true;
+        return VELO_OK;
+    }
+    G.wpr = 0; G.n_points_cap = 0;
+    VELO_TRY(G.cell_start.reserve((size_t)nc + 4));
     // count -> one-pass exclusive scan -> scatter, all in the table itself with an offset of one (grid_count_kernel, scan_lookback_kernel)
     const bool large_tiles = nc >= kLbLargeFrom;
     const int n_tiles = cdiv(nc, lb_tile(large_tiles ? kLbItemsLarge : kLbItemsSmall));
     VELO_TRY(c->lb_status.reserve((size_t)n_tiles + 1));               // tile status words + the ticket counter behind them
-    VELO_TRY(c->scan_total.reserve(1));
     HIP_TRY(hipMemsetAsync(G.cell_start.p, 0, sizeof(int) * ((size_t)nc + 4), c->stream));
     if (c->lb_zeroed < n_tiles + 1) HIP_TRY(hipMemsetAsync(c->lb_status.p, 0, sizeof(unsigned long long) * ((size_t)n_tiles + 1), c->stream));
     c->lb_zeroed = 0;                                                  // (about to be used)
@@ -787,6 +850,7 @@ void fill_seed_args(const velo_ctx* c, SeedArgs* A, const PoseScalars& S, const 
 // the asker list of a tube launch on a density-shrunk grid (see assoc_asker_kernel); enable = this launch may defer its askers
 int attach_askers(velo_ctx* c, AssocOut* out, bool enable) {
     out->ask_count = nullptr; out->ask_count_next = nullptr; out->ask_list = nullptr; out->ask_keys = nullptr; out->ask_rings = nullptr;
+    out->ask_map = c->ask_map;
     if (!enable || !c->asker_queue) return VELO_OK;
     const size_t nq = (size_t)std::max(c->n_q, 1);
     VELO_TRY(c->ask_count.reserve(2)); VELO_TRY(c->ask_list.reserve(nq)); VELO_TRY(c->ask_keys.reserve(2 * nq)); VELO_TRY(c->ask_rings.reserve(nq));
@@ -832,7 +896,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
         PoseScalars S;
         pose_scalars(x, &S);
         GridView V;
-        V.d = G->d; V.cell_start = G->table(); V.sorted = G->sorted.p; V.sring = G->sring.p;
+        G->view(&V);
         AssocOut out;
         out.p = c->cp.p; out.n = c->cn.p; out.v0 = c->cv0.p; out.aux0 = c->aux0.p; out.aux1 = c->aux1.p; out.n_valid = c->n_valid.p + c->nv_idx; out.dbg = c->dbg.p; out.wg_times = nullptr;
         out.first_ring = c->T->tgt_first_ring; out.first_point = c->T->tgt_first_point; out.partial = partial ? c->partials_rec.p : nullptr;
@@ -989,7 +1053,7 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                     a.h_safe = h_safe; a.out = out; a.want_aux = aux; a.group_perm = perm; a.dbg = c->dense_rows | (c->dense_far << 20); a.asker_rows = asker_rows;
                     hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, 2>), dim3(grid_groups, 1), dim3(256), c->assoc_lds_pad, c->stream,
                                           ev ? ev->first : nullptr, ev_stop, 0, B1);
-                    hipExtLaunchKernelGGL(assoc_asker_kernel, dim3(cdiv(qe - qb, kAskChunk)), dim3(64), 0, c->stream, nullptr, ev ? ev->second : nullptr, 0,
+                    hipExtLaunchKernelGGL(assoc_asker_kernel, dim3(cdiv(qe - qb, kAskChunk) + 8), dim3(64), 0, c->stream, nullptr, ev ? ev->second : nullptr, 0,
                                           S, P_dev, (const int*)(P_dev ? c->chain_fail.p : nullptr), V, c->qpts, (const float4*)c->T->tgt_pad.p, (const int*)c->T->tgt_off.p,
                                           gbits, c->P.icp_norm_condition, h_safe, out, aux);
                 }
@@ -1556,6 +1620,7 @@ int velo_create(velo_ctx** out, int device) {
         if (const char* e = dev_env("VELO_LM_MERGED_VIS")) c->lm_trace_vis_off = atoi(e) == 0;
         if (const char* e = dev_env("VELO_ASKER_QUEUE")) c->asker_queue = atoi(e);
         if (const char* e = dev_env("VELO_DENSE_ROWS")) c->dense_rows = std::min(std::max(atoi(e), 0), 0xfffff);
+        if (const char* e = dev_env("VELO_ASK_MAP")) c->ask_map = atoi(e) != 0 ? 1 : 0;
         if (const char* e = dev_env("VELO_DENSE_FAR")) c->dense_far = std::min(std::max(atoi(e), 0), 64);
         if (const char* e = dev_env("VELO_DENSE_BATCH")) c->dense_batch = atoi(e);
         if (const char* e = dev_env("VELO_ASSOC_DIRECT_MAX")) c->direct_max = std::max(atoi(e), 0);
@@ -1942,10 +2007,14 @@ int velo_cache_store(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t of_
         e.has_index = true;
         std::memcpy(e.bbox, c->T->bbox, sizeof(e.bbox));
         e.grid.d = G->d; e.grid.gate = G->gate; e.grid.h = G->h; e.grid.built = true;
-        const size_t nc = (size_t)G->d.ncells + 1, ns = (size_t)e.n + kGridPad;
-        if ((st = e.ring_of.reserve((size_t)std::max(e.n, 1))) == VELO_OK && (st = e.grid.cell_start.reserve(nc + 3)) == VELO_OK &&
-            (st = e.grid.sorted.reserve(ns)) == VELO_OK && (st = e.grid.sring.reserve(ns)) == VELO_OK) {
-            if (e.n > 0) he = hipMemcpyAsync(e.ring_of.p, c->T->tgt_ring_of.p, sizeof(int) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream);
+        e.grid.wpr = G->wpr; e.grid.n_points_cap = G->n_points_cap;
+        const size_t nc = G->table_len(), ns = (size_t)e.n + kGridPad, nw = G->wpr > 0 ? G->n_words() + 1 : 0;
+        if ((st = e.ring_of.reserve((size_t)std::max(e.n, 1))) == VELO_OK && (st = e.grid.cell_start.reserve(nc + 7)) == VELO_OK &&
+            (st = e.grid.sorted.reserve(ns)) == VELO_OK && (st = e.grid.sring.reserve(ns)) == VELO_OK &&
+            (nw == 0 || ((st = e.grid.wmask.reserve(nw)) == VELO_OK && (st = e.grid.wprefix.reserve(nw + 3)) == VELO_OK))) {
+            if (nw > 0) he = hipMemcpyAsync(e.grid.wmask.p, G->wmask.p, sizeof(unsigned long long) * nw, hipMemcpyDeviceToDevice, c->stream);
+            if (nw > 0 && he == hipSuccess) he = hipMemcpyAsync(e.grid.wprefix.p, G->wprefix.p, sizeof(int) * nw, hipMemcpyDeviceToDevice, c->stream);
+            if (e.n > 0 && he == hipSuccess) he = hipMemcpyAsync(e.ring_of.p, c->T->tgt_ring_of.p, sizeof(int) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream);
             if (he == hipSuccess) he = hipMemcpyAsync(e.grid.table(), G->table(), sizeof(int) * nc, hipMemcpyDeviceToDevice, c->stream);
             if (he == hipSuccess) he = hipMemcpyAsync(e.grid.sorted.p, G->sorted.p, sizeof(float4) * ns, hipMemcpyDeviceToDevice, c->stream);
             if (he == hipSuccess) he = hipMemcpyAsync(e.grid.sring.p, G->sring.p, sizeof(int) * ns, hipMemcpyDeviceToDevice, c->stream);
@@ -1994,8 +2063,13 @@ int velo_cache_load(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t as_t
     VELO_TRY(c->T->tgt_cell_of.reserve((size_t)std::max(e.n, 1)));                            // scratch of a later rebuild (velo_set_params)
     if (c->T->grids.empty()) c->T->grids.resize(1);
     Grid& G = c->T->grids[0];
-    const size_t nc = (size_t)e.grid.d.ncells + 1, ns = (size_t)e.n + kGridPad;
-    VELO_TRY(G.cell_start.reserve(nc + 3)); VELO_TRY(G.sorted.reserve(ns)); VELO_TRY(G.sring.reserve(ns));
+    const size_t nc = e.grid.table_len(), ns = (size_t)e.n + kGridPad, nw = e.grid.wpr > 0 ? e.grid.n_words() + 1 : 0;
+    VELO_TRY(G.cell_start.reserve(nc + 7)); VELO_TRY(G.sorted.reserve(ns)); VELO_TRY(G.sring.reserve(ns));
+    if (nw > 0) {
+        VELO_TRY(G.wmask.reserve(nw)); VELO_TRY(G.wprefix.reserve(nw + 3));
+        HIP_TRY(hipMemcpyAsync(G.wmask.p, e.grid.wmask.p, sizeof(unsigned long long) * nw, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(G.wprefix.p, e.grid.wprefix.p, sizeof(int) * nw, hipMemcpyDeviceToDevice, c->stream));
+    }
     HIP_TRY(hipMemcpyAsync(c->T->tgt_off.p, c->T->h_tgt_off.data(), sizeof(int) * ((size_t)e.n_rings + 1), hipMemcpyHostToDevice, c->stream));
     if (e.n > 0) HIP_TRY(hipMemcpyAsync(c->T->tgt_ring_of.p, e.ring_of.p, sizeof(int) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream));
     VELO_TRY(c->T->tgt_pad.reserve((size_t)e.n + 2 * (size_t)e.n_rings + 2));
@@ -2007,6 +2081,7 @@ int velo_cache_load(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t as_t
     HIP_TRY(hipMemcpyAsync(G.sorted.p, e.grid.sorted.p, sizeof(float4) * ns, hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(G.sring.p, e.grid.sring.p, sizeof(int) * ns, hipMemcpyDeviceToDevice, c->stream));
     G.d = e.grid.d; G.gate = e.grid.gate; G.h = e.grid.h; G.built = true;
+    G.wpr = e.grid.wpr; G.n_points_cap = e.grid.n_points_cap;
     std::memcpy(c->T->bbox, e.bbox, sizeof(c->T->bbox));
     VELO_TRY(build_direction_image(c));
     HIP_TRY(hipStreamSynchronize(c->stream));                                              // h_tgt_off (pageable) has been read; the entry may be evicted
@@ -2472,6 +2547,8 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
     }
     c->have_corr = false;
     c->chain_calls++;
+    velo_ctx::TimingMark tmark;
+    c->timing_mark(&tmark);
     int j = 0, r = 0;                                                // launch counter (its parity selects the double-buffer halves), round
     const int rounds = c->P.f2f_iterations * c->P.icp_iterations;
     // Over peers every rank must enqueue the same number of LM launches per solve (the all-reduce sits inside the step kernel): the
@@ -2506,6 +2583,7 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
             const bool peer = c->peer_on;
             if (small && !peer && (!visual || E.total() <= kSmallRows)) {     // no prediction needed: the launch runs the solve to its end
                 c->lm_kernel_name = E.nb_vis > 0 ? "lm_solve_small_kernel" : "lm_solve_small_icp_kernel";
+                c->lm_round_name[std::min(r, VELO_MAX_SOLVES - 1)] = c->lm_kernel_name;
                 if (E.nb_vis > 0)
                     VELO_LAUNCH_T(c, c->lm_kernel_name, 0, lm_solve_small_kernel, dim3(1), dim3(kEvalThreads), 0, c->stream, A, Q, c->state.p, (const double*)(r == 0 ? c->xdev.p : nullptr),
                                   nvp, E.nb_icp, E.nb_vis, c->P.max_num_iterations + 3, c->pose_rec.p, logp);
@@ -2516,6 +2594,7 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
                 continue;
             }
             if (peer || (visual && c->lm_trace_vis_off)) {           // sweep (+ visual sweep) + step per LM iteration, state single-buffered
+                c->lm_round_name[std::min(r, VELO_MAX_SOLVES - 1)] = nullptr;      // (separate sweep / step launches: no bytes booked on a name)
                 const int Kv = peer ? k_agreed[std::min(r, VELO_MAX_SOLVES - 1)]
                                     : std::min(std::max(c->pred_evals[std::min(r, VELO_MAX_SOLVES - 1)], 1) + margin_for(c, r), max_launches);
                 hipLaunchKernelGGL(lm_begin_kernel, dim3(1), dim3(64), 0, c->stream, c->state.p, c->eval_pt.p, (const double*)(r == 0 ? c->xdev.p : nullptr), nvp, c->pose_rec.p);
@@ -2531,6 +2610,7 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
             }
             const int K = std::min(std::max(c->pred_evals[std::min(r, VELO_MAX_SOLVES - 1)], 1) + 1 + margin_for(c, r), max_launches);
             c->lm_kernel_name = visual ? "lm_iter_vis_kernel" : "lm_iter_kernel";
+            c->lm_round_name[std::min(r, VELO_MAX_SOLVES - 1)] = c->lm_kernel_name;
             for (int k = 0; k < K; k++, j++) {
                 if (visual)
                     VELO_LAUNCH_T(c, c->lm_kernel_name, 0, lm_iter_vis_kernel, dim3(E.total()), dim3(kEvalThreads), 0, c->stream, A, Q, (const LMState*)(c->state.p + (j & 1)), c->state.p + ((j + 1) & 1),
@@ -2563,6 +2643,7 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
         c->nv_clean[0] = c->nv_clean[1] = false;                            // drained association launches did not clear the next round's counter
         c->ask_clean[0] = c->ask_clean[1] = false;
         c->chain_misses++;
+        c->timing_rewind(tmark);
         return VELO_OK;
     }
     const uint64_t nq = (uint64_t)c->n_q;
@@ -2584,7 +2665,7 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
         note_evals(c, k, L.evals);
         S->eval_kernel_launches += L.evals;
         S->algorithmic_bytes += (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull);
-        if (c->timing >= 2) kacc_add(c, c->lm_kernel_name, 0.0, 0, 0, (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull));
+        if (c->timing >= 2) kacc_add(c, c->lm_round_name[std::min(k, VELO_MAX_SOLVES - 1)], 0.0, 0, 0, (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull));
         if (S->n_solves < VELO_MAX_SOLVES) S->solves[S->n_solves] = ss;
         S->n_solves++;
     }
@@ -2713,7 +2794,7 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
     if (qe <= qb) return VELO_OK;
     pose_scalars(x, &A->P);
     A->P_dev = nullptr; A->chain_fail = nullptr;
-    A->G.d = G->d; A->G.cell_start = G->table(); A->G.sorted = G->sorted.p; A->G.sring = G->sring.p;
+    G->view(&A->G);
     A->qpts = c->qpts; A->q_begin = qb; A->q_end = qe;
     A->tgt_pad = c->T->tgt_pad.p; A->tgt_off = c->T->tgt_off.p;
     const double gate = gate_of_iter(c->P, iter);
@@ -2840,7 +2921,7 @@ static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::arr
 #endif
         else if (any_asker && all_queue) {
             hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, 2>), dim3(gmax, k), dim3(256), c->assoc_lds_pad, c->stream, ev ? ev->first : nullptr, nullptr, 0, B);
-            hipExtLaunchKernelGGL(assoc_asker_batch_kernel, dim3(cdiv(gmax * 64, kAskChunk), k), dim3(64), 0, c->stream, nullptr, ev ? ev->second : nullptr, 0, B);
+            hipExtLaunchKernelGGL(assoc_asker_batch_kernel, dim3(cdiv(gmax * 64, kAskChunk) + 8, k), dim3(64), 0, c->stream, nullptr, ev ? ev->second : nullptr, 0, B);
         }
         else if (any_asker) hipExtLaunchKernelGGL((assoc_search_v5_batch_kernel<4, 5, false, 2, true>), dim3(gmax, k), dim3(256), c->assoc_lds_pad, c->stream,
                                              ev ? ev->first : nullptr, ev ? ev->second : nullptr, 0, B);
@@ -2931,9 +3012,11 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
         VELO_TRY(c0->batch_pose.reserve((size_t)n)); VELO_TRY(c0->batch_logs.reserve((size_t)n * VELO_MAX_SOLVES)); VELO_TRY(c0->batch_fail.reserve((size_t)n));
         if (fresh) { HIP_TRY(hipMemsetAsync(c0->batch_fail.p, 0, sizeof(int) * (size_t)n, bs)); HIP_TRY(hipMemsetAsync(c0->batch_pose.p, 0, sizeof(PoseRecord) * (size_t)n, bs)); }
         bool any_matches = false;
+        std::vector<velo_ctx::TimingMark> tmarks((size_t)n);
         for (int i = 0; i < n; i++) {
             velo_ctx* c = ctxs[i];
             c->chain_calls++;
+            c->timing_mark(&tmarks[(size_t)i]);
             if (c->n_matches > 0) {                                  // block / residual counts per f2f iteration come back at the end
                 any_matches = true;
                 VELO_TRY(c->vis_counts.reserve(2 * VELO_MAX_STATS));
@@ -2986,6 +3069,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                     std::memset(&pk, 0, sizeof(pk));
                     for (int i = 0; i < n; i++) pk.item[i] = items_r[i];
                     c0->lm_kernel_name = "lm_iter_batch_lean_kernel";
+                    c0->lm_round_name[std::min(r, VELO_MAX_SOLVES - 1)] = c0->lm_kernel_name;
                     const size_t half = (size_t)(kMaxEvalBlocks + kMaxVisBlocks) * kNumAcc;
                     for (int k = 0; k <= K; k++, iter_launches++)
                         VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, lm_iter_batch_lean_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, pk, iter_launches & 1, k == 0 ? 1 : 0, half);
@@ -2999,6 +3083,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                         const int m = std::min(kItemsByValue, n - b0);
                         for (int i = 0; i < m; i++) pack.item[i] = items_r[b0 + i];
                         c0->lm_kernel_name = nbv_max > 0 ? "lm_solve_small_batch_kernel" : "lm_solve_small_icp_batch_kernel";
+                        c0->lm_round_name[std::min(r, VELO_MAX_SOLVES - 1)] = c0->lm_kernel_name;
                         if (nbv_max > 0) VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, lm_solve_small_batch_kernel, dim3(m), dim3(kEvalThreads), 0, bs, Q, pack, max_iters + 1);
                         else VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, lm_solve_small_icp_batch_kernel, dim3(m), dim3(kEvalThreads), 0, bs, Q, pack, max_iters + 1);
                     }
@@ -3011,6 +3096,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                         HIP_TRY(hipMemsetAsync(c0->solve_ctl.p, 0, sizeof(SolveCtl) * c0->solve_ctl.cap, bs));
                     }
                     c0->lm_kernel_name = "lm_solve_persist_batch_kernel";
+                    c0->lm_round_name[std::min(r, VELO_MAX_SOLVES - 1)] = c0->lm_kernel_name;
                     const int wgs = c0->lm_persist_wgs > 0 ? std::min(c0->lm_persist_wgs, nb_max) : nb_max;
                     VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, lm_solve_persist_batch_kernel, dim3(wgs, n), dim3(kEvalThreads), 0, bs, Q, d_items, c0->solve_ctl.p, max_iters + 2);
                     HIP_TRY(hipGetLastError());
@@ -3052,6 +3138,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                     hipLaunchKernelGGL(lm_step_batch_kernel, dim3(n), dim3(256), 0, bs, Q, d_items);
                 }
                 HIP_TRY(hipGetLastError());
+                c0->lm_round_name[std::min(r, VELO_MAX_SOLVES - 1)] = c0->lm_kernel_name;   // the kernel THIS round's evaluations ran in
 
             }
         }
@@ -3093,8 +3180,9 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                     Si->eval_kernel_launches += L.evals;
                     Si->algorithmic_bytes += (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 32ull * (uint64_t)ss.n_visual_blocks + 224ull);
                     if (c0->timing >= 2) {                           // the group's launches are logged on its first context
-                        kacc_add(c0, c0->lm_kernel_name, 0.0, 0, 0, (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 224ull));
-                        if (ss.n_visual_blocks > 0) kacc_add(c0, vis_in_launch ? c0->lm_kernel_name : "eval_visual_batch_kernel", 0.0, 0, 0, (uint64_t)L.evals * 32ull * (uint64_t)ss.n_visual_blocks);
+                        const char* rname = c0->lm_round_name[std::min(k, VELO_MAX_SOLVES - 1)];
+                        kacc_add(c0, rname, 0.0, 0, 0, (uint64_t)L.evals * (36ull * (uint64_t)L.n_valid + 224ull));
+                        if (ss.n_visual_blocks > 0) kacc_add(c0, vis_in_launch ? rname : "eval_visual_batch_kernel", 0.0, 0, 0, (uint64_t)L.evals * 32ull * (uint64_t)ss.n_visual_blocks);
                     }
                     Si->solves[Si->n_solves++] = ss;
                 }
@@ -3110,6 +3198,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
         for (int i = 0; i < n; i++) {
             velo_ctx* c = ctxs[i];
             c->chain_misses++;
+            c->timing_rewind(tmarks[(size_t)i]);
             c->nv_clean[0] = c->nv_clean[1] = false;                        // drained association launches did not clear the next round's counter
             c->ask_clean[0] = c->ask_clean[1] = false;
             note_miss(c);

@@ -38,10 +38,25 @@ struct GridDesc {
 constexpr int kGridPad = 16;
 struct GridView {
     GridDesc d;
-    const int* __restrict__ cell_start;      // [ncells + 1]
+    const int* __restrict__ cell_start;      // dense: [ncells + 1] start of every cell; compressed: start of every OCCUPIED cell, [n_occupied + 1]
     const float4* __restrict__ sorted;       // [n_finite + kGridPad]
     const int* __restrict__ sring;           // ring of sorted[j]
+    // Compressed table (large grids: an accumulated map's millions of cells, of which a few per cent hold points): per row (y, z) of
+    // the grid `wpr` 64-bit words, bit x & 63 of word x >> 6 = "cell x of this row is occupied", and the number of occupied cells before
+    // each word.  start(row, x) = cell_start[wprefix[w] + popcount(wmask[w] below bit x)] -- 0.19 bytes per cell instead of 4, so the
+    // table of the 2M-point map (11 M cells) is 2 MB and stays in every XCD's L2, at the price of one dependent load per look-up.
+    const unsigned long long* __restrict__ wmask;   // null: dense table
+    const int* __restrict__ wprefix;
+    int wpr;                                  // words per row = ceil(nx / 64)
 };
+// first sorted point of cell x (0..nx: nx = one past the row's last cell) of grid row `row` = z * ny + y
+__device__ __forceinline__ int grid_start(const GridView& G, int row, int x) {
+    if (G.wmask == nullptr) return G.cell_start[row * G.d.nx + x];
+    const int w = row * G.wpr + (x >> 6);
+    const unsigned long long m = G.wmask[w];
+    const int k = G.wprefix[w] + __popcll(m & ((1ull << (x & 63)) - 1ull));
+    return G.cell_start[k];
+}
 
 // ---- pose scalars of one association round, computed on the HOST in double with the same libm the CPU
 // restatement uses, so that the float coordinates of the transformed queries are bit-identical (row A1) -----
@@ -370,6 +385,51 @@ __global__ void grid_count_kernel(GridDesc g, const float4* __restrict__ pts, in
     if (head) atomicAdd(&table[c + 1], len);
 }
 
+// ---- compressed table (large grids) ----------------------------------------------------------------------------------------------------
+// mark: cell id per point (cell_of) + one bit per occupied cell (a run of equal cells sends one atomicOr); word_popc: occupied cells per
+// word, ready for the one-pass scan; ccount: every point's COMPACT cell number (its rank among the occupied cells, overwriting cell_of)
+// counted into table[k + 1] like grid_count_kernel does for the dense table.  Scan and scatter are the dense path's kernels on the
+// compact table: ~8 B per point of table traffic instead of 4 B per CELL read and written twice.
+__global__ void grid_mark_kernel(GridDesc g, const float4* __restrict__ pts, int n, int* __restrict__ cell_of, unsigned long long* __restrict__ wmask, int wpr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int c = -1;
+    if (i < n) {
+        const float4 p = pts[i];
+        if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) c = cell_of_point(g, p);
+        cell_of[i] = c;
+    }
+    bool head; int first, len;
+    run_of_lane(c, threadIdx.x & 63, &head, &first, &len);
+    if (head) {
+        const int row = c / g.nx, x = c - row * g.nx;
+        const unsigned long long bit = 1ull << (x & 63);
+        unsigned long long* w = &wmask[(size_t)row * wpr + (x >> 6)];
+        if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(w, bit);   // (a set bit stays set: most runs find theirs set already)
+    }
+}
+__global__ void word_popc_kernel(const unsigned long long* __restrict__ wmask, int n_words, int* __restrict__ wprefix) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_words) wprefix[i] = __popcll(wmask[i]);
+    else if (i == n_words) wprefix[i] = 0;                              // the sentinel word behind the last row
+}
+__global__ void grid_ccount_kernel(GridDesc g, int* __restrict__ cell_of, int n, const unsigned long long* __restrict__ wmask, const int* __restrict__ wprefix, int wpr,
+                                   int* __restrict__ table) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int k = -1;
+    if (i < n) {
+        const int c = cell_of[i];
+        if (c >= 0) {
+            const int row = c / g.nx, x = c - row * g.nx;
+            const int w = row * wpr + (x >> 6);
+            k = wprefix[w] + __popcll(wmask[w] & ((1ull << (x & 63)) - 1ull));
+        }
+        cell_of[i] = k;
+    }
+    bool head; int first, len;
+    run_of_lane(k, threadIdx.x & 63, &head, &first, &len);
+    if (head) atomicAdd(&table[k + 1], len);
+}
+
 constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;                      // per thread
 constexpr int kScanTile = kScanThreads * kScanItems;
@@ -572,6 +632,7 @@ struct AssocOut {
     int* __restrict__ ask_list;                  // [n_q] query indices
     unsigned long long* __restrict__ ask_keys;   // [2 n_q] best1 / best2 keys so far, by query
     int2* __restrict__ ask_rings;                // [n_q] their rings
+    int ask_map;                                 // which list entries a wave of the asker kernel takes: 0 strided, 1 a contiguous block, XCD-chunked
 };
 
 // Target-sharded mode (BASELINE config 5): what one rank knows about a query after searching ITS rings.
@@ -812,8 +873,8 @@ assoc_search_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, c
         if (x0 <= x1) {
             for (int z = z0; z <= z1; z++) {
                 for (int y = y0; y <= y1; y++) {
-                    const int row = (z * g.ny + y) * g.nx;
-                    const int j0 = G.cell_start[row + x0], j1 = G.cell_start[row + x1 + 1];
+                    const int row = (z * g.ny + y);
+                    const int j0 = grid_start(G, row, x0), j1 = grid_start(G, row, x1 + 1);
                     for (int j = j0; j < j1; j++) {
                         const float4 sp = G.sorted[j];
                         const float d2 = dist2_f(qx, qy, qz, sp.x, sp.y, sp.z);
@@ -966,14 +1027,14 @@ assoc_search_v3_kernel(PoseScalars P, GridView G, const float4* __restrict__ src
                 const int r = rbase + tid;
                 if (r < nrows) {
                     const int y = Y0 + r % nyb, z = Z0 + r / nyb;
-                    const int row = (z * g.ny + y) * g.nx;
+                    const int row = (z * g.ny + y);
                     const bool fresh = e_prev < 0 || y < py0 || y > py1 || z < pz0 || z > pz1;
                     if (fresh) {
-                        ja0 = G.cell_start[row + X0]; la = G.cell_start[row + X1 + 1] - ja0;
+                        ja0 = grid_start(G, row, X0); la = grid_start(G, row, X1 + 1) - ja0;
                     } else {                                            // old row: only the cells left of px0 and right of px1 are new
                         const int a1 = min(px0 - 1, X1), b0 = max(px1 + 1, X0);
-                        if (X0 <= a1) { ja0 = G.cell_start[row + X0]; la = G.cell_start[row + a1 + 1] - ja0; }
-                        if (b0 <= X1) { jb0 = G.cell_start[row + b0]; lb = G.cell_start[row + X1 + 1] - jb0; }
+                        if (X0 <= a1) { ja0 = grid_start(G, row, X0); la = grid_start(G, row, a1 + 1) - ja0; }
+                        if (b0 <= X1) { jb0 = grid_start(G, row, b0); lb = grid_start(G, row, X1 + 1) - jb0; }
                     }
                 }
                 // workgroup exclusive scan of (la + lb)
@@ -1398,14 +1459,14 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
                         int zq = (int)((float)r * rcp_nyb), yr = r - zq * nyb;
                         if (yr < 0) { zq--; yr += nyb; } else if (yr >= nyb) { zq++; yr -= nyb; }
                         const int y = Y0 + yr, z = Z0 + zq;
-                        const int row = (z * g.ny + y) * g.nx;
+                        const int row = (z * g.ny + y);
                         const int plo = (ph == 1) ? s_plo[tid] : big, phi = (ph == 1) ? s_phi[tid] : -big;
                         if (plo > phi) {                                // nothing of this row visited yet
-                            ja0 = G.cell_start[row + lo]; la = G.cell_start[row + hi + 1] - ja0;
+                            ja0 = grid_start(G, row, lo); la = grid_start(G, row, hi + 1) - ja0;
                         } else {                                        // only the cells left of plo and right of phi are new
                             const int a1 = min(plo - 1, hi), b0 = max(phi + 1, lo);
-                            if (lo <= a1) { ja0 = G.cell_start[row + lo]; la = G.cell_start[row + a1 + 1] - ja0; }
-                            if (b0 <= hi) { jb0 = G.cell_start[row + b0]; lb = G.cell_start[row + hi + 1] - jb0; }
+                            if (lo <= a1) { ja0 = grid_start(G, row, lo); la = grid_start(G, row, a1 + 1) - ja0; }
+                            if (b0 <= hi) { jb0 = grid_start(G, row, b0); lb = grid_start(G, row, hi + 1) - jb0; }
                         }
                     }
                 }
@@ -1592,8 +1653,8 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
                         if (r < nrows_a) {
                             int zq = (int)((float)r * rcp_ny), yr = r - zq * ny;
                             if (yr < 0) { zq--; yr += ny; } else if (yr >= ny) { zq++; yr -= ny; }
-                            const int row = ((z0 + zq) * g.ny + (y0 + yr)) * g.nx;
-                            j0 = G.cell_start[row + x0]; len = G.cell_start[row + x1 + 1] - j0;
+                            const int row = ((z0 + zq) * g.ny + (y0 + yr));
+                            j0 = grid_start(G, row, x0); len = grid_start(G, row, x1 + 1) - j0;
                         }
                         int inc = len;
 #pragma unroll
@@ -1718,8 +1779,8 @@ __device__ __forceinline__ void asker_search(const GridView& G, const GridDesc& 
         if (r < nrows_a) {
             int zq = (int)((float)r * rcp_ny), yr = r - zq * ny;
             if (yr < 0) { zq--; yr += ny; } else if (yr >= ny) { zq++; yr -= ny; }
-            const int row = ((z0 + zq) * g.ny + (y0 + yr)) * g.nx;
-            j0 = G.cell_start[row + x0]; len = G.cell_start[row + x1 + 1] - j0;
+            const int row = ((z0 + zq) * g.ny + (y0 + yr));
+            j0 = grid_start(G, row, x0); len = grid_start(G, row, x1 + 1) - j0;
         }
         int inc = len;
 #pragma unroll
@@ -1762,11 +1823,19 @@ assoc_asker_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_dev, 
     if (chain_fail && *chain_fail) return;                             // the tube launch ahead of this one has raised it if the record was not ready
     const int count = *out.ask_count;
     const int n_chunks = (count + kAskChunk - 1) / kAskChunk;
-    if (chunk >= n_chunks) return;
+    if (out.ask_map == 0 && chunk >= n_chunks) return;
     const PoseScalars& P = P_dev ? P_dev->P : P_in;
     const unsigned long long key_inf = ((unsigned long long)gate_bits + 1ull) << 32;
     const GridDesc g = G.d;
-    const int my_idx = chunk + lane * n_chunks;                        // stride: the list's neighbours (a clump of heavy queries) go to different waves
+    // Which kAskChunk entries this wave takes.  0: with a stride -- the list's neighbours (a clump of heavy queries) go to different waves,
+    // which evens the waves out but makes 8 different CUs on 8 different XCDs fetch the same cells of a clump.  1: a contiguous block, and
+    // blocks dealt so that workgroups 8 j + k (XCD k) take the k-th EIGHTH of the list: neighbours share a wave's L1 and an XCD's L2.
+    int my_idx = chunk + lane * n_chunks;
+    if (out.ask_map == 1) {
+        const int per = (n_chunks + 7) >> 3, blk = (chunk & 7) * per + (chunk >> 3);
+        if ((chunk >> 3) >= per || blk >= n_chunks) return;
+        my_idx = blk * kAskChunk + lane;
+    }
     const bool mine = lane < kAskChunk && my_idx < count;
     int qi = 0;
     float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -1806,7 +1875,7 @@ __global__ void __launch_bounds__(64)
 assoc_asker_batch_kernel(AssocBatch B) {
     const AssocArgs& a = B.item[blockIdx.y];
     const int n_waves = (a.q_end - a.q_begin + kAskChunk - 1) / kAskChunk;
-    if (!a.out.ask_list || (int)blockIdx.x >= n_waves) return;
+    if (!a.out.ask_list || (int)blockIdx.x >= n_waves + 8) return;      // (+ 8: the XCD-chunked map rounds the list up to eight equal parts)
     assoc_asker_body(a.P, a.P_dev, a.chain_fail, a.G, a.qpts, a.tgt_pad, a.tgt_off, a.gate_bits, a.norm_cond, a.h_safe, a.out, a.want_aux, (int)blockIdx.x, n_waves);
 }
 
@@ -2042,9 +2111,9 @@ assoc_lane_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_dev, i
 #pragma unroll
             for (int yy = 0; yy < 3; yy++) {
                 const bool on = zz < nzb && yy < nyb;
-                const int row = on ? ((z0 + zz) * g.ny + (y0 + yy)) * g.nx : 0;
-                a[zz * 3 + yy] = on ? G.cell_start[row + x0] : 0;
-                b[zz * 3 + yy] = on ? G.cell_start[row + x1 + 1] : 0;
+                const int row = on ? ((z0 + zz) * g.ny + (y0 + yy)) : 0;
+                a[zz * 3 + yy] = on ? grid_start(G, row, x0) : 0;
+                b[zz * 3 + yy] = on ? grid_start(G, row, x1 + 1) : 0;
             }
         }
 #pragma unroll
@@ -2091,8 +2160,8 @@ assoc_lane_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_dev, i
             if (r < nrows_a) {
                 int zq = (int)((float)r * rcp_ny), yr = r - zq * ny;
                 if (yr < 0) { zq--; yr += ny; } else if (yr >= ny) { zq++; yr -= ny; }
-                const int row = ((bz0 + zq) * g.ny + (by0 + yr)) * g.nx;
-                j0 = G.cell_start[row + bx0]; len = G.cell_start[row + bx1 + 1] - j0;
+                const int row = ((bz0 + zq) * g.ny + (by0 + yr));
+                j0 = grid_start(G, row, bx0); len = grid_start(G, row, bx1 + 1) - j0;
             }
             int inc = len;
 #pragma unroll
@@ -2293,14 +2362,14 @@ assoc_cluster_kernel(GridView G, AssocQueue Q, const float4* __restrict__ src, c
                     int zq = (int)(((float)r + 0.5f) * inv_nyb);      // r / nyb for small non-negative ints, fixed up below
                     zq = (zq * nyb > r) ? zq - 1 : ((zq + 1) * nyb <= r ? zq + 1 : zq);
                     const int y = Y0 + (r - zq * nyb), z = Z0 + zq;
-                    const int row = (z * g.ny + y) * g.nx;
+                    const int row = (z * g.ny + y);
                     const bool fresh = e_prev < 0 || y < py0 || y > py1 || z < pz0 || z > pz1;
                     if (fresh) {
-                        ja0 = G.cell_start[row + X0]; la = G.cell_start[row + X1 + 1] - ja0;
+                        ja0 = grid_start(G, row, X0); la = grid_start(G, row, X1 + 1) - ja0;
                     } else {
                         const int a1 = min(px0 - 1, X1), b0 = max(px1 + 1, X0);
-                        if (X0 <= a1) { ja0 = G.cell_start[row + X0]; la = G.cell_start[row + a1 + 1] - ja0; }
-                        if (b0 <= X1) { jb0 = G.cell_start[row + b0]; lb = G.cell_start[row + X1 + 1] - jb0; }
+                        if (X0 <= a1) { ja0 = grid_start(G, row, X0); la = grid_start(G, row, a1 + 1) - ja0; }
+                        if (b0 <= X1) { jb0 = grid_start(G, row, b0); lb = grid_start(G, row, X1 + 1) - jb0; }
                     }
                 }
                 const int mine = la + lb;
