@@ -37,6 +37,18 @@ def write_case(path, d, matches, skip):
         f.write(np.asarray(d["x0"], np.float64).tobytes())
 
 
+def test_plain_c99_caller_of_the_pose_handoff(tmp_path):
+    """include/velo_hip.h compiles as C99 and the drive loop's host-side entry point (velo_pose_handoff, main.cpp:311-331,408) gives the
+    hand-computed chain; velo_register_batch / _visual / velo_source_to_target resolve at link time.  Runs without a GPU."""
+    build.build_hip()
+    exe = str(tmp_path / "test_handoff")
+    csrc = os.path.dirname(build.LIB)
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(CPP, "test_handoff.c"), "-o", exe,
+                    "-L", csrc, "-lvelo_hip", "-lm", f"-Wl,-rpath,{csrc}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "handoff ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_adaptor_compiles_as_cxx11(tmp_path):
     assert os.path.exists(compile_adaptor(tmp_path))
 

@@ -194,6 +194,8 @@ struct velo_ctx {
     DevBuf<int> vis_counts;                       // chain mode: [f2f iteration][blocks, residuals] selected by the device-side gate
     DevBuf<int> scan_tiles, cursor, scan_total;   // scratch of an index build / of the segmenter's scans
     struct { const char* dsrc = nullptr; int64_t stride = 0; bool on = false; } src_raw;   // set_source: the records the fused ingest launch still has to read (source_finalize)
+    bool src_bbox_valid = false;         // h_int[16..21] hold the bounding-box keys of the source cloud (source_ingest; on the host after the call's sync)
+    bool target_early = false;           // promote_begin already sized and enqueued the index (box known): target_finalize_end has nothing to wait for
     int lb_zeroed = 0;                            // status words of the one-pass scan that target_ingest_kernel cleared for the next build (0: build_grid clears them)
     bool batch_load = false;                      // set while velo_register_batch loads this context's scans for a batch of two or more (see build_grid)
     DevBuf<unsigned long long> lb_status;         // one-pass scan: tile status words + ticket
@@ -1352,6 +1354,7 @@ int build_direction_image(velo_ctx* c) {
 // so one context's wait is covered by the next one's uploads.
 int target_finalize_begin(velo_ctx* c) {
     const int n = c->T->n_tgt, n_rings = c->T->n_tgt_rings;
+    c->target_early = false;
     c->prev_ready = false;                                            // seeds refer to points of the old target
     for (int r = 0; r < n_rings; r++) if (c->T->h_tgt_off[r + 1] <= c->T->h_tgt_off[r]) return fail(VELO_ERR_INVALID, "target ring %d is empty", r);
     VELO_TRY(c->T->tgt_off.reserve((size_t)n_rings + 1));
@@ -1381,6 +1384,7 @@ int target_finalize_begin(velo_ctx* c) {
 constexpr int kLbWordsCleared = (1 << 25) / lb_tile(kLbItemsLarge) + 2 > kLbLargeFrom / lb_tile(kLbItemsSmall) + 2 ? (1 << 25) / lb_tile(kLbItemsLarge) + 2 : kLbLargeFrom / lb_tile(kLbItemsSmall) + 2;                 // status words of the largest default table (+ ticket)
 int target_ingest(velo_ctx* c, const float* xyz, int64_t stride, int on_device) {
     const int n = c->T->n_tgt, n_rings = c->T->n_tgt_rings;
+    c->target_early = false;                                          // (a promotion that knows its box sets it again behind this call)
     c->prev_ready = false;                                            // seeds refer to points of the old target
     VELO_TRY(c->T->tgt.reserve((size_t)std::max(n, 1)));
     VELO_TRY(c->T->tgt_off.reserve((size_t)n_rings + 1 + 8));         // the six box keys ride behind the offsets
@@ -1415,6 +1419,7 @@ int target_ingest(velo_ctx* c, const float* xyz, int64_t stride, int on_device) 
     return VELO_OK;
 }
 int target_finalize_end(velo_ctx* c) {
+    if (c->target_early) { c->target_early = false; return VELO_OK; }     // promote_begin knew the box: everything is enqueued already
     HIP_TRY(hipStreamSynchronize(c->stream));
     unsigned keys[6];
     std::memcpy(keys, c->h_int + 8, sizeof(keys));
@@ -1448,23 +1453,27 @@ int source_ingest(velo_ctx* c) {
     c->src_skip = skip;
     const bool patch = want_patch(c);
     const size_t nq = (size_t)std::max(c->n_q, 1);
-    VELO_TRY(c->src_off.reserve(2 * ((size_t)R + 1)));                    // [ring offsets | query offsets]
+    VELO_TRY(c->src_off.reserve(2 * ((size_t)R + 1) + 8));                // [ring offsets | query offsets | six bounding-box keys]
     VELO_TRY(c->q_src.reserve(nq));
     const bool own_list = !(skip == 1 && !patch);                         // else q_src[i] == i and the source cloud itself is the list
     if (own_list) VELO_TRY(c->qpts_buf.reserve(nq));
     {
         int* pin = nullptr;
-        VELO_TRY(pin_acquire(c, 0, 2 * ((size_t)R + 1), &pin));
+        VELO_TRY(pin_acquire(c, 0, 2 * ((size_t)R + 1) + 8, &pin));
         std::memcpy(pin, c->h_src_off.data(), sizeof(int) * ((size_t)R + 1));
         std::memcpy(pin + R + 1, c->h_q_off.data(), sizeof(int) * ((size_t)R + 1));
-        HIP_TRY(hipMemcpyAsync(c->src_off.p, pin, sizeof(int) * 2 * ((size_t)R + 1), hipMemcpyHostToDevice, c->stream));
+        for (int k = 0; k < 6; k++) pin[2 * (R + 1) + k] = k < 3 ? -1 : 0;   // min keys all ones, max keys zero
+        HIP_TRY(hipMemcpyAsync(c->src_off.p, pin, sizeof(int) * (2 * ((size_t)R + 1) + 6), hipMemcpyHostToDevice, c->stream));
         VELO_TRY(pin_release(c, 0));
     }
     const int nb_pack = cdiv(c->n_src, 256), nb_q = c->n_q > 0 ? cdiv(c->n_q, 256) : 0;
     VELO_LAUNCH_T(c, "source_ingest_kernel", 28ull * (uint64_t)c->n_src + 32ull * (uint64_t)c->n_q, source_ingest_kernel, dim3(nb_pack + nb_q), dim3(256), 0, c->stream,
                   c->src_raw.dsrc, c->src_raw.stride, c->n_src, c->src.p, nb_pack, (const int*)c->src_off.p, (const int*)(c->src_off.p + R + 1), R, skip, c->n_q,
-                  patch ? 1 : 0, c->patch_rings, c->patch_len, c->q_src.p, own_list ? c->qpts_buf.p : (float4*)nullptr);
+                  patch ? 1 : 0, c->patch_rings, c->patch_len, c->q_src.p, own_list ? c->qpts_buf.p : (float4*)nullptr, reinterpret_cast<unsigned*>(c->src_off.p + 2 * (R + 1)));
     HIP_TRY(hipGetLastError());
+    // the box keys ride back on the stream; every way out of a call synchronises it, so a LATER call (a promotion) may read them
+    HIP_TRY(hipMemcpyAsync(c->h_int + 16, c->src_off.p + 2 * (R + 1), sizeof(unsigned) * 6, hipMemcpyDeviceToHost, c->stream));
+    c->src_bbox_valid = true;
     c->src_raw.on = false;
     c->q_patch = patch;
     c->qpts = own_list ? c->qpts_buf.p : c->src.p;
@@ -1649,7 +1658,7 @@ int velo_create(velo_ctx** out, int device) {
         HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_TRY(hipHostMalloc((void**)&c->h_status, sizeof(HostStatus), hipHostMallocDefault));
         HIP_TRY(hipHostMalloc((void**)&c->h_x, sizeof(double) * 64, hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void**)&c->h_int, sizeof(int) * 16, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void**)&c->h_int, sizeof(int) * 32, hipHostMallocDefault));   // [0] counters, [8..13] target box keys, [16..21] source box keys
         VELO_TRY(c->state.reserve(2));                       // [1]: the other half of the one-launch iteration's double buffer
         VELO_TRY(c->eval_pt.reserve(1));
         VELO_TRY(c->pose_rec.reserve(1)); VELO_TRY(c->solve_log.reserve(VELO_MAX_SOLVES)); VELO_TRY(c->chain_fail.reserve(1));
@@ -1809,7 +1818,7 @@ int velo_set_target_part(velo_ctx* c, const float* xyz, int64_t stride, const in
 }
 
 static int set_source_begin(velo_ctx* c, const float* xyz, int64_t stride, const int32_t* off, int32_t n_rings, int on_device) {
-    if (c) c->src_raw.on = false;
+    if (c) { c->src_raw.on = false; c->src_bbox_valid = false; }
     if (!c || !off || n_rings < 0) return fail(VELO_ERR_INVALID, "null/negative argument");
     if (stride < 12) return fail(VELO_ERR_INVALID, "stride_bytes must be >= 12");
     if (off[0] != 0) return fail(VELO_ERR_INVALID, "ring_offsets[0] must be 0");
@@ -1848,7 +1857,7 @@ int velo_set_scan_velodyne(velo_ctx* c, int32_t as_target, const float* xyzr, in
     if (as_target) own_target(c);
     DevBuf<float4>& dst = as_target ? c->T->tgt : c->src;
     std::vector<int>& h_off = as_target ? c->T->h_tgt_off : c->h_src_off;
-    if (as_target) { c->have_target = false; c->have_partials = false; c->T->tgt_first_ring = 0; c->T->tgt_first_point = 0; } else c->have_source = false;
+    if (as_target) { c->have_target = false; c->have_partials = false; c->T->tgt_first_ring = 0; c->T->tgt_first_point = 0; } else { c->have_source = false; c->src_bbox_valid = false; }
     c->have_corr = false;
     VELO_TRY(dst.reserve((size_t)std::max(n, 1)));
     int n_rings = 0;
@@ -1921,7 +1930,27 @@ static int promote_begin(velo_ctx* c) {
     c->have_source = false; c->have_target = false; c->have_corr = false; c->have_partials = false;
     c->n_src = 0; c->n_src_rings = 0; c->n_q = 0; c->h_src_off.assign(1, 0); c->h_q_off.assign(1, 0);
     for (int r = 0; r < c->T->n_tgt_rings; r++) if (c->T->h_tgt_off[r + 1] <= c->T->h_tgt_off[r]) return fail(VELO_ERR_INVALID, "target ring %d is empty", r);
-    return target_ingest(c, reinterpret_cast<const float*>(c->T->tgt.p), (int64_t)sizeof(float4), 1);
+    // The scan's bounding box came back with the call that loaded it as source (source_ingest_kernel takes it: the same keys
+    // target_ingest_kernel computes for the same points), so the grid can be sized and the index build enqueued right behind the ingest
+    // launch -- no host wait in the load of a drive's frame.
+#ifdef VELO_NO_EARLY_PROMOTE                                           // A/B build: the promotion waits for its own bounding box, as before round 4
+    const bool box_known = false;
+#else
+    const bool box_known = c->src_bbox_valid && c->T->n_tgt > 0;
+#endif
+    unsigned keys[6];
+    if (box_known) std::memcpy(keys, c->h_int + 16, sizeof(keys));
+    c->src_bbox_valid = false;
+    VELO_TRY(target_ingest(c, reinterpret_cast<const float*>(c->T->tgt.p), (int64_t)sizeof(float4), 1));
+    if (box_known) {
+        if (keys[0] == 0xffffffffu) { for (int k = 0; k < 6; k++) c->T->bbox[k] = 0.f; }      // no finite point at all
+        else for (int k = 0; k < 6; k++) c->T->bbox[k] = key2f(keys[k]);
+        for (Grid& G : c->T->grids) G.built = false;
+        VELO_TRY(build_grids(c));
+        c->have_target = true;
+        c->target_early = true;
+    }
+    return VELO_OK;
 }
 int velo_source_to_target(velo_ctx* c) {
     VELO_TRY(promote_begin(c));
@@ -2041,7 +2070,7 @@ int velo_cache_load(velo_scan_cache* k, int32_t frame, velo_ctx* c, int32_t as_t
         if (e.n > 0) HIP_TRY(hipMemcpyAsync(c->src.p, e.cloud.p, sizeof(float4) * (size_t)e.n, hipMemcpyDeviceToDevice, c->stream));
         c->h_src_off = e.h_off;
         c->n_src = e.n; c->n_src_rings = e.n_rings;
-        c->have_source = false;
+        c->have_source = false; c->src_bbox_valid = false;
         c->src_raw.on = false; return source_finalize(c);          // (the cloud is packed already)
     }
     for (int r = 0; r < e.n_rings; r++) if (e.h_off[(size_t)r + 1] <= e.h_off[(size_t)r]) return fail(VELO_ERR_INVALID, "target ring %d is empty", r);

@@ -328,12 +328,35 @@ target_ingest_kernel(const char* __restrict__ src, int64_t stride, int n, const 
 __global__ void __launch_bounds__(256)
 source_ingest_kernel(const char* __restrict__ raw, int64_t stride, int n, float4* __restrict__ src, int nb_pack,
                      const int* __restrict__ src_off, const int* __restrict__ q_off, int n_rings, int skip, int nq, int patch, int patch_rings, int patch_len,
-                     int* __restrict__ q_src, float4* __restrict__ qpts) {
+                     int* __restrict__ q_src, float4* __restrict__ qpts, unsigned* __restrict__ mnmx) {
     if ((int)blockIdx.x < nb_pack) {
+        // (the pack blocks also take the cloud's bounding box -- the keys target_ingest_kernel would compute for the same points: a drive
+        //  promotes this scan to target one frame later, and with the box already on the host the index build needs no host wait)
         const int i = blockIdx.x * 256 + threadIdx.x;
-        if (i >= n) return;
-        const float* p = (const float*)(raw + (int64_t)i * stride);
-        src[i] = make_float4(p[0], p[1], p[2], 0.0f);
+        float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        if (i < n) {
+            const float* p = (const float*)(raw + (int64_t)i * stride);
+            const float4 v = make_float4(p[0], p[1], p[2], 0.0f);
+            src[i] = v;
+            if (isfinite(v.x) && isfinite(v.y) && isfinite(v.z)) { mn[0] = mx[0] = v.x; mn[1] = mx[1] = v.y; mn[2] = mx[2] = v.z; }
+        }
+        if (!mnmx) return;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
+        }
+        __shared__ float red[4][6];
+        const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+        if (lane == 0) { for (int k = 0; k < 3; k++) { red[wid][k] = mn[k]; red[wid][3 + k] = mx[k]; } }
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            const int k = threadIdx.x;
+            float v = red[0][k];
+            for (int w = 1; w < 4; w++) v = (k < 3) ? fminf(v, red[w][k]) : fmaxf(v, red[w][k]);
+            const unsigned key = f2key(v), cur = mnmx[k];
+            if (k < 3) { if (v < 3.0e38f && key < cur) atomicMin(&mnmx[k], key); } else { if (v > -3.0e38f && key > cur) atomicMax(&mnmx[k], key); }
+        }
         return;
     }
     const int i = ((int)blockIdx.x - nb_pack) * 256 + threadIdx.x;
