@@ -15,7 +15,7 @@ def kline(rows):
 
 block = f"""* **This round's line** (`profiles/{tag}_bench.json`, same command as the driver's, one box; boxes differ by ± 5 %):
 
-  | Workload (8 different pairs in flight) | pairs/s | single pair | top kernels (share of kernel time, launch, bytes, fraction of 8 TB/s) |
+  | Workload (8 drives in flight, one frame per step; C4: 8 scans against the map) | pairs/s | single pair | top kernels (share of kernel time, launch, bytes, fraction of 8 TB/s) |
   |---|---|---|---|
   | **C2** (`configs[1]`, headline) | **{B['value']:.0f}** ({B['ms_per_step']:.2f} ms per step; chain {B['chain']['calls']} calls / {B['chain']['misses']} misses; {B['config']['lm_evaluations_per_pair']:.1f} LM evaluations per pair) | {sp.get('pairs_per_s', 0):.0f} /s (**{sp.get('ms_per_pair', 0):.2f} ms**) | {kline(B['kernels'])} |
 """ + "".join(
