@@ -66,6 +66,32 @@ def run(n_seeds, first_seed=0):
           assert np.array_equal(xsingle, xs[i]), ("single vs batch", seed, i)
           checked += 1
       for cc in ctxs: cc.close()
+      # a few frames of random small DRIVES through the bench's step (round 4): targets promoted on the device (VELO_SCAN_PROMOTE), the
+      # frame pair's matches handed over in the same call on half of the seeds (velo_register_batch_visual), guesses from the native
+      # hand-off -- every registration against the oracle on the same two frames and the same guess
+      import bench
+      nd, nf = int(rng.integers(2, 6)), int(rng.integers(3, 5))
+      nb, na = int(rng.choice([8, 16, 24])), int(rng.integers(100, 300))
+      drives = [synth.drive(nf, seed=int(rng.integers(0, 10 ** 6)), n_beams=nb, n_azimuth=na) for _ in range(nd)]
+      with_vis = rng.random() < 0.5
+      visd = [[synth.stereo_matches(int(rng.integers(5, 120)), seed=int(rng.integers(1, 10 ** 6)), mix="all", x_true=dr["x_true"][k]) for k in range(nf - 1)] for dr in drives] if with_vis else None
+      skip = int(rng.choice([1, 1, 3]))
+      ctxs = [api.Context(0, icp_skip=skip) for _ in range(nd)]
+      w = bench.DriveWalker(api, ctxs, [dr["frames"] for dr in drives], 0, visd)
+      for k in range(1, nf):
+          x0 = w.x0.copy()
+          xs, Ts, Ss = w.step()
+          for i in range(nd):
+              oo = O.Oracle(icp_skip=skip, threads=8)
+              oo.set_target(*drives[i]["frames"][k - 1]); oo.set_source(*drives[i]["frames"][k])
+              if with_vis: oo.set_visual(visd[i][k - 1])
+              xo, To, So = oo.frame_to_frame(x0[i])
+              assert H.pose_close(xs[i], xo), ("drive pose", seed, k, i, xs[i], xo)
+              a = [(Ss[i].solves[j].termination, Ss[i].solves[j].lm_iterations, Ss[i].solves[j].n_icp_valid, Ss[i].solves[j].n_visual_blocks) for j in range(Ss[i].n_solves)]
+              b = [(So.solves[j].termination, So.solves[j].lm_iterations, So.solves[j].n_icp_valid, So.solves[j].n_visual_blocks) for j in range(So.n_solves)]
+              assert a == b, ("drive solve summaries", seed, k, i, a, b)
+              checked += 1
+      for cc in ctxs: cc.close()
   return checked
 
 
