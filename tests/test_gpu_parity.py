@@ -886,3 +886,33 @@ def test_register_batch_visual_hands_matches_over_with_the_scans(hip_lib, oracle
     assert H.pose_close(x1[0], xo, 1e-9, 1e-10)
     for c in a + b:
         c.close()
+
+
+def test_batch_entry_points_report_bad_jobs_as_status_codes(hip_lib):
+    """The drive entry points refuse what they cannot do with a status, and leave the contexts usable: a PROMOTE target on a context that
+    holds no source, a negative match count, a null match pointer with a positive count, a missing count array."""
+    import ctypes as C
+    d = H.small_pair(16, 128)
+    ctxs = [api.Context(0, icp_skip=1) for _ in range(2)]
+    srcs = api.scan_refs([(d["src_xyz"], d["src_off"])] * 2, 0)
+    x0s = np.tile(d["x0"], (2, 1))
+    with pytest.raises(api.VeloError, match="no source cloud to promote"):
+        api.register_batch(ctxs, None, None, x0s, refs=(api.promote_refs(2), srcs))
+    tg = api.scan_refs([(d["tgt_xyz"], d["tgt_off"])] * 2, 0)
+    ptrs, cnt, keep = api.visual_refs([None, None])
+    cnt[1] = -3
+    with pytest.raises(api.VeloError, match="bad visual arguments"):
+        api.register_batch(ctxs, None, None, x0s, refs=(tg, srcs), visual=(ptrs, cnt, keep))
+    cnt[1] = 5                                                             # five matches announced, no pointer
+    with pytest.raises(api.VeloError, match="bad visual arguments"):
+        api.register_batch(ctxs, None, None, x0s, refs=(tg, srcs), visual=(ptrs, cnt, keep))
+    lib = ctxs[0]._lib
+    arr = (C.c_void_p * 2)(*[c.handle for c in ctxs])
+    x = np.zeros(12)
+    assert lib.velo_register_batch_visual(arr, 2, None, None, None, None, x.ctypes.data_as(C.POINTER(C.c_double)), None, None) != 0
+    # ... and the same contexts register normally afterwards, promotion included
+    xs, _, _ = api.register_batch(ctxs, None, None, x0s, refs=(tg, srcs))
+    xs2, _, _ = api.register_batch(ctxs, None, None, x0s, refs=(api.promote_refs(2), srcs))   # the source registered against itself
+    assert np.all(np.isfinite(xs)) and np.all(np.isfinite(xs2)) and np.linalg.norm(xs2[0][3:]) < 0.05
+    for c in ctxs:
+        c.close()
