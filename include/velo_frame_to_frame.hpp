@@ -21,6 +21,7 @@
 #define VELO_FRAME_TO_FRAME_HPP_
 
 #include <array>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -335,6 +336,59 @@ void triangulatePoints(Context& ctx, const Rig& rig, const std::vector<int>& ids
         p.x = pts[3 * l]; p.y = pts[3 * l + 1]; p.z = pts[3 * l + 2];
     }
 }
+
+// ---- the pose chain of the drive loop (main.cpp:179,305-331,407-437): host arithmetic, no GPU ----------------------------------------
+// What main.cpp does around frameToFrame, as one small object: the constant-velocity guess from the last two poses
+// (main.cpp:311-320,331; {0,0,0,0,0,1} for the first pair, main.cpp:170), the chained pose ceres_poses_mat[frame] =
+// ceres_poses_mat[frame-1] * dpose (main.cpp:408), the agreement of a registration with its prediction (main.cpp:416-424) and the rule
+// that skips an edge over dframe > 1 frames on poor agreement (main.cpp:426-437, thresholds kitti.h:33-35).  4x4s are row-major doubles.
+class PoseChain {
+public:
+    PoseChain() { std::array<double, 16> I{}; I[0] = I[5] = I[10] = I[15] = 1.0; poses_.push_back(I); }
+    size_t frames() const { return poses_.size(); }
+    const std::array<double, 16>& pose(size_t k) const { return poses_.at(k); }
+    // the guess frameToFrame starts from for frame `frames()` against frame `frames() - 1`  (the array main.cpp calls `transform`)
+    void predict(double transform[6]) const {
+        if (poses_.size() < 2) { const double first[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 1.0}; std::memcpy(transform, first, sizeof(first)); return; }
+        std::memcpy(transform, next_.data(), sizeof(double) * 6);
+    }
+    // the registration of the new frame returned dpose: chain it (main.cpp:408); returns the agreement 6-vector with the prediction
+    std::array<double, 6> push(const double dpose[16]) {
+        double guess[6], dT[16];
+        predict(guess);
+        check(velo_pose_vec_to_mat(guess, dT), "velo_pose_vec_to_mat");                       // main.cpp:315-319: what the prediction was, as a matrix
+        std::array<double, 6> ag = agreement(dpose, dT);
+        std::array<double, 16> P = poses_.back();
+        check(velo_pose_handoff(1, P.data(), dpose, next_.data()), "velo_pose_handoff");      // main.cpp:408 + the next frame's guess (main.cpp:311-331)
+        poses_.push_back(P);
+        return ag;
+    }
+    // main.cpp:416-417: pose_vec2mat(dpose * dT^-1), dT rigid
+    static std::array<double, 6> agreement(const double dpose[16], const double dT[16]) {
+        double inv[16] = {0}, M[16];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) inv[4 * i + j] = dT[4 * j + i];            // [R^T | -R^T t]
+        for (int i = 0; i < 3; i++) inv[4 * i + 3] = -(inv[4 * i] * dT[3] + inv[4 * i + 1] * dT[7] + inv[4 * i + 2] * dT[11]);
+        inv[15] = 1.0;
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { double v = 0.0; for (int k = 0; k < 4; k++) v += dpose[4 * i + k] * inv[4 * k + j]; M[4 * i + j] = v; }
+        std::array<double, 6> a;
+        check(velo_pose_mat_to_vec(M, a.data()), "velo_pose_mat_to_vec");
+        return a;
+    }
+    // main.cpp:426-437 (odometry pass): nullptr = keep the edge, else why it is skipped.  dframe == 1 edges are never skipped.
+    static const char* edge_rejected(const std::array<double, 6>& a, int dframe, double agreement_t_thresh = 0.1, double agreement_r_thresh = 0.05,
+                                     double loop_close_thresh = 10.0) {
+        if (dframe <= 1) return nullptr;
+        const double t = std::sqrt(a[3] * a[3] + a[4] * a[4] + a[5] * a[5]), r = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]);
+        const double lim = agreement_t_thresh * dframe < loop_close_thresh ? agreement_t_thresh * dframe : loop_close_thresh;
+        if (t > lim) return "poor t agreement";
+        if (r > agreement_r_thresh) return "poor r agreement";
+        return nullptr;
+    }
+
+private:
+    std::vector<std::array<double, 16>> poses_;      // ceres_poses_mat (main.cpp:179), pose 0 = identity
+    std::array<double, 6> next_{};                   // the guess for the next pair, from velo_pose_handoff
+};
 
 }  // namespace velo_hip
 #endif  // VELO_FRAME_TO_FRAME_HPP_

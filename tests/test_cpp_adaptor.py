@@ -49,6 +49,18 @@ def test_plain_c99_caller_of_the_pose_handoff(tmp_path):
     assert out.returncode == 0 and "handoff ok" in out.stdout, out.stdout + out.stderr
 
 
+def test_pose_chain_of_the_cxx_adaptor(tmp_path):
+    """velo_hip::PoseChain -- the reference's hand-off, chaining, agreement and edge-skipping rule (main.cpp:305-331,407-437) as the C++
+    adaptor offers them -- against hand-computed values.  CPU only."""
+    build.build_hip()
+    exe = str(tmp_path / "test_pose_chain")
+    csrc = os.path.dirname(build.LIB)
+    subprocess.run(["g++", "-std=c++11", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", CPP, os.path.join(CPP, "test_pose_chain.cpp"), "-o", exe,
+                    "-L", csrc, "-lvelo_hip", f"-Wl,-rpath,{csrc}", "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "pose chain ok" in out.stdout, out.stdout + out.stderr
+
+
 def test_adaptor_compiles_as_cxx11(tmp_path):
     assert os.path.exists(compile_adaptor(tmp_path))
 
