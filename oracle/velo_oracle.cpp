@@ -519,8 +519,9 @@ int build_visual(Oracle& o, const double x[6], int iter) {
             for (int k = 0; k < 3; k++) { b.c[k] = m.p3_1[k]; b.c[3 + k] = m.p3_2[k]; }
             b.loss = Loss{2, P.loss_thresh_3D3D, 1.0};
             block_eval(b.kind, b.c, x, r, nullptr);
-            const double th = P.loss_thresh_3D3D * P.outlier_reject / iter;
-            if (iter > 1 && r[0] * r[0] + r[1] * r[1] + r[2] * r[2] > th * th) continue;
+            // velo.h:674-681 as written: loss_thresh*outlier_reject/iter * loss_thresh*outlier_reject/iter, evaluated left to right
+            const double th2 = P.loss_thresh_3D3D * P.outlier_reject / iter * P.loss_thresh_3D3D * P.outlier_reject / iter;
+            if (iter > 1 && r[0] * r[0] + r[1] * r[1] + r[2] * r[2] > th2) continue;
             push(b, VELO_RESIDUAL_3D3D);
         }
         if (!d1 && !d2) {                                                         // velo.h:694-722
@@ -536,14 +537,15 @@ int build_visual(Oracle& o, const double x[6], int iter) {
             }
         }
         if (P.enable_3d2d) {
-            const double th = P.loss_thresh_3D2D * P.outlier_reject / iter;
+            // velo.h:739-742,772-775 as written (left to right, like the 3D3D gate)
+            const double th2 = P.loss_thresh_3D2D * P.outlier_reject / iter * P.loss_thresh_3D2D * P.outlier_reject / iter;
             if (d1) {                                                             // velo.h:724-756
                 Block b; b.kind = K_3D2D;
                 for (int k = 0; k < 3; k++) { b.c[k] = m.p3_1[k]; b.c[5 + k] = m.t_cam[k]; }
                 b.c[3] = m.p2_2[0]; b.c[4] = m.p2_2[1];
                 b.loss = Loss{2, P.loss_thresh_3D2D, P.weight_3D2D};
                 block_eval(b.kind, b.c, x, r, nullptr);
-                if (iter > 1 && r[0] * r[0] + r[1] * r[1] > th * th) continue;
+                if (iter > 1 && r[0] * r[0] + r[1] * r[1] > th2) continue;
                 push(b, VELO_RESIDUAL_3D2D);
             }
             if (d2) {                                                             // velo.h:757-789
@@ -552,7 +554,7 @@ int build_visual(Oracle& o, const double x[6], int iter) {
                 b.c[3] = m.p2_1[0]; b.c[4] = m.p2_1[1];
                 b.loss = Loss{2, P.loss_thresh_3D2D, P.weight_3D2D};
                 block_eval(b.kind, b.c, x, r, nullptr);
-                if (iter > 1 && r[0] * r[0] + r[1] * r[1] > th * th) continue;
+                if (iter > 1 && r[0] * r[0] + r[1] * r[1] > th2) continue;
                 push(b, VELO_RESIDUAL_2D3D);
             }
         }

@@ -2582,22 +2582,22 @@ __global__ void visual_gate_kernel(const double* __restrict__ xdev, VisualParams
     const double it = (double)iter;
     if (m.d1 && m.d2) {                                                      // velo.h:662-693
         visual_block_eval(P, m, 0, r, J);
-        const double th = V.th_3d3d * V.outlier_reject / it;
-        if (iter > 1 && r[0] * r[0] + r[1] * r[1] + r[2] * r[2] > th * th) stop = true; else f0 = 1 + 0;
+        const double th2 = V.th_3d3d * V.outlier_reject / it * V.th_3d3d * V.outlier_reject / it;      // velo.h:674-681, left to right as written
+        if (iter > 1 && r[0] * r[0] + r[1] * r[1] + r[2] * r[2] > th2) stop = true; else f0 = 1 + 0;
     }
     if (!stop && !m.d1 && !m.d2 && V.enable_2d2d) {                          // velo.h:694-722
         visual_block_eval(P, m, 0, r, J);
         if (iter > 1 && fabs(r[0]) > V.th_2d2d * V.outlier_reject / it) stop = true; else f0 = 1 + 3;
     }
     if (V.enable_3d2d) {
-        const double th = V.th_3d2d * V.outlier_reject / it;
+        const double th2 = V.th_3d2d * V.outlier_reject / it * V.th_3d2d * V.outlier_reject / it;      // velo.h:739-742,772-775
         if (!stop && m.d1) {                                                 // velo.h:724-756
             visual_block_eval(P, m, 1, r, J);
-            if (iter > 1 && r[0] * r[0] + r[1] * r[1] > th * th) stop = true; else f1 = 1 + 1;
+            if (iter > 1 && r[0] * r[0] + r[1] * r[1] > th2) stop = true; else f1 = 1 + 1;
         }
         if (!stop && m.d2) {                                                 // velo.h:757-789
             visual_block_eval(P, m, 2, r, J);
-            if (iter > 1 && r[0] * r[0] + r[1] * r[1] > th * th) stop = true; else f2 = 1 + 2;
+            if (iter > 1 && r[0] * r[0] + r[1] * r[1] > th2) stop = true; else f2 = 1 + 2;
         }
     }
     flags[3 * i + 0] = f0; flags[3 * i + 1] = f1; flags[3 * i + 2] = f2;
