@@ -142,3 +142,23 @@ def test_ring_segmenter_as_written():
     k = re.sub(r"\s+", "", open(os.path.join(REF, "kitti.h")).read())
     assert "floatprev_y=0;" in k and "if(i>0&&p.x>0&&(p.y>0)!=(prev_y>0)){scan_id++;}" in k
     assert "cloud_tmp->at(scan_ids[s][_i-1-(i+_i/2)%_i])" in k and "pcl::transformPointCloud(*point_cloud,*cloud_tmp,velo_to_cam);" in k
+
+
+def test_widened_rows_as_written():
+    """The lines the oracle's restatements of SURVEY 8(f) rows 3-4 follow: linterpolate in float (utility.h:7-29), the projection, window
+    test and occlusion-stack rules of projectLidarToCamera (velo.h:345-366), the bisection and acceptance test of featureDepthAssociation
+    (velo.h:397-422), the losses of triangulatePoint (velo.h:1078-1122)."""
+    u = re.sub(r"\s+", "", open(os.path.join(REF, "utility.h")).read())
+    assert u.count("floata=(mid-start)/(end-start);floatb=1-a;") == 2
+    assert "floatx=p1.x*b+p2.x*a;floaty=p1.y*b+p2.y*a;floatz=p1.z*b+p2.z*a;" in u and "returnp1*b+p2*a;" in u
+    v = re.sub(r"\s+", "", _velo())
+    assert "pcl::PointXYZpp(p.x+t(0),p.y+t(1),p.z+t(2));cv::Point2fc(pp.x/pp.z,pp.y/pp.z);" in v
+    assert "if(pp.z>0&&c.x>=min_x[cam]&&c.x<max_x[cam]&&c.y>=min_y[cam]&&c.y<max_y[cam])" in v
+    assert "while(projection[s].size()>0&&c.x<projection[s].back().x&&pp.z<projected_points.back().z)" in v       # pop what the new point occludes
+    assert "if(projection[s].size()>0&&c.x<projection[s].back().x&&pp.z>projected_points.back().z){bad++;continue;}" in v   # or drop the new point
+    assert "if(projection[s].size()<=1){last_interp=-1;continue;}" in v
+    assert "intlo=0,hi=projection[s].size()-2,mid=0;while(lo<=hi){mid=(lo+hi)/2;if(projection[s][mid].x>kp.x){hi=mid-1;}elseif(projection[s][mid+1].x<=kp.x){lo=mid+1;}else{found=true;" in v
+    assert ("if(last_interp!=-1&&(projection[s][mid].y>kp.y)!=(projection[s-1][last_interp].y>kp.y)&&abs(projection[s][mid].x-projection[s][mid+1].x)<depth_assoc_thresh"
+            "&&abs(projection[s-1][last_interp].x-projection[s-1][last_interp+1].x)<depth_assoc_thresh)") in v
+    tri = v[v.index("triangulatePoint("):]
+    assert "newceres::TrivialLoss," in tri and "newceres::ScaledLoss(newceres::CauchyLoss(loss_thresh_3D2D),weight_3D2D,ceres::TAKE_OWNERSHIP)" in tri
