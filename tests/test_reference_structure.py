@@ -162,3 +162,17 @@ def test_widened_rows_as_written():
             "&&abs(projection[s-1][last_interp].x-projection[s-1][last_interp+1].x)<depth_assoc_thresh)") in v
     tri = v[v.index("triangulatePoint("):]
     assert "newceres::TrivialLoss," in tri and "newceres::ScaledLoss(newceres::CauchyLoss(loss_thresh_3D2D),weight_3D2D,ceres::TAKE_OWNERSHIP)" in tri
+
+
+def test_residual_stats_as_written():
+    """velo.h:921-1025: evaluated WITHOUT loss functions; one number per block (sqrt of the squared rows for 3D3D / 3D2D / 2D3D, `abs` for
+    2D2D and for everything behind the visual residuals = 3DPD); sums in block order, then sort; printed: element size/2 and sum/size."""
+    v = re.sub(r"\s+", "", _velo())
+    st = v[v.rindex("voidresidualStats("):v.index("Eigen::Vector3dtriangulatePoint(") if "Eigen::Vector3dtriangulatePoint(" in v else len(v)]
+    assert "evaluate_options.apply_loss_function=false;" in st
+    assert "residuals_3D3D.push_back(sqrt(residuals[ri]*residuals[ri]+residuals[ri+1]*residuals[ri+1]+residuals[ri+2]*residuals[ri+2]));ri+=3;" in st
+    assert st.count("sqrt(residuals[ri]*residuals[ri]+residuals[ri+1]*residuals[ri+1]));ri+=2;") == 2
+    assert "residuals_2D2D.push_back(abs(residuals[ri]));ri++;" in st and "for(;ri<residuals.size();ri++){residuals_3DPD.push_back(abs(residuals[ri]));}" in st
+    assert st.index("for(autor:residuals_3DPD){sum_3DPD+=r;}") < st.index("std::sort(residuals_3D3D.begin(),residuals_3D3D.end());")
+    for t in ("3D3D", "3D2D", "2D3D", "2D2D", "3DPD"):
+        assert f"residuals_{t}[residuals_{t}.size()/2]" in st and f"sum_{t}/residuals_{t}.size()" in st, t
