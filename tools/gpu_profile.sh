@@ -7,13 +7,13 @@ WL=${WORKLOAD:-c2}          # WORKLOAD=c4 tools/gpu_profile.sh r02_c4: the same 
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-STEPS=${STEPS:-10}
+STEPS=${STEPS:-20}          # the driver's command: python bench.py --steps 20 --warmup 5
 # the drives' frames are synthesised ONCE, before any profiler is loaded (worker processes); every pass below reads them back
 export VELO_DRIVE_CACHE=/tmp/velo_drive_cache
-python3 $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-legs --workload $WL > $OUT/bench_plain.json 2> $OUT/bench_plain.err
+python3 $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-legs --workload $WL > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --batch 1 --no-cpu-baseline --no-legs --workload $WL > /dev/null 2>&1
 python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --batch 2 --no-cpu-baseline --no-legs --workload $WL > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-legs --workload $WL > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup 5 --no-cpu-baseline --no-legs --workload $WL > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --batch 1 --no-cpu-baseline --no-legs --workload $WL > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --batch 1 --no-cpu-baseline --no-legs --workload $WL > /dev/null 2>&1
 # the kernels of a lock-step group alone on the chip (one group of two contexts): HBM-side bytes per launch of the batched kernels

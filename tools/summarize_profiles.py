@@ -16,7 +16,13 @@ if f:
         for r in rows:
             w.writerow([r["Name"].split("(")[0], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
     wl = tag.rsplit("_", 1)[1] if tag.rsplit("_", 1)[-1] in ("c1", "c3", "c4") else "c2"
-    lines.append(f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-legs --workload {wl}  (default batch: 8 pairs in flight)")
+    st, wu = 20, 5
+    try:
+        dd = json.loads(open(os.path.join(src, "bench_under_rocprof.json")).read().strip().splitlines()[-1])
+        st, wu = dd["steps"], dd["warmup"]
+    except Exception:
+        pass
+    lines.append(f"rocprofv3 --kernel-trace --stats -- python3 bench.py --steps {st} --warmup {wu} --no-cpu-baseline --no-legs --workload {wl}  (default batch: 8 pairs in flight; the driver's command without its CPU leg and side legs)")
     for r in rows[:8]:
         lines.append(f"  {r['Name'].split('(')[0][:58]:58s} calls {r['Calls']:>6}  avg {float(r['AverageNs'])/1e3:8.1f} us  {r['Percentage']}%")
 b = os.path.join(src, "bench_under_rocprof.json")

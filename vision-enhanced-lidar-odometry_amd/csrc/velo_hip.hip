@@ -194,7 +194,8 @@ struct velo_ctx {
     DevBuf<int> vis_counts;                       // chain mode: [f2f iteration][blocks, residuals] selected by the device-side gate
     DevBuf<int> scan_tiles, cursor, scan_total;   // scratch of an index build / of the segmenter's scans
     struct { const char* dsrc = nullptr; int64_t stride = 0; bool on = false; } src_raw;   // set_source: the records the fused ingest launch still has to read (source_finalize)
-    bool src_bbox_valid = false;         // h_int[16..21] hold the bounding-box keys of the source cloud (source_ingest; on the host after the call's sync)
+    bool src_bbox_valid = false;         // h_int[16..21] hold the bounding-box keys of the source cloud (source_ingest; on the host once src_bbox_ev has passed)
+    hipEvent_t src_bbox_ev = nullptr;    // recorded behind the keys' copy: a promotion waits on it (a no-op after any completed call) before it trusts them
     bool target_early = false;           // promote_begin already sized and enqueued the index (box known): target_finalize_end has nothing to wait for
     int lb_zeroed = 0;                            // status words of the one-pass scan that target_ingest_kernel cleared for the next build (0: build_grid clears them)
     bool batch_load = false;                      // set while velo_register_batch loads this context's scans for a batch of two or more (see build_grid)
@@ -1473,6 +1474,8 @@ int source_ingest(velo_ctx* c) {
     HIP_TRY(hipGetLastError());
     // the box keys ride back on the stream; every way out of a call synchronises it, so a LATER call (a promotion) may read them
     HIP_TRY(hipMemcpyAsync(c->h_int + 16, c->src_off.p + 2 * (R + 1), sizeof(unsigned) * 6, hipMemcpyDeviceToHost, c->stream));
+    if (!c->src_bbox_ev) HIP_TRY(hipEventCreateWithFlags(&c->src_bbox_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->src_bbox_ev, c->stream));
     c->src_bbox_valid = true;
     c->src_raw.on = false;
     c->q_patch = patch;
@@ -1746,6 +1749,7 @@ int velo_destroy(velo_ctx* c) {
     if (c->h_x) (void)hipHostFree(c->h_x);
     if (c->h_int) (void)hipHostFree(c->h_int);
     for (auto& ps : c->pin) { if (ps.ev) (void)hipEventDestroy(ps.ev); if (ps.p) (void)hipHostFree(ps.p); }
+    if (c->src_bbox_ev) (void)hipEventDestroy(c->src_bbox_ev);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto& e : c->assoc_events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
@@ -1939,7 +1943,10 @@ static int promote_begin(velo_ctx* c) {
     const bool box_known = c->src_bbox_valid && c->T->n_tgt > 0;
 #endif
     unsigned keys[6];
-    if (box_known) std::memcpy(keys, c->h_int + 16, sizeof(keys));
+    if (box_known) {
+        HIP_TRY(hipEventSynchronize(c->src_bbox_ev));                  // passed long ago unless the loading call ended on an error before its synchronisation
+        std::memcpy(keys, c->h_int + 16, sizeof(keys));
+    }
     c->src_bbox_valid = false;
     VELO_TRY(target_ingest(c, reinterpret_cast<const float*>(c->T->tgt.p), (int64_t)sizeof(float4), 1));
     if (box_known) {
