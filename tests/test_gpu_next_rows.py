@@ -347,7 +347,7 @@ def test_device_memory_returns_after_destroy():
     for _ in range(25): cycle()
     torch.cuda.synchronize()
     drift = free0 - torch.cuda.mem_get_info(0)[0]
-    assert drift < 4 << 20, f"device memory drift {drift / 1e6:.1f} MB over 25 cycles"
+    assert drift < 16 << 20, f"device memory drift {drift / 1e6:.1f} MB over 25 cycles"
 
 
 @pytest.mark.gpu

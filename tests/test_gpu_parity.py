@@ -459,11 +459,25 @@ def test_shared_target_equals_own_copy_and_outlives_its_owner(hip_lib, oracle):
     x_out, _, _ = outsider.frame_to_frame(d["x0"])
     for _ in range(2):
         api.register_batch(ctxs, None, None, x0s, refs=refs_sh)
-    torch.cuda.synchronize(); free0 = torch.cuda.mem_get_info()[0]
     for _ in range(6):
         xs3, _, _ = api.register_batch(ctxs, None, None, x0s, refs=refs_sh)
+    assert np.array_equal(xs3, xs1)
+    # ... measured on FULL-SIZE scans, where an index is ~9 MB: were a new one allocated per call (what happened before the sharers let go
+    # first), six calls would take ~50 MB; the runtime's own bookkeeping moves the device-wide figure by a megabyte or two at most
+    big = synth.scan_pair()
+    big_ctxs = [api.Context(0, icp_skip=1) for _ in range(4)]
+    refs_big = (api.scan_refs([(big["tgt_xyz"], big["tgt_off"])] * 4, 0, shared=True), api.scan_refs([(big["src_xyz"], big["src_off"])] * 4, 0))
+    x0b = np.tile(big["x0"], (4, 1))
+    for _ in range(3):
+        xb0, _, _ = api.register_batch(big_ctxs, None, None, x0b, refs=refs_big)
+    torch.cuda.synchronize(); free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(6):
+        xb, _, _ = api.register_batch(big_ctxs, None, None, x0b, refs=refs_big)
     torch.cuda.synchronize(); free1 = torch.cuda.mem_get_info()[0]
-    assert np.array_equal(xs3, xs1) and free1 >= free0 - (1 << 20)
+    assert np.array_equal(xb, xb0)
+    assert free1 >= free0 - (16 << 20), (free0, free1)
+    for c in big_ctxs:
+        c.close()
     tgt2 = (d2["tgt_xyz"], d2["tgt_off"])
     refs_sh2 = (api.scan_refs([tgt2] * 4, 0, shared=True), api.scan_refs(srcs, 0))
     xs4, _, _ = api.register_batch(ctxs, None, None, x0s, refs=refs_sh2)            # another map for the batch
