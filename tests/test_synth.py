@@ -103,3 +103,47 @@ def test_scan_to_map_with_several_query_scans():
     assert len(qs) == 3 and np.array_equal(qs[0]["src_xyz"], m["src_xyz"])
     assert all(len(q["src_off"]) - 1 == 16 for q in qs) and not np.array_equal(qs[1]["src_xyz"], qs[2]["src_xyz"])
     assert "queries" not in synth.scan_to_map(3 * 16 * 100, n_beams=16, n_azimuth=100)
+
+
+def test_drive_plans_are_car_like_and_prefix_consistent():
+    """bench.py's default workload (synth.drive_plan): speed 0.6-1.4 m per frame changing by at most 0.1, the car inside the free lane
+    (boxes start 1.7 m from the centre line), smooth yaw; drives of up to 42 frames share their first poses with shorter ones (what the
+    profiling passes' frame cache relies on); every drive has its own scene and trajectory."""
+    for seed in range(8):
+        p = synth.drive_plan(40, seed)
+        X = np.array(p["x_true"])
+        v = np.linalg.norm(X[:, 3:], axis=1)
+        assert v.min() > 0.55 and v.max() < 1.45 and np.abs(np.diff(X[:, 5])).max() <= 0.11
+        assert np.abs(X[:, 1]).max() < 0.03 and np.abs(np.diff(X[:, 1])).max() < 0.01          # yaw about the camera's y axis
+        ys = np.array([T[1, 3] for T in p["poses_velo"]])
+        assert np.abs(ys).max() < 1.3
+        q = synth.drive_plan(26, seed)
+        assert q["scene_kw"] == p["scene_kw"]
+        assert all(np.array_equal(a, b) for a, b in zip(q["poses_velo"], p["poses_velo"][:26]))
+    a, b = synth.drive_plan(10, 0), synth.drive_plan(10, 1)
+    assert not np.allclose(a["x_true"][3], b["x_true"][3])
+    long = synth.drive_plan(211, 3)                                        # --steps 200: the road grows with the drive
+    assert long["scene_kw"]["half_length"] > 150 and long["scene_kw"]["box_horizon"] == 80.0
+    assert max(abs(T[0, 3]) for T in long["poses_velo"]) < long["scene_kw"]["half_length"] - 10
+
+
+def test_drive_frames_are_ring_scans_and_the_bench_cache_round_trips(tmp_path, monkeypatch):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    plan = synth.drive_plan(3, 5)
+    xyz, off = synth.drive_frame(plan, 1, n_beams=16, n_azimuth=128)
+    assert xyz.dtype == np.float32 and xyz.shape == (16 * 128, 3) and off[0] == 0 and off[-1] == 16 * 128 and len(off) in (17, 18)
+    again = synth.drive_frame(plan, 1, n_beams=16, n_azimuth=128)
+    assert np.array_equal(xyz, again[0])                                   # frames are functions of (plan, k): a pool may make them in any order
+    monkeypatch.setenv("VELO_DRIVE_CACHE", str(tmp_path))
+    small = synth.drive_frame
+    monkeypatch.setattr(synth, "drive_frame", lambda pl, k: small(pl, k, 8, 64))
+    bench._drives.clear()
+    a = bench.make_drives(2, 5, procs=1)
+    bench._drives.clear()
+    b = bench.make_drives(2, 4, procs=1)                                   # read back: a prefix of the cached drives
+    assert (tmp_path / "drives_b2.npz").exists()
+    assert all(np.array_equal(a[i]["frames"][k][0], b[i]["frames"][k][0]) and np.array_equal(a[i]["frames"][k][1], b[i]["frames"][k][1])
+               for i in range(2) for k in range(4))
+    bench._drives.clear()
