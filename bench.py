@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="independent pairs in flight per GPU (one context + stream each)")
     ap.add_argument("--same-pairs", action="store_true", help="A/B: B fixed, different pairs re-registered every step instead of B drives (what round 3 measured)")
     ap.add_argument("--same-pair", action="store_true", help="A/B: every context registers the canonical pair (what rounds 1-2 measured)")
+    ap.add_argument("--host-inputs", action="store_true", help="the drives' frames stay in host memory (numpy): every step uploads its B frames -- the PCIe-inclusive rate (never the headline)")
     ap.add_argument("--gen-procs", type=int, default=0, help="worker processes that synthesise the drives' frames (0: min(16, host cores))")
     ap.add_argument("--threads-per-pair", dest="batch_api", action="store_false",
                     help="drive every pair from its own host thread (frame_to_frame) instead of velo_register_batch")
@@ -377,7 +378,8 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
     else:
         tgts = [(resident(d["tgt_xyz"]), d["tgt_off"]) for d in pairs]
     srcs = [(resident(d["src_xyz"]), d["src_off"]) for d in pairs]
-    frames_dev = [[(resident(f[0]), f[1]) for f in p["frames"]] for p in drives[:B]] if drive else None
+    keep = (lambda arr: np.ascontiguousarray(arr)) if getattr(a, "host_inputs", False) else resident
+    frames_dev = [[(keep(f[0]), f[1]) for f in p["frames"]] for p in drives[:B]] if drive else None
     torch.cuda.synchronize()
     ctxs = [api.Context(rig.local_rank, icp_skip=icp_skip) for _ in range(B)]
     comm_info = None
@@ -576,7 +578,8 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
                   "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
         rf["traffic"] = None
         leg = {
-            "workload": label, "mode": mode, "pairs_in_flight_per_gpu": B, "distinct_pairs": W["distinct"] if mode == "replicas" else 1,
+            "workload": label + ("; inputs in HOST memory, uploaded every step (PCIe-inclusive)" if (drive and getattr(a, "host_inputs", False)) else ""),
+            "mode": mode, "pairs_in_flight_per_gpu": B, "distinct_pairs": W["distinct"] if mode == "replicas" else 1,
             "steps": steps, "warmup": warmup,
             "pairs_per_s": total_pairs / dt, "ms_per_step": 1e3 * dt / steps,
             "Nq": int(s0.n_queries), "Nt": int(s0.n_target),
