@@ -36,7 +36,8 @@ def test_single_gpu_bench_line_meets_the_contract(hip_lib, tmp_path):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert rf["kernel"].endswith("_kernel") and 0 < rf["frac"] < 1
     # traffic: the PMC figure of THIS kernel instantiation from the committed passes, or null -- never another instantiation's
-    tj = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
+    import glob
+    tj = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))[-1]))      # the file bench.py reads: the newest round's
     known = dict(tj.get("traffic_by_kernel") or {})
     known.update(tj.get("traffic_by_kernel_in_flight") or {})
     assert rf["traffic"] == known.get(rf["kernel"])
