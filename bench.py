@@ -614,8 +614,32 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
         torch.cuda.empty_cache()
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves -- as a CHILD process (torch.distributed.run), before
+    this process has imported torch or touched the GPU; relay its output and exit with its code.  Under a launcher (WORLD_SIZE set) the
+    world size must be the one --gpus names: a mismatch is an error, never a silent one-GPU measurement."""
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != a.gpus:
+            sys.exit(f"bench.py: --gpus {a.gpus} but the launcher started WORLD_SIZE={ws} ranks")
+        return
+    if a.gpus <= 1:
+        return
+    import socket
+    import subprocess
+    with socket.socket() as s:                               # a free rendezvous port on the loop-back address
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    print(f"[bench] --gpus {a.gpus} without a launcher: starting {a.gpus} ranks ({' '.join(cmd[1:8])} ...)", file=sys.stderr, flush=True)
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def main():
     a = parse()
+    self_launch(a)
     # the drives' frames are synthesised by worker processes BEFORE this process initialises the GPU (fork)
     drives = None
     if a.mode == "replicas" and not (a.same_pairs or a.same_pair) and a.workload in ("c1", "c2", "c3") and a.batch_api and not a.separate_loads \

@@ -123,14 +123,40 @@ def parse_functors(text):
     return out
 
 
+_ALLOWED_NODES = ("Module", "Assign", "AugAssign", "Expr", "BinOp", "UnaryOp", "Name", "Subscript", "Constant", "List", "Call", "Load", "Store",
+                  "Add", "Sub", "Mult", "Div", "USub", "UAdd", "Index")
+_ALLOWED_CALLS = ("_rot", "_sqrt")
+
+
+def check_arithmetic_only(src, where):
+    """The reference is untrusted text: the transpiled body may contain ONLY plain arithmetic -- assignments, + - * /, names, constant
+    subscripts, numeric constants, list displays and calls of the two helpers this script supplies.  Anything else (attributes,
+    imports, other calls, comprehensions, strings ...) is refused before a single statement runs."""
+    import ast
+    tree = ast.parse(src, filename=where, mode="exec")
+    for node in ast.walk(tree):
+        kind = type(node).__name__
+        if kind not in _ALLOWED_NODES:
+            raise ValueError(f"{where}: refusing to evaluate a {kind} node taken from the reference's text")
+        if isinstance(node, ast.Call):
+            if not (isinstance(node.func, ast.Name) and node.func.id in _ALLOWED_CALLS) or node.keywords:
+                raise ValueError(f"{where}: refusing a call other than {_ALLOWED_CALLS}")
+        if isinstance(node, ast.Constant) and not isinstance(node.value, (int, float)):
+            raise ValueError(f"{where}: refusing a non-numeric constant")
+        if isinstance(node, ast.Name) and node.id.startswith("__"):
+            raise ValueError(f"{where}: refusing the name {node.id}")
+    return tree
+
+
 def make_callable(name, parsed):
     params, args, src = parsed[name]
-    code = compile(src, f"<{name}::operator()>", "exec")
+    where = f"<{name}::operator()>"
+    code = compile(check_arithmetic_only(src, where), where, "exec")
 
     def f(consts, *call_args):
         """call_args in the order of the reference's operator() parameters; the last one is the residual array (filled)"""
         ns = {p: float(v) for p, v in zip(params, consts)}
-        ns.update(_rot=angle_axis_rotate_point, _sqrt=cmath.sqrt)
+        ns.update(_rot=angle_axis_rotate_point, _sqrt=cmath.sqrt, __builtins__={})   # whitelisted arithmetic, no builtins
         for a, v in zip(args, call_args):
             ns[a] = v
         exec(code, ns)

@@ -63,6 +63,22 @@ def test_committed_fixture_is_what_the_reference_text_yields_today():
     assert len(parsed["triangulation2D"][0]) == 11 and len(parsed["triangulation3D"][0]) == 9
 
 
+def test_transpiler_refuses_anything_but_arithmetic():
+    """the reference is untrusted text: a functor body that held anything but plain arithmetic is refused before it runs"""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_functor_ref as M
+    ok = "M = [0.0, 0.0, 0.0]\n_rot(x, m, M)\nM[0] += x[3] - s_x * M[2]\nresidual[0] = _sqrt(M[0] * M[0]) / 2.0"
+    M.check_arithmetic_only(ok, "<ok>")
+    for bad in ("residual[0] = __import__('os').system('true')", "residual[0] = x.__class__", "import os", "residual[0] = open('f')",
+                "residual[0] = [v for v in x]", "residual[0] = (lambda: 1)()", "residual[0] = 'text'", "residual[0] = _rot.__globals__",
+                "residual[0] = __builtins__", "residual[0] = x if x else 0", "residual[0] = _sqrt(v=1)"):
+        with pytest.raises((ValueError, SyntaxError)):
+            M.check_arithmetic_only(bad, "<bad>")
+    # and a body that passed the check still runs without builtins
+    f = M.make_callable("f", {"f": (["s_x"], ["x", "residual"], "residual[0] = x[0] * s_x")})
+    assert f([2.0], [3.0], [0.0])[0] == 6.0
+
+
 @pytest.mark.gpu
 def test_hip_functor_batch_equals_the_reference_derived_vectors(hip_lib):
     from velo_amd import api

@@ -45,3 +45,17 @@ def test_two_rank_bench_line_reports_both_sharded_modes(hip_lib):
         c.close()
         got = np.array(line["modes"][mode]["solution_x"])
         assert np.abs(got - x).max() <= 1e-9, (mode, got, x)
+
+
+def test_bench_starts_its_own_ranks_when_no_launcher_wraps_it(hip_lib):
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run: the script starts the two ranks itself (a plain --gpus N run must
+    never measure one GPU and print n_gpus: 1)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--force-device", "0", "--dist-backend", "gloo",
+           "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0
+    for mode in ("sharded", "target_sharded"):
+        assert line["modes"][mode]["communicator"]["ranks"] == 2, line["modes"][mode]
