@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="independent pairs in flight per GPU (one context + stream each)")
     ap.add_argument("--same-pairs", action="store_true", help="A/B: B fixed, different pairs re-registered every step instead of B drives (what round 3 measured)")
     ap.add_argument("--same-pair", action="store_true", help="A/B: every context registers the canonical pair (what rounds 1-2 measured)")
+    ap.add_argument("--sequences", action="store_true", help="A/B: ONE velo_register_sequences call for the timed frames (the lock-step groups walk their drives independently, no barrier "
+                    "between frames) instead of one velo_register_batch call per step.  Measured: the groups drift apart, every kernel runs faster in the mix "
+                    "(association 134 vs 149 us, LM launch 22.1 vs 23.7 us) but the call ends with its slowest group (3,297 vs 3,486 pairs/s)")
     ap.add_argument("--host-inputs", action="store_true", help="the drives' frames stay in host memory (numpy): every step uploads its B frames -- the PCIe-inclusive rate (never the headline)")
     ap.add_argument("--gen-procs", type=int, default=0, help="worker processes that synthesise the drives' frames (0: min(16, host cores))")
     ap.add_argument("--threads-per-pair", dest="batch_api", action="store_false",
@@ -212,9 +215,10 @@ def make_workload(name, B, same_pair=False):
     return out
 
 
-def cpu_baseline(d, vis, icp_skip=1):
+def cpu_baseline(d, vis, icp_skip=1, single_thread=True):
     """The CPU restatement (oracle = 'port') timed on this host on the canonical pair of the workload: (i) all cores, (ii) ONE thread --
-    the reference's configuration (velo.h:900) -- on the WHOLE pair, nothing extrapolated (about 15 s at icp_skip = 1)."""
+    the reference's configuration (velo.h:900) -- on the WHOLE pair, nothing extrapolated (about 15 s at icp_skip = 1).
+    single_thread=False (the 2M-point map: 1,067 searches per query, minutes on one thread): the all-cores run only."""
     import oracle_lib
     cores = oracle_lib.max_threads()
 
@@ -229,14 +233,15 @@ def cpu_baseline(d, vis, icp_skip=1):
         return time.perf_counter() - t0, x
 
     t_all, x = one(cores)
-    t_one, _ = one(1)
-    return {
-        "value": 1.0 / t_all, "unit": "scan-pairs/s", "cores": cores, "kind": "port",
-        "sample": f"the first pair of the workload (icp_skip={icp_skip}), whole: {cores} OpenMP threads = {t_all:.2f} s; "
-                  f"1 thread (the reference's configuration, velo.h:900) = {t_one:.2f} s",
-        "single_thread_pairs_per_s": 1.0 / t_one, "single_thread_s_per_pair": t_one, "single_thread_extrapolated": False,
-        "x": [float(v) for v in x],
-    }
+    out = {"value": 1.0 / t_all, "unit": "scan-pairs/s", "cores": cores, "kind": "port",
+           "sample": f"the first pair of the workload (icp_skip={icp_skip}), whole: {cores} OpenMP threads = {t_all:.2f} s", "x": [float(v) for v in x]}
+    if single_thread:
+        t_one, _ = one(1)
+        out["sample"] += f"; 1 thread (the reference's configuration, velo.h:900) = {t_one:.2f} s"
+        out.update(single_thread_pairs_per_s=1.0 / t_one, single_thread_s_per_pair=t_one, single_thread_extrapolated=False)
+    else:
+        out["sample"] += "; the one-thread run (the reference's configuration, velo.h:900) is not taken on this workload: minutes per pair"
+    return out
 
 
 class Rig:
@@ -300,8 +305,9 @@ class DriveWalker:
     next guess = pose_vec2mat(T[k]^-1 T[k+1]) (main.cpp:311-331).  One library call per step (velo_register_batch)."""
 
     def __init__(self, api, ctxs, frames, local_rank, vis=None):
-        self.api, self.ctxs, self.frames, self.vis = api, ctxs, frames, vis
+        self.api, self.ctxs, self.frames, self.vis, self.local_rank = api, ctxs, frames, vis, local_rank
         self.B = len(ctxs)
+        self.host_frames = isinstance(frames[0][0][0], np.ndarray)
         self.n_frames = min(len(f) for f in frames)
         self.promote = api.promote_refs(self.B)
         self.src_refs = [api.scan_refs([frames[i][k] for i in range(self.B)], local_rank) for k in range(self.n_frames)]
@@ -320,6 +326,8 @@ class DriveWalker:
 
     def step(self):
         k = self.k + 1
+        if self.host_frames and k + 1 < self.n_frames:       # frames in host memory: the NEXT frames' uploads run under this step's launches
+            self.api.hint_next_sources(self.ctxs, self.src_refs[k + 1][0])
         xs, Ts, Ss = self.api.register_batch(self.ctxs, None, None, self.x0, refs=(self.promote, self.src_refs[k]),
                                              visual=self.vis_refs[k - 1] if self.vis_refs is not None else None)
         # T[k] = T[k-1] dpose (main.cpp:408); next guess = pose_vec2mat(T[k-1]^-1 T[k]) (main.cpp:315-317,331) -- one native call for the B drives
@@ -327,6 +335,23 @@ class DriveWalker:
         self.k = k
         if k == 1:
             self.first = xs.copy()
+        return xs, Ts, Ss
+
+    def prepare(self, K):
+        """descriptors of the next K frames of every drive (and of their matches), laid out as velo_register_sequences takes them"""
+        k0 = self.k
+        refs, keep, _ = self.api.sequence_refs(self.frames, self.local_rank, first=k0 + 1, count=K)
+        vis = self.api.sequence_visual_refs(self.vis, first=k0, count=K) if self.vis is not None else None
+        return (k0, K, refs, keep, vis)
+
+    def walk(self, prep):
+        """K frames of every drive in ONE library call (velo_register_sequences): the lock-step groups walk their drives independently"""
+        k0, K, refs, _keep, vis = prep
+        assert k0 == self.k
+        xs, Ts, Ss = self.api.register_sequences(self.ctxs, refs, K, self.P_prev, self.x0, visual=vis)
+        if k0 == 0:
+            self.first = xs[0].copy()
+        self.k = k0 + K
         return xs, Ts, Ss
 
 
@@ -463,8 +488,14 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
             else:
                 list(pool.map(one_pair, range(B)))
 
-        for _ in range(warmup):
-            step()
+        seq = walker is not None and getattr(a, "sequences", False)                 # the drives' timed frames through ONE velo_register_sequences call
+        if seq:
+            if warmup > 0:
+                walker.walk(walker.prepare(warmup))
+            prep = walker.prepare(steps)                         # (descriptor arrays only: built off the clock)
+        else:
+            for _ in range(warmup):
+                step()
         # The harness's own interpreter must not stall the timed region: with torch imported a full pass of Python's cyclic garbage
         # collector takes ~55 ms, and when its allocation counter happened to trip inside a 12-step leg the leg read 860 instead of 1,450
         # pairs/s (kernel trace: all four queues idle for 56 ms in the middle of the region).  Collect now, keep it off until the leg ends
@@ -478,9 +509,15 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
         t0 = time.perf_counter()
         assoc_ms, assoc_n, alg_bytes, assoc_bytes, evals = 0.0, 0, 0, 0, 0
         kept = []                                            # the steps' summaries: added up behind the timed region (150 ctypes reads per step)
-        for _ in range(steps):
-            step()
-            kept.append([r[2] for r in results])
+        xs_seq = None
+        if seq:
+            xs_seq, Ts_seq, kept = walker.walk(prep)
+            for i in range(B):
+                results[i] = (xs_seq[-1][i], Ts_seq[-1][i], kept[-1][i])
+        else:
+            for _ in range(steps):
+                step()
+                kept.append([r[2] for r in results])
         rig.barrier(ctxs)
         dt = rig.max_over_ranks(time.perf_counter() - t0)
         for step_summaries in kept:
@@ -490,6 +527,15 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
                 alg_bytes += s.algorithmic_bytes
                 assoc_bytes += s.assoc_bytes
                 evals += sum(s.solves[k].evaluations for k in range(s.n_solves))
+        # every timed registration against the drive's simulated motion (off the clock): a drive that diverged -- a bad registration feeding a
+        # bad constant-velocity guess -- would change the iteration counts and still report a valid-looking rate
+        truth = None
+        if seq and xs_seq is not None:
+            k_first = walker.k - steps
+            et = max(float(np.linalg.norm(xs_seq[f][i][3:] - np.asarray(drives[i]["x_true"][k_first + f])[3:])) for f in range(steps) for i in range(B))
+            er = max(float(np.linalg.norm(xs_seq[f][i][:3] - np.asarray(drives[i]["x_true"][k_first + f])[:3])) for f in range(steps) for i in range(B))
+            truth = {"max_dt_m": et, "max_dw_rad": er, "pairs": steps * B, "ok": bool(et <= 0.05 and er <= 0.005),
+                     "note": "largest difference between a timed pair's solved pose and the drive's simulated relative pose (range noise sigma = 0.02 m)"}
         del kept
         chain1 = [c.chain_stats() for c in ctxs]
         kacc = {}
@@ -594,6 +640,10 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
             "kernels": ktab[:3],
             "solution_x": solutions[0], "solutions": solutions,
         }
+        if truth is not None:
+            leg["against_simulated_motion"] = truth
+        leg["call_shape"] = ("one velo_register_sequences call for the timed frames (groups walk their drives independently)" if seq else
+                             "one library call per step") if walker is not None else "one library call per step"
         if first_pair_solutions is not None:                 # a drive's last pair is not its first: the pose the CPU baseline is compared with
             leg["first_pair_solution_x"] = first_pair_solutions[0]
             leg["frames_per_drive"] = walker.n_frames
@@ -658,17 +708,42 @@ def main():
                 if name != a.workload:
                     kitti_c1 = name == "c1" and os.environ.get("VELO_KITTI_ROOT")
                     legs[name] = run_leg(rig, a, name, "replicas", a.batch, steps, 3, drives=None if kitti_c1 else drives)
-                    if name == "c1" and not a.no_cpu_baseline:
-                        # the reference's own constants on its own kind of host: icp_skip = 200, one thread (velo.h:900) and all cores
-                        W1 = make_workload("c1", a.batch, a.same_pair) if (drives is None or kitti_c1) else None
-                        d1 = W1["pairs"][0] if W1 is not None else dict(tgt_xyz=drives[0]["frames"][0][0], tgt_off=drives[0]["frames"][0][1],
-                                                                           src_xyz=drives[0]["frames"][1][0], src_off=drives[0]["frames"][1][1],
-                                                                           x0=np.array([0.0, 0.0, 0.0, 0.0, 0.0, 1.0]))
-                        cb1 = cpu_baseline(d1, None, 200)
-                        xo1 = np.array(cb1.pop("x"))
-                        xg1 = np.array(legs[name].get("first_pair_solution_x", legs[name]["solution_x"]))
-                        cb1["pose_diff_vs_gpu"] = {"dt_m": float(np.linalg.norm(xo1[3:] - xg1[3:])), "dw_rad": float(np.linalg.norm(xo1[:3] - xg1[:3]))}
-                        legs[name]["cpu_baseline"] = cb1
+                    if not a.no_cpu_baseline:
+                        # every leg next to the CPU restatement on its own first pair, with the pose difference.  c1: the reference's own constants on
+                        # its own kind of host (icp_skip = 200, one thread, velo.h:900, and all cores); c3: with the pair's stereo matches; c4: the
+                        # whole scan-to-map call on all cores (the one-thread run would take minutes)
+                        from velo_amd import synth
+                        if name == "c4" or drives is None or kitti_c1:
+                            dleg = make_workload(name, a.batch, a.same_pair)["pairs"][0]
+                        else:
+                            f0, f1 = drives[0]["frames"][0], drives[0]["frames"][1]
+                            dleg = dict(tgt_xyz=f0[0], tgt_off=f0[1], src_xyz=f1[0], src_off=f1[1], x0=synth.INITIAL_GUESS.copy(),
+                                        vis=synth.stereo_matches(1000, seed=3, x_true=drives[0]["x_true"][0]) if name == "c3" else None)
+                        cbl = cpu_baseline(dleg, dleg.get("vis"), 200 if name == "c1" else 1, single_thread=name != "c4")
+                        xol = np.array(cbl.pop("x"))
+                        xgl = np.array(legs[name].get("first_pair_solution_x", legs[name]["solution_x"]))
+                        cbl["pose_diff_vs_gpu"] = {"dt_m": float(np.linalg.norm(xol[3:] - xgl[3:])), "dw_rad": float(np.linalg.norm(xol[:3] - xgl[:3]))}
+                        legs[name]["cpu_baseline"] = cbl
+            if drives is not None and not getattr(a, "host_inputs", False):
+                # main.cpp:216,349 load a scan per frame: the same drives with their frames in pageable HOST memory -- every step uploads its B frames
+                # (the library announces the next frames to itself, velo_hint_next_source: their copies run under the current step's launches)
+                import copy
+                a_h = copy.copy(a)
+                a_h.host_inputs = True
+                hl = run_leg(rig, a_h, a.workload, "replicas", a.batch, a.steps, min(a.warmup, 3), single_leg=False, drives=drives)
+                legs["host_inputs"] = {"pairs_per_s": hl["pairs_per_s"], "ms_per_step": hl["ms_per_step"], "steps": hl["steps"], "chain": hl["chain"],
+                                       "of_resident_rate": hl["pairs_per_s"] / main_leg["pairs_per_s"], "solution_equal_to_resident": hl["solutions"] == main_leg["solutions"],
+                                       "note": "frames in pageable host memory, 1.44 MB uploaded per pair inside the step (PCIe-inclusive); never `value`"}
+            if a.workload == "c2" and not a.same_pair:
+                # SURVEY 8(d) "Motion": the canonical pair from the start-up guess {0,0,0,0,0,1} (main.cpp:170) in every context -- the unit of work the
+                # rounds before the drive workload measured (~40 LM evaluations per pair), kept so that rounds stay comparable
+                import copy
+                a_cp = copy.copy(a)
+                a_cp.same_pair = True
+                cp = run_leg(rig, a_cp, "c2", "replicas", a.batch, 10, 3, drives=None)
+                legs["canonical_pair"] = {k: cp[k] for k in ("workload", "pairs_per_s", "ms_per_step", "lm_evaluations_per_pair", "algorithmic_bytes_per_pair",
+                                                             "achieved_hbm_GBs_whole_path", "chain", "single_pair", "solution_x") if k in cp}
+                legs["canonical_pair"]["initial_guess"] = "start-up guess {0,0,0,0,0,1} (main.cpp:170); true motion: yaw 0.02 rad, t = (1.00, 0.02, 0.01) m (SURVEY 8d)"
         if world > 1 and a.mode == "replicas" and os.environ.get("VELO_BENCH_MODES", "1") != "0":
             # the north_star's multi-GPU modes, next to the replicas: one pair per step, strong scaling.  Never fatal for the headline:
             # a leg that fails on any rank is reported as an error by all of them (the ranks agree after every attempt), and a failed
@@ -740,7 +815,8 @@ def main():
                        "distinct_pairs": main_leg["distinct_pairs"], "frames_per_drive": main_leg.get("frames_per_drive"), "mode": a.mode,
                        "Nq": main_leg["Nq"], "Nt": main_leg["Nt"], "lm_evaluations_per_pair": main_leg["lm_evaluations_per_pair"],
                        "valid_correspondences_last_round": main_leg["valid_correspondences_last_round"],
-                       "algorithmic_bytes_per_pair": main_leg["algorithmic_bytes_per_pair"]},
+                       "algorithmic_bytes_per_pair": main_leg["algorithmic_bytes_per_pair"], "call_shape": main_leg.get("call_shape"),
+                       "initial_guess": "constant-velocity prediction from the drive's last two poses (main.cpp:311-331); start-up guess {0,0,0,0,0,1} for a drive's first pair (main.cpp:170)"},
             "achieved_hbm_GBs_whole_path": main_leg["achieved_hbm_GBs_whole_path"],
             "chain": main_leg["chain"],
             "roofline": rf,
@@ -751,8 +827,12 @@ def main():
             line["config"]["communicator"] = main_leg["communicator"]
         if single is not None:
             line["single_pair"] = single
+        if "against_simulated_motion" in main_leg:
+            line["against_simulated_motion"] = main_leg["against_simulated_motion"]
         if "shared_target" in main_leg:
             line["shared_target"] = main_leg["shared_target"]
+        if "host_inputs" in legs:
+            line["host_inputs"] = legs.pop("host_inputs")
         if legs:
             line["configs"] = {k: {kk: vv for kk, vv in v.items() if kk not in ("solution_x", "solutions")} for k, v in legs.items()}
             # the 2M-point map leg carries its own committed PMC pass (profiles/rNN_c4_traffic.json)

@@ -391,6 +391,25 @@ int velo_register_batch(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets
 int velo_register_batch_visual(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, const velo_scan_ref* sources,
                                const velo_match* const* matches /* n pointers */, const int32_t* n_matches /* n */,
                                double* x /* n*6 */, double* T /* n*16 */, velo_summary* summaries /* n or NULL */);
+/* The drive loop of n sequences for n_frames frames in ONE call -- main.cpp:207-413 (the per-frame loop: load the frame, predict the motion
+ * main.cpp:311-331, frameToFrame main.cpp:388-405, chain the pose main.cpp:408) for n sequences at a time; the reference runs sequences as
+ * independent processes (run.fish:2).  Context i holds the frame its drive starts from as SOURCE (velo_set_source, or the last frame of an
+ * earlier call).  For f = 0 .. n_frames-1: that frame is promoted to target (VELO_SCAN_PROMOTE), frames[f * n + i] is loaded as the new
+ * source (with matches[f * n + i] / n_matches[f * n + i] when given), the pair is registered from x_guess[i], x_out / T_out / summaries
+ * [f * n + i] receive what velo_register_batch returns for it, and poses[i] / x_guess[i] are handed over exactly as velo_pose_handoff
+ * does it.  The lock-step groups walk their drives' frames independently (no barrier across the batch between frames); per pair the
+ * results are bit-identical to the frame-by-frame calls.  poses: n 4x4 row-major in/out; x_guess: n*6 in/out (the start-up guess
+ * {0,0,0,0,0,1}, main.cpp:170, for a drive's first pair). */
+int velo_register_sequences(velo_ctx** ctxs, int32_t n, int32_t n_frames, const velo_scan_ref* frames /* n_frames*n */,
+                            const velo_match* const* matches /* n_frames*n or NULL */, const int32_t* n_matches /* n_frames*n or NULL */,
+                            double* poses /* n*16 */, double* x_guess /* n*6 */, double* x_out /* n_frames*n*6 */, double* T_out /* n_frames*n*16 or NULL */,
+                            velo_summary* summaries /* n_frames*n or NULL */);
+/* main.cpp:216,349 load a scan per frame.  A caller that knows which HOST cloud it will hand over as the context's NEXT source announces it
+ * here; the library uploads it on a copy stream of its own while the current registration's launches run (the upload is issued by the
+ * thread that is about to wait for them), and the very next velo_set_source / batch job / sequence frame that names the same pointer and
+ * size takes the uploaded copy instead of uploading again.  A different source drops the hint; device clouds ignore it; results never
+ * change.  velo_register_sequences does this by itself for the frames it is given. */
+int velo_hint_next_source(velo_ctx* ctx, const velo_scan_ref* next);
 
 /* --- pose helpers (utility.h:67-96; note the reference's swapped names) ---------------- */
 int velo_pose_vec_to_mat(const double x[6], double T[16]);  /* util::pose_mat2vec */

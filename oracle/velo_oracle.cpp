@@ -378,6 +378,9 @@ struct Oracle {
     bool variant_qr = false;           // solve the LM step in row space by Householder QR of [J; D] (Ceres' DENSE_QR path)
     bool variant_ftol_apply = false;   // a successful step that meets the function tolerance is applied before terminating
     bool variant_tie_high = false;     // exact in-ring distance ties go to the highest point index (FLANN's order is unpinned)
+    bool variant_norm_split = false;   // Eigen's unrolled 3-element reduction read as x^2 + (y^2 + z^2) instead of (x^2 + y^2) + z^2 (velo.h:873-874)
+    bool variant_cross_fma = false;    // the cross product's a*b - c*d contracted to fma(a, b, -(c*d)) (a reference built with FMA contraction, velo.h:868-870)
+    long long norm_skips = 0;          // correspondences dropped by the ||N|| < icp_norm_condition test since the last reset (velo.h:873)
     std::vector<vo_trace_row>* trace = nullptr;   // when set, solve() appends one row per LM iteration
 };
 
@@ -464,8 +467,17 @@ void associate_one(const Oracle& o, int sm, int smi, const double x[6], int iter
     const float a[3] = {v1[0] - v0[0], v1[1] - v0[1], v1[2] - v0[2]};
     const float b[3] = {v2[0] - v0[0], v2[1] - v0[1], v2[2] - v0[2]};
     float N[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
-    const float nn = std::sqrt(N[0] * N[0] + N[1] * N[1] + N[2] * N[2]);
-    if ((double)nn < o.P.icp_norm_condition) return;                              // velo.h:873
+    if (o.variant_cross_fma) {                                                    // parity-budget variant only
+        N[0] = std::fmaf(a[1], b[2], -(a[2] * b[1])); N[1] = std::fmaf(a[2], b[0], -(a[0] * b[2])); N[2] = std::fmaf(a[0], b[1], -(a[1] * b[0]));
+    }
+    const float nn = o.variant_norm_split ? std::sqrt(N[0] * N[0] + (N[1] * N[1] + N[2] * N[2])) : std::sqrt(N[0] * N[0] + N[1] * N[1] + N[2] * N[2]);
+    if ((double)nn < o.P.icp_norm_condition) {                                    // velo.h:873
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+        const_cast<Oracle&>(o).norm_skips++;
+        return;
+    }
     N[0] /= nn; N[1] /= nn; N[2] /= nn;
     out->n[0] = N[0]; out->n[1] = N[1]; out->n[2] = N[2];
     out->v0[0] = v0[0]; out->v0[1] = v0[1]; out->v0[2] = v0[2];
@@ -1169,6 +1181,12 @@ int vo_solve(void* h, double* x, velo_solve_summary* s) {
 }
 // --- parity-budget hooks (tests/test_parity_budget.py, tools/parity_budget.py) ------------------------------------------------
 // qr / ftol_apply: see Oracle::variant_*.  Both off = the restatement every parity test compares the HIP path with.
+// the float arithmetic of the plane normal under the other readings of Eigen (velo.h:868-874); -> the ||N|| skips counted since the last call
+long long vo_set_variant_normal(void* h, int norm_split, int cross_fma) {
+    Oracle* o = (Oracle*)h; o->variant_norm_split = norm_split != 0; o->variant_cross_fma = cross_fma != 0;
+    const long long n = o->norm_skips; o->norm_skips = 0;
+    return n;
+}
 int vo_set_variant(void* h, int qr, int ftol_apply, int tie_high) {
     Oracle* o = (Oracle*)h; o->variant_qr = qr != 0; o->variant_ftol_apply = ftol_apply != 0; o->variant_tie_high = tie_high != 0;
     for (KdTree& t : o->trees) t.tie_high = o->variant_tie_high;

@@ -50,8 +50,9 @@ def lib(libm: bool = False) -> C.CDLL:
                      "vo_set_visual", "vo_associate", "vo_get_correspondences", "vo_build_visual",
                      "vo_get_good_matches", "vo_evaluate", "vo_evaluate_rows", "vo_solve", "vo_frame_to_frame",
                      "vo_ring_nn", "vo_set_query_shard", "vo_max_threads", "vo_uses_libm", "vo_sincos",
-                     "vo_set_variant", "vo_solve_trace", "vo_get_blocks", "vo_tie_census"):
+                     "vo_set_variant", "vo_set_variant_normal", "vo_solve_trace", "vo_get_blocks", "vo_tie_census"):
             getattr(l, name).restype = C.c_int
+        l.vo_set_variant_normal.restype = C.c_longlong
         assert l.vo_uses_libm() == (1 if libm else 0)
         _libs[libm] = l
     return _libs[libm]
@@ -183,6 +184,13 @@ class Oracle:
         the 6x6 Cholesky; a successful step that meets the function tolerance applied before terminating; exact in-ring distance
         ties to the HIGHEST index (FLANN's traversal order is unpinned) instead of the lowest."""
         self._l.vo_set_variant(self._h, C.c_int(1 if qr else 0), C.c_int(1 if ftol_apply else 0), C.c_int(1 if tie_high else 0))
+
+    def set_variant_normal(self, norm_split=False, cross_fma=False):
+        """The plane normal's float arithmetic under the other readings of Eigen (velo.h:868-874): Vector3f::norm() summed as
+        x^2 + (y^2 + z^2) (the unrolled redux splitting 3 as 1 + 2) instead of (x^2 + y^2) + z^2; the cross product's a*b - c*d contracted
+        to one fma.  Returns the number of correspondences the ||N|| < 1e-5 test (velo.h:873) dropped since the last call."""
+        self._l.vo_set_variant_normal.restype = C.c_longlong
+        return int(self._l.vo_set_variant_normal(self._h, C.c_int(1 if norm_split else 0), C.c_int(1 if cross_fma else 0)))
 
     def solve_trace(self, x):
         """solve() plus one TRACE_DTYPE row per LM iteration."""

@@ -330,6 +330,34 @@ def test_config2_full_pair_pose_and_solves_match_oracle(full_ctx, oracle, pair):
     assert np.linalg.norm(x[3:] - pair["x_true"][3:]) < 0.02 and np.linalg.norm(x[:3] - pair["x_true"][:3]) < 2e-3
 
 
+def test_config4_full_pair_pose_and_solves_match_oracle(hip_lib, oracle):
+    """configs[3]: the WHOLE scan-to-map call -- 120k queries against the 2M-point map's 1,067 rings (velo.h:800-903 on every ring), six
+    association rounds + six LM solves -- against the CPU restatement: pose within the north_star tolerance (1e-4 m / 1e-5 rad), every
+    solve with the same termination, iteration, evaluation and valid-correspondence counts, the same algorithmic byte count; the lock-step
+    batch entry with the map SHARED by two contexts gives the same bits as the single call."""
+    m = synth.scan_to_map(2_000_000)
+    orc = oracle.Oracle(threads=oracle.max_threads(), icp_skip=1)
+    orc.set_target(m["tgt_xyz"], m["tgt_off"])
+    orc.set_source(m["src_xyz"], m["src_off"])
+    xo, To, so = orc.frame_to_frame(m["x0"])
+    ctxs = [api.Context(0, icp_skip=1) for _ in range(2)]
+    try:
+        c = ctxs[0]
+        c.set_target(m["tgt_xyz"], m["tgt_off"]); c.set_source(m["src_xyz"], m["src_off"])
+        x, T, s = c.frame_to_frame(m["x0"])
+        assert H.pose_close(x, xo, 1e-4, 1e-5), (x, xo)
+        assert s.n_solves == so.n_solves == 6 and _solve_counts(s) == _solve_counts(so)
+        assert s.algorithmic_bytes == so.algorithmic_bytes and s.n_queries == 120000 and s.n_target == 2_000_000
+        np.testing.assert_allclose(T, To, atol=1e-6)
+        refs = (api.scan_refs([(m["tgt_xyz"], m["tgt_off"])] * 2, 0, shared=True), api.scan_refs([(m["src_xyz"], m["src_off"])] * 2, 0))
+        xs, Ts, Ss = api.register_batch(ctxs, None, None, np.tile(m["x0"], (2, 1)), refs=refs)
+        for i in range(2):
+            assert np.array_equal(xs[i], x) and _solve_counts(Ss[i]) == _solve_counts(s)
+    finally:
+        for c in ctxs:
+            c.close()
+
+
 def test_config3_full_pair_with_2000_stereo_blocks_matches_oracle(hip_lib, oracle, pair):
     """configs[2]: the 120k pair + 1,000 matches x 2 cameras (2,000 reprojection blocks, 10 % gross outliers): pose, the outlier
     gate's good_matches list after the call (iter 2) and every solve's counts equal the oracle's; single call and lock-step

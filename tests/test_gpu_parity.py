@@ -537,12 +537,15 @@ def test_chain_mode_lockstep_batch_is_bit_identical(hip_lib, diag_lib, monkeypat
                       ("host_fused", {"VELO_CHAIN": "0", "VELO_LM_FUSED": "1"}), ("chain_two", {"VELO_CHAIN": "1", "VELO_LM_FUSED": "0"}),
                       # the lean one-launch iteration (every workgroup advances the state itself), with the default and with no margin
                       ("chain_iter", {"VELO_CHAIN": "1", "VELO_LM_FUSED": "1", "VELO_LM_ITER": "1"}),
-                      ("tight_iter", {"VELO_CHAIN": "1", "VELO_CHAIN_MARGIN": "0", "VELO_LM_FUSED": "1", "VELO_LM_ITER": "1"})):
+                      ("tight_iter", {"VELO_CHAIN": "1", "VELO_CHAIN_MARGIN": "0", "VELO_LM_FUSED": "1", "VELO_LM_ITER": "1"}),
+                      # a whole solve as ONE launch, all-gather form (lm_solve_ag_batch_kernel): no launch-count prediction, so no margin can miss
+                      ("chain_ag", {"VELO_CHAIN": "1", "VELO_CHAIN_MARGIN": "0", "VELO_LM_FUSED": "1", "VELO_LM_PERSIST": "2"}),
+                      ("chain_ag8", {"VELO_CHAIN": "1", "VELO_LM_FUSED": "1", "VELO_LM_PERSIST": "2"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        # VELO_LM_FUSED / VELO_LM_ITER exist in the diagnostics build only; the product library fuses (its three variants run on the product library)
-        ctxs = [api.Context(0, lib=diag_lib if (env["VELO_LM_FUSED"] == "0" or "VELO_LM_ITER" in env) else None, icp_skip=1) for _ in pairs]
-        monkeypatch.delenv("VELO_CHAIN_MARGIN", raising=False); monkeypatch.delenv("VELO_LM_ITER", raising=False)
+        # VELO_LM_FUSED / VELO_LM_ITER / VELO_LM_PERSIST exist in the diagnostics build only; the product library fuses (its three variants run on the product library)
+        ctxs = [api.Context(0, lib=diag_lib if (env["VELO_LM_FUSED"] == "0" or "VELO_LM_ITER" in env or "VELO_LM_PERSIST" in env) else None, icp_skip=1) for _ in pairs]
+        monkeypatch.delenv("VELO_CHAIN_MARGIN", raising=False); monkeypatch.delenv("VELO_LM_ITER", raising=False); monkeypatch.delenv("VELO_LM_PERSIST", raising=False)
         out = []
         for rep in range(3):
             order = pairs if rep != 1 else pairs[::-1]           # the second call gives every context another pair than predicted
@@ -556,7 +559,8 @@ def test_chain_mode_lockstep_batch_is_bit_identical(hip_lib, diag_lib, monkeypat
     assert all(st == (0, 0) for st in res["host"][1]) and all(st == (0, 0) for st in res["host_fused"][1])
     assert all(st[0] == 3 for st in res["chain"][1]) and all(st[0] == 3 for st in res["chain_two"][1]) and all(st[0] == 3 for st in res["chain_iter"][1])
     assert any(st[1] >= 1 for st in res["tight"][1]) and any(st[1] >= 1 for st in res["tight_iter"][1])
-    for name in ("chain", "tight", "host_fused", "chain_two", "chain_iter", "tight_iter"):
+    assert all(st == (3, 0) for st in res["chain_ag"][1]) and all(st == (3, 0) for st in res["chain_ag8"][1]), (res["chain_ag"][1], res["chain_ag8"][1])
+    for name in ("chain", "tight", "host_fused", "chain_two", "chain_iter", "tight_iter", "chain_ag", "chain_ag8"):
         for (x0, T0, s0, r0), (x1, T1, s1, r1) in zip(res["host"][0], res[name][0]):
             assert np.array_equal(x0, x1) and np.array_equal(T0, T1) and s0 == s1 and r0 == r1
 

@@ -59,19 +59,28 @@ def census(d, skip, vis, threads):
 
 def variant_budget(d, skip, vis, threads):
     """Pose of the whole frame-to-frame call under each alternative third-party behaviour, against the default restatement."""
-    def run(**variant):
+    def run(normal=None, **variant):
         o = ol.Oracle(threads=threads, icp_skip=skip)
         o.set_variant(**variant)
+        if normal:
+            o.set_variant_normal(**normal)
         o.set_target(d["tgt_xyz"], d["tgt_off"])
         o.set_source(d["src_xyz"], d["src_off"])
         if vis is not None:
             o.set_visual(vis)
         x, _T, s = o.frame_to_frame(d["x0"])
-        return x, [int(s.solves[i].evaluations) for i in range(s.n_solves)]
-    x0, e0 = run()
+        skips = o.set_variant_normal(**(normal or {}))           # (reads and resets the counter of ||N|| < 1e-5 skips, velo.h:873)
+        return x, [int(s.solves[i].evaluations) for i in range(s.n_solves)], skips, [int(s.solves[i].n_icp_valid) for i in range(s.n_solves)]
+    x0, e0, k0, v0 = run()
     out = {}
+    # the plane normal's float arithmetic under the other readings of Eigen (velo.h:868-874): the 3-element reduction order of norm(), an
+    # FMA-contracted cross product -- effect on the pose, on the evaluation counts, on the rows each solve holds and on the ||N|| skips
+    for name, normal in (("norm_split", dict(norm_split=True)), ("cross_fma", dict(cross_fma=True))):
+        x, e, k, v = run(normal=normal)
+        out[name] = dict(dt_m=float(np.linalg.norm(x[3:] - x0[3:])), dw_rad=float(np.linalg.norm(x[:3] - x0[:3])), evaluations=e, same_evaluation_counts=(e == e0),
+                         norm_skips=k, default_norm_skips=k0, same_valid_counts=(v == v0))
     for name in ("qr", "ftol_apply", "tie_high"):
-        x, e = run(**{name: True})
+        x, e, _k, _v = run(**{name: True})
         out[name] = dict(dt_m=float(np.linalg.norm(x[3:] - x0[3:])), dw_rad=float(np.linalg.norm(x[:3] - x0[:3])),
                          evaluations=e, same_evaluation_counts=(e == e0))
     out["default_evaluations"] = e0
@@ -82,7 +91,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("configs", nargs="*", default=["c1", "c2", "c3", "c4"])
     ap.add_argument("--threads", type=int, default=ol.max_threads())
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r04_parity_budget.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r05_parity_budget.json"))
     ap.add_argument("--no-variants", action="store_true", help="census only")
     a = ap.parse_args()
     out = {}

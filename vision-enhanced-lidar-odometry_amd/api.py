@@ -208,6 +208,8 @@ SIGNATURES = {
     "velo_frame_to_frame_batch": (C.c_int, [_P(_ctx), C.c_int32, _dp, _dp, _P(VeloSummary)]),
     "velo_register_batch": (C.c_int, [_P(_ctx), C.c_int32, C.c_void_p, C.c_void_p, _dp, _dp, _P(VeloSummary)]),
     "velo_register_batch_visual": (C.c_int, [_P(_ctx), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _dp, _dp, _P(VeloSummary)]),
+    "velo_hint_next_source": (C.c_int, [_ctx, C.c_void_p]),
+    "velo_register_sequences": (C.c_int, [_P(_ctx), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, _dp, _dp, _dp, _dp, _P(VeloSummary)]),
     "velo_pose_vec_to_mat": (C.c_int, [_dp, _dp]),
     "velo_pose_mat_to_vec": (C.c_int, [_dp, _dp]),
     "velo_pose_handoff": (C.c_int, [C.c_int32, _dp, _dp, _dp]),
@@ -787,6 +789,55 @@ def register_batch(ctxs, targets, sources, x0s, refs=None, visual=None):
         msg = lib.velo_last_error()
         raise VeloError(f"velo status {st}: {msg.decode() if msg else ''}")
     return x, T.reshape(n, 4, 4), list(S)
+
+
+def hint_next_sources(ctxs, refs):
+    """velo_hint_next_source for every context: refs = scan_refs(...)[0] of the clouds the NEXT call will hand over as sources (host clouds are
+    uploaded under the current call's launches; device clouds ignore the hint)."""
+    lib = ctxs[0]._lib if len(ctxs) else load_library()
+    for i, c in enumerate(ctxs):
+        st = lib.velo_hint_next_source(c.handle, C.addressof(refs[i]))
+        if st != 0:
+            msg = lib.velo_last_error()
+            raise VeloError(f"velo status {st}: {msg.decode() if msg else ''}")
+
+
+def sequence_refs(frames_per_drive, device=None, first=1, count=None):
+    """Descriptors of the frames a register_sequences call walks: frames_per_drive[i] = [(xyz, ring_offsets), ...] of drive i; frames
+    first .. first + count - 1 of every drive, laid out [frame][drive] as velo_register_sequences takes them.  -> (array, keep-alive)"""
+    n = len(frames_per_drive)
+    count = (min(len(f) for f in frames_per_drive) - first) if count is None else count
+    flat = [frames_per_drive[i][first + f] for f in range(count) for i in range(n)]
+    arr, keep = scan_refs(flat, device)
+    return arr, keep, count
+
+
+def sequence_visual_refs(matches_per_drive, first=0, count=None):
+    """matches_per_drive[i][k] = the matches of drive i's pair k (frame k+1 against frame k) -> pointer / count arrays laid out [frame][drive]"""
+    n = len(matches_per_drive)
+    count = (min(len(m) for m in matches_per_drive) - first) if count is None else count
+    return visual_refs([matches_per_drive[i][first + f] for f in range(count) for i in range(n)])
+
+
+def register_sequences(ctxs, frame_refs, n_frames, poses, x_guess, visual=None, summaries=True):
+    """velo_register_sequences: the drive loop of len(ctxs) sequences for n_frames frames in one call (every context holds its drive's
+    current frame as source).  frame_refs: sequence_refs(...)[0]; poses (n,4,4) and x_guess (n,6) float64 C-contiguous, UPDATED IN PLACE
+    (the drives' accumulated poses and the next frame's constant-velocity guesses).  -> xs (F,n,6), Ts (F,n,4,4), summaries [F][n] or None"""
+    lib = ctxs[0]._lib if len(ctxs) else load_library()
+    n = len(ctxs)
+    assert poses.dtype == np.float64 and poses.flags.c_contiguous and poses.shape == (n, 4, 4)
+    assert x_guess.dtype == np.float64 and x_guess.flags.c_contiguous and x_guess.shape == (n, 6)
+    arr = (_ctx * n)(*[c.handle for c in ctxs])
+    xs = np.zeros((n_frames, n, 6))
+    Ts = np.zeros((n_frames, n, 16))
+    S = (VeloSummary * (n * n_frames))() if summaries else None
+    vm = C.cast(visual[0], C.c_void_p) if visual is not None else None
+    vn = C.cast(visual[1], C.c_void_p) if visual is not None else None
+    st = lib.velo_register_sequences(arr, n, n_frames, C.cast(frame_refs, C.c_void_p), vm, vn, _ptr(poses), _ptr(x_guess), _ptr(xs), _ptr(Ts), S)
+    if st != 0:
+        msg = lib.velo_last_error()
+        raise VeloError(f"velo status {st}: {msg.decode() if msg else ''}")
+    return xs, Ts.reshape(n_frames, n, 4, 4), ([[S[f * n + i] for i in range(n)] for f in range(n_frames)] if summaries else None)
 
 
 def pose_handoff(poses: np.ndarray, dpose: np.ndarray):

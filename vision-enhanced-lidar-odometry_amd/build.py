@@ -18,16 +18,21 @@ ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libvelo_hip.so")
 LIB_DIAG = os.path.join(CSRC, "libvelo_hip_diag.so")     # the tools' build: -DVELO_DIAGNOSTICS (stamps, counters, VELO_DEBUG_SKIP)
-SOURCES = ["velo_hip.hip"]
-HEADERS = ["velo_kernels.h", "velo_depth_kernels.h", "velo_tri_kernels.h", "velo_device_math.h", os.path.join(ROOT, "include", "velo_hip.h")]
+# translation units, each with the flags only it gets.  velo_lm_ag.hip: the one-launch Levenberg-Marquardt solve, built without machine-level
+# loop-invariant code motion (velo_lm_ag_kernels.h says why); the units are compiled side by side and linked into ONE shared library.
+SOURCES = {"velo_hip.hip": [], "velo_lm_ag.hip": ["-mllvm", "-disable-machine-licm"]}
+HEADERS = ["velo_kernels.h", "velo_lm_ag_kernels.h", "velo_depth_kernels.h", "velo_tri_kernels.h", "velo_device_math.h", os.path.join(ROOT, "include", "velo_hip.h")]
 
 HIPCC_FLAGS = [
-    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     # the association compares float distances bit-for-bit with the CPU restatement: no FMA contraction anywhere
     "-ffp-contract=off", "-fno-fast-math",
     # the SLP vectoriser re-packs the plain f32 candidate sweep into v_pk_* instructions and costs 7 more VGPRs (measured: slower)
     "-fno-slp-vectorize",
     "-Wall", "-Wno-unused-function", "-Wno-unused-result",
+]
+LINK_FLAGS = [
+    "--offload-arch=gfx950", "-fPIC", "-shared",
     # calls between the library's own entry points bind inside the library: the product build and the diagnostics build export the
     # same C names, and a process that loads both (the variant tests) must not have one build's batch driver call the other's loaders
     "-Wl,-Bsymbolic",
@@ -49,7 +54,7 @@ def build_hip(force: bool = False, verbose: bool = False, extra_flags=(), diagno
     """The product library; diagnostics=True builds the tools' variant next to it (same source, -DVELO_DIAGNOSTICS: the
     VELO_DEBUG_SKIP hooks exist only there, so a leaked environment variable cannot corrupt a product registration)."""
     hipcc = shutil.which("hipcc") or os.path.join(_rocm(), "bin", "hipcc")
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]          # (the units share the kernel headers: any change rebuilds both)
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     out = out or (LIB_DIAG if diagnostics else LIB)      # out: an A/B build of the same source somewhere else (tools/ab_env.py, VELO_LIB_PATH)
     os.makedirs(os.path.dirname(out), exist_ok=True)
@@ -57,12 +62,24 @@ def build_hip(force: bool = False, verbose: bool = False, extra_flags=(), diagno
         extra_flags = (*extra_flags, "-DVELO_DIAGNOSTICS")
     if not force and not _stale(out, deps):
         return out
-    cmd = [hipcc, *HIPCC_FLAGS, *extra_flags, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(_rocm(), "include"),
-           *srcs, "-o", out, "-L", os.path.join(_rocm(), "lib"), "-lrccl", "-lpthread",
-           f"-Wl,-rpath,{os.path.join(_rocm(), 'lib')}"]
+    objdir = os.path.join(CSRC, "_obj", os.path.splitext(os.path.basename(out))[0])
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for src, own in SOURCES.items():
+        obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
+        cmd = [hipcc, *HIPCC_FLAGS, *own, *extra_flags, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(_rocm(), "include"),
+               "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        jobs.append((obj, subprocess.Popen(cmd)))
+    bad = [obj for obj, p in jobs if p.wait() != 0]
+    if bad:
+        raise subprocess.CalledProcessError(1, f"hipcc -c ({', '.join(os.path.basename(b) for b in bad)})")
+    link = [hipcc, *LINK_FLAGS, *[obj for obj, _ in jobs], "-o", out, "-L", os.path.join(_rocm(), "lib"), "-lrccl", "-lpthread",
+            f"-Wl,-rpath,{os.path.join(_rocm(), 'lib')}"]
     if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.run(cmd, check=True)
+        print(" ".join(link), file=sys.stderr)
+    subprocess.run(link, check=True)
     return out
 
 

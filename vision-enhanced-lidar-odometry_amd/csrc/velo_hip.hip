@@ -39,6 +39,10 @@
 
 using namespace velo;
 
+// velo_lm_ag.hip: the all-gather solve's launcher (a translation unit of its own, see velo_lm_ag_kernels.h)
+extern "C" int velo_launch_lm_solve_ag(int nb_max, int n, void* stream, const void* lm_params, size_t lm_params_bytes, const void* pack, size_t pack_bytes,
+                                       void* ctl, int kmax, size_t half, void* a, void* b);
+
 namespace {
 
 thread_local std::string g_err;
@@ -225,6 +229,7 @@ struct velo_ctx {
                                          // flight 2,742 vs 3,376 pairs/s -- the waiting workgroups hold registers the association kernels want
     int lm_persist_wgs = 0;              // workgroups per context of that launch (0 = one per virtual block); VELO_LM_PERSIST_WGS (diagnostics build)
     DevBuf<SolveCtl> solve_ctl;          // its per-context control blocks (owned by the first context of a group; zero between launches)
+    DevBuf<AgCtl> ag_ctl;                // all-gather solve (lm_solve_ag_batch_kernel, lm_persist == 2): epoch, abort word and flags per context of a group
     int lm_lean = -1;                    // lean fused LM kernel in lock-step groups: -1 = when several groups share the chip; VELO_LM_LEAN (diagnostics build) forces 0 / 1
     // chain mode: a whole frame_to_frame as ONE chain of launches (pose scalars of the next round and the solve summaries stay on the device)
     int patch_order = 1;                 // query list in patch order (VELO_PATCH_ORDER=0: the reference's ring order)
@@ -287,6 +292,12 @@ struct velo_ctx {
     bool have_source = false;
 
     DevBuf<char> staging;                // raw host clouds land here before packing
+    // velo_hint_next_source: the NEXT frame's raw host cloud is uploaded on a copy stream of its own while this frame's chain of launches runs
+    // (main.cpp:216 loads a scan per frame): two landing buffers, so the upload for frame k + 2 never touches what frame k + 1's ingest reads
+    struct Prefetch {
+        const void* host = nullptr; size_t bytes = 0; bool hinted = false, ready = false; int buf = 0;
+        DevBuf<char> land[2]; hipStream_t stream = nullptr; hipEvent_t ev = nullptr;
+    } pf;
     DevBuf<int> seg_flag, seg_excl, seg_ring, seg_off;   // device-side ring segmentation (velo_set_scan_velodyne)
 
     // correspondence table
@@ -493,6 +504,21 @@ int upload_cloud(velo_ctx* c, const float* xyz, int64_t stride, int n, int on_de
     }
     VELO_LAUNCH_T(c, "pack_points_kernel", 28ull * (uint64_t)n, pack_points_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, dsrc, stride, n, dst.p);
     HIP_TRY(hipGetLastError());
+    return VELO_OK;
+}
+
+// the hinted upload (velo_hint_next_source), issued where the calling thread is about to wait for this frame's chain anyway
+int prefetch_issue(velo_ctx* c) {
+    if (!c->pf.hinted || c->pf.ready || !c->pf.host || c->pf.bytes == 0) return VELO_OK;
+    if (!c->pf.stream) HIP_TRY(hipStreamCreateWithFlags(&c->pf.stream, hipStreamNonBlocking));
+    if (!c->pf.ev) HIP_TRY(hipEventCreateWithFlags(&c->pf.ev, hipEventDisableTiming));
+    const int nb = c->pf.buf ^ 1;
+    VELO_TRY(c->pf.land[nb].reserve(c->pf.bytes));
+    // (measured: staging the cloud through page-locked memory of the library's own -- memcpy + DMA -- is SLOWER than handing the runtime the
+    //  pageable pointer: 2,560-2,700 vs 3,206 pairs/s with 8 drives in flight, 3,426 with resident frames)
+    HIP_TRY(hipMemcpyAsync(c->pf.land[nb].p, c->pf.host, c->pf.bytes, hipMemcpyHostToDevice, c->pf.stream));
+    HIP_TRY(hipEventRecord(c->pf.ev, c->pf.stream));
+    c->pf.buf = nb; c->pf.ready = true; c->pf.hinted = false;
     return VELO_OK;
 }
 
@@ -1742,7 +1768,10 @@ int velo_destroy(velo_ctx* c) {
     if (c->h_batch) (void)hipHostFree(c->h_batch);
     c->batch_items.release(); c->batch_states.release(); c->batch_x.release();
     c->ask_count.release(); c->ask_list.release(); c->ask_keys.release(); c->ask_rings.release();
-    c->solve_ctl.release();
+    c->solve_ctl.release(); c->ag_ctl.release();
+    c->pf.land[0].release(); c->pf.land[1].release();
+    if (c->pf.stream) { (void)hipStreamSynchronize(c->pf.stream); (void)hipStreamDestroy(c->pf.stream); c->pf.stream = nullptr; }
+    if (c->pf.ev) { (void)hipEventDestroy(c->pf.ev); c->pf.ev = nullptr; }
     c->batch_tickets.release(); c->batch_pose.release(); c->batch_logs.release(); c->batch_fail.release(); c->pose_rec.release(); c->solve_log.release(); c->chain_fail.release();
     if (c->h_log) (void)hipHostFree(c->h_log);
     if (c->h_status) (void)hipHostFree(c->h_status);
@@ -1838,10 +1867,17 @@ static int set_source_begin(velo_ctx* c, const float* xyz, int64_t stride, const
     const char* dsrc = (const char*)xyz;
     if (!on_device && n > 0) {
         const size_t bytes = (size_t)(n - 1) * (size_t)stride + 12;
-        VELO_TRY(c->staging.reserve(bytes));
-        HIP_TRY(hipMemcpyAsync(c->staging.p, xyz, bytes, hipMemcpyHostToDevice, c->stream));
-        dsrc = c->staging.p;
+        if (c->pf.ready && c->pf.host == (const void*)xyz && c->pf.bytes == bytes) {
+            // this cloud was announced one call ago (velo_hint_next_source) and is on the device already: the ingest waits for its copy's event
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->pf.ev, 0));
+            dsrc = c->pf.land[c->pf.buf].p;
+        } else {
+            VELO_TRY(c->staging.reserve(bytes));
+            HIP_TRY(hipMemcpyAsync(c->staging.p, xyz, bytes, hipMemcpyHostToDevice, c->stream));
+            dsrc = c->staging.p;
+        }
     }
+    c->pf.ready = false;                                                  // (a hint is good for the very next source only)
     c->src_raw.dsrc = dsrc; c->src_raw.stride = stride; c->src_raw.on = n > 0;
     return VELO_OK;
 }
@@ -2671,6 +2707,7 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
         HIP_TRY(hipMemcpyAsync(c->h_vflags.data(), c->vflags.p, (size_t)3 * c->n_matches, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(h_vis_counts, c->vis_counts.p, sizeof(int) * 2 * VELO_MAX_STATS, hipMemcpyDeviceToHost, c->stream));
     }
+    VELO_TRY(prefetch_issue(c));                                     // the next frame's upload runs under this chain (velo_hint_next_source)
     HIP_TRY(hipStreamSynchronize(c->stream));
     VELO_TRY(peer_check(c));
     if (*h_fail || !c->h_status->s.done) {
@@ -3096,7 +3133,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                 const LMBatchItem* d_items = c0->batch_items.p + (size_t)r * n;
                 // groups of up to four contexts with the fused sweep + step: the items ride in the kernel arguments; device copies are needed by
                 // the kernels that take a pointer (the visual sweep, the two-launch path, the one-launch solve, the final state gather)
-                const bool by_value = n <= 4 && c0->lm_fused && !c0->lm_persist && nbv_max == 0;
+                const bool by_value = n <= 4 && c0->lm_fused && (!c0->lm_persist || c0->lm_persist == 2) && nbv_max == 0;
                 if (!by_value || r == 0) HIP_TRY(hipMemcpyAsync(c0->batch_items.p + (size_t)r * n, items_r, sizeof(LMBatchItem) * (size_t)n, hipMemcpyHostToDevice, bs));
                 bool small = c0->small_solve != 0 && !iter_mode;        // every solve of the group is ONE single-workgroup launch (lm_solve_small_kernel's body)
                 for (int i = 0; i < n; i++) small = small && items_r[i].n_rows >= 1 && items_r[i].n_rows <= kSmallRows;
@@ -3122,6 +3159,25 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                         c0->lm_round_name[std::min(r, VELO_MAX_SOLVES - 1)] = c0->lm_kernel_name;
                         if (nbv_max > 0) VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, lm_solve_small_batch_kernel, dim3(m), dim3(kEvalThreads), 0, bs, Q, pack, max_iters + 1);
                         else VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, lm_solve_small_icp_batch_kernel, dim3(m), dim3(kEvalThreads), 0, bs, Q, pack, max_iters + 1);
+                    }
+                    HIP_TRY(hipGetLastError());
+                    continue;
+                }
+                if (c0->lm_persist == 2 && c0->lm_fused && n <= 4 && nbv_max == 0) {   // all-gather form: one launch per solve, every workgroup steps itself
+                    if (c0->ag_ctl.cap < (size_t)n) {
+                        VELO_TRY(c0->ag_ctl.reserve((size_t)n));
+                        HIP_TRY(hipMemsetAsync(c0->ag_ctl.p, 0, sizeof(AgCtl) * c0->ag_ctl.cap, bs));
+                    }
+                    LMBatchPackV pk;
+                    std::memset(&pk, 0, sizeof(pk));
+                    for (int i = 0; i < n; i++) pk.item[i] = items_r[i];
+                    c0->lm_kernel_name = "lm_solve_ag_batch_kernel";
+                    c0->lm_round_name[std::min(r, VELO_MAX_SOLVES - 1)] = c0->lm_kernel_name;
+                    const size_t half = (size_t)(kMaxEvalBlocks + kMaxVisBlocks) * kNumAcc;
+                    {
+                        velo_ctx::TimedLaunch* tl = klog_slot(c0, c0->lm_kernel_name, 0);
+                        const int le = velo_launch_lm_solve_ag(nb_max, n, (void*)bs, &Q, sizeof(Q), &pk, sizeof(pk), c0->ag_ctl.p, max_iters + 2, half, tl ? (void*)tl->a : nullptr, tl ? (void*)tl->b : nullptr);
+                        if (le != 0) return fail(VELO_ERR_HIP, "lm_solve_ag launch: %s", hipGetErrorString((hipError_t)le));
                     }
                     HIP_TRY(hipGetLastError());
                     continue;
@@ -3191,6 +3247,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
             HIP_TRY(hipMemcpyAsync(c->h_vflags.data(), c->vflags.p, (size_t)3 * c->n_matches, hipMemcpyDeviceToHost, bs));
             HIP_TRY(hipMemcpyAsync(h_vis.data() + (size_t)i * 2 * VELO_MAX_STATS, c->vis_counts.p, sizeof(int) * 2 * VELO_MAX_STATS, hipMemcpyDeviceToHost, bs));
         }
+        for (int i = 0; i < n; i++) VELO_TRY(prefetch_issue(ctxs[i]));   // the next frames' uploads run under this chain (velo_hint_next_source)
         HIP_TRY(hipStreamSynchronize(bs));
         bool ok = true;
         for (int i = 0; i < n; i++) ok = ok && !h_fail[i] && h_states[i].done != 0;
@@ -3504,6 +3561,106 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
 
 int velo_frame_to_frame_batch(velo_ctx** ctxs, int32_t n, double* x, double* T, velo_summary* summaries) {
     return batch_impl(ctxs, n, nullptr, nullptr, x, T, summaries);
+}
+
+// The drive loop of n sequences for n_frames frames in ONE call (main.cpp:207-413 for n sequences; the reference runs its sequences as
+// independent processes, run.fish:2): every lock-step group walks ITS drives' frames on its own host thread -- promote the frame the
+// contexts hold to target (sd_prev, main.cpp:233,380), load the new frame, register from the constant-velocity guess, hand the pose over
+// (velo_pose_handoff: main.cpp:311-331,408) -- and starts frame f + 1 as soon as ITS frame f is done.  No barrier across the groups
+// between frames: one group's synchronisation, result read-back and hand-off run under the other groups' chains, a group whose solves
+// took fewer iterations does not wait for the slowest one, and the groups' chip-filling association launches drift apart instead of
+// meeting at every step.  Per pair the work and the results are those of n_frames velo_register_batch[_visual] calls with
+// VELO_SCAN_PROMOTE targets followed by velo_pose_handoff (tests compare them bit for bit).
+static int sequences_impl(velo_ctx** ctxs, int32_t n, int32_t n_frames, const velo_scan_ref* frames, const velo_match* const* matches, const int32_t* n_matches,
+                          double* poses, double* x_guess, double* x_out, double* T_out, velo_summary* summaries) {
+    if (!ctxs || n < 0 || n_frames < 0 || (n > 0 && n_frames > 0 && (!frames || !poses || !x_guess || !x_out))) return fail(VELO_ERR_INVALID, "bad sequence arguments");
+    if (matches && !n_matches) return fail(VELO_ERR_INVALID, "n_matches is null");
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i]) return fail(VELO_ERR_INVALID, "sequence entry %d is null", i);
+        for (int j = 0; j < i; j++) if (ctxs[j] == ctxs[i]) return fail(VELO_ERR_INVALID, "sequence entries %d and %d are the same context", j, i);
+        if (!ctxs[i]->have_source) return fail(VELO_ERR_STATE, "sequence %d: the context holds no frame to start from (velo_set_source)", i);
+    }
+    if (n == 0 || n_frames == 0) return VELO_OK;
+    struct BatchLoad {
+        velo_ctx** c; int n;
+        BatchLoad(velo_ctx** c_, int n_) : c(c_), n(n_) { for (int i = 0; i < n; i++) c[i]->batch_load = n >= 2; }
+        ~BatchLoad() { for (int i = 0; i < n; i++) { c[i]->batch_load = false; c[i]->src_raw.on = false; } }
+    } batch_load(ctxs, n);
+    velo_scan_ref promote;
+    std::memset(&promote, 0, sizeof(promote));
+    promote.stride_bytes = 16; promote.on_device = VELO_SCAN_ON_DEVICE | VELO_SCAN_PROMOTE;
+    const bool lockstep = n >= 2 && batch_can_lockstep(ctxs, n, true, true);
+    static const int groups_env = getenv("VELO_BATCH_GROUPS") ? std::max(atoi(getenv("VELO_BATCH_GROUPS")), 1) : 0;
+    const int G = !lockstep ? n : (groups_env > 0 ? std::max(1, std::min(groups_env, n / 2)) : (n >= 12 ? 2 : ((n == 9 || n == 10) ? 3 : std::max(1, std::min(4, n / 2)))));
+    std::vector<int> gst((size_t)G, VELO_OK);
+    std::vector<std::string> gerr((size_t)G);
+    std::atomic<bool> stop{false};
+    auto run_group = [&](int gi) {
+        const int b = (int)((int64_t)n * gi / G), e = (int)((int64_t)n * (gi + 1) / G), m = e - b;
+        std::vector<double> Tl((size_t)16 * m), xl((size_t)6 * m);
+        auto bail = [&](int st) { gst[(size_t)gi] = st; gerr[(size_t)gi] = g_err; stop.store(true); };
+        static const bool seq_trace = dev_env("VELO_SEQ_TRACE") != nullptr;        // dev aid: where a group's host thread spends a frame
+        double t_load = 0.0, t_reg = 0.0, t_hand = 0.0;
+        auto now = []() { return std::chrono::steady_clock::now(); };
+        auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point bb) { return std::chrono::duration<double, std::micro>(bb - a).count(); };
+        const auto t_begin = now();
+        for (int f = 0; f < n_frames && !stop.load(); f++) {
+            const auto t0 = now();
+            const velo_scan_ref* fr = frames + (size_t)f * n;
+            JobVisual V;
+            if (matches) { V.m = matches + (size_t)f * n; V.n = n_matches + (size_t)f * n; }
+            velo_summary* Sf = summaries ? summaries + (size_t)f * n + b : nullptr;
+            for (int i = 0; i < m; i++) for (int k = 0; k < 6; k++) xl[(size_t)6 * i + k] = x_guess[(size_t)6 * (b + i) + k];
+            int st = VELO_OK;
+            if (f + 1 < n_frames) for (int i = b; i < e; i++) (void)velo_hint_next_source(ctxs[i], frames + (size_t)(f + 1) * n + i);   // uploaded under this frame's chain
+            if (m == 1) {                                            // a drive of its own: the single-pair path
+                st = load_job_visual(ctxs[b], V, b);
+                if (st == VELO_OK) st = load_job(ctxs[b], &promote, fr + b);
+                if (st == VELO_OK) st = velo_frame_to_frame(ctxs[b], xl.data(), Tl.data(), Sf);
+            } else {
+                for (int i = b; i < e && st == VELO_OK; i++) {
+                    st = load_job_visual(ctxs[i], V, i);
+                    if (st == VELO_OK) st = load_job_begin(ctxs[i], &promote, fr + i);
+                }
+                for (int i = b; i < e && st == VELO_OK; i++) st = load_job_end(ctxs[i], true, true);
+                const auto t1 = now();
+                t_load += us(t0, t1);
+                if (st == VELO_OK) st = f2f_batch_lockstep(ctxs + b, m, xl.data(), Tl.data(), Sf, G > 1);
+                t_reg += us(t1, now());
+            }
+            if (st != VELO_OK) { bail(st); return; }
+            const auto t2 = now();
+            std::memcpy(x_out + ((size_t)f * n + b) * 6, xl.data(), sizeof(double) * 6 * (size_t)m);
+            if (T_out) std::memcpy(T_out + ((size_t)f * n + b) * 16, Tl.data(), sizeof(double) * 16 * (size_t)m);
+            st = velo_pose_handoff(m, poses + (size_t)16 * b, Tl.data(), x_guess + (size_t)6 * b);      // main.cpp:408, 311-331
+            if (st != VELO_OK) { bail(st); return; }
+            t_hand += us(t2, now());
+        }
+        if (seq_trace) fprintf(stderr, "[velo seq] group %d: %d frames in %.0f us: loads %.0f, registrations %.0f, hand-over %.0f us per frame\n", gi, n_frames,
+                               us(t_begin, now()), t_load / n_frames, t_reg / n_frames, t_hand / n_frames);
+    };
+    WorkerPool::instance().run(G, run_group);
+    for (int gi = 0; gi < G; gi++) if (gst[(size_t)gi] != VELO_OK) { g_err = gerr[(size_t)gi]; return gst[(size_t)gi]; }
+    return VELO_OK;
+}
+
+// main.cpp:216,349 load a scan per frame: the caller that knows which cloud it will hand over as the NEXT source says so, and the library
+// uploads it on a copy stream of its own while the current registration's chain of launches runs (issued by the thread that is about to
+// wait for that chain).  Host clouds only; the very next velo_set_source / batch job that names the same pointer and size takes the uploaded
+// copy, anything else drops it.  No effect on results.
+int velo_hint_next_source(velo_ctx* c, const velo_scan_ref* next) {
+    if (!c) return fail(VELO_ERR_INVALID, "null context");
+    c->pf.hinted = false;
+    if (!next || (next->on_device & VELO_SCAN_ON_DEVICE) || !next->xyz || !next->ring_offsets || next->n_rings <= 0 || next->stride_bytes < 12) return VELO_OK;
+    const int n = next->ring_offsets[next->n_rings];
+    if (n <= 0) return VELO_OK;
+    c->pf.host = next->xyz; c->pf.bytes = (size_t)(n - 1) * (size_t)next->stride_bytes + 12; c->pf.hinted = true; c->pf.ready = false;
+    return VELO_OK;
+}
+
+int velo_register_sequences(velo_ctx** ctxs, int32_t n, int32_t n_frames, const velo_scan_ref* frames, const velo_match* const* matches, const int32_t* n_matches,
+                            double* poses, double* x_guess, double* x_out, double* T_out, velo_summary* summaries) {
+    return sequences_impl(ctxs, n, n_frames, frames, matches, n_matches, poses, x_guess, x_out, T_out, summaries);
 }
 
 int velo_register_batch(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, const velo_scan_ref* sources, double* x, double* T, velo_summary* summaries) {

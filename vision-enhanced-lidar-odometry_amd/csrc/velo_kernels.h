@@ -2895,13 +2895,16 @@ __device__ __forceinline__ void block_reduce_store(double acc[kNumAcc], double* 
 // No release/acquire fence anywhere on that path -- on this chip an agent-scope fence writes back / invalidates a whole L2.
 __device__ __forceinline__ void store_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double load_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// tid_in (here and below): the thread's index as the CALLER holds it -- the all-gather solve hands in a copy that is opaque per loop
+// iteration, so that the index arithmetic derived from it is recomputed inside its loop instead of being hoisted out of it (hoisted,
+// ~100 thread-derived values stay live across the whole loop: 260 registers instead of 126); -1 = threadIdx.x
 template <bool COHERENT = false>
-__device__ __forceinline__ void block_reduce_store(double acc[kNumAcc], double* __restrict__ dst /* [28] */, double* __restrict__ scratch) {
+__device__ __forceinline__ void block_reduce_store(double acc[kNumAcc], double* __restrict__ dst /* [28] */, double* __restrict__ scratch, const int tid_in = -1) {
     constexpr int kCols = kEvalThreads / 4;                       // 64 partial sums per accumulator
     static_assert(kNumAcc * kCols <= kScratchDoubles / 2, "scratch size");
     double (*red)[kCols] = reinterpret_cast<double (*)[kCols]>(scratch);
     __shared__ double red2[kNumAcc][8];
-    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int t = tid_in < 0 ? (int)threadIdx.x : tid_in, lane = t & 63, wid = t >> 6;
 #pragma unroll
     for (int k = 0; k < kNumAcc; k++) acc[k] += __shfl_xor(acc[k], 32);
 #pragma unroll
@@ -2952,9 +2955,9 @@ constexpr int kPre = 4;
 template <int PRE> struct RowPrefetchT { float4 p[PRE], n[PRE], v[PRE]; };
 using RowPrefetch = RowPrefetchT<kPre>;
 template <int PRE = kPre>
-__device__ __forceinline__ RowPrefetchT<PRE> prefetch_rows(const EvalArgs& A, const int bx, const int nbx) {
+__device__ __forceinline__ RowPrefetchT<PRE> prefetch_rows(const EvalArgs& A, const int bx, const int nbx, const int tid_in = -1) {
     RowPrefetchT<PRE> f;
-    const int tid = bx * blockDim.x + threadIdx.x, nthreads = nbx * blockDim.x;
+    const int tid = bx * blockDim.x + (tid_in < 0 ? (int)threadIdx.x : tid_in), nthreads = nbx * blockDim.x;
 #pragma unroll
     for (int k = 0; k < PRE; k++) {
         const int i = min(A.q_begin + tid + k * nthreads, A.q_end - 1);
@@ -2992,8 +2995,8 @@ __device__ __forceinline__ void sweep_row(const EvalArgs& A, const LMEvalPoint& 
 // this workgroup's rows at the eval point in LDS -> the 28 accumulators of every thread (the prefetched rows first, with
 // compile-time indices, then whatever is left)
 template <bool M_FROM_LDS, int PRE = kPre>
-__device__ __forceinline__ void sweep_rows(const EvalArgs& A, const RowPrefetchT<PRE>& f, const LMEvalPoint& s_pt, const int bx, const int nbx, double acc[kNumAcc]) {
-    const int tid = bx * blockDim.x + threadIdx.x, nthreads = nbx * blockDim.x;
+__device__ __forceinline__ void sweep_rows(const EvalArgs& A, const RowPrefetchT<PRE>& f, const LMEvalPoint& s_pt, const int bx, const int nbx, double acc[kNumAcc], const int tid_in = -1) {
+    const int tid = bx * blockDim.x + (tid_in < 0 ? (int)threadIdx.x : tid_in), nthreads = nbx * blockDim.x;
     double Mreg[4][9];
     if (!M_FROM_LDS) {
 #pragma unroll
@@ -3460,16 +3463,18 @@ template <bool COHERENT = false, int CHUNK = kStepChunk, bool STATE_COHERENT = f
 __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __restrict__ Sin, const double* __restrict__ partials, int n_blocks, int first,
                                            const double* __restrict__ x_in, const int* __restrict__ n_valid,
                                            double* __restrict__ s_rows, LMState* sL, LMEvalPoint* s_pt, unsigned long long* trace, int trace_eval,
-                                           const PeerComm* comm = nullptr, PoseRecord* pose_out = nullptr, SolveLog* log = nullptr, bool writer = true) {
+                                           const PeerComm* comm = nullptr, PoseRecord* pose_out = nullptr, SolveLog* log = nullptr, bool writer = true,
+                                           bool load_state = true, const int tid_in = -1) {
     __shared__ double part[8][kNumAcc];
     __shared__ double E[kNumAcc];
     // CHUNK rows of partial sums at a time through s_rows (CHUNK x 28 doubles).  Thread (k, p) adds the rows b = p (mod 8) of its
     // accumulator k in increasing order whatever the chunk size (a multiple of 64), so every CHUNK gives the same bits.
     static_assert(CHUNK % 64 == 0 && CHUNK <= kStepChunk, "chunk geometry");
     constexpr int kPerThread = CHUNK * kNumAcc / 256;
-    const int t = threadIdx.x;
+    const int t = tid_in < 0 ? (int)threadIdx.x : tid_in;
     // STATE_COHERENT (the one-launch solve): the state was written by ANOTHER workgroup of this launch -- agent-scope loads
-    if (t < (int)(sizeof(LMState) / 8))
+    // load_state = false (the all-gather solve): the state has lived in this workgroup's LDS since the previous iteration of the same launch
+    if (load_state && t < (int)(sizeof(LMState) / 8))
         reinterpret_cast<unsigned long long*>(sL)[t] = STATE_COHERENT
             ? __hip_atomic_load(reinterpret_cast<const unsigned long long*>(Sin) + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
             : reinterpret_cast<const unsigned long long*>(Sin)[t];
@@ -3536,7 +3541,9 @@ __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __r
         __syncthreads();
         if (comm) peer_allreduce28(*comm, E);                // query-sharded: every rank continues with the same 28 sums
         VELO_LM_TRACE(trace, trace_eval, 6);
+#ifndef VELO_X1
         if (t < 64) lm_transition_wave(Q, sL, E, t);
+#endif
         if (t == 0 && sL->done && writer) {                  // the solve has just finished: what the host and the next round need
             if (log) {
                 for (int i = 0; i < 6; i++) log->x[i] = sL->x[i];
@@ -3547,7 +3554,9 @@ __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __r
                 double xf[6];
                 for (int i = 0; i < 6; i++) xf[i] = sL->x[i];
                 PoseScalars S;
+#ifndef VELO_X2
                 pose_scalars_compute(xf, &S);
+#endif
                 pose_out->P = S;
                 __threadfence();
                 pose_out->ready = 1;
@@ -3561,7 +3570,9 @@ __device__ __forceinline__ void lm_advance(const LMParams& Q, const LMState* __r
         const bool cand = sL->phase == PHASE_CAND;
 #pragma unroll
         for (int k = 0; k < 6; k++) x[k] = cand ? sL->xc[k] : sL->x[k];
+#ifndef VELO_X3
         eval_point_column(x, sL->done, t, s_pt);
+#endif
     }
     __syncthreads();
     VELO_LM_TRACE(trace, trace_eval, 8);
@@ -3950,6 +3961,14 @@ lm_iter_batch_lean_kernel(LMParams Q, LMBatchPackV P, int parity, int first, siz
     lm_iter_lean_body<true, VELO_LEAN_PRE, 64>(it.A, Q, it.S + parity, it.S + (parity ^ 1), it.A.partials + (size_t)parity * half, it.nb_icp,
                                                it.A.partials + (size_t)(parity ^ 1) * half, first, it.xd, it.n_valid, blockIdx.x, it.nb_icp, it.pose_out, it.log);
 }
+// (the all-gather solve, lm_solve_ag_batch_kernel, lives in velo_lm_ag_kernels.h / velo_lm_ag.hip: a translation unit of its own)
+__device__ __forceinline__ int ctl_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ctl_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#ifndef VELO_TEST_ATTR
+#define VELO_TEST_ATTR __attribute__((amdgpu_num_vgpr(152)))
+#endif
+struct AgCtl { int epoch, abort, pad[30]; int flag[2][kMaxEvalBlocks]; };
+
 // ---- a whole solve of a lock-step group in ONE launch ---------------------------------------------------------------------------------
 // A solve used to be one launch per LM iteration: ~48 launches per call and group, each paying the queue's hand-over (4-10 us between
 // two kernels of a queue when four queues are busy), the dispatch, the cold loads of eval point and rows, and -- arriving while other
@@ -3967,8 +3986,6 @@ lm_iter_batch_lean_kernel(LMParams Q, LMBatchPackV P, int parity, int first, siz
 // gen = eval points published so far, | kSolveDone once the solve has ended.
 struct SolveCtl { int ticket, pad0[31]; int arrived, pad1[31]; int gen, pad2[31]; int exited, pad3[31]; };
 constexpr int kSolveDone = 1 << 30;
-__device__ __forceinline__ int ctl_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void ctl_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // one ticket's work: block bx of iteration k.  -> 0 = swept, 1 = swept and this workgroup completed the iteration, -1 = the solve is over
 template <int PRE>
 __device__ __forceinline__ int persist_sweep(const EvalArgs& A, SolveCtl* __restrict__ ctl, const int k, const int bx, const int nb,
@@ -4146,7 +4163,9 @@ lm_solve_small_body(const EvalArgs& A, const LMParams& Q, LMState* Sg, const dou
                 double xf[6];
                 for (int i = 0; i < 6; i++) xf[i] = sL.x[i];
                 PoseScalars S;
+#ifndef VELO_X2
                 pose_scalars_compute(xf, &S);
+#endif
                 pose_out->P = S;
                 __threadfence();
                 pose_out->ready = 1;
