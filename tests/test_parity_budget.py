@@ -231,9 +231,36 @@ def test_tie_census_c1_has_no_ties_and_c2_ties_stay_inside_tolerance():
     assert same and dt <= 0.01 * T_TOL and dw <= 0.05 * R_TOL, (dt, dw)  # measured 4.5e-7 m / 1.7e-7 rad
 
 
+def test_plane_normal_arithmetic_variants_are_not_observable():
+    """velo.h:868-874 in Eigen's float arithmetic is third-party: (a) Vector3f::norm() through the unrolled redux, which splits three
+    elements as 1 + 2 -- x^2 + (y^2 + z^2) -- where the restatement and the kernel sum (x^2 + y^2) + z^2; (b) a reference built with FMA
+    contraction would round a*b - c*d of the cross product once less.  Both feed the 1e-5 skip (velo.h:873) and the last bit of every
+    normal.  Measured on the whole call: 1e-10 m / 1e-10 rad at most (six orders inside the tolerance), the same evaluation counts, the
+    same rows per solve, the same number of ||N|| skips."""
+    mini = H.small_pair()
+    full = synth.scan_pair()
+    for d, skip in ((mini, 1), (full, 200), (full, 1)):
+        o0 = _oracle(d, skip, None, threads=ol.max_threads())
+        x0, _T0, s0 = o0.frame_to_frame(d["x0"])
+        k0 = o0.set_variant_normal()
+        for normal in (dict(norm_split=True), dict(cross_fma=True), dict(norm_split=True, cross_fma=True)):
+            o = _oracle(d, skip, None, threads=ol.max_threads())
+            o.set_variant_normal(**normal)
+            x, _T, s = o.frame_to_frame(d["x0"])
+            k = o.set_variant_normal(**normal)
+            assert [s.solves[i].evaluations for i in range(6)] == [s0.solves[i].evaluations for i in range(6)]
+            assert [s.solves[i].n_icp_valid for i in range(6)] == [s0.solves[i].n_icp_valid for i in range(6)] and k == k0
+            assert np.linalg.norm(x[3:] - x0[3:]) <= 1e-4 * T_TOL and np.linalg.norm(x[:3] - x0[:3]) <= 1e-4 * R_TOL, (skip, normal, x - x0)
+    # the variants DO change bits: some normal of the mini pair differs in its last place (otherwise the rows above would measure nothing)
+    o0 = _oracle(mini, 1, None, threads=1); o0.associate(mini["x0"], 1); n0 = o0.correspondences()["n"].copy()
+    o1 = _oracle(mini, 1, None, threads=1); o1.set_variant_normal(norm_split=True, cross_fma=True); o1.associate(mini["x0"], 1)
+    n1 = o1.correspondences()["n"]
+    assert not np.array_equal(n0, n1) and np.abs(n0 - n1).max() <= 2e-6
+
+
 def test_committed_budget_file_supports_the_design_table():
-    """profiles/r04_parity_budget.json (tools/parity_budget.py, all of C1-C4 at full size) says what DESIGN.md section 2 claims."""
-    path = os.path.join(ROOT, "profiles", "r04_parity_budget.json")
+    """profiles/r05_parity_budget.json (tools/parity_budget.py, all of C1-C4 at full size) says what DESIGN.md section 2 claims."""
+    path = os.path.join(ROOT, "profiles", "r05_parity_budget.json")
     B = json.load(open(path))
     assert set(B) >= {"c1", "c2", "c3", "c4"}
     for name, b in B.items():
@@ -244,4 +271,7 @@ def test_committed_budget_file_supports_the_design_table():
         assert b["total"]["cross_ring_tie_first"] == 0 and b["total"]["cross_ring_tie_second"] == 0
         inside = v["ftol_apply"]["dt_m"] <= T_TOL and v["ftol_apply"]["dw_rad"] <= R_TOL
         assert inside == (name != "c1"), (name, v["ftol_apply"])
+        for row in ("norm_split", "cross_fma"):                  # the plane normal's float arithmetic (velo.h:868-874): six orders inside the tolerance
+            assert v[row]["dt_m"] <= 1e-4 * T_TOL and v[row]["dw_rad"] <= 1e-4 * R_TOL and v[row]["same_evaluation_counts"] and v[row]["same_valid_counts"]
+            assert v[row]["norm_skips"] == v[row]["default_norm_skips"]
     assert B["c1"]["total"]["in_ring_ties"] == 0
