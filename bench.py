@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--sequences", action="store_true", help="A/B: ONE velo_register_sequences call for the timed frames (the lock-step groups walk their drives independently, no barrier "
                     "between frames) instead of one velo_register_batch call per step.  Measured: the groups drift apart, every kernel runs faster in the mix "
                     "(association 134 vs 149 us, LM launch 22.1 vs 23.7 us) but the call ends with its slowest group (3,297 vs 3,486 pairs/s)")
+    ap.add_argument("--own-map-copies", action="store_true", help="c4 A/B: every context holds its own copy of the 2M-point map and builds its own index every step (rounds 1-4)")
     ap.add_argument("--host-inputs", action="store_true", help="the drives' frames stay in host memory (numpy): every step uploads its B frames -- the PCIe-inclusive rate (never the headline)")
     ap.add_argument("--gen-procs", type=int, default=0, help="worker processes that synthesise the drives' frames (0: min(16, host cores))")
     ap.add_argument("--threads-per-pair", dest="batch_api", action="store_false",
@@ -460,7 +461,11 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
         pool = ThreadPoolExecutor(max_workers=B) if B > 1 else None
         # (B == 1, whole target: the same single library call with one job -- velo_register_batch routes it to the single-pair path)
         one_call = B == 1 and a.batch_api and not sharded_part and mode == "replicas"
-        batch_refs = (api.scan_refs(tgts, rig.local_rank), api.scan_refs(srcs, rig.local_rank)) if (B > 1 or one_call) else None
+        # scan-to-map as it is used (BASELINE configs[3]): B scans against ONE accumulated map -- the jobs name the same target with
+        # VELO_SCAN_SHARED, the library uploads and indexes it once per step and the B contexts hold it by reference (one 110 MB map in HBM
+        # instead of B); --own-map-copies gives every context a copy and an index build of its own (what rounds 1-4 timed)
+        use_shared = bool(W["shared_map"]) and mode == "replicas" and B > 1 and a.batch_api and not getattr(a, "own_map_copies", False)
+        batch_refs = (api.scan_refs(tgts, rig.local_rank, shared=use_shared), api.scan_refs(srcs, rig.local_rank)) if (B > 1 or one_call) else None
         x0s = np.stack([np.asarray(d["x0"], dtype=np.float64) for d in pairs])
 
         walker = DriveWalker(api, ctxs, frames_dev, rig.local_rank, vis_all) if drive else None
@@ -594,9 +599,8 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
 
         shared = None
         if W["shared_map"] and mode == "replicas" and B > 1 and a.batch_api:
-            # scan-to-map as it is used: B scans against ONE map -- the jobs name the same target with VELO_SCAN_SHARED, the library
-            # indexes it once per step and the B contexts hold it by reference (one 110 MB map in HBM instead of B)
-            refs_sh = (api.scan_refs([tgts[0]] * B, rig.local_rank, shared=True), batch_refs[1])
+            # the other way of holding the map, next to the timed one (shared by default; see use_shared)
+            refs_sh = (api.scan_refs([tgts[0]] * B, rig.local_rank, shared=not use_shared), batch_refs[1])
             for _ in range(2):
                 api.register_batch(ctxs, None, None, x0s, refs=refs_sh)
             rig.barrier(ctxs)
@@ -607,8 +611,9 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
             rig.barrier(ctxs)
             dt_sh = rig.max_over_ranks(time.perf_counter() - t1)
             shared = {"pairs_per_s": n_sh * B * world / dt_sh, "ms_per_step": 1e3 * dt_sh / n_sh, "steps": n_sh,
-                      "pose_equal_to_unshared": bool(np.array_equal(xs_sh[0], results[0][0])),
-                      "note": "the B jobs share one target (VELO_SCAN_SHARED): one upload + index build per step instead of B"}
+                      "pose_equal_to_timed_leg": bool(np.array_equal(xs_sh[0], results[0][0])),
+                      "note": ("every context holds its OWN copy of the map: B uploads + index builds per step" if use_shared else
+                               "the B jobs share one target (VELO_SCAN_SHARED): one upload + index build per step instead of B")}
 
         n_pairs_rank = steps * B
         total_pairs = n_pairs_rank * (world if mode == "replicas" else 1)
@@ -650,7 +655,9 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
         if single is not None:
             leg["single_pair"] = single
         if shared is not None:
-            leg["shared_target"] = shared
+            leg["own_map_copies" if use_shared else "shared_target"] = shared
+        if W["shared_map"]:
+            leg["map"] = "one map shared by the B contexts (VELO_SCAN_SHARED): one index build per step" if use_shared else "one copy and one index build per context and step"
         if comm_info is not None:
             leg["communicator"] = comm_info
         return leg
@@ -829,8 +836,9 @@ def main():
             line["single_pair"] = single
         if "against_simulated_motion" in main_leg:
             line["against_simulated_motion"] = main_leg["against_simulated_motion"]
-        if "shared_target" in main_leg:
-            line["shared_target"] = main_leg["shared_target"]
+        for kk in ("shared_target", "own_map_copies", "map"):
+            if kk in main_leg:
+                line[kk] = main_leg[kk]
         if "host_inputs" in legs:
             line["host_inputs"] = legs.pop("host_inputs")
         if legs:

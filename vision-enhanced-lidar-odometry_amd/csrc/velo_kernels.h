@@ -965,6 +965,9 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // so the walk stops once (e * cell)^2 > max over member lanes of b2d (second-best squared distance, or the gate when a
 // lane has no second ring yet): no unvisited point can enter any lane's result.  In the dense part of a scan this ends
 // after the first phase; the answer is still the exact exhaustive one.
+#ifndef VELO_ASSOC_SYNC_LEAN
+#define VELO_ASSOC_SYNC_LEAN 1
+#endif
 constexpr int kTileCap = 512;      // candidates per LDS tile (keeps the workgroup under 20 KB of LDS: 8 workgroups per CU)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -1297,6 +1300,35 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
     const GridDesc g = G.d;
     // Set-up once per GROUP, not once per wave: wave 0 transforms the 64 queries (double precision) and enters the warm-start
     // seeds, the other waves pick the result up from LDS (scratch aliases the tile, which is not in use yet).
+#if VELO_ASSOC_SYNC_LEAN
+    // Round 5: EVERY wave sets itself up -- the same coalesced loads (three of the four waves hit the L2 lines the first one pulled), the
+    // same arithmetic, hence the same state in every wave -- instead of wave 0 computing and handing over through LDS behind two workgroup
+    // barriers.  A barrier costs this kernel ~1 us (four waves, each sharing its SIMD with four other workgroups' waves); the redundant
+    // ~100 double-precision instructions per wave cost far less.  s_q receives identical values from all four waves, and a lane only
+    // reads back the slot it wrote itself.
+    {
+        float qx = 0.f, qy = 0.f, qz = 0.f;
+        if (active) {
+            const float4 psrc = qpts[qi];
+            const bool seeded = out.prev_a && !(DBG && (dbg & 512));
+            float4 sa = make_float4(0.f, 0.f, 0.f, __int_as_float(-1)), sb = sa;
+            int2 sr = make_int2(-1, -1);
+            if (seeded) { sa = out.prev_a[qi]; sb = out.prev_b[qi]; sr = out.prev_r[qi]; }
+            transform_query(P, psrc, &qx, &qy, &qz);
+            if (__float_as_int(sa.w) >= 0) {
+                const float d = dist2_f(sa.x, sa.y, sa.z, qx, qy, qz);
+                if (__float_as_uint(d) <= gate_bits) top2_update(t, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(__float_as_int(sa.w) + out.first_point), sr.x);
+            }
+            if (__float_as_int(sb.w) >= 0) {
+                const float d = dist2_f(sb.x, sb.y, sb.z, qx, qy, qz);
+                if (__float_as_uint(d) <= gate_bits) top2_update(t, ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)(__float_as_int(sb.w) + out.first_point), sr.y);
+            }
+        }
+        s_q[0][lane] = qx; s_q[1][lane] = qy; s_q[2][lane] = qz;
+        // the per-row interval slots start out empty; from then on the thread that consumes a row's interval empties it again (see the run list)
+        s_lo[tid] = 1 << 28; s_hi[tid] = -(1 << 28); s_plo[tid] = 1 << 28; s_phi[tid] = -(1 << 28);
+    }
+#else
     {
         unsigned long long* sb = reinterpret_cast<unsigned long long*>(s_zg);   // [2][64] best1 / best2 keys
         int* sr = s_ring;                                                        // [2][64] their rings
@@ -1333,6 +1365,7 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
         }
         __syncthreads();                                                         // the tile may be overwritten from here on
     }
+#endif
     VELO_STAMP(0);
     float* s_xy_f = reinterpret_cast<float*>(s_xy);
     float* s_zg_f = reinterpret_cast<float*>(s_zg);
@@ -1443,9 +1476,11 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
                     if (__ballot(hit) == 0ull) continue;
                 }
                 // ---- 0. per-row x-intervals ----
+#if !VELO_ASSOC_SYNC_LEAN
                 s_lo[tid] = big; s_hi[tid] = -big;
                 if (ph == 1) { s_plo[tid] = big; s_phi[tid] = -big; }
                 __syncthreads();
+#endif
                 if (asks) {                                            // the rows of this query's box: z-layers dealt over the waves
                     const int bx0 = s_box[ph][0][lane], bx1 = s_box[ph][1][lane], by0 = s_box[ph][2][lane], by1 = s_box[ph][3][lane];
                     const int bz0 = s_box[ph][4][lane], bz1 = s_box[ph][5][lane];
@@ -1475,15 +1510,22 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
                 // ---- 1. run list ----
                 int ja0 = 0, la = 0, jb0 = 0, lb = 0;
                 const int r = rbase + tid;
+#if VELO_ASSOC_SYNC_LEAN
+                const int lo_raw = s_lo[tid], hi_raw = s_hi[tid], plo_raw = s_plo[tid], phi_raw = s_phi[tid];
+                s_lo[tid] = big; s_hi[tid] = -big; s_plo[tid] = big; s_phi[tid] = -big;   // emptied by their consumer: the next chunk / phase / cluster needs no barrier to start filling
+                                                                                          // (its atomics come behind the two barriers of the scan below)
+#else
+                const int lo_raw = s_lo[tid], hi_raw = s_hi[tid], plo_raw = (ph == 1) ? s_plo[tid] : big, phi_raw = (ph == 1) ? s_phi[tid] : -big;
+#endif
                 if (r < nrows) {
-                    const int lo = max(s_lo[tid], 0), hi = min(s_hi[tid], g.nx - 1);
+                    const int lo = max(lo_raw, 0), hi = min(hi_raw, g.nx - 1);
                     if (lo <= hi) {
                         // r / nyb without the integer-division sequence: r < 2^24 (bounded cluster radius), one float multiply + fix-up
                         int zq = (int)((float)r * rcp_nyb), yr = r - zq * nyb;
                         if (yr < 0) { zq--; yr += nyb; } else if (yr >= nyb) { zq++; yr -= nyb; }
                         const int y = Y0 + yr, z = Z0 + zq;
                         const int row = (z * g.ny + y);
-                        const int plo = (ph == 1) ? s_plo[tid] : big, phi = (ph == 1) ? s_phi[tid] : -big;
+                        const int plo = (ph == 1) ? plo_raw : big, phi = (ph == 1) ? phi_raw : -big;
                         if (plo > phi) {                                // nothing of this row visited yet
                             ja0 = grid_start(G, row, lo); la = grid_start(G, row, hi + 1) - ja0;
                         } else {                                        // only the cells left of plo and right of phi are new
@@ -1591,7 +1633,9 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
                     if (c1 < t.b2) top2_update(t, c1, mr[w][lane]);
                     if (c2 < t.b2) top2_update(t, c2, mr2[w][lane]);
                 }
-                __syncthreads();
+                // (lean: the scratch aliases the tile, and every way from here to the next write into the tile -- the staging of a later phase or
+                //  cluster -- passes the barrier behind a box computation and the two of a scan; the query-by-query paths write it at once)
+                if (!VELO_ASSOC_SYNC_LEAN || ASKER != 0) __syncthreads();
             }
             VELO_STAMP(6);
         }
@@ -1719,6 +1763,9 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
             VELO_STAMP(6);
         }
         pending = pending && !member;
+        // lean: a group of several clusters -- wave 0 of the next cluster publishes s_phase / s_box while a slow wave may still be reading this
+        // cluster's (the barrier the merge used to end with kept them apart)
+        if (VELO_ASSOC_SYNC_LEAN && ASKER == 0 && __ballot(pending) != 0ull) __syncthreads();
     }
     if (NW > 1 && wid != lead) return;
     VELO_Q(qx, qy, qz);
