@@ -3821,6 +3821,9 @@ int velo_comm_peer_export(velo_ctx* c, char handle[64]) {
     // restarting at attach, such a block written into a re-used slab could be taken for a new one.  The old slab is therefore
     // retired, not cleared and re-used: stale stores land in memory nobody reads any more (4.5 KB per recovery, freed with the context).
     if (c->peer_slab) { c->peer_retired.push_back(c->peer_slab); c->peer_slab = nullptr; }
+    // ... but not for ever: a context that exports per leg or per recovery would grow by an allocation granule each time.  Only a call that
+    // timed out (5 s bound) before the LAST TWO exports could still be storing into an older slab; those are freed here.
+    while (c->peer_retired.size() > 2) { (void)hipFree(c->peer_retired.front()); c->peer_retired.erase(c->peer_retired.begin()); }
     {
         // fine-grained device memory: stores of a peer on another GPU become visible while the kernels run
         void* p = nullptr;

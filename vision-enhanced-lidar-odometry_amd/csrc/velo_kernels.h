@@ -280,9 +280,13 @@ bbox_kernel(const float4* __restrict__ pts, int n, unsigned* __restrict__ mnmx /
 // source_ingest_kernel is pack_points + query_list + gather_queries (the query blocks read the caller's records themselves, so they
 // do not wait for the packed copy).  Same arithmetic, same tables as the separate kernels, which the other entries keep using.
 constexpr int kIngestPerThread = 4;                                    // points per thread: 1,024 per workgroup, 6 bounding-box atomics per workgroup at most
+// IN-PLACE CONTRACT: a promotion (promote_begin: the source scan becomes the target) runs this kernel with src == tgt and stride 16 -- the
+// records are already packed.  src and tgt therefore carry NO __restrict__, and the body must keep to "thread i reads record i of src, then
+// writes record i of tgt": no staging of other threads' records, no reads of a neighbour's record from src (pad sentinels take the thread's
+// OWN point p), no vector loads across records.  tests/test_gpu_next_rows.py compares a promoted target with a freshly loaded one bit for bit.
 __global__ void __launch_bounds__(256)
-target_ingest_kernel(const char* __restrict__ src, int64_t stride, int n, const int* __restrict__ off, int n_rings, int first_ring,
-                     float4* __restrict__ tgt, int* __restrict__ ring_of, float4* __restrict__ pad, unsigned* __restrict__ mnmx,
+target_ingest_kernel(const char* src, int64_t stride, int n, const int* __restrict__ off, int n_rings, int first_ring,
+                     float4* tgt, int* __restrict__ ring_of, float4* __restrict__ pad, unsigned* __restrict__ mnmx,
                      unsigned long long* __restrict__ lb_status, int lb_words) {
     for (int j = blockIdx.x * 256 + threadIdx.x; j < lb_words; j += gridDim.x * 256) lb_status[j] = 0ull;
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
