@@ -3040,7 +3040,9 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
     // pinned + device scratch
     const int rounds = P.f2f_iterations * P.icp_iterations;
     const size_t n_item_slots = (size_t)n * (size_t)std::max(rounds, 1);                // chain mode: one item array per round
-    const size_t need = n_item_slots * sizeof(LMBatchItem) + (size_t)n * (sizeof(LMState) + 8 * sizeof(double) + sizeof(SolveLog) * VELO_MAX_SOLVES + 8);
+    size_t vis_bytes = 0;                                            // chain mode with visual blocks: flags and block counts come back through page-locked memory too
+    for (int i = 0; i < n; i++) vis_bytes += (((size_t)3 * (size_t)std::max(ctxs[i]->n_matches, 0) + 15) & ~(size_t)15) + sizeof(int) * 2 * VELO_MAX_STATS;
+    const size_t need = n_item_slots * sizeof(LMBatchItem) + (size_t)n * (sizeof(LMState) + 8 * sizeof(double) + sizeof(SolveLog) * VELO_MAX_SOLVES + 8) + 16 + vis_bytes;
     if (c0->h_batch_bytes < need) {
         if (c0->h_batch) (void)hipHostFree(c0->h_batch);
         c0->h_batch = nullptr; c0->h_batch_bytes = 0;
@@ -3052,6 +3054,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
     double* h_x = (double*)(h_states + n);
     SolveLog* h_logs = (SolveLog*)(h_x + 8 * (size_t)n);
     int* h_fail = (int*)(h_logs + (size_t)n * VELO_MAX_SOLVES);
+    unsigned char* h_vis_pin = (unsigned char*)(((uintptr_t)(h_fail + 2 * n) + 15) & ~(uintptr_t)15);
     VELO_TRY(c0->batch_items.reserve(n_item_slots)); VELO_TRY(c0->batch_states.reserve((size_t)n)); VELO_TRY(c0->batch_x.reserve((size_t)8 * n));
     if (c0->batch_tickets.cap < (size_t)n) { VELO_TRY(c0->batch_tickets.reserve((size_t)n)); HIP_TRY(hipMemsetAsync(c0->batch_tickets.p, 0, sizeof(int) * c0->batch_tickets.cap, bs)); }
 
@@ -3133,7 +3136,9 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                 const LMBatchItem* d_items = c0->batch_items.p + (size_t)r * n;
                 // groups of up to four contexts with the fused sweep + step: the items ride in the kernel arguments; device copies are needed by
                 // the kernels that take a pointer (the visual sweep, the two-launch path, the one-launch solve, the final state gather)
-                const bool by_value = n <= 4 && c0->lm_fused && (!c0->lm_persist || c0->lm_persist == 2) && nbv_max == 0;
+                // (round 5: the lean launch that carries the visual blocks takes them by value too -- six copies and their queue hand-overs less per call)
+                const bool by_value_vis = n <= 4 && c0->lm_fused && !c0->lm_persist && nbv_max > 0 && vis_in_launch && lean;
+                const bool by_value = (n <= 4 && c0->lm_fused && (!c0->lm_persist || c0->lm_persist == 2) && nbv_max == 0) || by_value_vis;
                 if (!by_value || r == 0) HIP_TRY(hipMemcpyAsync(c0->batch_items.p + (size_t)r * n, items_r, sizeof(LMBatchItem) * (size_t)n, hipMemcpyHostToDevice, bs));
                 bool small = c0->small_solve != 0 && !iter_mode;        // every solve of the group is ONE single-workgroup launch (lm_solve_small_kernel's body)
                 for (int i = 0; i < n; i++) small = small && items_r[i].n_rows >= 1 && items_r[i].n_rows <= kSmallRows;
@@ -3207,6 +3212,13 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                     c0->lm_kernel_name = lean ? "eval_step_batch_lean_v_kernel" : "eval_step_batch_v_kernel";
                 }
                 for (int k = 0; k < K; k++) {
+                    if (by_value_vis) {
+                        int nb_all = 0;
+                        for (int i = 0; i < n; i++) nb_all = std::max(nb_all, items_r[i].nb_icp + items_r[i].nb_vis);
+                        c0->lm_kernel_name = "eval_step_batch_lean_vis_kernel";          // (one name for both argument forms: the same body)
+                        VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_lean_vis_v_kernel, dim3(nb_all, n), dim3(kEvalThreads), 0, bs, Q, packv, c0->batch_tickets.p, k == 0 ? 1 : 0);
+                        continue;
+                    }
                     if (by_value) {
                         if (lean) VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_lean_v_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, packv, c0->batch_tickets.p, k == 0 ? 1 : 0);
                         else VELO_LAUNCH_T(c0, c0->lm_kernel_name, 0, eval_step_batch_v_kernel, dim3(nb_max, n), dim3(kEvalThreads), 0, bs, Q, packv, c0->batch_tickets.p, k == 0 ? 1 : 0);
@@ -3240,15 +3252,28 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
         HIP_TRY(hipMemcpyAsync(h_logs, c0->batch_logs.p, sizeof(SolveLog) * (size_t)n * VELO_MAX_SOLVES, hipMemcpyDeviceToHost, bs));
         HIP_TRY(hipMemcpyAsync(h_fail, c0->batch_fail.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, bs));
         std::vector<int> h_vis((size_t)n * 2 * VELO_MAX_STATS, 0);
-        for (int i = 0; i < n && any_matches; i++) {
-            velo_ctx* c = ctxs[i];
-            if (c->n_matches <= 0) continue;
-            c->h_vflags.resize((size_t)3 * c->n_matches);
-            HIP_TRY(hipMemcpyAsync(c->h_vflags.data(), c->vflags.p, (size_t)3 * c->n_matches, hipMemcpyDeviceToHost, bs));
-            HIP_TRY(hipMemcpyAsync(h_vis.data() + (size_t)i * 2 * VELO_MAX_STATS, c->vis_counts.p, sizeof(int) * 2 * VELO_MAX_STATS, hipMemcpyDeviceToHost, bs));
+        std::vector<unsigned char*> pin_flags((size_t)n, nullptr);
+        std::vector<int*> pin_counts((size_t)n, nullptr);
+        {
+            unsigned char* q = h_vis_pin;
+            for (int i = 0; i < n && any_matches; i++) {             // (pageable destinations make each of these copies a staged, host-blocking one)
+                velo_ctx* c = ctxs[i];
+                const size_t fb = ((size_t)3 * (size_t)std::max(c->n_matches, 0) + 15) & ~(size_t)15;
+                pin_flags[(size_t)i] = q; pin_counts[(size_t)i] = (int*)(q + fb);
+                q += fb + sizeof(int) * 2 * VELO_MAX_STATS;
+                if (c->n_matches <= 0) continue;
+                HIP_TRY(hipMemcpyAsync(pin_flags[(size_t)i], c->vflags.p, (size_t)3 * c->n_matches, hipMemcpyDeviceToHost, bs));
+                HIP_TRY(hipMemcpyAsync(pin_counts[(size_t)i], c->vis_counts.p, sizeof(int) * 2 * VELO_MAX_STATS, hipMemcpyDeviceToHost, bs));
+            }
         }
         for (int i = 0; i < n; i++) VELO_TRY(prefetch_issue(ctxs[i]));   // the next frames' uploads run under this chain (velo_hint_next_source)
         HIP_TRY(hipStreamSynchronize(bs));
+        for (int i = 0; i < n && any_matches; i++) {
+            velo_ctx* c = ctxs[i];
+            if (c->n_matches <= 0) continue;
+            c->h_vflags.assign(pin_flags[(size_t)i], pin_flags[(size_t)i] + (size_t)3 * c->n_matches);
+            std::memcpy(h_vis.data() + (size_t)i * 2 * VELO_MAX_STATS, pin_counts[(size_t)i], sizeof(int) * 2 * VELO_MAX_STATS);
+        }
         bool ok = true;
         for (int i = 0; i < n; i++) ok = ok && !h_fail[i] && h_states[i].done != 0;
         if (ok) {

@@ -3982,6 +3982,10 @@ __global__ void __launch_bounds__(kEvalThreads) __attribute__((amdgpu_num_vgpr(1
 eval_step_batch_lean_v_kernel(LMParams Q, LMBatchPackV P, int* __restrict__ tickets, int first) {
     eval_step_batch_body<true, VELO_LEAN_PRE, 64>(Q, P.item[blockIdx.y], tickets, first);
 }
+__global__ void __launch_bounds__(kEvalThreads) __attribute__((amdgpu_num_vgpr(152)))
+eval_step_batch_lean_vis_v_kernel(LMParams Q, LMBatchPackV P, int* __restrict__ tickets, int first) {
+    eval_step_batch_body<true, VELO_LEAN_PRE, 64, true>(Q, P.item[blockIdx.y], tickets, first);
+}
 // The one-launch iteration of the single-pair path (every workgroup runs the transition itself, then sweeps: no last-workgroup hand-over
 // inside the launch) for the contexts of a lock-step group, in the LEAN shape of eval_step_batch_lean_kernel (matrices from LDS, one
 // prefetched row, 64-row chunks), items by value.  parity selects the halves of every context's state / partial-row double buffer (a
