@@ -2702,13 +2702,15 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
     HIP_TRY(hipMemcpyAsync(h_fail, c->chain_fail.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&c->h_status->s, c->state.p + (j & 1), sizeof(LMState), hipMemcpyDeviceToHost, c->stream));
     int* h_vis_counts = h_fail + 1;                                  // 2 x VELO_MAX_STATS ints behind the failure flag (the pinned block has 64 spare bytes)
-    if (visual) {
-        c->h_vflags.resize((size_t)3 * c->n_matches);
-        HIP_TRY(hipMemcpyAsync(c->h_vflags.data(), c->vflags.p, (size_t)3 * c->n_matches, hipMemcpyDeviceToHost, c->stream));
+    int* pin_flags = nullptr;
+    if (visual) {                                                    // (through page-locked memory: a pageable destination makes the copy a staged, host-blocking one)
+        VELO_TRY(pin_acquire(c, 3, ((size_t)3 * c->n_matches + sizeof(int) - 1) / sizeof(int), &pin_flags));
+        HIP_TRY(hipMemcpyAsync(pin_flags, c->vflags.p, (size_t)3 * c->n_matches, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(h_vis_counts, c->vis_counts.p, sizeof(int) * 2 * VELO_MAX_STATS, hipMemcpyDeviceToHost, c->stream));
     }
     VELO_TRY(prefetch_issue(c));                                     // the next frame's upload runs under this chain (velo_hint_next_source)
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (visual) { const unsigned char* pf = reinterpret_cast<const unsigned char*>(pin_flags); c->h_vflags.assign(pf, pf + (size_t)3 * c->n_matches); }
     VELO_TRY(peer_check(c));
     if (*h_fail || !c->h_status->s.done) {
         HIP_TRY(hipMemsetAsync(c->chain_fail.p, 0, sizeof(int), c->stream));
