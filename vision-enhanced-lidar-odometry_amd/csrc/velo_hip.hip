@@ -90,6 +90,11 @@ struct DevBuf {
         if (n <= cap) return VELO_OK;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = n + n / 8 + 64;
+#ifdef VELO_DIAGNOSTICS
+        // A/B (VELO_ALLOC_2MB=1): buffers of 256 KB and more padded to whole 2 MB -- does the page-table fragment size matter to the gathers?
+        static const bool pad2m = getenv("VELO_ALLOC_2MB") && atoi(getenv("VELO_ALLOC_2MB")) != 0;
+        if (pad2m && want * sizeof(T) >= (256u << 10)) want = ((want * sizeof(T) + (2u << 20) - 1) / (2u << 20)) * (2u << 20) / sizeof(T);
+#endif
         hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
         if (e != hipSuccess) return fail(VELO_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e));
         cap = want;
