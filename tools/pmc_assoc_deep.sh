@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX: what the tube kernel waits for -- SQ issue / wait split by instruction class, LDS conflicts, texture-addresser and L1 stalls,
-# L1->L2 read latency, L2 hits -- one rocprofv3 --pmc pass per counter group on bench.py's single-pair shape (ARGS overrides the bench arguments).
+# (a TA_* + GRBM group aborted rocprofv3 and hung the box until the time limit: the TA / TCP / TCC groups are gone) -- one rocprofv3 --pmc pass per counter group on bench.py's single-pair shape (ARGS overrides the bench arguments).
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_deep
 rm -rf $OUT; mkdir -p $OUT
@@ -17,10 +17,6 @@ done <<'GROUPS'
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_WAIT_INST_LDS SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS
 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_LDS_ATOMIC SQ_INSTS_LDS_LOAD SQ_INSTS_LDS_STORE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL
-TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_TOTAL_WAVEFRONTS_sum GRBM_GUI_ACTIVE
-TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum
-TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TOTAL_ACCESSES_sum TCP_GATE_EN1_sum
-TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_TAG_STALL_sum
 GROUPS
 python3 - <<'PY'
 import csv, glob, os, collections
