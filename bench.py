@@ -75,6 +75,7 @@ def parse():
     ap.add_argument("--separate-loads", action="store_true",
                     help="A/B: velo_set_target/source from B host threads, then velo_frame_to_frame_batch (instead of velo_register_batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--legs-in-process", action="store_true", help="A/B: the c1 / c3 / c4 / host-inputs / canonical-pair legs inside this process, behind the main leg, instead of one child process each")
     ap.add_argument("--no-legs", action="store_true", help="only the timed workload: no c1/c3/c4 legs, no multi-GPU mode legs")
     ap.add_argument("--comm", choices=["peer", "rccl"], default="peer", help="all-reduce of the sharded mode: peer-mapped slabs or RCCL")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for the barrier / max-over-ranks (nccl = RCCL)")
@@ -730,6 +731,10 @@ def main():
     if a.mode == "replicas" and not (a.same_pairs or a.same_pair) and a.workload in ("c1", "c2", "c3") and a.batch_api and not a.separate_loads \
             and not (a.workload == "c1" and os.environ.get("VELO_KITTI_ROOT")):
         import velo_amd  # noqa: F401
+        if not a.no_legs and not os.environ.get("VELO_DRIVE_CACHE") and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+            import tempfile                                  # the legs run as child processes and read these frames back instead of synthesising them again
+            os.environ["VELO_DRIVE_CACHE"] = tempfile.mkdtemp(prefix="velo_drives_")
+            a._own_cache = os.environ["VELO_DRIVE_CACHE"]
         drives = make_drives(max(1, a.batch), a.warmup + a.steps + 1, a.gen_procs)
     rig = Rig(a)
     world, rank = rig.world, rig.rank
@@ -737,13 +742,43 @@ def main():
     legs, modes = {}, {}
     if not a.no_legs:
         if world == 1 and a.mode == "replicas":
-            # short legs of the other single-GPU configs (each a complete bench of its own: warm-up, barrier-bracketed timed region);
-            # c1 / c3 walk the SAME drives as the headline (as many steps as their frames allow), c4 registers B scans against the 2M-point map
+            # Short legs of the other single-GPU configs, EACH IN A PROCESS OF ITS OWN (`python bench.py --workload <leg> --no-legs`, started as a
+            # child once this process has released its contexts and buffers): a leg is a complete bench -- warm-up, barrier-bracketed timed
+            # region, single-pair latency -- of that config, measured the way the driver measures the headline.  (Run inside this process behind
+            # the main leg, the host-bound legs read 15-25 % low -- c3 2.4-2.65 k against 3.1-3.25 k pairs/s alone, c1 6.9-7.9 k against 8.0-8.5 k --
+            # with the same kernels, the same four evenly busy queues and more idle time between their operations; `--legs-in-process` keeps
+            # that form for A/B.)  c1 / c3 walk the SAME drives as the headline (as many steps as their frames allow: the children read the
+            # parent's frames back from VELO_DRIVE_CACHE), c4 registers B scans against the 2M-point map.
+            import subprocess
+
+            def child_leg(workload, steps, warmup, extra=()):
+                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", workload, "--steps", str(steps), "--warmup", str(warmup), "--batch", str(a.batch),
+                       "--timing", str(a.timing), "--no-legs", "--no-cpu-baseline", *extra]
+                out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+                rows = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+                if out.returncode != 0 or not rows:
+                    return {"error": (out.stderr or "no output")[-400:]}
+                ln = json.loads(rows[-1])
+                leg = {"workload": ln["config"]["workload"], "mode": ln["config"]["mode"], "pairs_in_flight_per_gpu": ln["config"]["pairs_in_flight_per_gpu"],
+                       "distinct_pairs": ln["config"]["distinct_pairs"], "steps": ln["steps"], "warmup": ln["warmup"], "pairs_per_s": ln["value"], "ms_per_step": ln["ms_per_step"],
+                       "Nq": ln["config"]["Nq"], "Nt": ln["config"]["Nt"], "lm_evaluations_per_pair": ln["config"]["lm_evaluations_per_pair"],
+                       "algorithmic_bytes_per_pair": ln["config"]["algorithmic_bytes_per_pair"], "achieved_hbm_GBs_whole_path": ln["achieved_hbm_GBs_whole_path"],
+                       "chain": ln["chain"], "roofline": ln["roofline"], "kernels": ln["kernels"], "solution_x": ln["solution_x"], "process": "a child process of its own"}
+                for kk in ("single_pair", "against_simulated_motion", "own_map_copies", "shared_target", "map", "first_pair_solution_x"):
+                    if kk in ln:
+                        leg[kk] = ln[kk]
+                return leg
+
+            in_proc = getattr(a, "legs_in_process", False)
             for name, steps in (("c1", 100), ("c3", 40), ("c4", 12)):
                 if name != a.workload:
                     kitti_c1 = name == "c1" and os.environ.get("VELO_KITTI_ROOT")
-                    legs[name] = run_leg(rig, a, name, "replicas", a.batch, steps, 3, drives=None if kitti_c1 else drives)
-                    if not a.no_cpu_baseline:
+                    if in_proc:
+                        legs[name] = run_leg(rig, a, name, "replicas", a.batch, steps, 3, drives=None if kitti_c1 else drives)
+                    else:
+                        n_leg = steps if (drives is None or kitti_c1 or name == "c4") else max(1, min(steps, len(drives[0]["frames"]) - 1 - 3))
+                        legs[name] = child_leg(name, n_leg, 3)
+                    if not a.no_cpu_baseline and "error" not in legs[name]:
                         # every leg next to the CPU restatement on its own first pair, with the pose difference.  c1: the reference's own constants on
                         # its own kind of host (icp_skip = 200, one thread, velo.h:900, and all cores); c3: with the pair's stereo matches; c4: the
                         # whole scan-to-map call on all cores (the one-thread run would take minutes)
@@ -762,22 +797,34 @@ def main():
             if drives is not None and not getattr(a, "host_inputs", False):
                 # main.cpp:216,349 load a scan per frame: the same drives with their frames in pageable HOST memory -- every step uploads its B frames
                 # (the library announces the next frames to itself, velo_hint_next_source: their copies run under the current step's launches)
-                import copy
-                a_h = copy.copy(a)
-                a_h.host_inputs = True
-                hl = run_leg(rig, a_h, a.workload, "replicas", a.batch, a.steps, a.warmup, single_leg=False, drives=drives)
-                legs["host_inputs"] = {"pairs_per_s": hl["pairs_per_s"], "ms_per_step": hl["ms_per_step"], "steps": hl["steps"], "chain": hl["chain"],
-                                       "of_resident_rate": hl["pairs_per_s"] / main_leg["pairs_per_s"], "solution_equal_to_resident": hl["solutions"] == main_leg["solutions"],
-                                       "note": "frames in pageable host memory, 1.44 MB uploaded per pair inside the step (PCIe-inclusive); never `value`"}
+                if in_proc:
+                    import copy
+                    a_h = copy.copy(a)
+                    a_h.host_inputs = True
+                    hl = run_leg(rig, a_h, a.workload, "replicas", a.batch, a.steps, a.warmup, single_leg=False, drives=drives)
+                    hl_sol = hl["solutions"]
+                else:
+                    hl = child_leg(a.workload, a.steps, a.warmup, ("--host-inputs",))
+                    hl_sol = None
+                if "error" in hl:
+                    legs["host_inputs"] = hl
+                else:
+                    legs["host_inputs"] = {"pairs_per_s": hl["pairs_per_s"], "ms_per_step": hl["ms_per_step"], "steps": hl["steps"], "chain": hl["chain"],
+                                           "of_resident_rate": hl["pairs_per_s"] / main_leg["pairs_per_s"],
+                                           "solution_equal_to_resident": (hl_sol == main_leg["solutions"]) if hl_sol is not None else (hl["solution_x"] == main_leg["solution_x"]),
+                                           "note": "frames in pageable host memory, 1.44 MB uploaded per pair inside the step (PCIe-inclusive); never `value`"}
             if a.workload == "c2" and not a.same_pair:
                 # SURVEY 8(d) "Motion": the canonical pair from the start-up guess {0,0,0,0,0,1} (main.cpp:170) in every context -- the unit of work the
                 # rounds before the drive workload measured (~40 LM evaluations per pair), kept so that rounds stay comparable
-                import copy
-                a_cp = copy.copy(a)
-                a_cp.same_pair = True
-                cp = run_leg(rig, a_cp, "c2", "replicas", a.batch, 10, 3, drives=None)
+                if in_proc:
+                    import copy
+                    a_cp = copy.copy(a)
+                    a_cp.same_pair = True
+                    cp = run_leg(rig, a_cp, "c2", "replicas", a.batch, 10, 3, drives=None)
+                else:
+                    cp = child_leg("c2", 10, 3, ("--same-pair",))
                 legs["canonical_pair"] = {k: cp[k] for k in ("workload", "pairs_per_s", "ms_per_step", "lm_evaluations_per_pair", "algorithmic_bytes_per_pair",
-                                                             "achieved_hbm_GBs_whole_path", "chain", "single_pair", "solution_x") if k in cp}
+                                                             "achieved_hbm_GBs_whole_path", "chain", "single_pair", "solution_x", "error") if k in cp}
                 legs["canonical_pair"]["initial_guess"] = "start-up guess {0,0,0,0,0,1} (main.cpp:170); true motion: yaw 0.02 rad, t = (1.00, 0.02, 0.01) m (SURVEY 8d)"
         if world > 1 and a.mode == "replicas" and os.environ.get("VELO_BENCH_MODES", "1") != "0":
             # the north_star's multi-GPU modes, next to the replicas: one pair per step, strong scaling.  Never fatal for the headline:
@@ -858,6 +905,8 @@ def main():
             "kernels": main_leg["kernels"],
             "solution_x": main_leg["solution_x"],
         }
+        if "first_pair_solution_x" in main_leg:
+            line["first_pair_solution_x"] = main_leg["first_pair_solution_x"]
         if "communicator" in main_leg:
             line["config"]["communicator"] = main_leg["communicator"]
         if single is not None:
@@ -901,6 +950,9 @@ def main():
             cb["pose_diff_vs_gpu"] = {"dt_m": float(np.linalg.norm(xo[3:] - xg[3:])), "dw_rad": float(np.linalg.norm(xo[:3] - xg[:3]))}
             line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
+    if getattr(a, "_own_cache", None):
+        import shutil
+        shutil.rmtree(a._own_cache, ignore_errors=True)
     if rig.dist is not None:
         rig.dist.barrier()
         rig.dist.destroy_process_group()
