@@ -339,6 +339,15 @@ def test_device_memory_returns_after_destroy():
             cache.store(f, ctxs[0], True)
         cache.load(2, ctxs[1], True)
         cache.close()
+        # round 5: a frame announced ahead (velo_hint_next_source: two landing buffers, a copy stream, an event) and the drive loop in one call
+        host = (np.ascontiguousarray(d["src_xyz"]), d["src_off"])
+        refs = api.scan_refs([host], 0)
+        api.hint_next_sources(ctxs[:1], refs[0])
+        api.register_batch(ctxs[:1], None, None, np.asarray(d["x0"])[None, :], refs=(api.promote_refs(1), refs))
+        seq_refs, _keep, _n = api.sequence_refs([[host, host, host]], 0, first=1)
+        api.register_sequences(ctxs[:1], seq_refs, 2, np.tile(np.eye(4), (1, 1, 1)), np.asarray(d["x0"], dtype=np.float64)[None, :].copy())
+        for _ in range(4):                      # every export hands out a new slab; the retired ones are capped
+            ctxs[1].comm_peer_export()
         for c in ctxs: c.close()
 
     for _ in range(3): cycle()
