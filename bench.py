@@ -2,7 +2,8 @@
 """bench.py -- scan-pairs/s of the MI355X scan-matching core on BASELINE.json's workload.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: under python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ..., or plainly: without a launcher the
+     script starts its N ranks itself, as a child process; a launcher whose WORLD_SIZE is not N is an error)
 
 One "step" = B DRIVES advancing one frame each (the reference's loop, main.cpp:305-413, B sequences at a time): context i registers
 frame k+1 of drive i against frame k -- the previous frame, registered as source in the last step, is promoted to target ON THE DEVICE
@@ -21,7 +22,10 @@ The same JSON line also carries
             name, velo_set_timing(ctx, 2)) with its algorithmic bytes, achieved GB/s and fraction of the HBM peak; `kernels` = the
             same for the top three
   configs   short legs of the other single-GPU workloads (c1: reference constants -- on KITTI frames when VELO_KITTI_ROOT names a
-            dataset root --, c3: + 2,000 stereo blocks, c4: 2M-point map), each a complete bench of its own               (N = 1)
+            dataset root --, c3: + 2,000 stereo blocks, c4: 2M-point map shared by the B contexts, canonical_pair: the start-up-guess pair of
+            rounds 1-3), each a complete bench of its own IN A CHILD PROCESS of its own, each with its cpu_baseline                (N = 1)
+  host_inputs  the headline's drives with their frames in pageable host memory, uploaded inside the step (PCIe-inclusive; never `value`)
+  against_simulated_motion  every timed pair's pose against the drive's simulated motion
   modes     N > 1 only: the north_star's multi-GPU modes next to the replicas --
             sharded          ONE pair per step, queries split 1/N per rank, the 28-double normal-equation block all-reduced
                              every LM evaluation (peer-mapped slabs inside the LM step; --comm rccl: ncclAllReduce)  -> strong scaling
@@ -754,7 +758,10 @@ def main():
             def child_leg(workload, steps, warmup, extra=()):
                 cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", workload, "--steps", str(steps), "--warmup", str(warmup), "--batch", str(a.batch),
                        "--timing", str(a.timing), "--no-legs", "--no-cpu-baseline", *extra]
-                out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+                try:
+                    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+                except Exception as e:       # noqa: BLE001  (a leg never takes the headline down)
+                    return {"error": f"{type(e).__name__}: {str(e)[:300]}"}
                 rows = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
                 if out.returncode != 0 or not rows:
                     return {"error": (out.stderr or "no output")[-400:]}
