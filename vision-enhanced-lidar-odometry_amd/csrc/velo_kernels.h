@@ -108,6 +108,9 @@ __device__ __forceinline__ int cell_coord(float p, float o, float inv_h, int n) 
     return (int)floorf(f);
 }
 
+// (velo_lm_ag.hip, the translation unit of the all-gather solve, defines VELO_UNIT_LM_ONLY: it needs the solver half of this header only, and every
+//  kernel it would compile here -- ingest, index build, the association family -- would be a second, unused copy in the shared library)
+#ifndef VELO_UNIT_LM_ONLY
 // ---- point packing: (stride-addressed xyz) -> float4 ---------------------------------------------------------
 __global__ void pack_points_kernel(const char* __restrict__ src, int64_t stride, int n, float4* __restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2548,6 +2551,7 @@ assoc_cluster_kernel(GridView G, AssocQueue Q, const float4* __restrict__ src, c
     }
 }
 
+#endif  // VELO_UNIT_LM_ONLY
 // ---- visual blocks (rows G1, R2-R5) ------------------------------------------------------------------------------------
 // One record per match, three block slots: slot 0 = 3D3D or 2D2D, slot 1 = 3D2D, slot 2 = 2D3D (velo.h order).
 struct VisualMatch {      // device copy of velo_match, floats kept as floats and widened at use (costfunctions.h ctors)
@@ -3325,6 +3329,7 @@ __global__ void __launch_bounds__(64) peer_agree_kernel(PeerComm C, AgreeCounts 
     if (t == 0) *C.kseq = seq;
 }
 
+#ifndef VELO_UNIT_LM_ONLY        // (the record exchange of the target-sharded mode takes the association unit's PartialRec)
 // ---- target-sharded mode over the same peers (BASELINE config 5): the per-round exchange of the per-query top-2 records -------------
 // Every rank has searched ITS rings for ALL queries (PartialRec per query).  Rank r must end up with everybody's records of ITS
 // query share: each rank stores the slices straight into the owners' receive areas (peer-mapped, fine-grained memory; area of
@@ -3381,6 +3386,7 @@ peer_reduce_kernel(const double* __restrict__ partials, int n_blocks, PeerComm C
     if (threadIdx.x < kNumAcc) out[threadIdx.x] = E[threadIdx.x];
 }
 
+#endif  // VELO_UNIT_LM_ONLY
 // sums the per-workgroup partials in a fixed order into out[28] (used before the RCCL all-reduce and by velo_evaluate)
 __global__ void reduce_partials_kernel(const LMState* __restrict__ state, const double* __restrict__ partials, int n_blocks, double* __restrict__ out) {
     if (state && state->done) return;

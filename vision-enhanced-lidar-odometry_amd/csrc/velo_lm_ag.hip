@@ -7,6 +7,7 @@
 
 #include "../../include/velo_hip.h"
 
+#define VELO_UNIT_LM_ONLY 1
 namespace {
 #include "velo_device_math.h"
 #include "velo_kernels.h"
