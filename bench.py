@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--sequences", action="store_true", help="A/B: ONE velo_register_sequences call for the timed frames (the lock-step groups walk their drives independently, no barrier "
                     "between frames) instead of one velo_register_batch call per step.  Measured: the groups drift apart, every kernel runs faster in the mix "
                     "(association 134 vs 149 us, LM launch 22.1 vs 23.7 us) but the call ends with its slowest group (3,297 vs 3,486 pairs/s)")
+    ap.add_argument("--sequences-lockstep", action="store_true", help="A/B: ONE velo_register_sequences call with VELO_SEQ_LOCKSTEP (a barrier between frames inside the library): "
+                    "the per-step form without the harness's interpreter in the loop")
     ap.add_argument("--own-map-copies", action="store_true", help="c4 A/B: every context holds its own copy of the 2M-point map and builds its own index every step (rounds 1-4)")
     ap.add_argument("--host-inputs", action="store_true", help="the drives' frames stay in host memory (numpy): every step uploads its B frames -- the PCIe-inclusive rate (never the headline)")
     ap.add_argument("--gen-procs", type=int, default=0, help="worker processes that synthesise the drives' frames (0: min(16, host cores))")
@@ -374,11 +376,12 @@ class DriveWalker:
         vis = self.api.sequence_visual_refs(self.vis, first=k0, count=K) if self.vis is not None else None
         return (k0, K, refs, keep, vis)
 
-    def walk(self, prep):
-        """K frames of every drive in ONE library call (velo_register_sequences): the lock-step groups walk their drives independently"""
+    def walk(self, prep, lockstep=False):
+        """K frames of every drive in ONE library call (velo_register_sequences): the lock-step groups walk their drives independently, or
+        (lockstep) start every frame together"""
         k0, K, refs, _keep, vis = prep
         assert k0 == self.k
-        xs, Ts, Ss = self.api.register_sequences(self.ctxs, refs, K, self.P_prev, self.x0, visual=vis)
+        xs, Ts, Ss = self.api.register_sequences(self.ctxs, refs, K, self.P_prev, self.x0, visual=vis, lockstep=lockstep)
         if k0 == 0:
             self.first = xs[0].copy()
         self.k = k0 + K
@@ -522,7 +525,7 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
             else:
                 list(pool.map(one_pair, range(B)))
 
-        seq = walker is not None and getattr(a, "sequences", False)                 # the drives' timed frames through ONE velo_register_sequences call
+        seq = walker is not None and (getattr(a, "sequences", False) or getattr(a, "sequences_lockstep", False))                 # the drives' timed frames through ONE velo_register_sequences call
         if seq:
             if warmup > 0:
                 walker.walk(walker.prepare(warmup))
@@ -545,7 +548,7 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
         kept = []                                            # the steps' summaries: added up behind the timed region (150 ctypes reads per step)
         xs_seq = None
         if seq:
-            xs_seq, Ts_seq, kept = walker.walk(prep)
+            xs_seq, Ts_seq, kept = walker.walk(prep, lockstep=getattr(a, "sequences_lockstep", False))
             for i in range(B):
                 results[i] = (xs_seq[-1][i], Ts_seq[-1][i], kept[-1][i])
         else:

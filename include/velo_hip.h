@@ -399,11 +399,13 @@ int velo_register_batch_visual(velo_ctx** ctxs, int32_t n, const velo_scan_ref* 
  * [f * n + i] receive what velo_register_batch returns for it, and poses[i] / x_guess[i] are handed over exactly as velo_pose_handoff
  * does it.  The lock-step groups walk their drives' frames independently (no barrier across the batch between frames); per pair the
  * results are bit-identical to the frame-by-frame calls.  poses: n 4x4 row-major in/out; x_guess: n*6 in/out (the start-up guess
- * {0,0,0,0,0,1}, main.cpp:170, for a drive's first pair). */
+ * {0,0,0,0,0,1}, main.cpp:170, for a drive's first pair).  flags: VELO_SEQ_LOCKSTEP -- the groups start every frame together (a barrier
+ * between frames: the timing of one velo_register_batch call per frame, without the caller in the loop); 0 -- no barrier. */
+#define VELO_SEQ_LOCKSTEP 1
 int velo_register_sequences(velo_ctx** ctxs, int32_t n, int32_t n_frames, const velo_scan_ref* frames /* n_frames*n */,
                             const velo_match* const* matches /* n_frames*n or NULL */, const int32_t* n_matches /* n_frames*n or NULL */,
                             double* poses /* n*16 */, double* x_guess /* n*6 */, double* x_out /* n_frames*n*6 */, double* T_out /* n_frames*n*16 or NULL */,
-                            velo_summary* summaries /* n_frames*n or NULL */);
+                            velo_summary* summaries /* n_frames*n or NULL */, int32_t flags);
 /* main.cpp:216,349 load a scan per frame.  A caller that knows which HOST cloud it will hand over as the context's NEXT source announces it
  * here; the library uploads it on a copy stream of its own while the current registration's launches run (the upload is issued by the
  * thread that is about to wait for them), and the very next velo_set_source / batch job / sequence frame that names the same pointer and

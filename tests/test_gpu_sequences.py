@@ -46,8 +46,8 @@ def test_sequences_equal_frame_by_frame_calls(hip_lib, B, with_vis):
     w = bench.DriveWalker(api, ctxs, [d["frames"] for d in drives], 0, vis)
     # two calls: 2 frames, then the remaining 3 -- a call continues where the last one stopped (the contexts hold their drives' current frames)
     got = []
-    for K in (2, 3):
-        xs, Ts, Ss = w.walk(w.prepare(K))
+    for K, lockstep in ((2, False), (3, True)):                      # free-running groups, then frames in lock step: the same registrations
+        xs, Ts, Ss = w.walk(w.prepare(K), lockstep=lockstep)
         for f in range(K):
             got.append((xs[f], Ts[f], [_summary_tuple(s) for s in Ss[f]]))
     assert len(got) == len(ref) == n_frames - 1

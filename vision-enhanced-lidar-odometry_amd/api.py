@@ -209,7 +209,7 @@ SIGNATURES = {
     "velo_register_batch": (C.c_int, [_P(_ctx), C.c_int32, C.c_void_p, C.c_void_p, _dp, _dp, _P(VeloSummary)]),
     "velo_register_batch_visual": (C.c_int, [_P(_ctx), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _dp, _dp, _P(VeloSummary)]),
     "velo_hint_next_source": (C.c_int, [_ctx, C.c_void_p]),
-    "velo_register_sequences": (C.c_int, [_P(_ctx), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, _dp, _dp, _dp, _dp, _P(VeloSummary)]),
+    "velo_register_sequences": (C.c_int, [_P(_ctx), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, _dp, _dp, _dp, _dp, _P(VeloSummary), C.c_int32]),
     "velo_pose_vec_to_mat": (C.c_int, [_dp, _dp]),
     "velo_pose_mat_to_vec": (C.c_int, [_dp, _dp]),
     "velo_pose_handoff": (C.c_int, [C.c_int32, _dp, _dp, _dp]),
@@ -819,10 +819,14 @@ def sequence_visual_refs(matches_per_drive, first=0, count=None):
     return visual_refs([matches_per_drive[i][first + f] for f in range(count) for i in range(n)])
 
 
-def register_sequences(ctxs, frame_refs, n_frames, poses, x_guess, visual=None, summaries=True):
+SEQ_LOCKSTEP = 1
+
+
+def register_sequences(ctxs, frame_refs, n_frames, poses, x_guess, visual=None, summaries=True, lockstep=False):
     """velo_register_sequences: the drive loop of len(ctxs) sequences for n_frames frames in one call (every context holds its drive's
     current frame as source).  frame_refs: sequence_refs(...)[0]; poses (n,4,4) and x_guess (n,6) float64 C-contiguous, UPDATED IN PLACE
-    (the drives' accumulated poses and the next frame's constant-velocity guesses).  -> xs (F,n,6), Ts (F,n,4,4), summaries [F][n] or None"""
+    (the drives' accumulated poses and the next frame's constant-velocity guesses).  lockstep: the groups start every frame together
+    (VELO_SEQ_LOCKSTEP).  -> xs (F,n,6), Ts (F,n,4,4), summaries [F][n] or None"""
     lib = ctxs[0]._lib if len(ctxs) else load_library()
     n = len(ctxs)
     assert poses.dtype == np.float64 and poses.flags.c_contiguous and poses.shape == (n, 4, 4)
@@ -833,7 +837,8 @@ def register_sequences(ctxs, frame_refs, n_frames, poses, x_guess, visual=None, 
     S = (VeloSummary * (n * n_frames))() if summaries else None
     vm = C.cast(visual[0], C.c_void_p) if visual is not None else None
     vn = C.cast(visual[1], C.c_void_p) if visual is not None else None
-    st = lib.velo_register_sequences(arr, n, n_frames, C.cast(frame_refs, C.c_void_p), vm, vn, _ptr(poses), _ptr(x_guess), _ptr(xs), _ptr(Ts), S)
+    st = lib.velo_register_sequences(arr, n, n_frames, C.cast(frame_refs, C.c_void_p), vm, vn, _ptr(poses), _ptr(x_guess), _ptr(xs), _ptr(Ts), S,
+                                     SEQ_LOCKSTEP if lockstep else 0)
     if st != 0:
         msg = lib.velo_last_error()
         raise VeloError(f"velo status {st}: {msg.decode() if msg else ''}")

@@ -3604,7 +3604,7 @@ int velo_frame_to_frame_batch(velo_ctx** ctxs, int32_t n, double* x, double* T, 
 // meeting at every step.  Per pair the work and the results are those of n_frames velo_register_batch[_visual] calls with
 // VELO_SCAN_PROMOTE targets followed by velo_pose_handoff (tests compare them bit for bit).
 static int sequences_impl(velo_ctx** ctxs, int32_t n, int32_t n_frames, const velo_scan_ref* frames, const velo_match* const* matches, const int32_t* n_matches,
-                          double* poses, double* x_guess, double* x_out, double* T_out, velo_summary* summaries) {
+                          double* poses, double* x_guess, double* x_out, double* T_out, velo_summary* summaries, int32_t flags) {
     if (!ctxs || n < 0 || n_frames < 0 || (n > 0 && n_frames > 0 && (!frames || !poses || !x_guess || !x_out))) return fail(VELO_ERR_INVALID, "bad sequence arguments");
     if (matches && !n_matches) return fail(VELO_ERR_INVALID, "n_matches is null");
     for (int i = 0; i < n; i++) {
@@ -3627,16 +3627,31 @@ static int sequences_impl(velo_ctx** ctxs, int32_t n, int32_t n_frames, const ve
     std::vector<int> gst((size_t)G, VELO_OK);
     std::vector<std::string> gerr((size_t)G);
     std::atomic<bool> stop{false};
+    // VELO_SEQ_LOCKSTEP: the groups start every frame together (what a caller that makes one velo_register_batch call per frame gets, without
+    // the caller in the loop): a counting barrier between frames, generation by generation
+    const bool lockstep_frames = (flags & VELO_SEQ_LOCKSTEP) != 0 && G > 1;
+    std::mutex bar_m;
+    std::condition_variable bar_cv;
+    int bar_count = 0, bar_gen = 0;
+    auto frame_barrier = [&]() {
+        std::unique_lock<std::mutex> lk(bar_m);
+        const int gen = bar_gen;
+        if (++bar_count == G) { bar_count = 0; bar_gen++; bar_cv.notify_all(); }
+        else bar_cv.wait(lk, [&]() { return bar_gen != gen; });
+    };
     auto run_group = [&](int gi) {
         const int b = (int)((int64_t)n * gi / G), e = (int)((int64_t)n * (gi + 1) / G), m = e - b;
         std::vector<double> Tl((size_t)16 * m), xl((size_t)6 * m);
-        auto bail = [&](int st) { gst[(size_t)gi] = st; gerr[(size_t)gi] = g_err; stop.store(true); };
+        // (a failing group keeps meeting the others at the barrier until the last frame: nobody waits for a group that has left)
+        int failed = VELO_OK;
+        auto bail = [&](int st) { gst[(size_t)gi] = st; gerr[(size_t)gi] = g_err; stop.store(true); failed = st; };
         static const bool seq_trace = dev_env("VELO_SEQ_TRACE") != nullptr;        // dev aid: where a group's host thread spends a frame
         double t_load = 0.0, t_reg = 0.0, t_hand = 0.0;
         auto now = []() { return std::chrono::steady_clock::now(); };
         auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point bb) { return std::chrono::duration<double, std::micro>(bb - a).count(); };
         const auto t_begin = now();
-        for (int f = 0; f < n_frames && !stop.load(); f++) {
+        for (int f = 0; f < n_frames && (lockstep_frames || !stop.load()); f++) {
+            if (lockstep_frames) { if (f > 0) frame_barrier(); if (failed != VELO_OK || stop.load()) continue; }
             const auto t0 = now();
             const velo_scan_ref* fr = frames + (size_t)f * n;
             JobVisual V;
@@ -3660,12 +3675,12 @@ static int sequences_impl(velo_ctx** ctxs, int32_t n, int32_t n_frames, const ve
                 if (st == VELO_OK) st = f2f_batch_lockstep(ctxs + b, m, xl.data(), Tl.data(), Sf, G > 1);
                 t_reg += us(t1, now());
             }
-            if (st != VELO_OK) { bail(st); return; }
+            if (st != VELO_OK) { bail(st); if (!lockstep_frames) return; continue; }
             const auto t2 = now();
             std::memcpy(x_out + ((size_t)f * n + b) * 6, xl.data(), sizeof(double) * 6 * (size_t)m);
             if (T_out) std::memcpy(T_out + ((size_t)f * n + b) * 16, Tl.data(), sizeof(double) * 16 * (size_t)m);
             st = velo_pose_handoff(m, poses + (size_t)16 * b, Tl.data(), x_guess + (size_t)6 * b);      // main.cpp:408, 311-331
-            if (st != VELO_OK) { bail(st); return; }
+            if (st != VELO_OK) { bail(st); if (!lockstep_frames) return; continue; }
             t_hand += us(t2, now());
         }
         if (seq_trace) fprintf(stderr, "[velo seq] group %d: %d frames in %.0f us: loads %.0f, registrations %.0f, hand-over %.0f us per frame\n", gi, n_frames,
@@ -3691,8 +3706,8 @@ int velo_hint_next_source(velo_ctx* c, const velo_scan_ref* next) {
 }
 
 int velo_register_sequences(velo_ctx** ctxs, int32_t n, int32_t n_frames, const velo_scan_ref* frames, const velo_match* const* matches, const int32_t* n_matches,
-                            double* poses, double* x_guess, double* x_out, double* T_out, velo_summary* summaries) {
-    return sequences_impl(ctxs, n, n_frames, frames, matches, n_matches, poses, x_guess, x_out, T_out, summaries);
+                            double* poses, double* x_guess, double* x_out, double* T_out, velo_summary* summaries, int32_t flags) {
+    return sequences_impl(ctxs, n, n_frames, frames, matches, n_matches, poses, x_guess, x_out, T_out, summaries, flags);
 }
 
 int velo_register_batch(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, const velo_scan_ref* sources, double* x, double* T, velo_summary* summaries) {
