@@ -336,10 +336,12 @@ class DriveWalker:
     promotes it to target on the device, registers frame k+1 against it and hands the pose over -- T[k+1] = T[k] * dpose (main.cpp:408),
     next guess = pose_vec2mat(T[k]^-1 T[k+1]) (main.cpp:311-331).  One library call per step (velo_register_batch)."""
 
-    def __init__(self, api, ctxs, frames, local_rank, vis=None):
+    def __init__(self, api, ctxs, frames, local_rank, vis=None, ahead=None):
         self.api, self.ctxs, self.frames, self.vis, self.local_rank = api, ctxs, frames, vis, local_rank
         self.B = len(ctxs)
         self.host_frames = isinstance(frames[0][0][0], np.ndarray)
+        # velo_hint_next_frame before every step (A/B: VELO_BENCH_NO_AHEAD=1 -- every step loads its own frame, as in rounds 4 and before)
+        self.ahead = (not os.environ.get("VELO_BENCH_NO_AHEAD")) if ahead is None else bool(ahead)
         self.n_frames = min(len(f) for f in frames)
         self.promote = api.promote_refs(self.B)
         self.src_refs = [api.scan_refs([frames[i][k] for i in range(self.B)], local_rank) for k in range(self.n_frames)]
@@ -358,7 +360,9 @@ class DriveWalker:
 
     def step(self):
         k = self.k + 1
-        if self.host_frames and k + 1 < self.n_frames:       # frames in host memory: the NEXT frames' uploads run under this step's launches
+        if k + 1 < self.n_frames and self.ahead:             # the next step announced: its promotion, ingest and index build (and, for frames in host
+            self.api.hint_next_frames(self.ctxs, self.src_refs[k + 1][0])     # memory, the upload) are enqueued behind this step's launches
+        elif self.host_frames and k + 1 < self.n_frames:     # frames in host memory: the NEXT frames' uploads run under this step's launches
             self.api.hint_next_sources(self.ctxs, self.src_refs[k + 1][0])
         xs, Ts, Ss = self.api.register_batch(self.ctxs, None, None, self.x0, refs=(self.promote, self.src_refs[k]),
                                              visual=self.vis_refs[k - 1] if self.vis_refs is not None else None)

@@ -412,6 +412,13 @@ int velo_register_sequences(velo_ctx** ctxs, int32_t n, int32_t n_frames, const 
  * size takes the uploaded copy instead of uploading again.  A different source drops the hint; device clouds ignore it; results never
  * change.  velo_register_sequences does this by itself for the frames it is given. */
 int velo_hint_next_source(velo_ctx* ctx, const velo_scan_ref* next);
+/* The whole next STEP of a drive announced one call ahead (main.cpp:216,233,349,380): the next job on this context will promote its source
+ * (VELO_SCAN_PROMOTE) and bring `next` as the new source.  A chained registration (velo_register_batch[_visual], velo_frame_to_frame through
+ * the batch entries) then enqueues that promotion, the ingest and the index build BEHIND its own launches before its thread waits for them:
+ * they run while the host reads the results and hands the pose over, and the next call finds the frame in place.  Until then the context is
+ * one frame ahead -- any other job on it returns VELO_ERR_STATE.  A call that had to be repeated host-driven first gets its own pair back
+ * (the old target's cloud is kept for that).  Results never change. */
+int velo_hint_next_frame(velo_ctx* ctx, const velo_scan_ref* next);
 
 /* --- pose helpers (utility.h:67-96; note the reference's swapped names) ---------------- */
 int velo_pose_vec_to_mat(const double x[6], double T[16]);  /* util::pose_mat2vec */

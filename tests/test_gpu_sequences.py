@@ -20,17 +20,19 @@ def _summary_tuple(s):
              s.solves[k].initial_cost, s.solves[k].final_cost) for k in range(s.n_solves)]
 
 
-def _stepwise(drives, vis, n_frames, host):
+def _stepwise(drives, vis, n_frames, host, ahead=None, stats=None):
     import bench
     B = len(drives)
     ctxs = [api.Context(0, icp_skip=1) for _ in range(B)]
     frames = [[(np.ascontiguousarray(f[0]) if host else f[0], f[1]) for f in d["frames"]] for d in drives]
-    w = bench.DriveWalker(api, ctxs, frames, 0, vis)
+    w = bench.DriveWalker(api, ctxs, frames, 0, vis, ahead=ahead)
     out = []
     for _ in range(n_frames - 1):
         xs, Ts, Ss = w.step()
         out.append((xs.copy(), Ts.copy(), [_summary_tuple(s) for s in Ss], w.P_prev.copy(), w.x0.copy()))
     for c in ctxs:
+        if stats is not None:
+            stats.append(c.chain_stats())
         c.close()
     return out
 
@@ -96,6 +98,83 @@ def test_hinted_uploads_change_nothing_but_where_the_copy_runs(hip_lib):
     x2, _, _ = api.register_batch([c], None, None, x1, refs=(api.promote_refs(1), refs[2]))
     assert np.array_equal(x1[0], ref[0][0][0]) and np.abs(x2[0] - ref[1][0][0]).max() < 1e-6      # (the guess differs from the hand-off's in its last bits)
     c.close()
+
+
+def _same_steps(a, b):
+    assert len(a) == len(b)
+    for k, (p, q) in enumerate(zip(a, b)):
+        assert np.array_equal(p[0], q[0]), (k, p[0], q[0])                              # poses
+        assert np.array_equal(p[1], q[1]) and p[2] == q[2], k                           # 4x4s, every solve's summary
+        assert np.array_equal(p[3], q[3]) and np.array_equal(p[4], q[4]), k             # accumulated poses, next guesses
+
+
+@pytest.mark.parametrize("B,with_vis,host", [(4, False, False), (8, False, False), (2, False, True), (5, True, False), (1, False, False)])
+def test_frames_loaded_ahead_change_nothing_but_when_the_loads_run(hip_lib, B, with_vis, host):
+    """velo_hint_next_frame: every step announces the next one, whose promotion, ingest and index build are enqueued behind the step's own
+    chain of launches (what bench.py's drive steps do).  Same registrations bit for bit as steps that load their own frames; one job, the
+    single-pair path, does not load ahead and is none the worse for the announcement."""
+    n_frames = 6
+    drives = [synth.drive(n_frames, seed=80 + s, n_beams=16, n_azimuth=160) for s in range(B)]
+    vis = [[synth.stereo_matches(150, seed=9 + 100 * i + k, x_true=drives[i]["x_true"][k]) for k in range(n_frames - 1)] for i in range(B)] if with_vis else None
+    st0, st1 = [], []
+    plain = _stepwise(drives, vis, n_frames, host, ahead=False, stats=st0)
+    ahead = _stepwise(drives, vis, n_frames, host, ahead=True, stats=st1)
+    _same_steps(plain, ahead)
+    assert st0 == st1 and all(s[0] == n_frames - 1 for s in st1)                        # every pair through one chain of launches, as many repeats
+
+
+@pytest.mark.parametrize("B", [4, 1])                                                   # lock-step groups; the single-pair chain
+def test_a_repeated_call_gets_its_pair_back_from_a_frame_loaded_ahead(hip_lib, monkeypatch, B):
+    """With no spare launches (VELO_CHAIN_MARGIN=0) calls outrun their chains and are repeated host-driven -- after the next frame was
+    enqueued behind them.  The contexts are put back on the pair they registered (the old target's cloud is kept for that), the repeat
+    gives the same registration, and the drive goes on from there."""
+    pick = (0, 0, 0, 1, 2, 4, 5, 8, 9)                                               # a car that stands, then pulls away, frames left out: the
+    n_frames = len(pick)                                                                # constant-velocity guess is off, solves take MORE iterations than one call ago
+    drives = [synth.drive(pick[-1] + 1, seed=120 + s, n_beams=32, n_azimuth=400) for s in range(B)]    # (large enough for many-launch solves)
+    drives = [dict(frames=[d["frames"][k] for k in pick]) for d in drives]
+    plain = _stepwise(drives, None, n_frames, False, ahead=False)
+    monkeypatch.setenv("VELO_CHAIN_MARGIN", "0")
+    stats = []
+    tight = _stepwise(drives, None, n_frames, False, ahead=True, stats=stats)
+    monkeypatch.delenv("VELO_CHAIN_MARGIN", raising=False)
+    _same_steps(plain, tight)
+    assert sum(s[1] for s in stats) > 0, stats                                          # at least one call WAS repeated
+
+
+def test_a_context_one_frame_ahead_takes_only_the_announced_job(hip_lib):
+    B, n_frames = 2, 5
+    drives = [synth.drive(n_frames, seed=140 + s, n_beams=16, n_azimuth=160) for s in range(B)]
+    ctxs = [api.Context(0, icp_skip=1) for _ in range(B)]
+    frames = [d["frames"] for d in drives]
+    refs = [api.scan_refs([frames[i][k] for i in range(B)], 0) for k in range(n_frames)]
+    promote = api.promote_refs(B)
+    for i, c in enumerate(ctxs):
+        c.set_source(*frames[i][0])
+    x0 = np.tile(synth.INITIAL_GUESS, (B, 1))
+    api.hint_next_frames(ctxs, refs[2][0])
+    x1, _, _ = api.register_batch(ctxs, None, None, x0, refs=(promote, refs[1]))         # frame 2 is loaded behind this call
+    with pytest.raises(api.VeloError, match="loaded ahead"):
+        api.register_batch(ctxs, None, None, x1, refs=(promote, refs[3]))                # not the announced frame
+    with pytest.raises(api.VeloError, match="loaded ahead"):
+        ctxs[0].frame_to_frame(x1[0])                                                   # nor a registration of what the context "held"
+    x2, _, _ = api.register_batch(ctxs, None, None, x1, refs=(promote, refs[2]))         # the announced job: nothing to load
+    # without an announcement the same two steps
+    fresh = [api.Context(0, icp_skip=1) for _ in range(B)]
+    for i, c in enumerate(fresh):
+        c.set_source(*frames[i][0])
+    y1, _, _ = api.register_batch(fresh, None, None, x0, refs=(promote, refs[1]))
+    y2, _, _ = api.register_batch(fresh, None, None, y1, refs=(promote, refs[2]))
+    assert np.array_equal(x1, y1) and np.array_equal(x2, y2)
+    # the latest announcement before a call is the one that counts
+    api.hint_next_frames(ctxs, refs[0][0])
+    api.hint_next_frames(ctxs, refs[4][0])
+    x3, _, _ = api.register_batch(ctxs, None, None, x2, refs=(promote, refs[3]))
+    x4, _, _ = api.register_batch(ctxs, None, None, x3, refs=(promote, refs[4]))
+    y3, _, _ = api.register_batch(fresh, None, None, y2, refs=(promote, refs[3]))
+    y4, _, _ = api.register_batch(fresh, None, None, y3, refs=(promote, refs[4]))
+    assert np.array_equal(x3, y3) and np.array_equal(x4, y4)
+    for c in ctxs + fresh:
+        c.close()
 
 
 def test_sequences_report_bad_arguments_as_status_codes(hip_lib):

@@ -209,6 +209,7 @@ SIGNATURES = {
     "velo_register_batch": (C.c_int, [_P(_ctx), C.c_int32, C.c_void_p, C.c_void_p, _dp, _dp, _P(VeloSummary)]),
     "velo_register_batch_visual": (C.c_int, [_P(_ctx), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _dp, _dp, _P(VeloSummary)]),
     "velo_hint_next_source": (C.c_int, [_ctx, C.c_void_p]),
+    "velo_hint_next_frame": (C.c_int, [_ctx, C.c_void_p]),
     "velo_register_sequences": (C.c_int, [_P(_ctx), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, _dp, _dp, _dp, _dp, _P(VeloSummary), C.c_int32]),
     "velo_pose_vec_to_mat": (C.c_int, [_dp, _dp]),
     "velo_pose_mat_to_vec": (C.c_int, [_dp, _dp]),
@@ -797,6 +798,17 @@ def hint_next_sources(ctxs, refs):
     lib = ctxs[0]._lib if len(ctxs) else load_library()
     for i, c in enumerate(ctxs):
         st = lib.velo_hint_next_source(c.handle, C.addressof(refs[i]))
+        if st != 0:
+            msg = lib.velo_last_error()
+            raise VeloError(f"velo status {st}: {msg.decode() if msg else ''}")
+
+
+def hint_next_frames(ctxs, refs):
+    """velo_hint_next_frame for every context: refs = scan_refs(...)[0] of the frames the NEXT call will bring as sources behind a promotion
+    (the step of a drive): their loads are enqueued behind the current call's launches."""
+    lib = ctxs[0]._lib if len(ctxs) else load_library()
+    for i, c in enumerate(ctxs):
+        st = lib.velo_hint_next_frame(c.handle, C.addressof(refs[i]))
         if st != 0:
             msg = lib.velo_last_error()
             raise VeloError(f"velo status {st}: {msg.decode() if msg else ''}")

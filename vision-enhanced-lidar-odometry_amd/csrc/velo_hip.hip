@@ -303,6 +303,19 @@ struct velo_ctx {
         const void* host = nullptr; size_t bytes = 0; bool hinted = false, ready = false; int buf = 0;
         DevBuf<char> land[2]; hipStream_t stream = nullptr; hipEvent_t ev = nullptr;
     } pf;
+    // velo_hint_next_frame: the NEXT frame of a drive -- promote the scan held as source, load the announced scan as the new source, build the
+    // index -- is enqueued BEHIND the current registration's chain of launches, before the calling thread waits for it: the loads of frame
+    // k + 1 run while the host wakes up, reads frame k's results and hands the pose over (the step boundary, where every queue used to
+    // drain).  The old target's cloud is kept until the call is known to be good: a call that has to be repeated host-driven gets its pair back.
+    struct NextFrame {
+        enum State { NONE = 0, LOADED = 2, CONSUMED = 3 };
+        int state = NONE;                   // of the frame loaded ahead: LOADED until the job that brings it arrives, CONSUMED while that job runs
+        velo_scan_ref ref{};                // ... and its descriptor
+        bool hint_valid = false;            // an announcement waiting for the end of the current call's enqueue (it may arrive while `state` is LOADED:
+        velo_scan_ref hint{};               //  the caller announces frame k + 1 before the job of frame k, loaded ahead one call ago, has been handed over)
+        DevBuf<float4> undo_cloud; std::vector<int> undo_off; int undo_n = 0, undo_rings = 0;
+        hipEvent_t call_done = nullptr;     // behind the call's last read-back copy: what the calling thread waits for when more has been enqueued behind it
+    } nf;
     DevBuf<int> seg_flag, seg_excl, seg_ring, seg_off;   // device-side ring segmentation (velo_set_scan_velodyne)
 
     // correspondence table
@@ -1153,12 +1166,16 @@ int read_assoc_timing(velo_ctx* c, velo_summary* S) {
         if (c->timing >= 2 && k < (int)c->assoc_event_info.size()) kacc_add(c, c->assoc_event_info[(size_t)k].first, t, 0, 1, 0);   // (counted when enqueued)
     }
     if (S) S->assoc_kernel_ms = ms;
-    for (int k = 0; k < c->klog_used; k++) {
+    int done = 0;
+    for (; done < c->klog_used; done++) {
         float t = 0.f;
-        HIP_TRY(hipEventElapsedTime(&t, c->klog[(size_t)k].a, c->klog[(size_t)k].b));
-        kacc_add(c, c->klog[(size_t)k].name, t, 0, 1, 0);       // (the launch and its bytes were counted when it was enqueued)
+        const hipError_t e = hipEventElapsedTime(&t, c->klog[(size_t)done].a, c->klog[(size_t)done].b);
+        if (e == hipErrorNotReady) { (void)hipGetLastError(); break; }   // launches of the NEXT frame, enqueued behind this call (velo_hint_next_frame): read one call later
+        if (e != hipSuccess) return fail(VELO_ERR_HIP, "hipEventElapsedTime: %s", hipGetErrorString(e));
+        kacc_add(c, c->klog[(size_t)done].name, t, 0, 1, 0);    // (the launch and its bytes were counted when it was enqueued)
     }
-    c->klog_used = 0;
+    for (int k = done; k < c->klog_used; k++) std::swap(c->klog[(size_t)(k - done)], c->klog[(size_t)k]);
+    c->klog_used -= done;
     return VELO_OK;
 }
 
@@ -1774,7 +1791,8 @@ int velo_destroy(velo_ctx* c) {
     c->batch_items.release(); c->batch_states.release(); c->batch_x.release();
     c->ask_count.release(); c->ask_list.release(); c->ask_keys.release(); c->ask_rings.release();
     c->solve_ctl.release(); c->ag_ctl.release();
-    c->pf.land[0].release(); c->pf.land[1].release();
+    c->pf.land[0].release(); c->pf.land[1].release(); c->nf.undo_cloud.release();
+    if (c->nf.call_done) { (void)hipEventDestroy(c->nf.call_done); c->nf.call_done = nullptr; }
     if (c->pf.stream) { (void)hipStreamSynchronize(c->pf.stream); (void)hipStreamDestroy(c->pf.stream); c->pf.stream = nullptr; }
     if (c->pf.ev) { (void)hipEventDestroy(c->pf.ev); c->pf.ev = nullptr; }
     c->batch_tickets.release(); c->batch_pose.release(); c->batch_logs.release(); c->batch_fail.release(); c->pose_rec.release(); c->solve_log.release(); c->chain_fail.release();
@@ -2560,6 +2578,8 @@ int velo_solve(velo_ctx* c, double x[6], velo_solve_summary* summary) {
 // Launch-count prediction of solve k = what the same solve of the previous call needed + a margin.  The margin follows how far that
 // count has moved over the last four calls (1 + spread, between 1 and 3); until four calls have been seen, and after a miss, it is
 // the default 2.  A launch behind the end of a solve costs ~3.5 us, a miss a whole repeated call.
+static int preload_next_frame(velo_ctx* c);      // velo_hint_next_frame: defined with the batch driver below
+static int undo_preload(velo_ctx* c);
 static void note_evals(velo_ctx* c, int k, int evals) {
     if (k < 0 || k >= VELO_MAX_SOLVES) return;
     c->pred_evals[k] = evals;
@@ -2713,11 +2733,22 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
         HIP_TRY(hipMemcpyAsync(pin_flags, c->vflags.p, (size_t)3 * c->n_matches, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipMemcpyAsync(h_vis_counts, c->vis_counts.p, sizeof(int) * 2 * VELO_MAX_STATS, hipMemcpyDeviceToHost, c->stream));
     }
+    // what the summary says about THIS call's scans, before a frame loaded ahead replaces them
+    const int nq_call = c->n_q, nt_call = c->T->n_tgt;
+    const bool ahead = c->nf.hint_valid && !c->peer_on && !c->comm;   // (sharded registrations load their slices together: nothing ahead)
+    if (ahead) {
+        if (!c->nf.call_done) HIP_TRY(hipEventCreateWithFlags(&c->nf.call_done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(c->nf.call_done, c->stream));
+    }
     VELO_TRY(prefetch_issue(c));                                     // the next frame's upload runs under this chain (velo_hint_next_source)
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (ahead) VELO_TRY(preload_next_frame(c));                      // ... and its promotion, ingest and index build behind it (velo_hint_next_frame)
+    const bool preloaded = c->nf.state == velo_ctx::NextFrame::LOADED;
+    if (preloaded) HIP_TRY(hipEventSynchronize(c->nf.call_done));    // the results are in; the next frame's loads are still running
+    else HIP_TRY(hipStreamSynchronize(c->stream));
     if (visual) { const unsigned char* pf = reinterpret_cast<const unsigned char*>(pin_flags); c->h_vflags.assign(pf, pf + (size_t)3 * c->n_matches); }
     VELO_TRY(peer_check(c));
     if (*h_fail || !c->h_status->s.done) {
+        if (preloaded) { HIP_TRY(hipStreamSynchronize(c->stream)); VELO_TRY(undo_preload(c)); }     // the repeat runs on the pair this call registered
         HIP_TRY(hipMemsetAsync(c->chain_fail.p, 0, sizeof(int), c->stream));
         note_miss(c);
         c->nv_clean[0] = c->nv_clean[1] = false;                            // drained association launches did not clear the next round's counter
@@ -2726,12 +2757,12 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
         c->timing_rewind(tmark);
         return VELO_OK;
     }
-    const uint64_t nq = (uint64_t)c->n_q;
+    const uint64_t nq = (uint64_t)nq_call;
     for (int k = 0; k < rounds; k++) {
         const SolveLog& L = c->h_log[std::min(k, VELO_MAX_SOLVES - 1)];
         S->n_assoc_rounds++;
-        S->n_queries = c->n_q;
-        const uint64_t b_assoc = 12ull * nq + 12ull * (uint64_t)c->T->n_tgt + 28ull * nq;
+        S->n_queries = nq_call;
+        const uint64_t b_assoc = 12ull * nq + 12ull * (uint64_t)nt_call + 28ull * nq;
         S->assoc_bytes += b_assoc; S->algorithmic_bytes += b_assoc;
         S->assoc_kernel_launches++;
         velo_solve_summary ss;
@@ -2781,6 +2812,9 @@ int velo_chain_stats(const velo_ctx* c, int32_t* calls, int32_t* misses) {
 int velo_frame_to_frame(velo_ctx* c, double x[6], double T[16], velo_summary* summary) {
     if (!c || !x) return fail(VELO_ERR_INVALID, "null argument");
     if (!c->have_target || !c->have_source) return fail(VELO_ERR_STATE, "frame_to_frame needs set_target and set_source first");
+    if (c->nf.state == velo_ctx::NextFrame::LOADED) return fail(VELO_ERR_STATE, "the context holds a frame loaded ahead (velo_hint_next_frame): the job that brings it must come first");
+    if (c->nf.state == velo_ctx::NextFrame::CONSUMED) c->nf.state = velo_ctx::NextFrame::NONE;
+    struct HintEnd { velo_ctx* c; ~HintEnd() { c->nf.hint_valid = false; } } hint_end{c};
     HIP_TRY(hipSetDevice(c->device));
     velo_summary local;
     velo_summary* S = summary ? summary : &local;
@@ -3018,9 +3052,49 @@ static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::arr
 // largest single item of a step.  There the association workgroups get kAssocPadShared bytes of unused dynamic LDS (27.9 KB each: five
 // per CU, 360 VGPRs per SIMD) and the LM launches use the lean instantiation (<= 152 VGPRs, 19 KB), which always fits beside them.
 constexpr int kAssocPadShared = 5632;
+// ---- velo_hint_next_frame: the next frame's loads behind the current chain ---------------------------------------------------------------
+// Called by the thread that has just enqueued a chained call on c->stream and is about to wait for it.  Everything here is enqueued on that
+// same stream, i.e. it runs when the chain has finished reading the old target and source.
+static int preload_next_frame(velo_ctx* c) {
+    if (!c->nf.hint_valid || c->nf.state == velo_ctx::NextFrame::LOADED || !c->have_source || !c->have_target || !c->src_bbox_valid) return VELO_OK;   // (without the source's box the promotion would wait for the chain)
+    c->nf.hint_valid = false;
+    c->nf.ref = c->nf.hint;
+    const velo_scan_ref& r = c->nf.ref;
+    // the old target's cloud, until this call is known to be good (a repeat needs the pair back): 16 bytes per point, device to device
+    c->nf.undo_n = c->T->n_tgt; c->nf.undo_rings = c->T->n_tgt_rings; c->nf.undo_off = c->T->h_tgt_off;
+    VELO_TRY(c->nf.undo_cloud.reserve((size_t)std::max(c->nf.undo_n, 1)));
+    if (c->nf.undo_n > 0) HIP_TRY(hipMemcpyAsync(c->nf.undo_cloud.p, c->T->tgt.p, sizeof(float4) * (size_t)c->nf.undo_n, hipMemcpyDeviceToDevice, c->stream));
+    VELO_TRY(promote_begin(c));
+    VELO_TRY(set_source_begin(c, r.xyz, r.stride_bytes, r.ring_offsets, r.n_rings, r.on_device & 1));
+    VELO_TRY(target_finalize_end(c));
+    VELO_TRY(source_finalize(c));
+    c->nf.state = velo_ctx::NextFrame::LOADED;
+    return VELO_OK;
+}
+// A preloaded context whose call has to be repeated: the pair it registered comes back -- the frame that was promoted (now the target's cloud)
+// as source again, the kept cloud of the old target as target -- through the ordinary loaders.  The stream has been synchronised.
+static int undo_preload(velo_ctx* c) {
+    if (c->nf.state != velo_ctx::NextFrame::LOADED) return VELO_OK;
+    c->nf.state = velo_ctx::NextFrame::NONE;
+    const std::vector<int> src_off = c->T->h_tgt_off;                    // the promoted frame's rings (copied: the loaders rewrite the tables)
+    const int src_rings = c->T->n_tgt_rings;
+    VELO_TRY(set_source_begin(c, reinterpret_cast<const float*>(c->T->tgt.p), (int64_t)sizeof(float4), src_off.data(), src_rings, 1));
+    { const int st = source_finalize(c); c->src_raw.on = false; if (st != VELO_OK) return st; }
+    const std::vector<int> tgt_off = c->nf.undo_off;
+    VELO_TRY(set_target_begin(c, reinterpret_cast<const float*>(c->nf.undo_cloud.p), (int64_t)sizeof(float4), tgt_off.data(), c->nf.undo_rings, 0, 0, 1));
+    VELO_TRY(target_finalize_end(c));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return VELO_OK;
+}
+
 static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo_summary* summaries, bool shared_chip = false) {
     velo_ctx* c0 = ctxs[0];
     HIP_TRY(hipSetDevice(c0->device));
+    for (int i = 0; i < n; i++) {
+        if (ctxs[i]->nf.state == velo_ctx::NextFrame::LOADED) return fail(VELO_ERR_STATE, "context %d holds a frame loaded ahead (velo_hint_next_frame): the job that brings it must come first", i);
+        if (ctxs[i]->nf.state == velo_ctx::NextFrame::CONSUMED) ctxs[i]->nf.state = velo_ctx::NextFrame::NONE;
+    }
+    struct HintEnd { velo_ctx** c; int n; ~HintEnd() { for (int i = 0; i < n; i++) c[i]->nf.hint_valid = false; } } hint_end{ctxs, n};   // an announcement is good for ONE call
     const bool lean = c0->lm_lean >= 0 ? c0->lm_lean != 0 : shared_chip;
     struct PadRestore { velo_ctx** c; int n; std::vector<int> old; ~PadRestore() { for (int i = 0; i < n; i++) c[i]->assoc_lds_pad = old[(size_t)i]; } } pad_restore{ctxs, n, {}};
     // A group with visual blocks: its LM launches carry the visual sweep.  With at most one block slot per thread (3 n_matches <= 64 x 256:
@@ -3273,8 +3347,22 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                 HIP_TRY(hipMemcpyAsync(pin_counts[(size_t)i], c->vis_counts.p, sizeof(int) * 2 * VELO_MAX_STATS, hipMemcpyDeviceToHost, bs));
             }
         }
+        // what the summaries say about THIS call's scans, before a frame loaded ahead replaces them
+        std::vector<int> nq_call((size_t)n), nt_call((size_t)n);
+        bool hinted = false;
+        for (int i = 0; i < n; i++) { nq_call[(size_t)i] = ctxs[i]->n_q; nt_call[(size_t)i] = ctxs[i]->T->n_tgt; hinted = hinted || ctxs[i]->nf.hint_valid; }
+        if (hinted) {
+            if (!c0->nf.call_done) HIP_TRY(hipEventCreateWithFlags(&c0->nf.call_done, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(c0->nf.call_done, bs));
+        }
         for (int i = 0; i < n; i++) VELO_TRY(prefetch_issue(ctxs[i]));   // the next frames' uploads run under this chain (velo_hint_next_source)
-        HIP_TRY(hipStreamSynchronize(bs));
+        bool preloaded = false;
+        for (int i = 0; i < n && hinted; i++) {                          // velo_hint_next_frame: the next frame's promotion, ingest and index build behind this chain
+            VELO_TRY(preload_next_frame(ctxs[i]));
+            preloaded = preloaded || ctxs[i]->nf.state == velo_ctx::NextFrame::LOADED;
+        }
+        if (preloaded) HIP_TRY(hipEventSynchronize(c0->nf.call_done));   // the results are in; the next frame's loads are still running
+        else HIP_TRY(hipStreamSynchronize(bs));
         for (int i = 0; i < n && any_matches; i++) {
             velo_ctx* c = ctxs[i];
             if (c->n_matches <= 0) continue;
@@ -3287,11 +3375,11 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
             for (int i = 0; i < n; i++) {
                 velo_ctx* c = ctxs[i];
                 velo_summary* Si = S[(size_t)i];
-                const uint64_t nq = (uint64_t)c->n_q;
+                const uint64_t nq = (uint64_t)nq_call[(size_t)i];
                 for (int k = 0; k < rounds; k++) {
                     const SolveLog& L = h_logs[(size_t)i * VELO_MAX_SOLVES + k];
-                    Si->n_assoc_rounds++; Si->n_queries = c->n_q;
-                    const uint64_t b_assoc = 12ull * nq + 12ull * (uint64_t)c->T->n_tgt + 28ull * nq;
+                    Si->n_assoc_rounds++; Si->n_queries = nq_call[(size_t)i];
+                    const uint64_t b_assoc = 12ull * nq + 12ull * (uint64_t)nt_call[(size_t)i] + 28ull * nq;
                     Si->assoc_bytes += b_assoc; Si->algorithmic_bytes += b_assoc;
                     velo_solve_summary ss;
                     std::memset(&ss, 0, sizeof(ss));
@@ -3319,6 +3407,10 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
             return VELO_OK;
         }
         // a solve outran its predicted launches: repeat the call with a host round trip per solve (same kernels, same results)
+        if (preloaded) {                                                 // ... on the pair it registered: the frame loaded ahead goes back
+            HIP_TRY(hipStreamSynchronize(bs));
+            for (int i = 0; i < n; i++) VELO_TRY(undo_preload(ctxs[i]));
+        }
         HIP_TRY(hipMemsetAsync(c0->batch_fail.p, 0, sizeof(int) * (size_t)n, bs));
         for (int i = 0; i < n; i++) {
             velo_ctx* c = ctxs[i];
@@ -3445,7 +3537,23 @@ static int load_job_visual(velo_ctx* c, const JobVisual& V, int i) {
     if (V.n[i] < 0 || (V.n[i] > 0 && (!V.m || !V.m[i]))) return fail(VELO_ERR_INVALID, "job %d: bad visual arguments", i);
     return set_visual_impl(c, V.n[i] > 0 ? V.m[i] : nullptr, V.n[i], false);
 }
+// A context that loaded an announced frame ahead (velo_hint_next_frame) holds it already: the job that brings exactly that frame -- a promoted
+// target and the announced source -- loads nothing; any other job is an error (the context is one frame ahead of what the caller thinks).
+// -> 1: the job's scans are in, 0: load as usual, < 0: status
+static int take_preloaded(velo_ctx* c, const velo_scan_ref* tg, const velo_scan_ref* sr) {
+    if (c->nf.state == velo_ctx::NextFrame::CONSUMED) c->nf.state = velo_ctx::NextFrame::NONE;   // (left by a call that failed between its loads and its registration)
+    if (c->nf.state != velo_ctx::NextFrame::LOADED) return 0;
+    const velo_scan_ref& r = c->nf.ref;
+    // (the same cloud: address, stride, residence and ring table -- by content, as the context holds it: two descriptors of one frame match)
+    const bool match = tg && (tg->on_device & VELO_SCAN_PROMOTE) && sr && sr->xyz == r.xyz && sr->stride_bytes == r.stride_bytes && sr->ring_offsets &&
+                       sr->n_rings == r.n_rings && (sr->on_device & 1) == (r.on_device & 1) && (int)c->h_src_off.size() == r.n_rings + 1 &&
+                       std::equal(c->h_src_off.begin(), c->h_src_off.end(), sr->ring_offsets);
+    if (!match) return fail(VELO_ERR_STATE, "the frame announced with velo_hint_next_frame has been loaded ahead: the next job must promote the source and bring that frame");
+    c->nf.state = velo_ctx::NextFrame::CONSUMED;
+    return 1;
+}
 static int load_job(velo_ctx* c, const velo_scan_ref* tg, const velo_scan_ref* sr) {
+    { const int t = take_preloaded(c, tg, sr); if (t < 0) return t; if (t > 0) return VELO_OK; }
     if (tg && (tg->on_device & VELO_SCAN_PROMOTE)) VELO_TRY(velo_source_to_target(c));
     else if (tg) VELO_TRY(velo_set_target(c, tg->xyz, tg->stride_bytes, tg->ring_offsets, tg->n_rings, tg->on_device & 1));
     if (sr) VELO_TRY(velo_set_source(c, sr->xyz, sr->stride_bytes, sr->ring_offsets, sr->n_rings, sr->on_device & 1));
@@ -3453,12 +3561,14 @@ static int load_job(velo_ctx* c, const velo_scan_ref* tg, const velo_scan_ref* s
 }
 // the same in two halves: everything that needs no answer from the device (uploads, ring tables, the bounding-box request), then the rest
 static int load_job_begin(velo_ctx* c, const velo_scan_ref* tg, const velo_scan_ref* sr) {
+    { const int t = take_preloaded(c, tg, sr); if (t < 0) return t; if (t > 0) return VELO_OK; }
     if (tg && (tg->on_device & VELO_SCAN_PROMOTE)) VELO_TRY(promote_begin(c));
     else if (tg) VELO_TRY(set_target_begin(c, tg->xyz, tg->stride_bytes, tg->ring_offsets, tg->n_rings, 0, 0, tg->on_device & 1));
     if (sr) VELO_TRY(set_source_begin(c, sr->xyz, sr->stride_bytes, sr->ring_offsets, sr->n_rings, sr->on_device & 1));
     return VELO_OK;
 }
 static int load_job_end(velo_ctx* c, bool tg, bool sr) {
+    if (c->nf.state == velo_ctx::NextFrame::CONSUMED) return VELO_OK;       // loaded ahead, one call ago
     if (tg) VELO_TRY(target_finalize_end(c));
     if (sr) VELO_TRY(source_finalize(c));
     return VELO_OK;
@@ -3659,7 +3769,8 @@ static int sequences_impl(velo_ctx** ctxs, int32_t n, int32_t n_frames, const ve
             velo_summary* Sf = summaries ? summaries + (size_t)f * n + b : nullptr;
             for (int i = 0; i < m; i++) for (int k = 0; k < 6; k++) xl[(size_t)6 * i + k] = x_guess[(size_t)6 * (b + i) + k];
             int st = VELO_OK;
-            if (f + 1 < n_frames) for (int i = b; i < e; i++) (void)velo_hint_next_source(ctxs[i], frames + (size_t)(f + 1) * n + i);   // uploaded under this frame's chain
+            // the next frame of the group's drives: uploaded under this frame's chain, promoted / ingested / indexed behind it (velo_hint_next_frame)
+            if (f + 1 < n_frames) for (int i = b; i < e; i++) (void)velo_hint_next_frame(ctxs[i], frames + (size_t)(f + 1) * n + i);
             if (m == 1) {                                            // a drive of its own: the single-pair path
                 st = load_job_visual(ctxs[b], V, b);
                 if (st == VELO_OK) st = load_job(ctxs[b], &promote, fr + b);
@@ -3703,6 +3814,20 @@ int velo_hint_next_source(velo_ctx* c, const velo_scan_ref* next) {
     if (n <= 0) return VELO_OK;
     c->pf.host = next->xyz; c->pf.bytes = (size_t)(n - 1) * (size_t)next->stride_bytes + 12; c->pf.hinted = true; c->pf.ready = false;
     return VELO_OK;
+}
+
+// The step of a drive announced one call ahead (main.cpp:216,233,349,380: every frame promotes the previous scan and loads a new one): the next
+// call WILL promote this context's source to target and bring `next` as the new source.  A chained registration then enqueues exactly those
+// loads behind its own launches before its thread waits, so they run while the host reads the results and hands the pose over; the next
+// call finds the frame in place.  Until that call the context is one frame ahead: any other job on it is VELO_ERR_STATE.  A call that had to be
+// repeated host-driven gets its own pair back first.  Results never change.  Host clouds are uploaded ahead as velo_hint_next_source does.
+int velo_hint_next_frame(velo_ctx* c, const velo_scan_ref* next) {
+    if (!c) return fail(VELO_ERR_INVALID, "null context");
+    c->nf.hint_valid = false;
+    if (!next || !next->xyz || !next->ring_offsets || next->n_rings <= 0 || next->stride_bytes < 12 || (next->on_device & (VELO_SCAN_PROMOTE | VELO_SCAN_SHARED))) return VELO_OK;
+    c->nf.hint = *next;
+    c->nf.hint_valid = true;
+    return velo_hint_next_source(c, next);
 }
 
 int velo_register_sequences(velo_ctx** ctxs, int32_t n, int32_t n_frames, const velo_scan_ref* frames, const velo_match* const* matches, const int32_t* n_matches,
