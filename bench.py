@@ -336,7 +336,7 @@ class DriveWalker:
     promotes it to target on the device, registers frame k+1 against it and hands the pose over -- T[k+1] = T[k] * dpose (main.cpp:408),
     next guess = pose_vec2mat(T[k]^-1 T[k+1]) (main.cpp:311-331).  One library call per step (velo_register_batch)."""
 
-    def __init__(self, api, ctxs, frames, local_rank, vis=None, ahead=None):
+    def __init__(self, api, ctxs, frames, local_rank, vis=None, ahead=None, one_call=None):
         self.api, self.ctxs, self.frames, self.vis, self.local_rank = api, ctxs, frames, vis, local_rank
         self.B = len(ctxs)
         self.host_frames = isinstance(frames[0][0][0], np.ndarray)
@@ -348,18 +348,46 @@ class DriveWalker:
         # the front-end's matches of every frame pair, handed over with the scans in the same call (velo_register_batch_visual)
         self.vis_refs = [api.visual_refs([vis[i][k] for i in range(self.B)]) for k in range(self.n_frames - 1)] if vis is not None else None
         self.restart()
+        # A step as ONE library call (api.DriveStep: velo_register_sequences for one frame, the next one announced) with every argument
+        # prepared here, off the clock -- what the loop body of a compiled caller costs.  VELO_BENCH_TWO_CALLS=1: velo_register_batch +
+        # velo_pose_handoff through the general wrappers (two calls and a dozen numpy / ctypes objects per step), as rounds 4 and before.
+        self.one_call = self.ahead and ((not os.environ.get("VELO_BENCH_TWO_CALLS")) if one_call is None else bool(one_call))
+        if self.one_call:
+            import ctypes as C
+            self._call = api.DriveStep(ctxs, self.P_prev, self.x0)
+            self._xs, self._Ts, self._S, self._out = self._call.outputs(self.n_frames - 1)
+            self._pairs = []                                 # frames k and k + 1 of every drive, side by side
+            for k in range(self.n_frames):
+                arr = (api.VeloScanRef * (2 * self.B))()
+                for i in range(self.B):
+                    arr[i] = self.src_refs[k][0][i]
+                    if k + 1 < self.n_frames:
+                        arr[self.B + i] = self.src_refs[k + 1][0][i]
+                self._pairs.append((arr, C.cast(arr, C.c_void_p)))
+            self._vis = [(C.cast(v[0], C.c_void_p), C.cast(v[1], C.c_void_p)) for v in self.vis_refs] if self.vis_refs is not None else None
 
     def restart(self):
         from velo_amd import synth
         for i, c in enumerate(self.ctxs):
             c.set_source(*self.frames[i][0])                 # frame 0 waits on the device as "source"
         self.k = 0
-        self.P_prev = np.ascontiguousarray(np.tile(np.eye(4), (self.B, 1, 1)))
-        self.x0 = np.tile(synth.INITIAL_GUESS, (self.B, 1))  # main.cpp:170
+        if getattr(self, "P_prev", None) is None:
+            self.P_prev = np.ascontiguousarray(np.tile(np.eye(4), (self.B, 1, 1)))
+            self.x0 = np.tile(synth.INITIAL_GUESS, (self.B, 1))  # main.cpp:170
+        else:                                                # (in place: a prepared step holds their addresses)
+            self.P_prev[...] = np.eye(4)
+            self.x0[...] = synth.INITIAL_GUESS
         self.first = None
 
     def step(self):
         k = self.k + 1
+        if self.one_call:
+            j = k - 1
+            self._call(self._pairs[k][1], self._out[j], self._S[j], self._vis[j] if self._vis is not None else None, announce=k + 1 < self.n_frames)
+            self.k = k
+            if k == 1:
+                self.first = self._xs[j].copy()
+            return self._xs[j], self._Ts[j], self._S[j]
         if k + 1 < self.n_frames and self.ahead:             # the next step announced: its promotion, ingest and index build (and, for frames in host
             self.api.hint_next_frames(self.ctxs, self.src_refs[k + 1][0])     # memory, the upload) are enqueued behind this step's launches
         elif self.host_frames and k + 1 < self.n_frames:     # frames in host memory: the NEXT frames' uploads run under this step's launches

@@ -400,9 +400,14 @@ int velo_register_batch_visual(velo_ctx** ctxs, int32_t n, const velo_scan_ref* 
  * does it.  The lock-step groups walk their drives' frames independently (no barrier across the batch between frames); per pair the
  * results are bit-identical to the frame-by-frame calls.  poses: n 4x4 row-major in/out; x_guess: n*6 in/out (the start-up guess
  * {0,0,0,0,0,1}, main.cpp:170, for a drive's first pair).  flags: VELO_SEQ_LOCKSTEP -- the groups start every frame together (a barrier
- * between frames: the timing of one velo_register_batch call per frame, without the caller in the loop); 0 -- no barrier. */
+ * between frames: the timing of one velo_register_batch call per frame, without the caller in the loop); 0 -- no barrier.
+ * VELO_SEQ_ANNOUNCE -- `frames` holds ONE MORE frame per sequence, frames[n_frames * n + i], which is not registered but announced
+ * (velo_hint_next_frame): its loads run behind the last frame's launches, and the next call, which must start with exactly that frame,
+ * finds it in place.  A caller that gets its frames one at a time makes the step of a drive ONE call this way: n_frames = 1 with the frame
+ * after it announced -- load, register, chain the pose, predict the motion (main.cpp:305-413 for n sequences). */
 #define VELO_SEQ_LOCKSTEP 1
-int velo_register_sequences(velo_ctx** ctxs, int32_t n, int32_t n_frames, const velo_scan_ref* frames /* n_frames*n */,
+#define VELO_SEQ_ANNOUNCE 2
+int velo_register_sequences(velo_ctx** ctxs, int32_t n, int32_t n_frames, const velo_scan_ref* frames /* n_frames*n (+ n with VELO_SEQ_ANNOUNCE) */,
                             const velo_match* const* matches /* n_frames*n or NULL */, const int32_t* n_matches /* n_frames*n or NULL */,
                             double* poses /* n*16 */, double* x_guess /* n*6 */, double* x_out /* n_frames*n*6 */, double* T_out /* n_frames*n*16 or NULL */,
                             velo_summary* summaries /* n_frames*n or NULL */, int32_t flags);

@@ -20,12 +20,12 @@ def _summary_tuple(s):
              s.solves[k].initial_cost, s.solves[k].final_cost) for k in range(s.n_solves)]
 
 
-def _stepwise(drives, vis, n_frames, host, ahead=None, stats=None):
+def _stepwise(drives, vis, n_frames, host, ahead=None, stats=None, one_call=None):
     import bench
     B = len(drives)
     ctxs = [api.Context(0, icp_skip=1) for _ in range(B)]
     frames = [[(np.ascontiguousarray(f[0]) if host else f[0], f[1]) for f in d["frames"]] for d in drives]
-    w = bench.DriveWalker(api, ctxs, frames, 0, vis, ahead=ahead)
+    w = bench.DriveWalker(api, ctxs, frames, 0, vis, ahead=ahead, one_call=one_call)
     out = []
     for _ in range(n_frames - 1):
         xs, Ts, Ss = w.step()
@@ -116,11 +116,13 @@ def test_frames_loaded_ahead_change_nothing_but_when_the_loads_run(hip_lib, B, w
     n_frames = 6
     drives = [synth.drive(n_frames, seed=80 + s, n_beams=16, n_azimuth=160) for s in range(B)]
     vis = [[synth.stereo_matches(150, seed=9 + 100 * i + k, x_true=drives[i]["x_true"][k]) for k in range(n_frames - 1)] for i in range(B)] if with_vis else None
-    st0, st1 = [], []
+    st0, st1, st2 = [], [], []
     plain = _stepwise(drives, vis, n_frames, host, ahead=False, stats=st0)
-    ahead = _stepwise(drives, vis, n_frames, host, ahead=True, stats=st1)
+    ahead = _stepwise(drives, vis, n_frames, host, ahead=True, stats=st1, one_call=False)   # velo_hint_next_frame + velo_register_batch + velo_pose_handoff
     _same_steps(plain, ahead)
-    assert st0 == st1 and all(s[0] == n_frames - 1 for s in st1)                        # every pair through one chain of launches, as many repeats
+    one = _stepwise(drives, vis, n_frames, host, ahead=True, stats=st2, one_call=True)      # the step as ONE call: velo_register_sequences, VELO_SEQ_ANNOUNCE
+    _same_steps(plain, one)
+    assert st0 == st1 == st2 and all(s[0] == n_frames - 1 for s in st1)                 # every pair through one chain of launches, as many repeats
 
 
 @pytest.mark.parametrize("B", [4, 1])                                                   # lock-step groups; the single-pair chain
@@ -135,10 +137,13 @@ def test_a_repeated_call_gets_its_pair_back_from_a_frame_loaded_ahead(hip_lib, m
     plain = _stepwise(drives, None, n_frames, False, ahead=False)
     monkeypatch.setenv("VELO_CHAIN_MARGIN", "0")
     stats = []
-    tight = _stepwise(drives, None, n_frames, False, ahead=True, stats=stats)
+    tight = _stepwise(drives, None, n_frames, False, ahead=True, stats=stats, one_call=False)
+    stats1 = []
+    tight1 = _stepwise(drives, None, n_frames, False, ahead=True, stats=stats1, one_call=True)
     monkeypatch.delenv("VELO_CHAIN_MARGIN", raising=False)
     _same_steps(plain, tight)
-    assert sum(s[1] for s in stats) > 0, stats                                          # at least one call WAS repeated
+    _same_steps(plain, tight1)
+    assert sum(s[1] for s in stats) > 0 and stats1 == stats, (stats, stats1)            # at least one call WAS repeated
 
 
 def test_a_context_one_frame_ahead_takes_only_the_announced_job(hip_lib):

@@ -831,7 +831,7 @@ def sequence_visual_refs(matches_per_drive, first=0, count=None):
     return visual_refs([matches_per_drive[i][first + f] for f in range(count) for i in range(n)])
 
 
-SEQ_LOCKSTEP = 1
+SEQ_LOCKSTEP, SEQ_ANNOUNCE = 1, 2
 
 
 def register_sequences(ctxs, frame_refs, n_frames, poses, x_guess, visual=None, summaries=True, lockstep=False):
@@ -855,6 +855,39 @@ def register_sequences(ctxs, frame_refs, n_frames, poses, x_guess, visual=None, 
         msg = lib.velo_last_error()
         raise VeloError(f"velo status {st}: {msg.decode() if msg else ''}")
     return xs, Ts.reshape(n_frames, n, 4, 4), ([[S[f * n + i] for i in range(n)] for f in range(n_frames)] if summaries else None)
+
+
+class DriveStep:
+    """The step of len(ctxs) drives as ONE C call with every argument prepared once: velo_register_sequences for one frame, the frame after it
+    announced (VELO_SEQ_ANNOUNCE) -- promote, load, register, chain the pose, predict the motion (main.cpp:305-413 for n sequences).  What a
+    compiled caller's loop body costs on the host; register_batch + pose_handoff build a dozen numpy / ctypes objects per step.
+    poses (n,4,4) and x_guess (n,6): float64 C-contiguous, UPDATED IN PLACE by every step."""
+
+    def __init__(self, ctxs, poses, x_guess):
+        self._lib = ctxs[0]._lib
+        self.n = n = len(ctxs)
+        assert poses.dtype == np.float64 and poses.flags.c_contiguous and poses.shape == (n, 4, 4)
+        assert x_guess.dtype == np.float64 and x_guess.flags.c_contiguous and x_guess.shape == (n, 6)
+        self._keep = (ctxs, poses, x_guess)
+        self._arr = (_ctx * n)(*[c.handle for c in ctxs])
+        self._pp, self._xg = _ptr(poses), _ptr(x_guess)
+
+    def outputs(self, n_steps):
+        """result blocks for n_steps steps, allocated once: (xs (S,n,6), Ts (S,n,4,4), summaries [S] of VeloSummary * n, per-step pointers)"""
+        n = self.n
+        xs, Ts = np.zeros((n_steps, n, 6)), np.zeros((n_steps, n, 16))
+        S = [(VeloSummary * n)() for _ in range(n_steps)]
+        ptrs = [(C.cast(xs[k].ctypes.data, _dp), C.cast(Ts[k].ctypes.data, _dp)) for k in range(n_steps)]
+        return xs, Ts.reshape(n_steps, n, 4, 4), S, ptrs
+
+    def __call__(self, frames_ptr, out_ptrs, summaries, visual=None, announce=False):
+        """frames_ptr: c_void_p of n (announce: 2 n) velo_scan_ref -- this step's frames, then the next step's; out_ptrs / summaries: one step's
+        entries of outputs(); visual: (pointer array, count array) cast to c_void_p, or None"""
+        st = self._lib.velo_register_sequences(self._arr, self.n, 1, frames_ptr, visual[0] if visual else None, visual[1] if visual else None, self._pp, self._xg,
+                                               out_ptrs[0], out_ptrs[1], summaries, SEQ_LOCKSTEP | (SEQ_ANNOUNCE if announce else 0))
+        if st != 0:
+            msg = self._lib.velo_last_error()
+            raise VeloError(f"velo status {st}: {msg.decode() if msg else ''}")
 
 
 def pose_handoff(poses: np.ndarray, dpose: np.ndarray):

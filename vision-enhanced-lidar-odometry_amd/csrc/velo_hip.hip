@@ -313,9 +313,11 @@ struct velo_ctx {
         velo_scan_ref ref{};                // ... and its descriptor
         bool hint_valid = false;            // an announcement waiting for the end of the current call's enqueue (it may arrive while `state` is LOADED:
         velo_scan_ref hint{};               //  the caller announces frame k + 1 before the job of frame k, loaded ahead one call ago, has been handed over)
-        DevBuf<float4> undo_cloud; std::vector<int> undo_off; int undo_n = 0, undo_rings = 0;
+        DevBuf<float4> undo_cloud; std::vector<int> undo_off; int undo_n = 0, undo_rings = 0;   // the old target's cloud: its BUFFER, rotated out (no copy)
+        DevBuf<unsigned> keys; int parity = 0;   // group-batched loads (AdvJob): the source's bounding-box keys in two slots, used alternately
         hipEvent_t call_done = nullptr;     // behind the call's last read-back copy: what the calling thread waits for when more has been enqueued behind it
     } nf;
+    AdvJob* adv = nullptr;               // set while a group's loads are being COLLECTED (preload_group): target_ingest / build_grid / source_ingest fill it instead of launching
     DevBuf<int> seg_flag, seg_excl, seg_ring, seg_off;   // device-side ring segmentation (velo_set_scan_velodyne)
 
     // correspondence table
@@ -648,6 +650,14 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
     HIP_TRY(hipMemsetAsync(G.cell_start.p, 0, sizeof(int) * ((size_t)nc + 4), c->stream));
     if (c->lb_zeroed < n_tiles + 1) HIP_TRY(hipMemsetAsync(c->lb_status.p, 0, sizeof(unsigned long long) * ((size_t)n_tiles + 1), c->stream));
     c->lb_zeroed = 0;                                                  // (about to be used)
+    if (c->adv) {                                                      // collected: count rides in the group's ingest launch, scan and scatter in the group's
+        AdvJob& J = *c->adv;
+        J.g = G.d; J.cell_of = c->T->tgt_cell_of.p; J.table = G.table(); J.nc = nc; J.n_tiles = n_tiles;
+        J.lb_status = c->lb_status.p; J.lb_ticket = reinterpret_cast<int*>(c->lb_status.p + n_tiles); J.scan_total = c->scan_total.p;
+        J.sorted = G.sorted.p; J.sring = G.sring.p; J.first_point = c->T->tgt_first_point; J.nb_sc = cdiv(std::max(n, kGridPad), 256);
+        G.built = true;
+        return VELO_OK;
+    }
     // (bytes: what each kernel must move given this index layout -- count: cloud in, cell ids out; scan: table in + out; scatter: cloud + ids in, sorted copy out)
     if (n > 0) VELO_LAUNCH_T(c, "grid_count_kernel", 20ull * (uint64_t)n, grid_count_kernel, dim3(cdiv(n, 256)), dim3(256), 0, c->stream, G.d, c->T->tgt.p, n, c->T->tgt_cell_of.p, G.table());
     if (large_tiles) VELO_LAUNCH_T(c, "scan_lookback_kernel", 8ull * (uint64_t)nc, scan_lookback_kernel<kLbItemsLarge>, dim3(n_tiles), dim3(kScanThreads), 0, c->stream, G.table() + 1, nc, c->lb_status.p,
@@ -1441,6 +1451,15 @@ int target_ingest(velo_ctx* c, const float* xyz, int64_t stride, int on_device) 
     VELO_TRY(c->T->tgt_cell_of.reserve((size_t)std::max(n, 1)));
     VELO_TRY(c->T->tgt_pad.reserve((size_t)n + 2 * (size_t)n_rings + 2));
     VELO_TRY(c->lb_status.reserve((size_t)kLbWordsCleared));
+    if (c->adv) {                                                     // a promotion inside preload_group (packed cloud in place, box known): collected, launched with the group's
+        AdvJob& J = *c->adv;
+        J.tgt = c->T->tgt.p; J.tgt_off_dev = c->T->tgt_off.p; J.ring_of = c->T->tgt_ring_of.p; J.pad = c->T->tgt_pad.p;
+        J.lb_status = c->lb_status.p; J.lb_words = kLbWordsCleared;
+        J.n_t = n; J.n_rings_t = n_rings; J.first_ring = c->T->tgt_first_ring; J.nb_t = cdiv(n, 256 * kIngestPerThread);
+        std::memcpy(J.off_t, c->T->h_tgt_off.data(), sizeof(int) * ((size_t)n_rings + 1));
+        c->lb_zeroed = kLbWordsCleared;
+        return VELO_OK;
+    }
     const char* dsrc = (const char*)xyz;
     if (!on_device && n > 0) {
         const size_t bytes = (size_t)(n - 1) * (size_t)stride + 12;
@@ -1506,6 +1525,31 @@ int source_ingest(velo_ctx* c) {
     VELO_TRY(c->q_src.reserve(nq));
     const bool own_list = !(skip == 1 && !patch);                         // else q_src[i] == i and the source cloud itself is the list
     if (own_list) VELO_TRY(c->qpts_buf.reserve(nq));
+    if (c->adv) {                                                         // collected (preload_group): launched with the group's, the box comes back behind that launch
+        AdvJob& J = *c->adv;
+        if (c->nf.keys.cap < 16) {
+            VELO_TRY(c->nf.keys.reserve(16));
+            const unsigned init[16] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u, 0u, 0u};
+            HIP_TRY(hipMemcpy(c->nf.keys.p, init, sizeof(init), hipMemcpyHostToDevice));
+            c->nf.parity = 0;
+        }
+        J.raw = c->src_raw.dsrc; J.stride = c->src_raw.stride; J.src = c->src.p; J.src_off_dev = c->src_off.p; J.q_src = c->q_src.p;
+        J.qpts = own_list ? c->qpts_buf.p : (float4*)nullptr;
+        J.keys = c->nf.keys.p + 8 * c->nf.parity; J.keys_next = c->nf.keys.p + 8 * (c->nf.parity ^ 1);
+        c->nf.parity ^= 1;
+        J.n_s = c->n_src; J.n_rings_s = R; J.nb_pack = cdiv(c->n_src, 256); J.nb_q = c->n_q > 0 ? cdiv(c->n_q, 256) : 0;
+        J.skip = skip; J.nq = c->n_q; J.patch = patch ? 1 : 0; J.patch_rings = c->patch_rings; J.patch_len = c->patch_len;
+        std::memcpy(J.off_s, c->h_src_off.data(), sizeof(int) * ((size_t)R + 1));
+        c->src_bbox_valid = true;                                         // (the keys' copy and its event: advance_launch)
+        c->src_raw.on = false;
+        c->q_patch = patch;
+        c->qpts = own_list ? c->qpts_buf.p : c->src.p;
+        VELO_TRY(c->cp.reserve(nq)); VELO_TRY(c->cn.reserve(nq)); VELO_TRY(c->cv0.reserve(nq));
+        VELO_TRY(c->aux0.reserve(nq)); VELO_TRY(c->aux1.reserve(nq));
+        c->have_corr = false;
+        c->have_source = true;
+        return VELO_OK;
+    }
     {
         int* pin = nullptr;
         VELO_TRY(pin_acquire(c, 0, 2 * ((size_t)R + 1) + 8, &pin));
@@ -2578,7 +2622,7 @@ int velo_solve(velo_ctx* c, double x[6], velo_solve_summary* summary) {
 // Launch-count prediction of solve k = what the same solve of the previous call needed + a margin.  The margin follows how far that
 // count has moved over the last four calls (1 + spread, between 1 and 3); until four calls have been seen, and after a miss, it is
 // the default 2.  A launch behind the end of a solve costs ~3.5 us, a miss a whole repeated call.
-static int preload_next_frame(velo_ctx* c);      // velo_hint_next_frame: defined with the batch driver below
+static int preload_group(velo_ctx** ctxs, int n, hipStream_t bs, bool* any_loaded);      // velo_hint_next_frame: defined with the batch driver below
 static int undo_preload(velo_ctx* c);
 static void note_evals(velo_ctx* c, int k, int evals) {
     if (k < 0 || k >= VELO_MAX_SOLVES) return;
@@ -2741,8 +2785,8 @@ static int frame_to_frame_chain(velo_ctx* c, double xc[6], velo_summary* S, bool
         HIP_TRY(hipEventRecord(c->nf.call_done, c->stream));
     }
     VELO_TRY(prefetch_issue(c));                                     // the next frame's upload runs under this chain (velo_hint_next_source)
-    if (ahead) VELO_TRY(preload_next_frame(c));                      // ... and its promotion, ingest and index build behind it (velo_hint_next_frame)
-    const bool preloaded = c->nf.state == velo_ctx::NextFrame::LOADED;
+    bool preloaded = false;
+    if (ahead) VELO_TRY(preload_group(&c, 1, c->stream, &preloaded));  // ... and its promotion, ingest and index build behind it (velo_hint_next_frame)
     if (preloaded) HIP_TRY(hipEventSynchronize(c->nf.call_done));    // the results are in; the next frame's loads are still running
     else HIP_TRY(hipStreamSynchronize(c->stream));
     if (visual) { const unsigned char* pf = reinterpret_cast<const unsigned char*>(pin_flags); c->h_vflags.assign(pf, pf + (size_t)3 * c->n_matches); }
@@ -3055,20 +3099,81 @@ constexpr int kAssocPadShared = 5632;
 // ---- velo_hint_next_frame: the next frame's loads behind the current chain ---------------------------------------------------------------
 // Called by the thread that has just enqueued a chained call on c->stream and is about to wait for it.  Everything here is enqueued on that
 // same stream, i.e. it runs when the chain has finished reading the old target and source.
-static int preload_next_frame(velo_ctx* c) {
+static int preload_next_frame(velo_ctx* c, AdvJob* job) {
     if (!c->nf.hint_valid || c->nf.state == velo_ctx::NextFrame::LOADED || !c->have_source || !c->have_target || !c->src_bbox_valid) return VELO_OK;   // (without the source's box the promotion would wait for the chain)
+    if (c->T.use_count() != 1) return VELO_OK;                         // a target other contexts hold cannot be given back after a repeat
     c->nf.hint_valid = false;
     c->nf.ref = c->nf.hint;
     const velo_scan_ref& r = c->nf.ref;
-    // the old target's cloud, until this call is known to be good (a repeat needs the pair back): 16 bytes per point, device to device
+    // the loads of ALL contexts of the group in three launches (AdvJob), when the ring tables fit the kernel arguments and the general
+    // loaders would build exactly this index (dense table, no direction image); else through the general loaders, launch by launch
+    const int n_next = r.ring_offsets[r.n_rings];
+    static const bool compress = dev_env("VELO_GRID_COMPRESS") && atoi(dev_env("VELO_GRID_COMPRESS")) != 0;
+    static const bool no_batch = dev_env("VELO_ADV_BATCH") && atoi(dev_env("VELO_ADV_BATCH")) == 0;      // A/B (diagnostics build)
+    const bool batched = job && !no_batch && !compress && !(c->dimg_seeds && c->warm_start) && c->n_src > 0 && c->n_src_rings <= kAdvRings && r.n_rings <= kAdvRings && n_next > 0;
+    struct AdvScope { velo_ctx* c; ~AdvScope() { c->adv = nullptr; } } scope{c};
+    if (batched) { std::memset(job, 0, sizeof(*job)); c->adv = job; }
+    // the old target's cloud stays until this call is known to be good (a repeat needs the pair back) -- its BUFFER: the promotion swaps the
+    // clouds' buffers (the old target's becomes the source's), and the source side then takes the spare one instead
     c->nf.undo_n = c->T->n_tgt; c->nf.undo_rings = c->T->n_tgt_rings; c->nf.undo_off = c->T->h_tgt_off;
-    VELO_TRY(c->nf.undo_cloud.reserve((size_t)std::max(c->nf.undo_n, 1)));
-    if (c->nf.undo_n > 0) HIP_TRY(hipMemcpyAsync(c->nf.undo_cloud.p, c->T->tgt.p, sizeof(float4) * (size_t)c->nf.undo_n, hipMemcpyDeviceToDevice, c->stream));
     VELO_TRY(promote_begin(c));
+    std::swap(c->src.p, c->nf.undo_cloud.p); std::swap(c->src.cap, c->nf.undo_cloud.cap);
     VELO_TRY(set_source_begin(c, r.xyz, r.stride_bytes, r.ring_offsets, r.n_rings, r.on_device & 1));
     VELO_TRY(target_finalize_end(c));
     VELO_TRY(source_finalize(c));
     c->nf.state = velo_ctx::NextFrame::LOADED;
+    return batched ? 1 : VELO_OK;
+}
+// the collected loads of a group's contexts (jobs[i] valid where used[i]): three launches on the group's stream, then every box's way back
+static int advance_launch(velo_ctx** ctxs, int n, const AdvJob* jobs, const std::vector<char>& used, hipStream_t bs) {
+    velo_ctx* c0 = ctxs[0];
+    for (int b = 0; b < n;) {
+        AdvBatch B;
+        std::memset(&B, 0, sizeof(B));
+        int m = 0, gx_a = 0, gx_sc = 0, tiles[2] = {0, 0};
+        uint64_t by_a = 0, by_s = 0, by_c = 0;
+        velo_ctx* owner[kAdvJobs];
+        for (; b < n && m < kAdvJobs; b++) {
+            if (!used[(size_t)b]) continue;
+            const AdvJob& J = jobs[b];
+            B.job[m] = J; owner[m] = ctxs[b]; m++;
+            gx_a = std::max(gx_a, J.nb_t + J.nb_pack + J.nb_q); gx_sc = std::max(gx_sc, J.nb_sc);
+            tiles[J.nc >= kLbLargeFrom ? 1 : 0] = std::max(tiles[J.nc >= kLbLargeFrom ? 1 : 0], J.n_tiles);
+            by_a += 40ull * (uint64_t)J.n_t + 28ull * (uint64_t)J.n_s + 32ull * (uint64_t)J.nq; by_s += 8ull * (uint64_t)J.nc; by_c += 44ull * (uint64_t)J.n_t;
+        }
+        if (m == 0) break;
+        VELO_LAUNCH_T(c0, "advance_ingest_kernel", by_a, advance_ingest_kernel, dim3(gx_a, m), dim3(256), 0, bs, B);
+        for (int large = 0; large < 2; large++) {                      // (a group's tables are of one kind in practice: one launch)
+            if (tiles[large] == 0) continue;
+            AdvBatch S = B;
+            for (int k = 0; k < m; k++) if ((S.job[k].nc >= kLbLargeFrom ? 1 : 0) != large) S.job[k].n_tiles = 0;
+            if (large) VELO_LAUNCH_T(c0, "advance_scan_kernel", by_s, advance_scan_kernel<kLbItemsLarge>, dim3(tiles[1], m), dim3(kScanThreads), 0, bs, S);
+            else VELO_LAUNCH_T(c0, "advance_scan_kernel", by_s, advance_scan_kernel<kLbItemsSmall>, dim3(tiles[0], m), dim3(kScanThreads), 0, bs, S);
+        }
+        VELO_LAUNCH_T(c0, "advance_scatter_kernel", by_c, advance_scatter_kernel, dim3(gx_sc, m), dim3(256), 0, bs, B);
+        HIP_TRY(hipGetLastError());
+        for (int k = 0; k < m; k++) {                                  // the boxes ride back on the stream (a LATER call, the next promotion, reads them)
+            velo_ctx* c = owner[k];
+            HIP_TRY(hipMemcpyAsync(c->h_int + 16, B.job[k].keys, sizeof(unsigned) * 6, hipMemcpyDeviceToHost, bs));
+            if (!c->src_bbox_ev) HIP_TRY(hipEventCreateWithFlags(&c->src_bbox_ev, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(c->src_bbox_ev, bs));
+        }
+    }
+    return VELO_OK;
+}
+// every context of a group that announced its next frame: loads collected, then launched together
+static int preload_group(velo_ctx** ctxs, int n, hipStream_t bs, bool* any_loaded) {
+    std::vector<AdvJob> jobs((size_t)n);
+    std::vector<char> used((size_t)n, 0);
+    bool any = false;
+    *any_loaded = false;
+    for (int i = 0; i < n; i++) {
+        const int st = preload_next_frame(ctxs[i], &jobs[(size_t)i]);
+        if (st < 0) return st;
+        used[(size_t)i] = st == 1; any = any || st == 1;
+        *any_loaded = *any_loaded || ctxs[i]->nf.state == velo_ctx::NextFrame::LOADED;
+    }
+    if (any) VELO_TRY(advance_launch(ctxs, n, jobs.data(), used, bs));
     return VELO_OK;
 }
 // A preloaded context whose call has to be repeated: the pair it registered comes back -- the frame that was promoted (now the target's cloud)
@@ -3113,7 +3218,15 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
     const velo_params P = c0->P;
     const LMParams Q = lm_params(P);
     // everything queued on the contexts' own streams (set_target / set_source) must be done before the shared stream uses it
-    for (int i = 0; i < n; i++) HIP_TRY(hipStreamSynchronize(ctxs[i]->stream));
+    static const bool turn_trace = dev_env("VELO_TURN_TRACE") != nullptr;     // dev aid: the step boundary as the group's host thread sees it
+    static thread_local std::chrono::steady_clock::time_point t_results;
+    static thread_local bool t_results_valid = false;
+    const auto t_entry = std::chrono::steady_clock::now();
+    // (what is queued on the group's OWN stream -- a frame loaded ahead, velo_hint_next_frame -- is ordered before this call's launches by the stream itself)
+    for (int i = 0; i < n; i++) if (ctxs[i]->stream != c0->stream) HIP_TRY(hipStreamSynchronize(ctxs[i]->stream));
+    if (turn_trace && t_results_valid)
+        fprintf(stderr, "[velo turn] results in -> next call's registration entered %.0f us; then waited %.0f us for the loads enqueued ahead\n",
+                std::chrono::duration<double, std::micro>(t_entry - t_results).count(), std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_entry).count());
     std::vector<hipStream_t> own((size_t)n);
     for (int i = 0; i < n; i++) { own[(size_t)i] = ctxs[i]->stream; ctxs[i]->stream = c0->stream; }
     struct Restore { velo_ctx** c; std::vector<hipStream_t>& s; int n; ~Restore() { for (int i = 0; i < n; i++) c[i]->stream = s[(size_t)i]; } } restore{ctxs, own, n};
@@ -3357,12 +3470,22 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
         }
         for (int i = 0; i < n; i++) VELO_TRY(prefetch_issue(ctxs[i]));   // the next frames' uploads run under this chain (velo_hint_next_source)
         bool preloaded = false;
-        for (int i = 0; i < n && hinted; i++) {                          // velo_hint_next_frame: the next frame's promotion, ingest and index build behind this chain
-            VELO_TRY(preload_next_frame(ctxs[i]));
-            preloaded = preloaded || ctxs[i]->nf.state == velo_ctx::NextFrame::LOADED;
-        }
+        static const bool ahead_trace = dev_env("VELO_AHEAD_TRACE") != nullptr;   // dev aid: how long the loads enqueued behind the chain take on the stream
+        static thread_local hipEvent_t tr0 = nullptr, tr1 = nullptr;
+        if (ahead_trace && hinted) { if (!tr0) { HIP_TRY(hipEventCreate(&tr0)); HIP_TRY(hipEventCreate(&tr1)); } HIP_TRY(hipEventRecord(tr0, bs)); }
+        if (hinted) VELO_TRY(preload_group(ctxs, n, bs, &preloaded));    // velo_hint_next_frame: the next frame's promotion, ingest and index build behind this chain
+        if (ahead_trace && hinted) HIP_TRY(hipEventRecord(tr1, bs));
         if (preloaded) HIP_TRY(hipEventSynchronize(c0->nf.call_done));   // the results are in; the next frame's loads are still running
         else HIP_TRY(hipStreamSynchronize(bs));
+        if (turn_trace) { t_results = std::chrono::steady_clock::now(); t_results_valid = true; }
+        if (ahead_trace && hinted) {
+            const auto th = std::chrono::steady_clock::now();
+            HIP_TRY(hipEventSynchronize(tr1));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, tr0, tr1));
+            fprintf(stderr, "[velo ahead] %d contexts: loads behind the chain %.0f us on the stream; still running %.0f us after the results were in\n", n, 1e3 * ms,
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - th).count());
+        }
         for (int i = 0; i < n && any_matches; i++) {
             velo_ctx* c = ctxs[i];
             if (c->n_matches <= 0) continue;
@@ -3770,7 +3893,7 @@ static int sequences_impl(velo_ctx** ctxs, int32_t n, int32_t n_frames, const ve
             for (int i = 0; i < m; i++) for (int k = 0; k < 6; k++) xl[(size_t)6 * i + k] = x_guess[(size_t)6 * (b + i) + k];
             int st = VELO_OK;
             // the next frame of the group's drives: uploaded under this frame's chain, promoted / ingested / indexed behind it (velo_hint_next_frame)
-            if (f + 1 < n_frames) for (int i = b; i < e; i++) (void)velo_hint_next_frame(ctxs[i], frames + (size_t)(f + 1) * n + i);
+            if (f + 1 < n_frames || (flags & VELO_SEQ_ANNOUNCE)) for (int i = b; i < e; i++) (void)velo_hint_next_frame(ctxs[i], frames + (size_t)(f + 1) * n + i);
             if (m == 1) {                                            // a drive of its own: the single-pair path
                 st = load_job_visual(ctxs[b], V, b);
                 if (st == VELO_OK) st = load_job(ctxs[b], &promote, fr + b);

@@ -493,8 +493,8 @@ constexpr int kLbLargeFrom = 1 << 22;              // table entries from which t
 __host__ __device__ constexpr int lb_tile(int items) { return kScanThreads * items; }
 constexpr unsigned long long kLbAgg = 1ull << 62, kLbPrefix = 2ull << 62, kLbFlags = 3ull << 62;
 template <int kLbItems>
-__global__ void __launch_bounds__(kScanThreads)
-scan_lookback_kernel(int* __restrict__ data, int n, unsigned long long* __restrict__ status, int* __restrict__ ticket, int* __restrict__ grand_total) {
+__device__ __forceinline__ void
+scan_lookback_body(int* __restrict__ data, int n, unsigned long long* __restrict__ status, int* __restrict__ ticket, int* __restrict__ grand_total) {
     // A tile = kLbItems / 4 sub-tiles of kScanThreads x 4 ints; thread t holds the int4 number t of EVERY sub-tile, so a wave's loads and
     // stores are 1 KB of consecutive memory.  The sub-tiles' prefixes come out of ONE round of wave scans (all sub-tiles at once) and
     // one barrier.
@@ -570,6 +570,11 @@ scan_lookback_kernel(int* __restrict__ data, int n, unsigned long long* __restri
         if (i <= n - 1 && n - 1 < i + 4) *grand_total = q.w + v[k].w;  // the thread that holds the last element: its running sum is the total (elements beyond n are zero)
     }
 }
+template <int kLbItems>
+__global__ void __launch_bounds__(kScanThreads)
+scan_lookback_kernel(int* __restrict__ data, int n, unsigned long long* __restrict__ status, int* __restrict__ ticket, int* __restrict__ grand_total) {
+    scan_lookback_body<kLbItems>(data, n, status, ticket, grand_total);
+}
 // (three-kernel scan, kept for the device ring segmenter's small arrays)
 // pass 1: tile-local exclusive scan in place (counts -> local offsets), tile totals out
 __global__ void scan_tiles_kernel(int* __restrict__ data, int n, int* __restrict__ tile_sums) {
@@ -608,10 +613,10 @@ __global__ void scan_add_kernel(int* __restrict__ data, int n, const int* __rest
     if (i < n) { const int v = data[i] + tile_sums[i / kScanTile]; data[i] = v; cursor[i] = v; }
     else if (i == n) data[n] = *grand_total;
 }
-__global__ void grid_scatter_kernel(const float4* __restrict__ pts, const int* __restrict__ cell_of, const int* __restrict__ ring_of, int n,
-                                    int* __restrict__ cursor, const int* __restrict__ n_finite, int first_point,
-                                    float4* __restrict__ sorted, int* __restrict__ sring) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void grid_scatter_body(const float4* __restrict__ pts, const int* __restrict__ cell_of, const int* __restrict__ ring_of, int n,
+                                                  int* __restrict__ cursor, const int* __restrict__ n_finite, int first_point,
+                                                  float4* __restrict__ sorted, int* __restrict__ sring, const int bx) {
+    const int i = bx * 256 + threadIdx.x;
     if (i < kGridPad) {   // sentinels behind the last real point: +inf coordinates can never pass the gate
         const int j = *n_finite + i;
         sorted[j] = make_float4(__builtin_inff(), __builtin_inff(), __builtin_inff(), __int_as_float(0x7fffffff));
@@ -627,6 +632,140 @@ __global__ void grid_scatter_kernel(const float4* __restrict__ pts, const int* _
     const float4 p = pts[i];
     sorted[slot] = make_float4(p.x, p.y, p.z, __int_as_float(i + first_point));
     sring[slot] = ring_of[i];
+}
+__global__ void __launch_bounds__(256)
+grid_scatter_kernel(const float4* __restrict__ pts, const int* __restrict__ cell_of, const int* __restrict__ ring_of, int n,
+                    int* __restrict__ cursor, const int* __restrict__ n_finite, int first_point, float4* __restrict__ sorted, int* __restrict__ sring) {
+    grid_scatter_body(pts, cell_of, ring_of, n, cursor, n_finite, first_point, sorted, sring, (int)blockIdx.x);
+}
+
+// ---- the next frame of a drive in three launches for a whole lock-step group (velo_hint_next_frame) -------------------------------------
+// A drive's step loads a frame on both sides: the scan the context holds as source becomes the target (ring ids, padded rings, index), the
+// announced scan becomes the source (packed copy, query list, bounding box).  Through the general loaders that is thirteen queue operations
+// per context -- two ring-table copies, ingest, count, scan, scatter, source ingest, the box's way back, fills -- at 5-10 us of hand-over
+// each with four busy queues: 170-290 us on the stream for a group of two, as long as the host takes to turn a step around.  Here the jobs
+// of ALL contexts of a group ride in the kernel arguments (ring tables included: up to kAdvRings rings), and the stages that do not depend
+// on each other share a launch:
+//   advance_ingest_kernel   target side: ring ids + padded rings of the (already packed) promoted cloud, cell ids and the cells' counts
+//                           (the box is known from the frame's time as source, so the grid is sized before anything runs);
+//                           source side: source_ingest_kernel's work; both sides' ring tables written for the kernels that follow
+//   advance_scan_kernel     the one-pass scan of every context's table
+//   advance_scatter_kernel  the cell-sorted copies
+// Same arithmetic and the same tables as the general loaders, which every other entry keeps using (tests compare the two bit for bit).
+constexpr int kAdvRings = 64, kAdvJobs = 4;
+struct AdvJob {
+    // target side
+    const float4* tgt; int* tgt_off_dev; int* ring_of; float4* pad; unsigned long long* lb_status; int* cell_of; int* table;
+    float4* sorted; int* sring; int* scan_total; int* lb_ticket;
+    GridDesc g;
+    int n_t, n_rings_t, first_ring, first_point, lb_words, nb_t, nc, n_tiles, nb_sc;
+    // source side
+    const char* raw; long long stride; float4* src; int* src_off_dev; int* q_src; float4* qpts; unsigned* keys; unsigned* keys_next;
+    int n_s, n_rings_s, nb_pack, nb_q, skip, nq, patch, patch_rings, patch_len;
+    int off_t[kAdvRings + 1], off_s[kAdvRings + 1];
+};
+struct AdvBatch { AdvJob job[kAdvJobs]; };
+
+__global__ void __launch_bounds__(256)
+advance_ingest_kernel(AdvBatch B) {
+    const AdvJob& J = B.job[blockIdx.y];
+    __shared__ int s_off[kAdvRings + 2], s_qoff[kAdvRings + 2];
+    __shared__ float red[4][6];
+    const int tid = threadIdx.x, lane = tid & 63;
+    int bx = blockIdx.x;
+    if (bx < J.nb_t) {
+        // ---- target side: target_ingest_kernel on a packed cloud in place (nothing to pack, box known) + grid_count_kernel ----
+        const int R = J.n_rings_t, n = J.n_t;
+        if (tid <= R) s_off[tid] = J.off_t[tid];
+        for (int j = bx * 256 + tid; j < J.lb_words; j += J.nb_t * 256) J.lb_status[j] = 0ull;
+        __syncthreads();
+        if (bx == 0 && tid <= R) J.tgt_off_dev[tid] = s_off[tid];
+#pragma unroll
+        for (int u = 0; u < kIngestPerThread; u++) {
+            const int i = (bx * kIngestPerThread + u) * 256 + tid;
+            int c = -1;
+            if (i < n) {
+                const float4 p = J.tgt[i];
+                int lo = 0, hi = R;   // find r with off[r] <= i < off[r+1]
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid; }
+                J.ring_of[i] = lo + J.first_ring;
+                const int base = s_off[lo], end = s_off[lo + 1];
+                J.pad[i + 2 * lo + 1] = p;
+                if (i == base) J.pad[end + 2 * lo + 1] = p;          // trailing sentinel = first point
+                if (i == end - 1) J.pad[base + 2 * lo] = p;          // leading sentinel = last point
+                if (isfinite(p.x) && isfinite(p.y) && isfinite(p.z)) c = cell_of_point(J.g, p);
+                J.cell_of[i] = c;
+            }
+            bool head; int first, len;
+            run_of_lane(c, lane, &head, &first, &len);
+            if (head) atomicAdd(&J.table[c + 1], len);
+        }
+        return;
+    }
+    bx -= J.nb_t;
+    if (bx >= J.nb_pack + J.nb_q) return;
+    // ---- source side: source_ingest_kernel, ring and query tables from the arguments ----
+    const int R = J.n_rings_s;
+    if (tid <= R) s_off[tid] = J.off_s[tid];
+    if (tid < 64) {                                                    // query offsets: smi = 0, skip, 2 skip, ... < n per ring (velo.h:807)
+        int cnt = tid < R ? (J.off_s[tid + 1] - J.off_s[tid] + J.skip - 1) / J.skip : 0;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(cnt, o); if (lane >= o) cnt += t; }
+        if (tid == 0) s_qoff[0] = 0;
+        if (tid < R) s_qoff[tid + 1] = cnt;
+    }
+    __syncthreads();
+    if (bx == 0) {
+        if (tid <= R) { J.src_off_dev[tid] = s_off[tid]; J.src_off_dev[R + 1 + tid] = s_qoff[tid]; }
+        if (tid < 6) J.keys_next[tid] = tid < 3 ? 0xffffffffu : 0u;     // the keys of the frame after this one (the two slots alternate)
+    }
+    if (bx < J.nb_pack) {
+        const int i = bx * 256 + tid;
+        float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+        if (i < J.n_s) {
+            const float* p = (const float*)(J.raw + (int64_t)i * J.stride);
+            const float4 v = make_float4(p[0], p[1], p[2], 0.0f);
+            J.src[i] = v;
+            if (isfinite(v.x) && isfinite(v.y) && isfinite(v.z)) { mn[0] = mx[0] = v.x; mn[1] = mx[1] = v.y; mn[2] = mx[2] = v.z; }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
+        }
+        const int wid = tid >> 6;
+        if (lane == 0) { for (int k = 0; k < 3; k++) { red[wid][k] = mn[k]; red[wid][3 + k] = mx[k]; } }
+        __syncthreads();
+        if (tid < 6) {
+            const int k = tid;
+            float v = red[0][k];
+            for (int w = 1; w < 4; w++) v = (k < 3) ? fminf(v, red[w][k]) : fmaxf(v, red[w][k]);
+            const unsigned key = f2key(v), cur = J.keys[k];
+            if (k < 3) { if (v < 3.0e38f && key < cur) atomicMin(&J.keys[k], key); } else { if (v > -3.0e38f && key > cur) atomicMax(&J.keys[k], key); }
+        }
+        return;
+    }
+    const int i = (bx - J.nb_pack) * 256 + tid;
+    if (i >= J.nq) return;
+    int lo = 0, hi = R;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_qoff[mid] <= i) lo = mid; else hi = mid; }
+    const int k = i - s_qoff[lo];
+    const int pos = J.patch ? patch_position(s_qoff, R, lo, k, J.patch_rings, J.patch_len) : i, si = s_off[lo] + k * J.skip;
+    J.q_src[pos] = si;
+    if (J.qpts) { const float* p = (const float*)(J.raw + (int64_t)si * J.stride); J.qpts[pos] = make_float4(p[0], p[1], p[2], 0.0f); }
+}
+template <int kLbItems>
+__global__ void __launch_bounds__(kScanThreads)
+advance_scan_kernel(AdvBatch B) {
+    const AdvJob& J = B.job[blockIdx.y];
+    if ((int)blockIdx.x >= J.n_tiles) return;
+    scan_lookback_body<kLbItems>(J.table + 1, J.nc, J.lb_status, J.lb_ticket, J.scan_total);
+}
+__global__ void __launch_bounds__(256)
+advance_scatter_kernel(AdvBatch B) {
+    const AdvJob& J = B.job[blockIdx.y];
+    if ((int)blockIdx.x >= J.nb_sc) return;
+    grid_scatter_body(J.tgt, J.cell_of, J.ring_of, J.n_t, J.table + 1, J.scan_total, J.first_point, J.sorted, J.sring, (int)blockIdx.x);
 }
 
 // ---- association ------------------------------------------------------------------------------------------------
