@@ -88,6 +88,7 @@ struct DevBuf {
     ~DevBuf() { release(); }             // every buffer a context owns goes with it (velo_destroy -> delete)
     int reserve(size_t n) {
         if (n <= cap) return VELO_OK;
+        const size_t cap_before = cap; (void)cap_before;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = n + n / 8 + 64;
 #ifdef VELO_DIAGNOSTICS
@@ -95,11 +96,18 @@ struct DevBuf {
         static const bool pad2m = getenv("VELO_ALLOC_2MB") && atoi(getenv("VELO_ALLOC_2MB")) != 0;
         if (pad2m && want * sizeof(T) >= (256u << 10)) want = ((want * sizeof(T) + (2u << 20) - 1) / (2u << 20)) * (2u << 20) / sizeof(T);
 #endif
+#ifdef VELO_DIAGNOSTICS
+        static const bool alloc_trace = getenv("VELO_ALLOC_TRACE") != nullptr;   // dev aid: a (re)allocation synchronises the device -- which buffers still grow in a warm loop?
+        if (alloc_trace) fprintf(stderr, "[velo alloc] device buffer of %zu-byte elements: %zu -> %zu elements\n", sizeof(T), cap_before, want);
+#endif
         hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
         if (e != hipSuccess) return fail(VELO_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", want * sizeof(T), hipGetErrorString(e));
         cap = want;
         return VELO_OK;
     }
+    // for buffers whose size moves from frame to frame (the index table follows the scan's bounding box): when it has to grow, grow by `extra`
+    // elements more -- a reallocation synchronises the device, and the queues stall for 6-7 ms one step later (measured: tools/step_times.py)
+    int reserve_roomy(size_t n, size_t extra) { return n <= cap ? VELO_OK : reserve(n + extra); }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
@@ -642,7 +650,7 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
         return VELO_OK;
     }
     G.wpr = 0; G.n_points_cap = 0;
-    VELO_TRY(G.cell_start.reserve((size_t)nc + 4));
+    VELO_TRY(G.cell_start.reserve_roomy((size_t)nc + 4, (size_t)nc / 2));
     // count -> one-pass exclusive scan -> scatter, all in the table itself with an offset of one (grid_count_kernel, scan_lookback_kernel)
     const bool large_tiles = nc >= kLbLargeFrom;
     const int n_tiles = cdiv(nc, lb_tile(large_tiles ? kLbItemsLarge : kLbItemsSmall));
@@ -703,6 +711,8 @@ int pin_acquire(velo_ctx* c, int k, size_t n, int** out) {
     velo_ctx::PinSlot& s = c->pin[k];
     if (s.pending) { HIP_TRY(hipEventSynchronize(s.ev)); s.pending = false; }
     if (s.cap < n) {
+        static const bool alloc_trace = dev_env("VELO_ALLOC_TRACE") != nullptr;
+        if (alloc_trace) fprintf(stderr, "[velo alloc] pinned slot %d: %zu -> %zu ints\n", k, s.cap, n + 64);
         if (s.p) { (void)hipHostFree(s.p); s.p = nullptr; s.cap = 0; }
         HIP_TRY(hipHostMalloc((void**)&s.p, (n + 64) * sizeof(int)));
         s.cap = n + 64;
@@ -3238,6 +3248,8 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
     for (int i = 0; i < n; i++) vis_bytes += (((size_t)3 * (size_t)std::max(ctxs[i]->n_matches, 0) + 15) & ~(size_t)15) + sizeof(int) * 2 * VELO_MAX_STATS;
     const size_t need = n_item_slots * sizeof(LMBatchItem) + (size_t)n * (sizeof(LMState) + 8 * sizeof(double) + sizeof(SolveLog) * VELO_MAX_SOLVES + 8) + 16 + vis_bytes;
     if (c0->h_batch_bytes < need) {
+        static const bool alloc_trace = dev_env("VELO_ALLOC_TRACE") != nullptr;
+        if (alloc_trace) fprintf(stderr, "[velo alloc] pinned batch block: %zu -> %zu bytes\n", c0->h_batch_bytes, need);
         if (c0->h_batch) (void)hipHostFree(c0->h_batch);
         c0->h_batch = nullptr; c0->h_batch_bytes = 0;
         HIP_TRY(hipHostMalloc(&c0->h_batch, need, hipHostMallocDefault));
