@@ -815,11 +815,14 @@ def main():
             for name, steps in (("c1", 100), ("c3", 40), ("c4", 12)):
                 if name != a.workload:
                     kitti_c1 = name == "c1" and os.environ.get("VELO_KITTI_ROOT")
+                    # (warm-up as the headline's: a context's buffers are allocated over its first three steps, and an allocation stalls the queues
+                    #  for 6-7 ms one step later -- tools/step_times.py)
+                    w_leg = 3 if name == "c4" else max(a.warmup, 5)
                     if in_proc:
-                        legs[name] = run_leg(rig, a, name, "replicas", a.batch, steps, 3, drives=None if kitti_c1 else drives)
+                        legs[name] = run_leg(rig, a, name, "replicas", a.batch, steps, w_leg, drives=None if kitti_c1 else drives)
                     else:
-                        n_leg = steps if (drives is None or kitti_c1 or name == "c4") else max(1, min(steps, len(drives[0]["frames"]) - 1 - 3))
-                        legs[name] = child_leg(name, n_leg, 3)
+                        n_leg = steps if (drives is None or kitti_c1 or name == "c4") else max(1, min(steps, len(drives[0]["frames"]) - 1 - w_leg))
+                        legs[name] = child_leg(name, n_leg, w_leg)
                     if not a.no_cpu_baseline and "error" not in legs[name]:
                         # every leg next to the CPU restatement on its own first pair, with the pose difference.  c1: the reference's own constants on
                         # its own kind of host (icp_skip = 200, one thread, velo.h:900, and all cores); c3: with the pair's stereo matches; c4: the

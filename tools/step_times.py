@@ -14,7 +14,8 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 B, NF = 8, 26
 drives = bench.make_drives(B, NF)
-frames = [[(torch.from_numpy(np.ascontiguousarray(f[0])).cuda(), f[1]) for f in d["frames"]] for d in drives]
+host = os.environ.get("STEP_TIMES_HOST")              # frames stay in pageable host memory (bench.py --host-inputs)
+frames = [[(np.ascontiguousarray(f[0]) if host else torch.from_numpy(np.ascontiguousarray(f[0])).cuda(), f[1]) for f in d["frames"]] for d in drives]
 vis = [[synth.stereo_matches(1000, seed=3 + 1000 * i + k, x_true=drives[i]["x_true"][k]) for k in range(NF - 1)] for i in range(B)] if wl == "c3" else None
 ctxs = [api.Context(0, icp_skip=1) for _ in range(B)]
 w = bench.DriveWalker(api, ctxs, frames, 0, vis)
