@@ -25,7 +25,7 @@ for r in range(runs):
     ts = []
     for _ in range(NF - 1):
         t = time.perf_counter(); w.step(); ts.append(1e3 * (time.perf_counter() - t))
-        if os.environ.get("VELO_ALLOC_TRACE"):
+        if os.environ.get("VELO_ALLOC_TRACE") or os.environ.get("VELO_BATCH_TRACE"):
             print(f"[step {len(ts)}] {ts[-1]:.2f} ms", file=sys.stderr, flush=True)
     gc.enable()
     t20 = ts[5:]

@@ -2263,32 +2263,56 @@ int velo_get_cloud(velo_ctx* c, int32_t of_target, float* xyz_out, int32_t capac
     return VELO_OK;
 }
 
-static int set_visual_impl(velo_ctx* c, const velo_match* m, int32_t n, bool wait);
+static int set_visual_impl(velo_ctx* c, const velo_match* m, int32_t n, bool wait, hipStream_t on = nullptr);
 int velo_set_visual(velo_ctx* c, const velo_match* m, int32_t n) { return set_visual_impl(c, m, n, true); }
 // wait = false: the copy stays queued on the context's stream (the records were copied into the context first), for callers that
 // order the stream against their launches themselves (velo_register_batch_visual: the group driver synchronises the contexts' streams)
-static int set_visual_impl(velo_ctx* c, const velo_match* m, int32_t n, bool wait) {
+// on: the stream the copies are queued on instead of the context's own (the lock-step group's: a context's own stream shares a hardware queue
+// with some OTHER group's chain of launches, and a host thread was seen to spend 8.5 ms in this function once in a hundred steps)
+static int set_visual_impl(velo_ctx* c, const velo_match* m, int32_t n, bool wait, hipStream_t on) {
     if (!c || n < 0 || (n > 0 && !m)) return fail(VELO_ERR_INVALID, "bad visual arguments");
+    const hipStream_t st = on ? on : c->stream;
     static_assert(sizeof(VisualMatch) == sizeof(velo_match), "device/host match layout");
+    static const bool slow_trace = dev_env("VELO_SLOW_TRACE") != nullptr;     // dev aid: which host call of this function takes milliseconds once in a hundred steps?
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!slow_trace) return;
+        const auto t = std::chrono::steady_clock::now();
+        const double us = std::chrono::duration<double, std::micro>(t - t_last).count();
+        if (us > 500.0) fprintf(stderr, "[velo slow] set_visual: %s took %.0f us\n", what, us);
+        t_last = t;
+    };
     HIP_TRY(hipSetDevice(c->device));
+    lap("hipSetDevice");
     c->n_matches = n;
     c->h_matches.assign(m, m + n);
     c->vflags_valid = false;
     c->h_vflags.clear();
+    lap("host copy of the records");
     if (n > 0) {
         VELO_TRY(c->vm.reserve((size_t)n));
         VELO_TRY(c->vflags.reserve((size_t)3 * n));
+        lap("reserve");
         if (wait) {
-            HIP_TRY(hipMemcpyAsync(c->vm.p, c->h_matches.data(), sizeof(velo_match) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(c->vm.p, c->h_matches.data(), sizeof(velo_match) * (size_t)n, hipMemcpyHostToDevice, st));
         } else {                                                      // through a pinned slot: the copy is really asynchronous
             int* pin = nullptr;
             VELO_TRY(pin_acquire(c, 3, (sizeof(velo_match) * (size_t)n + sizeof(int) - 1) / sizeof(int), &pin));
+            lap("pin_acquire");
             std::memcpy(pin, m, sizeof(velo_match) * (size_t)n);
-            HIP_TRY(hipMemcpyAsync(c->vm.p, pin, sizeof(velo_match) * (size_t)n, hipMemcpyHostToDevice, c->stream));
-            VELO_TRY(pin_release(c, 3));
+            lap("memcpy into the pinned slot");
+            static_assert(sizeof(velo_match) % sizeof(int) == 0, "records are copied word by word");
+            const int n_words = (int)(sizeof(velo_match) / sizeof(int)) * n;
+            hipLaunchKernelGGL(upload_words_kernel, dim3(cdiv(n_words, 256)), dim3(256), 0, st, (const int*)pin, reinterpret_cast<int*>(c->vm.p), n_words);
+            HIP_TRY(hipGetLastError());
+            lap("upload launch");
+            HIP_TRY(hipEventRecord(c->pin[3].ev, st));
+            c->pin[3].pending = true;
+            lap("hipEventRecord");
         }
-        HIP_TRY(hipMemsetAsync(c->vflags.p, 0, (size_t)3 * n, c->stream));
-        if (wait) HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemsetAsync(c->vflags.p, 0, (size_t)3 * n, st));
+        lap("hipMemsetAsync");
+        if (wait) HIP_TRY(hipStreamSynchronize(st));
     }
     return VELO_OK;
 }
@@ -3667,10 +3691,10 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
 
 // upload (optional) + register: the scans of job i go into context i (velo_set_target / velo_set_source semantics), then the batch runs
 struct JobVisual { const velo_match* const* m = nullptr; const int32_t* n = nullptr; };   // per-job matches of velo_register_batch_visual (or none)
-static int load_job_visual(velo_ctx* c, const JobVisual& V, int i) {
+static int load_job_visual(velo_ctx* c, const JobVisual& V, int i, hipStream_t on = nullptr) {
     if (!V.n) return VELO_OK;
     if (V.n[i] < 0 || (V.n[i] > 0 && (!V.m || !V.m[i]))) return fail(VELO_ERR_INVALID, "job %d: bad visual arguments", i);
-    return set_visual_impl(c, V.n[i] > 0 ? V.m[i] : nullptr, V.n[i], false);
+    return set_visual_impl(c, V.n[i] > 0 ? V.m[i] : nullptr, V.n[i], false, on);
 }
 // A context that loaded an announced frame ahead (velo_hint_next_frame) holds it already: the job that brings exactly that frame -- a promoted
 // target and the announced source -- loads nothing; any other job is an error (the context is one frame ahead of what the caller thinks).
@@ -3787,7 +3811,7 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
         //  11: 3 groups 2,490, 4 groups 2,700 -- a launch serves up to four contexts, so groups of five split theirs 4 + 1)
         const int G = groups_env > 0 ? std::min(groups_env, n / 2) : (n >= 12 ? 2 : ((n == 9 || n == 10) ? 3 : std::min(4, n / 2)));
         if (G <= 1) {
-            for (int i = 0; i < n; i++) { VELO_TRY(load_job_visual(ctxs[i], V, i)); VELO_TRY(load_job(ctxs[i], target_of(i), sources ? sources + i : nullptr)); }
+            for (int i = 0; i < n; i++) { VELO_TRY(load_job_visual(ctxs[i], V, i, ctxs[0]->stream)); VELO_TRY(load_job(ctxs[i], target_of(i), sources ? sources + i : nullptr)); }
             return f2f_batch_lockstep(ctxs, n, x, T, summaries);
         }
         std::vector<int> gst((size_t)G, VELO_OK);
@@ -3802,7 +3826,7 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
             // slower, 2.32-2.34 k vs 2.42-2.47 k pairs/s: more host threads contending for the runtime's submission path.)
             // (in two passes: all contexts' uploads and bounding-box requests are in flight before the first context waits for its answer)
             for (int i = b; i < e; i++) {
-                int st = load_job_visual(ctxs[i], V, i);
+                int st = load_job_visual(ctxs[i], V, i, ctxs[b]->stream);   // (on the group's stream: the registration runs there)
                 if (st == VELO_OK) st = load_job_begin(ctxs[i], target_of(i), sources ? sources + i : nullptr);
                 if (st != VELO_OK) { gst[(size_t)gi] = st; gerr[(size_t)gi] = g_err; return; }
             }
@@ -3912,7 +3936,7 @@ static int sequences_impl(velo_ctx** ctxs, int32_t n, int32_t n_frames, const ve
                 if (st == VELO_OK) st = velo_frame_to_frame(ctxs[b], xl.data(), Tl.data(), Sf);
             } else {
                 for (int i = b; i < e && st == VELO_OK; i++) {
-                    st = load_job_visual(ctxs[i], V, i);
+                    st = load_job_visual(ctxs[i], V, i, ctxs[b]->stream);   // (on the group's stream: the registration runs there)
                     if (st == VELO_OK) st = load_job_begin(ctxs[i], &promote, fr + i);
                 }
                 for (int i = b; i < e && st == VELO_OK; i++) st = load_job_end(ctxs[i], true, true);

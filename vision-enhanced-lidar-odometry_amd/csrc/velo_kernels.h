@@ -112,6 +112,12 @@ __device__ __forceinline__ int cell_coord(float p, float o, float inv_h, int n) 
 //  kernel it would compile here -- ingest, index build, the association family -- would be a second, unused copy in the shared library)
 #ifndef VELO_UNIT_LM_ONLY
 // ---- point packing: (stride-addressed xyz) -> float4 ---------------------------------------------------------
+// records from page-locked host memory into a device buffer, as a launch: the runtime's copy of a few tens of KB (its DMA path) was seen to
+// block the submitting thread for 6-14 ms once in a hundred steps with four busy queues; a launch never does
+__global__ void __launch_bounds__(256) upload_words_kernel(const int* __restrict__ src, int* __restrict__ dst, int n_words) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_words) dst[i] = __builtin_nontemporal_load(src + i);
+}
 __global__ void pack_points_kernel(const char* __restrict__ src, int64_t stride, int n, float4* __restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
