@@ -231,6 +231,8 @@ struct velo_ctx {
     DevBuf<float4> prev_a;               // tube kernel warm start: last round's two winners per query with their coordinates (index -1 = none; [0, nq) best, [nq, 2 nq) second),
     DevBuf<int2> prev_r;                 // and their rings; reset with every new source / target
     bool prev_ready = false;             // the seed arrays hold n_q initialised entries for the current source and target
+    bool prev_filled = false;            // ... they hold "no previous winner" everywhere already (written by the launch that loaded the source: advance_ingest_kernel)
+    int prev_filled_nq = -1;             // ... for this many queries
     int warm_start = 1;                  // VELO_WARM_START=0 turns the seeds off (A/B; results are identical either way)
     int assoc_lds_pad = 0;               // bytes of unused dynamic LDS per association workgroup -- caps the association kernel's workgroups per
                                          // CU so that LM workgroups of other pairs in flight find room at once.  Set by the lock-step batch
@@ -902,7 +904,8 @@ int attach_seeds(velo_ctx* c, AssocOut* out, bool image_seeds = false, int* had_
     const size_t nq = (size_t)std::max(c->n_q, 1);
     if (!c->prev_ready) {
         VELO_TRY(c->prev_a.reserve(2 * nq)); VELO_TRY(c->prev_r.reserve(nq));   // both winners' arrays in one allocation: one fill
-        if (!image_seeds) HIP_TRY(hipMemsetAsync(c->prev_a.p, 0xff, sizeof(float4) * 2 * nq, c->stream));   // (the seed kernel writes every entry itself)
+        if (!image_seeds && !(c->prev_filled && c->prev_filled_nq == c->n_q)) HIP_TRY(hipMemsetAsync(c->prev_a.p, 0xff, sizeof(float4) * 2 * nq, c->stream));   // (the seed kernel writes every entry itself)
+        c->prev_filled = false;
         c->prev_ready = true;
         c->seed_rounds = 0;
     } else if (had_prev) *had_prev = 1;
@@ -1552,6 +1555,11 @@ int source_ingest(velo_ctx* c) {
         J.n_s = c->n_src; J.n_rings_s = R; J.nb_pack = cdiv(c->n_src, 256); J.nb_q = c->n_q > 0 ? cdiv(c->n_q, 256) : 0;
         J.skip = skip; J.nq = c->n_q; J.patch = patch ? 1 : 0; J.patch_rings = c->patch_rings; J.patch_len = c->patch_len;
         std::memcpy(J.off_s, c->h_src_off.data(), sizeof(int) * ((size_t)R + 1));
+        if (c->warm_start && c->n_q > 0) {                                // the seed arrays of the new queries: "no previous winner", written by the query blocks
+            VELO_TRY(c->prev_a.reserve(2 * nq)); VELO_TRY(c->prev_r.reserve(nq));
+            J.seed_fill = c->prev_a.p;
+            c->prev_filled = true; c->prev_filled_nq = c->n_q;
+        } else c->prev_filled = false;
         c->src_bbox_valid = true;                                         // (the keys' copy and its event: advance_launch)
         c->src_raw.on = false;
         c->q_patch = patch;
@@ -3334,7 +3342,9 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
             c->have_corr = false; c->last_n_valid = 0;
             for (int k = 0; k < 6; k++) h_x[8 * (size_t)i + k] = xc[(size_t)i][(size_t)k];
         }
-        HIP_TRY(hipMemcpyAsync(c0->batch_x.p, h_x, sizeof(double) * 8 * (size_t)n, hipMemcpyHostToDevice, bs));
+        // (the start poses stay in the page-locked block: the first LM launch's workgroups -- and the visual gate -- read their six doubles from there,
+        //  one queue operation less; nothing writes the block before the call's results are in)
+        const double* d_x0 = h_x;
         // (A/B, measured: the LM launches on a high-priority stream of their own halve the throughput -- 1,530 vs 3,020 pairs/s: more than four
         //  active hardware queues are time-sliced, the same effect as GPU_MAX_HW_QUEUES=8)
         int r = 0;
@@ -3344,7 +3354,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
             for (int i = 0; i < n && any_matches; i++) {             // residual-type choice + outlier gate of this iteration (velo.h:622-792), on the device
                 velo_ctx* c = ctxs[i];
                 if (c->n_matches <= 0) continue;
-                hipLaunchKernelGGL(visual_gate_kernel, dim3(cdiv(c->n_matches, 128)), dim3(128), 0, bs, (const double*)(iter == 1 ? c0->batch_x.p + 8 * (size_t)i : c->state.p->x),
+                hipLaunchKernelGGL(visual_gate_kernel, dim3(cdiv(c->n_matches, 128)), dim3(128), 0, bs, (const double*)(iter == 1 ? d_x0 + 8 * (size_t)i : c->state.p->x),
                                    visual_params(c->P), c->vm.p, c->n_matches, iter, c->vflags.p, c->vis_counts.p + 2 * (iter - 1));
             }
             for (int icp_iter = 0; icp_iter < P.icp_iterations; icp_iter++, r++) {
@@ -3356,7 +3366,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                     LMBatchItem& it = items_r[i];
                     it.A = eval_args(c, nullptr);
                     const EvalPlan E = eval_plan(it.A);
-                    it.S = c->state.p; it.xd = r == 0 ? c0->batch_x.p + 8 * (size_t)i : nullptr;
+                    it.S = c->state.p; it.xd = r == 0 ? d_x0 + 8 * (size_t)i : nullptr;
                     it.n_valid = c->n_valid.p + c->nv_idx;
                     it.nb_icp = E.nb_icp; it.nb_vis = E.nb_vis; it.n_rows = E.total();
                     it.A.vis_row0 = E.nb_icp;
@@ -3371,7 +3381,8 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
                 // (round 5: the lean launch that carries the visual blocks takes them by value too -- six copies and their queue hand-overs less per call)
                 const bool by_value_vis = n <= 4 && c0->lm_fused && !c0->lm_persist && nbv_max > 0 && vis_in_launch && lean;
                 const bool by_value = (n <= 4 && c0->lm_fused && (!c0->lm_persist || c0->lm_persist == 2) && nbv_max == 0) || by_value_vis;
-                if (!by_value || r == 0) HIP_TRY(hipMemcpyAsync(c0->batch_items.p + (size_t)r * n, items_r, sizeof(LMBatchItem) * (size_t)n, hipMemcpyHostToDevice, bs));
+                // (the first round's copy used to serve the final state gather as well: chain_finish_kernel takes its pointers by value)
+                if (!by_value || (r == 0 && n > kFinishJobs)) HIP_TRY(hipMemcpyAsync(c0->batch_items.p + (size_t)r * n, items_r, sizeof(LMBatchItem) * (size_t)n, hipMemcpyHostToDevice, bs));
                 bool small = c0->small_solve != 0 && !iter_mode;        // every solve of the group is ONE single-workgroup launch (lm_solve_small_kernel's body)
                 for (int i = 0; i < n; i++) small = small && items_r[i].n_rows >= 1 && items_r[i].n_rows <= kSmallRows;
                 if (iter_mode) {                                        // K + 1 launches: the last one only advances the state over the K-th sweep's rows
@@ -3478,21 +3489,42 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
 
             }
         }
-        hipLaunchKernelGGL(lm_gather_states_kernel, dim3(n), dim3(128), 0, bs, (const LMBatchItem*)c0->batch_items.p, c0->batch_states.p, iter_launches & 1);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(h_states, c0->batch_states.p, sizeof(LMState) * (size_t)n, hipMemcpyDeviceToHost, bs));
-        HIP_TRY(hipMemcpyAsync(h_logs, c0->batch_logs.p, sizeof(SolveLog) * (size_t)n * VELO_MAX_SOLVES, hipMemcpyDeviceToHost, bs));
-        HIP_TRY(hipMemcpyAsync(h_fail, c0->batch_fail.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, bs));
         std::vector<int> h_vis((size_t)n * 2 * VELO_MAX_STATS, 0);
         std::vector<unsigned char*> pin_flags((size_t)n, nullptr);
         std::vector<int*> pin_counts((size_t)n, nullptr);
         {
             unsigned char* q = h_vis_pin;
-            for (int i = 0; i < n && any_matches; i++) {             // (pageable destinations make each of these copies a staged, host-blocking one)
-                velo_ctx* c = ctxs[i];
-                const size_t fb = ((size_t)3 * (size_t)std::max(c->n_matches, 0) + 15) & ~(size_t)15;
+            for (int i = 0; i < n && any_matches; i++) {
+                const size_t fb = ((size_t)3 * (size_t)std::max(ctxs[i]->n_matches, 0) + 15) & ~(size_t)15;
                 pin_flags[(size_t)i] = q; pin_counts[(size_t)i] = (int*)(q + fb);
                 q += fb + sizeof(int) * 2 * VELO_MAX_STATS;
+            }
+        }
+        if (n <= kFinishJobs) {
+            // the call's results in ONE launch that writes the page-locked block itself (chain_finish_kernel): final states, solve logs, failure
+            // flags, and the visual flags / block counts of the contexts that have matches
+            ChainFinish F;
+            std::memset(&F, 0, sizeof(F));
+            for (int i = 0; i < n; i++) {
+                velo_ctx* c = ctxs[i];
+                F.S[i] = c->state.p + (iter_launches & 1);
+                if (any_matches && c->n_matches > 0) {
+                    F.vflags[i] = c->vflags.p; F.n_vflags[i] = 3 * c->n_matches; F.vis_counts[i] = c->vis_counts.p;
+                    F.h_vflags[i] = pin_flags[(size_t)i]; F.h_vis_counts[i] = pin_counts[(size_t)i];
+                }
+            }
+            F.logs = c0->batch_logs.p; F.fail = c0->batch_fail.p; F.h_states = h_states; F.h_logs = h_logs; F.h_fail = h_fail;
+            F.n = n; F.n_logs = VELO_MAX_SOLVES; F.n_counts = 2 * VELO_MAX_STATS;
+            hipLaunchKernelGGL(chain_finish_kernel, dim3(n), dim3(256), 0, bs, F);
+            HIP_TRY(hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(lm_gather_states_kernel, dim3(n), dim3(128), 0, bs, (const LMBatchItem*)c0->batch_items.p, c0->batch_states.p, iter_launches & 1);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(h_states, c0->batch_states.p, sizeof(LMState) * (size_t)n, hipMemcpyDeviceToHost, bs));
+            HIP_TRY(hipMemcpyAsync(h_logs, c0->batch_logs.p, sizeof(SolveLog) * (size_t)n * VELO_MAX_SOLVES, hipMemcpyDeviceToHost, bs));
+            HIP_TRY(hipMemcpyAsync(h_fail, c0->batch_fail.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, bs));
+            for (int i = 0; i < n && any_matches; i++) {             // (pageable destinations make each of these copies a staged, host-blocking one)
+                velo_ctx* c = ctxs[i];
                 if (c->n_matches <= 0) continue;
                 HIP_TRY(hipMemcpyAsync(pin_flags[(size_t)i], c->vflags.p, (size_t)3 * c->n_matches, hipMemcpyDeviceToHost, bs));
                 HIP_TRY(hipMemcpyAsync(pin_counts[(size_t)i], c->vis_counts.p, sizeof(int) * 2 * VELO_MAX_STATS, hipMemcpyDeviceToHost, bs));

@@ -667,6 +667,7 @@ struct AdvJob {
     int n_t, n_rings_t, first_ring, first_point, lb_words, nb_t, nc, n_tiles, nb_sc;
     // source side
     const char* raw; long long stride; float4* src; int* src_off_dev; int* q_src; float4* qpts; unsigned* keys; unsigned* keys_next;
+    float4* seed_fill;                                                  // both winners' seed arrays (2 nq entries) set to "none" here, or null
     int n_s, n_rings_s, nb_pack, nb_q, skip, nq, patch, patch_rings, patch_len;
     int off_t[kAdvRings + 1], off_s[kAdvRings + 1];
 };
@@ -753,6 +754,10 @@ advance_ingest_kernel(AdvBatch B) {
     }
     const int i = (bx - J.nb_pack) * 256 + tid;
     if (i >= J.nq) return;
+    if (J.seed_fill) {                                                 // (what attach_seeds' fill of 0xff bytes writes: no previous winner)
+        const float4 none = make_float4(__int_as_float(-1), __int_as_float(-1), __int_as_float(-1), __int_as_float(-1));
+        J.seed_fill[i] = none; J.seed_fill[J.nq + i] = none;
+    }
     int lo = 0, hi = R;
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_qoff[mid] <= i) lo = mid; else hi = mid; }
     const int k = i - s_qoff[lo];
@@ -4297,6 +4302,38 @@ __global__ void lm_gather_states_kernel(const LMBatchItem* __restrict__ items, L
     const unsigned* src = reinterpret_cast<const unsigned*>(items[blockIdx.x].S + which);
     unsigned* dst = reinterpret_cast<unsigned*>(out + blockIdx.x);
     for (int k = threadIdx.x; k < (int)(sizeof(LMState) / 4); k += blockDim.x) dst[k] = src[k];
+}
+
+// The end of a chained call of a lock-step group in ONE launch instead of a gather launch + three to seven copies: every context's final
+// state, the solve logs, the chain's failure flags (and, with visual blocks, the match flags and block counts) written straight into the
+// group's page-locked result block -- with four busy queues every queue operation costs ~12 us of stream time whatever it does.
+constexpr int kFinishJobs = 8;
+struct ChainFinish {
+    const LMState* S[kFinishJobs];
+    const unsigned char* vflags[kFinishJobs]; const int* vis_counts[kFinishJobs];
+    unsigned char* h_vflags[kFinishJobs]; int* h_vis_counts[kFinishJobs];
+    int n_vflags[kFinishJobs];
+    const SolveLog* logs; const int* fail;
+    LMState* h_states; SolveLog* h_logs; int* h_fail;
+    int n, n_logs, n_counts;
+};
+__global__ void __launch_bounds__(256) chain_finish_kernel(ChainFinish F) {
+    const int i = blockIdx.x, t = threadIdx.x;
+    {
+        const unsigned* src = reinterpret_cast<const unsigned*>(F.S[i]);
+        unsigned* dst = reinterpret_cast<unsigned*>(F.h_states + i);
+        for (int k = t; k < (int)(sizeof(LMState) / 4); k += 256) dst[k] = src[k];
+    }
+    {
+        const unsigned* src = reinterpret_cast<const unsigned*>(F.logs + (size_t)i * F.n_logs);
+        unsigned* dst = reinterpret_cast<unsigned*>(F.h_logs + (size_t)i * F.n_logs);
+        for (int k = t; k < (int)(sizeof(SolveLog) / 4) * F.n_logs; k += 256) dst[k] = src[k];
+    }
+    if (t == 0) F.h_fail[i] = F.fail[i];
+    if (F.n_vflags[i] > 0) {
+        for (int k = t; k < F.n_vflags[i]; k += 256) F.h_vflags[i][k] = F.vflags[i][k];
+        for (int k = t; k < F.n_counts; k += 256) F.h_vis_counts[i][k] = F.vis_counts[i][k];
+    }
 }
 
 // A whole ceres::Solve in ONE single-workgroup launch, for problems whose sweep is at most kSmallRows workgroups anyway (the
