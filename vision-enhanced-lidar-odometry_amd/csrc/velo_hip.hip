@@ -1086,8 +1086,8 @@ int do_associate(velo_ctx* c, const double x[6], int iter, bool want_aux, bool w
                 const int asker_rows = c->asker_rows >= 0 ? c->asker_rows : (reach_cells > 5 ? 0 : (1 << 30));
                 const int* perm = nullptr;
                 if (c->tube_map >= 0) { VELO_TRY(build_group_perm(c, qb, qe, c->tube_map)); perm = c->group_perm.p; }
-                else if (c->xcd_chunks) perm = kXcdChunks;
-                const int grid_groups = perm == kXcdChunks ? 8 * cdiv(groups, 8) : groups;
+                else if (c->xcd_chunks) perm = c->xcd_chunks == 2 ? kXcdTiles : kXcdChunks;
+                const int grid_groups = perm == kXcdChunks ? 8 * cdiv(groups, 8) : (perm == kXcdTiles ? 64 * cdiv(groups, 64) : groups);
                 // density-shrunk grid, default instantiation, COLD round (no seeds yet: half of the queries ask, the heavy ones in clumps): the asking
                 // queries go on a list and are searched by a second launch.  Measured per round on the 2M-point map, list vs in place: cold 399 vs
                 // 688 us; seeded rounds 237 / 326 / 246 / 183 / 160 vs 230 / 272 / 207 / 138 / 116 us (few askers: the second launch only adds its
@@ -3026,7 +3026,7 @@ static int prepare_assoc_v5(velo_ctx* c, const double x[6], int iter, AssocArgs*
     }
     out.n_valid_next = c->n_valid.p + (c->nv_idx ^ 1);
     c->nv_clean[c->nv_idx ^ 1] = true;
-    A->want_aux = 0; A->group_perm = c->xcd_chunks ? kXcdChunks : nullptr; A->dbg = 0;
+    A->want_aux = 0; A->group_perm = c->xcd_chunks ? (c->xcd_chunks == 2 ? kXcdTiles : kXcdChunks) : nullptr; A->dbg = 0;
     const int reach_cells = (int)std::ceil(std::sqrt(std::max(gate_of_iter(c->P, 1), 0.0)) / (G->h * 0.999));
     A->asker_rows = c->asker_rows >= 0 ? c->asker_rows : (reach_cells > 5 ? 0 : (1 << 30));
     *asker = A->asker_rows < (1 << 30);
@@ -3083,7 +3083,7 @@ static int do_associate_group(velo_ctx** ctxs, int n, const std::vector<std::arr
             gmax = std::max(gmax, groups); any_asker = any_asker || asker; k++;
         }
         if (k == 0) continue;
-        if (ctxs[first]->xcd_chunks) gmax = 8 * cdiv(gmax, 8);
+        if (ctxs[first]->xcd_chunks) gmax = ctxs[first]->xcd_chunks == 2 ? 64 * cdiv(gmax, 64) : 8 * cdiv(gmax, 8);
         velo_ctx* c = ctxs[first];
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
         uint64_t bytes = 0;                                           // B_assoc of every context this launch serves

@@ -1393,6 +1393,7 @@ __device__ __forceinline__ void top2_merge_xor(Top2& t, int mask) {
 // Tubes do not blow up with the length of the segment, so the cluster radius can be large (one cluster per group).
 //   * rounds after the first are warm-started from the previous round's winners (AssocOut::prev).
 #define kXcdChunks (reinterpret_cast<const int*>(8))
+#define kXcdTiles (reinterpret_cast<const int*>(16))
 template <int NW, int MINW, bool DBG, int PPT, int ASKER>
 __device__ __forceinline__ void
 assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_dev, int* __restrict__ chain_fail, const GridView& G, const float4* __restrict__ qpts, int q_begin, int q_end,
@@ -1445,6 +1446,14 @@ assoc_search_v5_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_d
         const int n_groups = (q_end - q_begin + 63) / 64, per = (n_groups + 7) / 8;
         group = (block_x & 7) * per + (block_x >> 3);
         if (group >= n_groups) return;
+    } else if (group_perm == kXcdTiles) {
+        // kXcdTiles: the list cut into 64 tiles (in patch order: 8 bands of rings x 8 stretches of azimuth); XCD k takes the tiles (band b,
+        // stretch (k - b) mod 8) -- one compact piece of every band, an eighth of the scene in all, and every XCD the same mix of cheap and
+        // dear bands (kXcdChunks gives an XCD ONE band: local, but the bands cost differently).  The grid has 64 * ceil(groups / 64) blocks.
+        const int n_groups = (q_end - q_begin + 63) / 64, per = (n_groups + 63) / 64;
+        const int k = block_x & 7, j = block_x >> 3, b = j / per, w = j - b * per;
+        group = (b * 8 + ((k + 8 - (b & 7)) & 7)) * per + w;
+        if (b >= 8 || group >= n_groups) return;
     } else if (group_perm) group = group_perm[block_x];
     if (out.n_valid_next && block_x == 0 && tid == 0) *out.n_valid_next = 0;   // its last reader ran before this launch (same stream)
     if (ASKER == 2 && block_x == 0 && tid == 0) *out.ask_count_next = 0;
@@ -1977,7 +1986,7 @@ template <int NW, int MINW, bool DBG, int PPT, int ASKER>
 __global__ void __launch_bounds__(NW * 64, MINW)
 assoc_search_v5_batch_kernel(AssocBatch B) {
     const AssocArgs& a = B.item[blockIdx.y];
-    if (a.group_perm != kXcdChunks && (int)blockIdx.x * 64 >= a.q_end - a.q_begin) return;
+    if (a.group_perm != kXcdChunks && a.group_perm != kXcdTiles && (int)blockIdx.x * 64 >= a.q_end - a.q_begin) return;
     assoc_search_v5_body<NW, MINW, DBG, PPT, ASKER>(a.P, a.P_dev, a.chain_fail, a.G, a.qpts, a.q_begin, a.q_end, a.tgt_pad, a.tgt_off, a.gate_bits, a.norm_cond,
                                                     a.cluster_w, a.h_safe, a.out, a.want_aux, a.group_perm, a.dbg, a.asker_rows, (int)blockIdx.x);
 }
