@@ -422,7 +422,10 @@ int velo_hint_next_source(velo_ctx* ctx, const velo_scan_ref* next);
  * the batch entries) then enqueues that promotion, the ingest and the index build BEHIND its own launches before its thread waits for them:
  * they run while the host reads the results and hands the pose over, and the next call finds the frame in place.  Until then the context is
  * one frame ahead -- any other job on it returns VELO_ERR_STATE.  A call that had to be repeated host-driven first gets its own pair back
- * (the old target's cloud is kept for that).  Results never change. */
+ * (the old target's cloud is kept for that).  Results never change.  `next` itself is copied; the cloud and the ring table it names must
+ * stay valid and unchanged until the call that brings the frame has returned (they are read during the announcing call's registration and
+ * compared by the next one).  A scan that cannot be promoted or an announcement the loaders would refuse is not loaded ahead: the call that
+ * brings it reports the error, as without the announcement. */
 int velo_hint_next_frame(velo_ctx* ctx, const velo_scan_ref* next);
 
 /* --- pose helpers (utility.h:67-96; note the reference's swapped names) ---------------- */

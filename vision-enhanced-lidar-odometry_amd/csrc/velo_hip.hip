@@ -3146,6 +3146,12 @@ constexpr int kAssocPadShared = 5632;
 static int preload_next_frame(velo_ctx* c, AdvJob* job) {
     if (!c->nf.hint_valid || c->nf.state == velo_ctx::NextFrame::LOADED || !c->have_source || !c->have_target || !c->src_bbox_valid) return VELO_OK;   // (without the source's box the promotion would wait for the chain)
     if (c->T.use_count() != 1) return VELO_OK;                         // a target other contexts hold cannot be given back after a repeat
+    for (int r = 0; r < c->n_src_rings; r++) if (c->h_src_off[(size_t)r + 1] <= c->h_src_off[(size_t)r]) return VELO_OK;   // (a scan that cannot be promoted: the NEXT call says so, not this one)
+    {
+        const velo_scan_ref& h = c->nf.hint;                           // (an announcement the loaders would refuse is left to the call that brings it, too)
+        if (h.n_rings <= 0 || !h.ring_offsets || h.ring_offsets[0] != 0) return VELO_OK;
+        for (int r = 0; r < h.n_rings; r++) if (h.ring_offsets[r + 1] < h.ring_offsets[r]) return VELO_OK;
+    }
     c->nf.hint_valid = false;
     c->nf.ref = c->nf.hint;
     const velo_scan_ref& r = c->nf.ref;
