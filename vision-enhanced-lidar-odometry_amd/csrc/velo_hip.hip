@@ -327,6 +327,7 @@ struct velo_ctx {
         DevBuf<unsigned> keys; int parity = 0;   // group-batched loads (AdvJob): the source's bounding-box keys in two slots, used alternately
         hipEvent_t call_done = nullptr;     // behind the call's last read-back copy: what the calling thread waits for when more has been enqueued behind it
     } nf;
+    double last_chain_us = 0.0;          // the previous chained lock-step call this context led: enqueue -> results in (sizes the stagger of the groups' starts)
     AdvJob* adv = nullptr;               // set while a group's loads are being COLLECTED (preload_group): target_ingest / build_grid / source_ingest fill it instead of launching
     DevBuf<int> seg_flag, seg_excl, seg_ring, seg_off;   // device-side ring segmentation (velo_set_scan_velodyne)
 
@@ -3242,7 +3243,14 @@ static int undo_preload(velo_ctx* c) {
     return VELO_OK;
 }
 
-static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo_summary* summaries, bool shared_chip = false) {
+// stagger_slot: this group's place among the lock-step groups of the call (0 = the first).  Groups that start a step together stay
+// together: their association launches overlap (each at a fraction of the chip), then all of them are in their LM phases at once and no
+// association kernel runs at all -- a quarter of the wall time with four groups.  Group k therefore enqueues its chain k x (its own
+// previous chain's duration / kStaggerDiv) late: the phases stay apart for the whole step, and the chains shorten by more than the last
+// group's delay (C2: +2-3 %; free-running groups, which drift apart by themselves, +6 %).  Results do not depend on it.
+constexpr double kStaggerDiv = 27.0;             // a C2 chain of 1.9 ms: 70 us per slot (measured best among 40 / 70 / 100 / 130)
+constexpr int kStaggerMinQueries = 16384;        // 256 association workgroups per context: a launch that takes the whole chip
+static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo_summary* summaries, bool shared_chip = false, int stagger_slot = 0) {
     velo_ctx* c0 = ctxs[0];
     HIP_TRY(hipSetDevice(c0->device));
     for (int i = 0; i < n; i++) {
@@ -3330,6 +3338,20 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
         }
     }
     if (chain) {
+        const auto t_chain0 = std::chrono::steady_clock::now();
+        {
+            static const double div_env = dev_env("VELO_STAGGER_DIV") ? atof(dev_env("VELO_STAGGER_DIV")) : -1.0;      // A/B (diagnostics build): 0 = no stagger
+            const double div = div_env >= 0.0 ? div_env : kStaggerDiv;
+            int nq_min = 1 << 30;
+            for (int i = 0; i < n; i++) nq_min = std::min(nq_min, ctxs[i]->n_q);
+            // (only where a group's association launch fills the chip by itself: the sparse rounds of the reference's own constants -- 640 queries,
+            //  a launch of 40 us on a tenth of the chip -- have nothing to keep apart, and a late start is all they get: C1 12.8 k against 13.2 k)
+            if (shared_chip && stagger_slot > 0 && div > 0.0 && c0->last_chain_us > 0.0 && nq_min >= kStaggerMinQueries) {
+                const auto until = t_chain0 + std::chrono::nanoseconds((long long)(1e3 * std::min(c0->last_chain_us / div, 400.0) * stagger_slot));
+                while (std::chrono::steady_clock::now() < until) { }
+            }
+        }
+        const auto t_chain1 = std::chrono::steady_clock::now();
         const bool fresh = c0->batch_pose.cap < (size_t)n;
         VELO_TRY(c0->batch_pose.reserve((size_t)n)); VELO_TRY(c0->batch_logs.reserve((size_t)n * VELO_MAX_SOLVES)); VELO_TRY(c0->batch_fail.reserve((size_t)n));
         if (fresh) { HIP_TRY(hipMemsetAsync(c0->batch_fail.p, 0, sizeof(int) * (size_t)n, bs)); HIP_TRY(hipMemsetAsync(c0->batch_pose.p, 0, sizeof(PoseRecord) * (size_t)n, bs)); }
@@ -3553,6 +3575,7 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
         if (ahead_trace && hinted) HIP_TRY(hipEventRecord(tr1, bs));
         if (preloaded) HIP_TRY(hipEventSynchronize(c0->nf.call_done));   // the results are in; the next frame's loads are still running
         else HIP_TRY(hipStreamSynchronize(bs));
+        c0->last_chain_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_chain1).count();   // (enqueue -> results in)
         if (turn_trace) { t_results = std::chrono::steady_clock::now(); t_results_valid = true; }
         if (ahead_trace && hinted) {
             const auto th = std::chrono::steady_clock::now();
@@ -3876,7 +3899,7 @@ static int batch_impl(velo_ctx** ctxs, int32_t n, const velo_scan_ref* targets, 
                 if (st != VELO_OK) { gst[(size_t)gi] = st; gerr[(size_t)gi] = g_err; return; }
             }
             const auto t2 = std::chrono::steady_clock::now();
-            gst[(size_t)gi] = f2f_batch_lockstep(ctxs + b, e - b, x + 6 * (size_t)b, T ? T + 16 * (size_t)b : nullptr, summaries ? summaries + b : nullptr, true);
+            gst[(size_t)gi] = f2f_batch_lockstep(ctxs + b, e - b, x + 6 * (size_t)b, T ? T + 16 * (size_t)b : nullptr, summaries ? summaries + b : nullptr, true, gi);
             if (gst[(size_t)gi] != VELO_OK) gerr[(size_t)gi] = g_err;
             if (batch_trace) {
                 const auto t3 = std::chrono::steady_clock::now();
@@ -3969,7 +3992,19 @@ static int sequences_impl(velo_ctx** ctxs, int32_t n, int32_t n_frames, const ve
             for (int i = 0; i < m; i++) for (int k = 0; k < 6; k++) xl[(size_t)6 * i + k] = x_guess[(size_t)6 * (b + i) + k];
             int st = VELO_OK;
             // the next frame of the group's drives: uploaded under this frame's chain, promoted / ingested / indexed behind it (velo_hint_next_frame)
-            if (f + 1 < n_frames || (flags & VELO_SEQ_ANNOUNCE)) for (int i = b; i < e; i++) (void)velo_hint_next_frame(ctxs[i], frames + (size_t)(f + 1) * n + i);
+            // A/B (diagnostics build, VELO_LATE_PRELOAD=1): every other group loads its frame at the START of its step (the same three launches)
+            // instead of behind the previous step's chain -- its chains run half a round out of phase with the other groups' at no extra work
+            static const int late_env = dev_env("VELO_LATE_PRELOAD") ? atoi(dev_env("VELO_LATE_PRELOAD")) : 0;
+            const bool late_group = late_env != 0 && lockstep_frames && (gi & 1) && m > 1;
+            if (!late_group && (f + 1 < n_frames || (flags & VELO_SEQ_ANNOUNCE))) for (int i = b; i < e; i++) (void)velo_hint_next_frame(ctxs[i], frames + (size_t)(f + 1) * n + i);
+            if (late_group) {
+                std::vector<hipStream_t> own((size_t)m);
+                for (int i = 0; i < m; i++) { own[(size_t)i] = ctxs[b + i]->stream; ctxs[b + i]->stream = ctxs[b]->stream; ctxs[b + i]->nf.hint = fr[b + i]; ctxs[b + i]->nf.hint_valid = true; }
+                bool any = false;
+                st = preload_group(ctxs + b, m, ctxs[b]->stream, &any);
+                for (int i = 0; i < m; i++) { ctxs[b + i]->stream = own[(size_t)i]; ctxs[b + i]->nf.hint_valid = false; }
+            }
+            if (st != VELO_OK) { bail(st); if (!lockstep_frames) return; continue; }
             if (m == 1) {                                            // a drive of its own: the single-pair path
                 st = load_job_visual(ctxs[b], V, b);
                 if (st == VELO_OK) st = load_job(ctxs[b], &promote, fr + b);
@@ -3982,7 +4017,16 @@ static int sequences_impl(velo_ctx** ctxs, int32_t n, int32_t n_frames, const ve
                 for (int i = b; i < e && st == VELO_OK; i++) st = load_job_end(ctxs[i], true, true);
                 const auto t1 = now();
                 t_load += us(t0, t1);
-                if (st == VELO_OK) st = f2f_batch_lockstep(ctxs + b, m, xl.data(), Tl.data(), Sf, G > 1);
+                {   // A/B (diagnostics build): every other group starts its chain late -- do the groups' association phases stay apart?
+                    static const int stagger_us = dev_env("VELO_GROUP_STAGGER_US") ? atoi(dev_env("VELO_GROUP_STAGGER_US")) : 0;
+                    static const int stagger_mode = dev_env("VELO_GROUP_STAGGER_MODE") ? atoi(dev_env("VELO_GROUP_STAGGER_MODE")) : 0;   // 0: odd groups; 1: the upper half; 2: gi * us
+                    const int mult = stagger_mode == 2 ? gi : (stagger_mode == 1 ? (gi >= G / 2 ? 1 : 0) : (gi & 1));
+                    if (stagger_us > 0 && mult > 0 && (lockstep_frames || f == 0)) {   // (free-running groups: once, at the first frame)
+                        const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds((long long)stagger_us * mult);
+                        while (std::chrono::steady_clock::now() < until) { }
+                    }
+                }
+                if (st == VELO_OK) st = f2f_batch_lockstep(ctxs + b, m, xl.data(), Tl.data(), Sf, G > 1, lockstep_frames ? gi : 0);
                 t_reg += us(t1, now());
             }
             if (st != VELO_OK) { bail(st); if (!lockstep_frames) return; continue; }
