@@ -867,7 +867,7 @@ def main():
                     a_cp.same_pair = True
                     cp = run_leg(rig, a_cp, "c2", "replicas", a.batch, 10, 3, drives=None)
                 else:
-                    cp = child_leg("c2", 10, 3, ("--same-pair",))
+                    cp = child_leg("c2", 10, 5, ("--same-pair",))
                 legs["canonical_pair"] = {k: cp[k] for k in ("workload", "pairs_per_s", "ms_per_step", "lm_evaluations_per_pair", "algorithmic_bytes_per_pair",
                                                              "achieved_hbm_GBs_whole_path", "chain", "single_pair", "solution_x", "error") if k in cp}
                 legs["canonical_pair"]["initial_guess"] = "start-up guess {0,0,0,0,0,1} (main.cpp:170); true motion: yaw 0.02 rad, t = (1.00, 0.02, 0.01) m (SURVEY 8d)"
