@@ -872,9 +872,16 @@ EvalArgs eval_args(velo_ctx* c, const double* x_override) {
 EvalPlan eval_plan(const EvalArgs& A) {
     EvalPlan E;
     const int nq = A.q_end - A.q_begin;
-    static const int per_thread = dev_env("VELO_EVAL_PER_THREAD") ? std::max(atoi(dev_env("VELO_EVAL_PER_THREAD")), 1) : kEvalPerThread;
-    E.nb_icp = nq > 0 ? std::min(std::max(cdiv(nq, kEvalThreads * per_thread), 1), kMaxEvalBlocks) : 0;
+    static const int per_thread_env = dev_env("VELO_EVAL_PER_THREAD") ? std::max(atoi(dev_env("VELO_EVAL_PER_THREAD")), 1) : 0;
     E.nb_vis = A.n_matches > 0 ? std::min(std::max(cdiv(3 * A.n_matches, kEvalThreads), 1), kMaxVisBlocks) : 0;
+    // With visual blocks the sweep's workgroups of a lock-step group of two (2 x (118 + 24) at C3) no longer fit one per CU beside the
+    // association workgroups: the launch gets a second wave of workgroups.  The point-to-plane rows then go five (six ...) to a thread until a
+    // context's workgroups are at most half the CUs again (C3: 94 + 24; 3,721 -> 3,810 pairs/s, one pair 0.991 -> 0.967 ms).  The partition
+    // is a function of the problem's size alone, so every path sums the same rows in the same order.
+    int per_thread = per_thread_env > 0 ? per_thread_env : kEvalPerThread;
+    if (per_thread_env == 0 && E.nb_vis > 0 && nq > 0)
+        while (per_thread < 8 && cdiv(nq, kEvalThreads * per_thread) + E.nb_vis > 128) per_thread++;
+    E.nb_icp = nq > 0 ? std::min(std::max(cdiv(nq, kEvalThreads * per_thread), 1), kMaxEvalBlocks) : 0;
     return E;
 }
 
