@@ -549,7 +549,13 @@ int prefetch_issue(velo_ctx* c) {
     VELO_TRY(c->pf.land[nb].reserve(c->pf.bytes));
     // (measured: staging the cloud through page-locked memory of the library's own -- memcpy + DMA -- is SLOWER than handing the runtime the
     //  pageable pointer: 2,560-2,700 vs 3,206 pairs/s with 8 drives in flight, 3,426 with resident frames)
+    static const bool slow_trace = dev_env("VELO_SLOW_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpyAsync(c->pf.land[nb].p, c->pf.host, c->pf.bytes, hipMemcpyHostToDevice, c->pf.stream));
+    if (slow_trace) {
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (us > 1000.0) fprintf(stderr, "[velo slow] prefetch_issue: hipMemcpyAsync of %zu pageable bytes took %.0f us\n", c->pf.bytes, us);
+    }
     HIP_TRY(hipEventRecord(c->pf.ev, c->pf.stream));
     c->pf.buf = nb; c->pf.ready = true; c->pf.hinted = false;
     return VELO_OK;
