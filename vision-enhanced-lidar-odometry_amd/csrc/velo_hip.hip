@@ -312,6 +312,7 @@ struct velo_ctx {
     struct Prefetch {
         const void* host = nullptr; size_t bytes = 0; bool hinted = false, ready = false; int buf = 0;
         DevBuf<char> land[2]; hipStream_t stream = nullptr; hipEvent_t ev = nullptr;
+        char* pin[2] = {nullptr, nullptr}; size_t pin_cap[2] = {0, 0}; bool in_pin = false;   // the announced cloud in page-locked memory of the library's own (see prefetch_issue)
     } pf;
     // velo_hint_next_frame: the NEXT frame of a drive -- promote the scan held as source, load the announced scan as the new source, build the
     // index -- is enqueued BEHIND the current registration's chain of launches, before the calling thread waits for it: the loads of frame
@@ -543,12 +544,27 @@ int upload_cloud(velo_ctx* c, const float* xyz, int64_t stride, int n, int on_de
 // the hinted upload (velo_hint_next_source), issued where the calling thread is about to wait for this frame's chain anyway
 int prefetch_issue(velo_ctx* c) {
     if (!c->pf.hinted || c->pf.ready || !c->pf.host || c->pf.bytes == 0) return VELO_OK;
+    const int nb = c->pf.buf ^ 1;
+    // A/B (diagnostics build, VELO_PF_PINNED=1): the announced cloud copied into page-locked memory of the library's own by the thread that is
+    // about to wait for the running chain, and read from there by the launch that ingests it -- no copy of the runtime's at all.  Steady
+    // (3,550-3,570 pairs/s in ten runs of ten) but slower than handing the runtime the caller's pageable pointer (4,050-4,090): the ingest's
+    // 12-byte reads and the query blocks' gathers cross the bus badly.  The runtime's pageable path, the default, blocks its caller for 5-12 ms
+    // once in ~ 200 copies with four busy queues: one run of the host_inputs leg in four reads 10-25 % low.
+    static const bool pageable = dev_env("VELO_PF_PINNED") == nullptr;
+    if (!pageable) {
+        if (c->pf.pin_cap[nb] < c->pf.bytes) {
+            if (c->pf.pin[nb]) { (void)hipHostFree(c->pf.pin[nb]); c->pf.pin[nb] = nullptr; c->pf.pin_cap[nb] = 0; }
+            const size_t want = c->pf.bytes + c->pf.bytes / 8 + 4096;
+            HIP_TRY(hipHostMalloc((void**)&c->pf.pin[nb], want, hipHostMallocDefault));
+            c->pf.pin_cap[nb] = want;
+        }
+        std::memcpy(c->pf.pin[nb], c->pf.host, c->pf.bytes);
+        c->pf.buf = nb; c->pf.ready = true; c->pf.hinted = false; c->pf.in_pin = true;
+        return VELO_OK;
+    }
     if (!c->pf.stream) HIP_TRY(hipStreamCreateWithFlags(&c->pf.stream, hipStreamNonBlocking));
     if (!c->pf.ev) HIP_TRY(hipEventCreateWithFlags(&c->pf.ev, hipEventDisableTiming));
-    const int nb = c->pf.buf ^ 1;
     VELO_TRY(c->pf.land[nb].reserve(c->pf.bytes));
-    // (measured: staging the cloud through page-locked memory of the library's own -- memcpy + DMA -- is SLOWER than handing the runtime the
-    //  pageable pointer: 2,560-2,700 vs 3,206 pairs/s with 8 drives in flight, 3,426 with resident frames)
     static const bool slow_trace = dev_env("VELO_SLOW_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpyAsync(c->pf.land[nb].p, c->pf.host, c->pf.bytes, hipMemcpyHostToDevice, c->pf.stream));
@@ -557,7 +573,7 @@ int prefetch_issue(velo_ctx* c) {
         if (us > 1000.0) fprintf(stderr, "[velo slow] prefetch_issue: hipMemcpyAsync of %zu pageable bytes took %.0f us\n", c->pf.bytes, us);
     }
     HIP_TRY(hipEventRecord(c->pf.ev, c->pf.stream));
-    c->pf.buf = nb; c->pf.ready = true; c->pf.hinted = false;
+    c->pf.buf = nb; c->pf.ready = true; c->pf.hinted = false; c->pf.in_pin = false;
     return VELO_OK;
 }
 
@@ -1870,6 +1886,7 @@ int velo_destroy(velo_ctx* c) {
     c->ask_count.release(); c->ask_list.release(); c->ask_keys.release(); c->ask_rings.release();
     c->solve_ctl.release(); c->ag_ctl.release();
     c->pf.land[0].release(); c->pf.land[1].release(); c->nf.undo_cloud.release();
+    for (int k = 0; k < 2; k++) if (c->pf.pin[k]) { (void)hipHostFree(c->pf.pin[k]); c->pf.pin[k] = nullptr; c->pf.pin_cap[k] = 0; }
     if (c->nf.call_done) { (void)hipEventDestroy(c->nf.call_done); c->nf.call_done = nullptr; }
     if (c->pf.stream) { (void)hipStreamSynchronize(c->pf.stream); (void)hipStreamDestroy(c->pf.stream); c->pf.stream = nullptr; }
     if (c->pf.ev) { (void)hipEventDestroy(c->pf.ev); c->pf.ev = nullptr; }
@@ -1970,8 +1987,8 @@ static int set_source_begin(velo_ctx* c, const float* xyz, int64_t stride, const
         const size_t bytes = (size_t)(n - 1) * (size_t)stride + 12;
         if (c->pf.ready && c->pf.host == (const void*)xyz && c->pf.bytes == bytes) {
             // this cloud was announced one call ago (velo_hint_next_source) and is on the device already: the ingest waits for its copy's event
-            HIP_TRY(hipStreamWaitEvent(c->stream, c->pf.ev, 0));
-            dsrc = c->pf.land[c->pf.buf].p;
+            if (c->pf.in_pin) dsrc = c->pf.pin[c->pf.buf];                // (page-locked host memory: the ingest launch reads it over the bus)
+            else { HIP_TRY(hipStreamWaitEvent(c->stream, c->pf.ev, 0)); dsrc = c->pf.land[c->pf.buf].p; }
         } else {
             VELO_TRY(c->staging.reserve(bytes));
             HIP_TRY(hipMemcpyAsync(c->staging.p, xyz, bytes, hipMemcpyHostToDevice, c->stream));
