@@ -558,7 +558,11 @@ int prefetch_issue(velo_ctx* c) {
             HIP_TRY(hipHostMalloc((void**)&c->pf.pin[nb], want, hipHostMallocDefault));
             c->pf.pin_cap[nb] = want;
         }
+        static const bool slow_trace_p = dev_env("VELO_SLOW_TRACE") != nullptr;
+        const auto tm0 = std::chrono::steady_clock::now();
         std::memcpy(c->pf.pin[nb], c->pf.host, c->pf.bytes);
+        if (slow_trace_p) fprintf(stderr, "[velo slow] prefetch_issue: memcpy of %zu bytes into the page-locked buffer %.0f us\n", c->pf.bytes,
+                                  std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tm0).count());
         c->pf.buf = nb; c->pf.ready = true; c->pf.hinted = false; c->pf.in_pin = true;
         return VELO_OK;
     }
