@@ -545,12 +545,14 @@ int upload_cloud(velo_ctx* c, const float* xyz, int64_t stride, int n, int on_de
 int prefetch_issue(velo_ctx* c) {
     if (!c->pf.hinted || c->pf.ready || !c->pf.host || c->pf.bytes == 0) return VELO_OK;
     const int nb = c->pf.buf ^ 1;
-    // A/B (diagnostics build, VELO_PF_PINNED=1): the announced cloud copied into page-locked memory of the library's own by the thread that is
-    // about to wait for the running chain, and read from there by the launch that ingests it -- no copy of the runtime's at all.  Steady
-    // (3,550-3,570 pairs/s in ten runs of ten) but slower than handing the runtime the caller's pageable pointer (4,050-4,090): the ingest's
-    // 12-byte reads and the query blocks' gathers cross the bus badly.  The runtime's pageable path, the default, blocks its caller for 5-12 ms
-    // once in ~ 200 copies with four busy queues: one run of the host_inputs leg in four reads 10-25 % low.
-    static const bool pageable = dev_env("VELO_PF_PINNED") == nullptr;
+    // The announced cloud goes into page-locked memory of the library's own, copied by the thread that is about to wait for the running chain
+    // (65 us per 1.44 MB, hidden there), and the launch that ingests it reads that memory itself, every record once, with 16-byte loads
+    // (advance_ingest_kernel: 2.9 MB for a group of two in ~45 us more, the bus's rate) -- no copy of the runtime's at all: 3,840-3,870 pairs/s
+    // in every run, 0.94 x the resident rate.  Handing the runtime the caller's pageable pointer (its staged path, on a copy stream of our
+    // own: VELO_PF_PAGEABLE=1 in the diagnostics build) gives 4,080-4,110 when nothing goes wrong, but the call blocks its caller for 5-12 ms
+    // once in ~ 200 copies with four busy queues: two runs in five read 3,020-3,050.  The two buffers alternate: the one filled now is read
+    // by the ingest enqueued right behind this call's chain, the other one by the ingest of one step ago, which has long run.
+    static const bool pageable = dev_env("VELO_PF_PAGEABLE") != nullptr;
     if (!pageable) {
         if (c->pf.pin_cap[nb] < c->pf.bytes) {
             if (c->pf.pin[nb]) { (void)hipHostFree(c->pf.pin[nb]); c->pf.pin[nb] = nullptr; c->pf.pin_cap[nb] = 0; }
@@ -1586,7 +1588,7 @@ int source_ingest(velo_ctx* c) {
         J.qpts = own_list ? c->qpts_buf.p : (float4*)nullptr;
         J.keys = c->nf.keys.p + 8 * c->nf.parity; J.keys_next = c->nf.keys.p + 8 * (c->nf.parity ^ 1);
         c->nf.parity ^= 1;
-        J.n_s = c->n_src; J.n_rings_s = R; J.nb_pack = cdiv(c->n_src, 256); J.nb_q = c->n_q > 0 ? cdiv(c->n_q, 256) : 0;
+        J.n_s = c->n_src; J.n_rings_s = R; J.nb_pack = cdiv(c->n_src, 256); J.nb_q = 0;   // (the pack workgroups emit the queries themselves)
         J.skip = skip; J.nq = c->n_q; J.patch = patch ? 1 : 0; J.patch_rings = c->patch_rings; J.patch_len = c->patch_len;
         std::memcpy(J.off_s, c->h_src_off.data(), sizeof(int) * ((size_t)R + 1));
         if (c->warm_start && c->n_q > 0) {                                // the seed arrays of the new queries: "no previous winner", written by the query blocks

@@ -710,7 +710,7 @@ advance_ingest_kernel(AdvBatch B) {
         return;
     }
     bx -= J.nb_t;
-    if (bx >= J.nb_pack + J.nb_q) return;
+    if (bx >= J.nb_pack) return;
     // ---- source side: source_ingest_kernel, ring and query tables from the arguments ----
     const int R = J.n_rings_s;
     if (tid <= R) s_off[tid] = J.off_s[tid];
@@ -726,44 +726,65 @@ advance_ingest_kernel(AdvBatch B) {
         if (tid <= R) { J.src_off_dev[tid] = s_off[tid]; J.src_off_dev[R + 1 + tid] = s_qoff[tid]; }
         if (tid < 6) J.keys_next[tid] = tid < 3 ? 0xffffffffu : 0u;     // the keys of the frame after this one (the two slots alternate)
     }
-    if (bx < J.nb_pack) {
-        const int i = bx * 256 + tid;
-        float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-        if (i < J.n_s) {
-            const float* p = (const float*)(J.raw + (int64_t)i * J.stride);
-            const float4 v = make_float4(p[0], p[1], p[2], 0.0f);
-            J.src[i] = v;
-            if (isfinite(v.x) && isfinite(v.y) && isfinite(v.z)) { mn[0] = mx[0] = v.x; mn[1] = mx[1] = v.y; mn[2] = mx[2] = v.z; }
+    if (bx >= J.nb_pack) return;
+    // ONE pass over the caller's records: the workgroup's 256 records come in with 16-byte loads where the layout allows (stride 12: 3 KB
+    // of consecutive bytes through LDS; stride 16: one load per record) -- the records may live in page-locked HOST memory, where every
+    // load instruction is a trip over the bus -- and the thread that packs point i also emits its query: ring r, every skip-th point
+    // (velo.h:807) -> position in the (patch-ordered) list, the same map source_ingest_kernel's query blocks walk from the other side.
+    __shared__ float s_raw[256 * 3];
+    const int i = bx * 256 + tid;
+    const bool have = i < J.n_s;
+    const bool aligned = (reinterpret_cast<unsigned long long>(J.raw) & 15ull) == 0ull;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (J.stride == 12 && aligned) {
+        const char* base = J.raw + (long long)bx * 3072;
+        const int nbytes = min(3072, (J.n_s - bx * 256) * 12);
+        if (tid < 192) {
+            if (tid * 16 + 16 <= nbytes) *reinterpret_cast<uint4*>(&s_raw[tid * 4]) = *reinterpret_cast<const uint4*>(base + tid * 16);
+            else for (int f = 0; f < 4; f++) if (tid * 16 + 4 * f + 4 <= nbytes) s_raw[tid * 4 + f] = *reinterpret_cast<const float*>(base + tid * 16 + 4 * f);
         }
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
-        }
-        const int wid = tid >> 6;
-        if (lane == 0) { for (int k = 0; k < 3; k++) { red[wid][k] = mn[k]; red[wid][3 + k] = mx[k]; } }
         __syncthreads();
-        if (tid < 6) {
-            const int k = tid;
-            float v = red[0][k];
-            for (int w = 1; w < 4; w++) v = (k < 3) ? fminf(v, red[w][k]) : fmaxf(v, red[w][k]);
-            const unsigned key = f2key(v), cur = J.keys[k];
-            if (k < 3) { if (v < 3.0e38f && key < cur) atomicMin(&J.keys[k], key); } else { if (v > -3.0e38f && key > cur) atomicMax(&J.keys[k], key); }
+        if (have) v = make_float4(s_raw[3 * tid], s_raw[3 * tid + 1], s_raw[3 * tid + 2], 0.0f);
+    } else if (have) {
+        const char* q = J.raw + (long long)i * J.stride;
+        if (J.stride == 16 && aligned) { const float4 w = *reinterpret_cast<const float4*>(q); v = make_float4(w.x, w.y, w.z, 0.0f); }
+        else { const float* p = reinterpret_cast<const float*>(q); v = make_float4(p[0], p[1], p[2], 0.0f); }
+    }
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    if (have) {
+        J.src[i] = v;
+        if (isfinite(v.x) && isfinite(v.y) && isfinite(v.z)) { mn[0] = mx[0] = v.x; mn[1] = mx[1] = v.y; mn[2] = mx[2] = v.z; }
+        if (J.nq > 0) {
+            int lo = 0, hi = R;                                            // ring of point i
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_off[mid] <= i) lo = mid; else hi = mid; }
+            const int j = i - s_off[lo];
+            if (j % J.skip == 0) {
+                const int k = j / J.skip;
+                const int pos = J.patch ? patch_position(s_qoff, R, lo, k, J.patch_rings, J.patch_len) : s_qoff[lo] + k;
+                J.q_src[pos] = i;
+                if (J.qpts) J.qpts[pos] = v;
+                if (J.seed_fill) {                                     // (what attach_seeds' fill of 0xff bytes writes: no previous winner)
+                    const float4 none = make_float4(__int_as_float(-1), __int_as_float(-1), __int_as_float(-1), __int_as_float(-1));
+                    J.seed_fill[pos] = none; J.seed_fill[J.nq + pos] = none;
+                }
+            }
         }
-        return;
     }
-    const int i = (bx - J.nb_pack) * 256 + tid;
-    if (i >= J.nq) return;
-    if (J.seed_fill) {                                                 // (what attach_seeds' fill of 0xff bytes writes: no previous winner)
-        const float4 none = make_float4(__int_as_float(-1), __int_as_float(-1), __int_as_float(-1), __int_as_float(-1));
-        J.seed_fill[i] = none; J.seed_fill[J.nq + i] = none;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
     }
-    int lo = 0, hi = R;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_qoff[mid] <= i) lo = mid; else hi = mid; }
-    const int k = i - s_qoff[lo];
-    const int pos = J.patch ? patch_position(s_qoff, R, lo, k, J.patch_rings, J.patch_len) : i, si = s_off[lo] + k * J.skip;
-    J.q_src[pos] = si;
-    if (J.qpts) { const float* p = (const float*)(J.raw + (int64_t)si * J.stride); J.qpts[pos] = make_float4(p[0], p[1], p[2], 0.0f); }
+    const int wid = tid >> 6;
+    if (lane == 0) { for (int k = 0; k < 3; k++) { red[wid][k] = mn[k]; red[wid][3 + k] = mx[k]; } }
+    __syncthreads();
+    if (tid < 6) {
+        const int k = tid;
+        float vv = red[0][k];
+        for (int w = 1; w < 4; w++) vv = (k < 3) ? fminf(vv, red[w][k]) : fmaxf(vv, red[w][k]);
+        const unsigned key = f2key(vv), cur = J.keys[k];
+        if (k < 3) { if (vv < 3.0e38f && key < cur) atomicMin(&J.keys[k], key); } else { if (vv > -3.0e38f && key > cur) atomicMax(&J.keys[k], key); }
+    }
 }
 template <int kLbItems>
 __global__ void __launch_bounds__(kScanThreads)
