@@ -60,11 +60,27 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+#ifdef VELO_DIAGNOSTICS
+// dev aid (VELO_API_TRACE=<us>, diagnostics build): every runtime call that keeps its caller longer than that is reported with its text --
+// how the copies that block for milliseconds were found.  Synchronisations are expected to wait and are not reported.
+static const double g_api_trace_us = getenv("VELO_API_TRACE") ? atof(getenv("VELO_API_TRACE")) : 0.0;
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        const auto t__ = g_api_trace_us > 0.0 ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point(); \
+        hipError_t e__ = (expr);                                                                        \
+        if (g_api_trace_us > 0.0) {                                                                     \
+            const double us__ = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t__).count(); \
+            if (us__ > g_api_trace_us && !strstr(#expr, "Synchronize")) fprintf(stderr, "[velo api] %.0f us in %s (line %d)\n", us__, #expr, __LINE__); \
+        }                                                                                               \
+        if (e__ != hipSuccess) return fail(VELO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+    } while (0)
+#else
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e__ = (expr);                                                                        \
         if (e__ != hipSuccess) return fail(VELO_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
     } while (0)
+#endif
 #define NCCL_TRY(expr)                                                                                  \
     do {                                                                                                \
         ncclResult_t r__ = (expr);                                                                      \
