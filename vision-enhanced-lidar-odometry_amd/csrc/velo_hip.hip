@@ -1603,6 +1603,7 @@ int source_ingest(velo_ctx* c) {
         J.raw = c->src_raw.dsrc; J.stride = c->src_raw.stride; J.src = c->src.p; J.src_off_dev = c->src_off.p; J.q_src = c->q_src.p;
         J.qpts = own_list ? c->qpts_buf.p : (float4*)nullptr;
         J.keys = c->nf.keys.p + 8 * c->nf.parity; J.keys_next = c->nf.keys.p + 8 * (c->nf.parity ^ 1);
+        J.h_keys = reinterpret_cast<unsigned*>(c->h_int + 16);
         c->nf.parity ^= 1;
         J.n_s = c->n_src; J.n_rings_s = R; J.nb_pack = cdiv(c->n_src, 256); J.nb_q = 0;   // (the pack workgroups emit the queries themselves)
         J.skip = skip; J.nq = c->n_q; J.patch = patch ? 1 : 0; J.patch_rings = c->patch_rings; J.patch_len = c->patch_len;
@@ -3257,7 +3258,7 @@ static int advance_launch(velo_ctx** ctxs, int n, const AdvJob* jobs, const std:
         HIP_TRY(hipGetLastError());
         for (int k = 0; k < m; k++) {                                  // the boxes ride back on the stream (a LATER call, the next promotion, reads them)
             velo_ctx* c = owner[k];
-            HIP_TRY(hipMemcpyAsync(c->h_int + 16, B.job[k].keys, sizeof(unsigned) * 6, hipMemcpyDeviceToHost, bs));
+            // (advance_scatter_kernel wrote the keys into the page-locked words itself)
             if (!c->src_bbox_ev) HIP_TRY(hipEventCreateWithFlags(&c->src_bbox_ev, hipEventDisableTiming));
             HIP_TRY(hipEventRecord(c->src_bbox_ev, bs));
         }

@@ -667,6 +667,7 @@ struct AdvJob {
     int n_t, n_rings_t, first_ring, first_point, lb_words, nb_t, nc, n_tiles, nb_sc;
     // source side
     const char* raw; long long stride; float4* src; int* src_off_dev; int* q_src; float4* qpts; unsigned* keys; unsigned* keys_next;
+    unsigned* h_keys;                                                   // page-locked host memory: the source's box keys ride back with the last launch
     float4* seed_fill;                                                  // both winners' seed arrays (2 nq entries) set to "none" here, or null
     int n_s, n_rings_s, nb_pack, nb_q, skip, nq, patch, patch_rings, patch_len;
     int off_t[kAdvRings + 1], off_s[kAdvRings + 1];
@@ -797,6 +798,9 @@ __global__ void __launch_bounds__(256)
 advance_scatter_kernel(AdvBatch B) {
     const AdvJob& J = B.job[blockIdx.y];
     if ((int)blockIdx.x >= J.nb_sc) return;
+    // (the source's bounding box, complete since the ingest launch ended, written where the host reads it before the scan's promotion one
+    //  step later: two copies per group and step less)
+    if (blockIdx.x == 0 && threadIdx.x < 6 && J.h_keys) J.h_keys[threadIdx.x] = J.keys[threadIdx.x];
     grid_scatter_body(J.tgt, J.cell_of, J.ring_of, J.n_t, J.table + 1, J.scan_total, J.first_point, J.sorted, J.sring, (int)blockIdx.x);
 }
 
