@@ -3400,7 +3400,13 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
             // (only where a group's association launch fills the chip by itself: the sparse rounds of the reference's own constants -- 640 queries,
             //  a launch of 40 us on a tenth of the chip -- have nothing to keep apart, and a late start is all they get: C1 12.8 k against 13.2 k)
             if (shared_chip && stagger_slot > 0 && div > 0.0 && c0->last_chain_us > 0.0 && nq_min >= kStaggerMinQueries) {
-                const auto until = t_chain0 + std::chrono::nanoseconds((long long)(1e3 * std::min(c0->last_chain_us / div, 400.0) * stagger_slot));
+                double mult = (double)stagger_slot;
+                if (const char* pat = dev_env("VELO_STAGGER_PATTERN")) {     // A/B (diagnostics build): the slots' multipliers, e.g. "0,1,1,2"
+                    double m[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+                    std::sscanf(pat, "%lf,%lf,%lf,%lf", &m[0], &m[1], &m[2], &m[3]);
+                    mult = m[std::min(stagger_slot, 7)];
+                }
+                const auto until = t_chain0 + std::chrono::nanoseconds((long long)(1e3 * std::min(c0->last_chain_us / div, 400.0) * mult));
                 while (std::chrono::steady_clock::now() < until) { }
             }
         }
