@@ -3438,7 +3438,21 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
         const bool iter_mode = c0->lm_iter && n <= 4 && !any_matches && c0->lm_fused && !c0->lm_persist;
         int iter_launches = 0;                                       // iter_mode: parity of every context's state / partial-row double buffer
         for (int iter = 1; iter <= P.f2f_iterations; iter++) {
-            for (int i = 0; i < n && any_matches; i++) {             // residual-type choice + outlier gate of this iteration (velo.h:622-792), on the device
+            if (any_matches && n <= kGateJobs) {                     // residual-type choice + outlier gate of this iteration (velo.h:622-792), on the device:
+                GateBatch Gb;                                        // the group's contexts in ONE launch (the contexts share their parameters: batch_can_lockstep)
+                std::memset(&Gb, 0, sizeof(Gb));
+                int k = 0, gx = 0;
+                for (int i = 0; i < n; i++) {
+                    velo_ctx* c = ctxs[i];
+                    if (c->n_matches <= 0) continue;
+                    Gb.x[k] = iter == 1 ? d_x0 + 8 * (size_t)i : c->state.p->x; Gb.m[k] = c->vm.p; Gb.flags[k] = c->vflags.p;
+                    Gb.counts[k] = c->vis_counts.p + 2 * (iter - 1); Gb.n[k] = c->n_matches;
+                    gx = std::max(gx, cdiv(c->n_matches, 128)); k++;
+                }
+                Gb.V = visual_params(c0->P); Gb.iter = iter;
+                if (k > 0) hipLaunchKernelGGL(visual_gate_batch_kernel, dim3(gx, k), dim3(128), 0, bs, Gb);
+            } else
+            for (int i = 0; i < n && any_matches; i++) {
                 velo_ctx* c = ctxs[i];
                 if (c->n_matches <= 0) continue;
                 hipLaunchKernelGGL(visual_gate_kernel, dim3(cdiv(c->n_matches, 128)), dim3(128), 0, bs, (const double*)(iter == 1 ? d_x0 + 8 * (size_t)i : c->state.p->x),

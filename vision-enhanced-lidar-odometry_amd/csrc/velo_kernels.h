@@ -2805,9 +2805,8 @@ __device__ __forceinline__ int visual_block_eval(const PoseEval& P, const Visual
 
 // flags[3*m + slot]: 0 = no block, 1 + residual_type = block present
 // counts (chain mode, may be null): [0] += blocks, [1] += residuals selected here -- the host reads them once, at the end of the call
-__global__ void visual_gate_kernel(const double* __restrict__ xdev, VisualParams V, const VisualMatch* __restrict__ matches, int n, int iter,
-                                   unsigned char* __restrict__ flags, int* __restrict__ counts) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void visual_gate_body(const double* __restrict__ xdev, const VisualParams& V, const VisualMatch* __restrict__ matches, int n, int iter,
+                                                 unsigned char* __restrict__ flags, int* __restrict__ counts, const int i) {
     if (i >= n) return;
     double x[6];
 #pragma unroll
@@ -2845,6 +2844,20 @@ __global__ void visual_gate_kernel(const double* __restrict__ xdev, VisualParams
         const int nr = (f0 ? (f0 - 1 == VELO_RESIDUAL_3D3D ? 3 : 1) : 0) + (f1 ? 2 : 0) + (f2 ? 2 : 0);     // f0: 3D3D (3 rows) or 2D2D (1 row)
         if (nb) { atomicAdd(&counts[0], nb); atomicAdd(&counts[1], nr); }
     }
+}
+__global__ void visual_gate_kernel(const double* __restrict__ xdev, VisualParams V, const VisualMatch* __restrict__ matches, int n, int iter,
+                                   unsigned char* __restrict__ flags, int* __restrict__ counts) {
+    visual_gate_body(xdev, V, matches, n, iter, flags, counts, (int)(blockIdx.x * blockDim.x + threadIdx.x));
+}
+// the gates of all contexts of a lock-step group in one launch (a queue operation per context and f2f iteration less)
+constexpr int kGateJobs = 8;
+struct GateBatch {
+    const double* x[kGateJobs]; const VisualMatch* m[kGateJobs]; unsigned char* flags[kGateJobs]; int* counts[kGateJobs]; int n[kGateJobs];
+    VisualParams V; int iter;
+};
+__global__ void __launch_bounds__(128) visual_gate_batch_kernel(GateBatch G) {
+    const int j = blockIdx.y;
+    visual_gate_body(G.x[j], G.V, G.m[j], G.n[j], G.iter, G.flags[j], G.counts[j], (int)(blockIdx.x * 128 + threadIdx.x));
 }
 
 // ---- LM state (row S1) ------------------------------------------------------------------------------------------------------
