@@ -704,12 +704,13 @@ int build_grid(velo_ctx* c, Grid& G, double gate) {
     const bool large_tiles = nc >= kLbLargeFrom;
     const int n_tiles = cdiv(nc, lb_tile(large_tiles ? kLbItemsLarge : kLbItemsSmall));
     VELO_TRY(c->lb_status.reserve((size_t)n_tiles + 1));               // tile status words + the ticket counter behind them
-    HIP_TRY(hipMemsetAsync(G.cell_start.p, 0, sizeof(int) * ((size_t)nc + 4), c->stream));
+    if (!c->adv) HIP_TRY(hipMemsetAsync(G.cell_start.p, 0, sizeof(int) * ((size_t)nc + 4), c->stream));   // (collected loads: the group's clear launch, advance_clear_kernel)
     if (c->lb_zeroed < n_tiles + 1) HIP_TRY(hipMemsetAsync(c->lb_status.p, 0, sizeof(unsigned long long) * ((size_t)n_tiles + 1), c->stream));
     c->lb_zeroed = 0;                                                  // (about to be used)
     if (c->adv) {                                                      // collected: count rides in the group's ingest launch, scan and scatter in the group's
         AdvJob& J = *c->adv;
         J.g = G.d; J.cell_of = c->T->tgt_cell_of.p; J.table = G.table(); J.nc = nc; J.n_tiles = n_tiles;
+        J.clear = G.cell_start.p; J.n_clear = (int)std::min((((size_t)nc + 4 + 3) / 4) * 4, G.cell_start.cap);
         J.lb_status = c->lb_status.p; J.lb_ticket = reinterpret_cast<int*>(c->lb_status.p + n_tiles); J.scan_total = c->scan_total.p;
         J.sorted = G.sorted.p; J.sring = G.sring.p; J.first_point = c->T->tgt_first_point; J.nb_sc = cdiv(std::max(n, kGridPad), 256);
         G.built = true;
@@ -3246,6 +3247,7 @@ static int advance_launch(velo_ctx** ctxs, int n, const AdvJob* jobs, const std:
             by_a += 40ull * (uint64_t)J.n_t + 28ull * (uint64_t)J.n_s + 32ull * (uint64_t)J.nq; by_s += 8ull * (uint64_t)J.nc; by_c += 44ull * (uint64_t)J.n_t;
         }
         if (m == 0) break;
+        hipLaunchKernelGGL(advance_clear_kernel, dim3(256, m), dim3(256), 0, bs, B);
         VELO_LAUNCH_T(c0, "advance_ingest_kernel", by_a, advance_ingest_kernel, dim3(gx_a, m), dim3(256), 0, bs, B);
         for (int large = 0; large < 2; large++) {                      // (a group's tables are of one kind in practice: one launch)
             if (tiles[large] == 0) continue;

@@ -662,7 +662,7 @@ constexpr int kAdvRings = 64, kAdvJobs = 4;
 struct AdvJob {
     // target side
     const float4* tgt; int* tgt_off_dev; int* ring_of; float4* pad; unsigned long long* lb_status; int* cell_of; int* table;
-    float4* sorted; int* sring; int* scan_total; int* lb_ticket;
+    float4* sorted; int* sring; int* scan_total; int* lb_ticket; int* clear; int n_clear;   // clear: the index table's words, zeroed ahead of the counts
     GridDesc g;
     int n_t, n_rings_t, first_ring, first_point, lb_words, nb_t, nc, n_tiles, nb_sc;
     // source side
@@ -674,6 +674,14 @@ struct AdvJob {
 };
 struct AdvBatch { AdvJob job[kAdvJobs]; };
 
+// every context's index table zeroed in one launch (the runtime's fill is a queue operation per table)
+__global__ void __launch_bounds__(256)
+advance_clear_kernel(AdvBatch B) {
+    const AdvJob& J = B.job[blockIdx.y];
+    int4* p = reinterpret_cast<int4*>(J.clear);                        // (hipMalloc'd: 256-byte aligned; n_clear rounded up to whole int4s by the host, inside the allocation)
+    const int n4 = J.n_clear >> 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) p[i] = make_int4(0, 0, 0, 0);
+}
 __global__ void __launch_bounds__(256)
 advance_ingest_kernel(AdvBatch B) {
     const AdvJob& J = B.job[blockIdx.y];
