@@ -125,6 +125,19 @@ def test_frames_loaded_ahead_change_nothing_but_when_the_loads_run(hip_lib, B, w
     assert st0 == st1 == st2 and all(s[0] == n_frames - 1 for s in st1)                 # every pair through one chain of launches, as many repeats
 
 
+def test_frames_of_more_rings_than_the_group_launches_take_are_loaded_ahead_too(hip_lib):
+    """The three launches that load a whole group's next frames carry the ring tables in their arguments: up to 64 rings.  Scans of more rings
+    are loaded ahead through the general loaders, launch by launch -- same registrations."""
+    B, n_frames = 4, 5
+    drives = [synth.drive(n_frames, seed=160 + s, n_beams=72, n_azimuth=120) for s in range(B)]
+    assert len(drives[0]["frames"][0][1]) - 1 > 64
+    plain = _stepwise(drives, None, n_frames, False, ahead=False)
+    one = _stepwise(drives, None, n_frames, False, ahead=True, one_call=True)
+    two = _stepwise(drives, None, n_frames, False, ahead=True, one_call=False)
+    _same_steps(plain, one)
+    _same_steps(plain, two)
+
+
 @pytest.mark.parametrize("B", [4, 1])                                                   # lock-step groups; the single-pair chain
 def test_a_repeated_call_gets_its_pair_back_from_a_frame_loaded_ahead(hip_lib, monkeypatch, B):
     """With no spare launches (VELO_CHAIN_MARGIN=0) calls outrun their chains and are repeated host-driven -- after the next frame was
