@@ -2734,7 +2734,8 @@ static int margin_for(const velo_ctx* c, int k) {
     if (c->chain_margin_fixed || c->eval_hist_n[k] < 4) return c->chain_margin;
     int mn = c->eval_hist[k][0], mx = mn;
     for (int i = 1; i < 4; i++) { mn = std::min(mn, c->eval_hist[k][i]); mx = std::max(mx, c->eval_hist[k][i]); }
-    return std::min(std::max(1 + (mx - mn), 1), 3);
+    static const int base = dev_env("VELO_MARGIN_BASE") ? atoi(dev_env("VELO_MARGIN_BASE")) : 1;      // A/B (diagnostics build)
+    return std::min(std::max(base + (mx - mn), 1), 3);
 }
 static void note_miss(velo_ctx* c) {
     for (int k = 0; k < VELO_MAX_SOLVES; k++) { c->pred_evals[k] += 2; c->eval_hist_n[k] = 0; }    // the host-driven repeat records the real counts
