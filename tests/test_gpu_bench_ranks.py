@@ -27,7 +27,10 @@ def test_two_rank_bench_line_reports_both_sharded_modes(hip_lib):
            "--dist-backend", "gloo", "--force-device", "0", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    text = out.stdout.strip().splitlines()[-1]
+    assert len(text) <= 8192, len(text)                      # the N > 1 line adds `modes`: still small enough for the driver's parser
+    assert [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")] == [text]
+    line = json.loads(text)
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
     for mode in ("sharded", "target_sharded"):
         m = line["modes"][mode]
@@ -55,7 +58,9 @@ def test_bench_starts_its_own_ranks_when_no_launcher_wraps_it(hip_lib):
            "--steps", "4", "--warmup", "1", "--no-cpu-baseline"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    text = out.stdout.strip().splitlines()[-1]
+    assert len(text) <= 8192, len(text)
+    line = json.loads(text)
     assert line["n_gpus"] == 2 and line["value"] > 0
     for mode in ("sharded", "target_sharded"):
         assert line["modes"][mode]["communicator"]["ranks"] == 2, line["modes"][mode]
