@@ -61,7 +61,8 @@ def test_single_gpu_bench_line_meets_the_contract(hip_lib, tmp_path):
     tj = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_traffic.json")))[-1]))      # the file bench.py reads: the newest round's
     known = dict(tj.get("traffic_by_kernel") or {})
     known.update(tj.get("traffic_by_kernel_in_flight") or {})
-    assert rf["traffic"] == known.get(rf["kernel"])
+    assert rf["traffic"] == pytest.approx(known.get(rf["kernel"]), rel=1e-5)            # (6 significant digits in the line)
+    assert full["roofline"]["traffic"] == known.get(rf["kernel"])
     cb = line["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in cb, key
