@@ -13,11 +13,18 @@ import numpy as np
 import velo_amd  # noqa: F401
 from velo_amd import api, synth
 
-k = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+c4 = len(sys.argv) > 1 and sys.argv[1] == "c4"
+k = 3 if c4 else (int(sys.argv[1]) if len(sys.argv) > 1 else 3)
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-plan = synth.drive(k + 2, seed=0)
-tgt, src = plan["frames"][k], plan["frames"][k + 1]
-x_guess = np.asarray(plan["x_true"][k - 1], dtype=np.float64)        # constant velocity: the previous pair's motion
+if c4:                                                                # the scan-to-map pair of BASELINE configs[3]
+    m = synth.scan_to_map(2_000_000)
+    tgt, src = (m["tgt_xyz"], m["tgt_off"]), (m["src_xyz"], m["src_off"])
+    x_guess = np.asarray(m["x0"], dtype=np.float64)
+    plan = {"x_true": {k: np.asarray(m["x_true"])}}
+else:
+    plan = synth.drive(k + 2, seed=0)
+    tgt, src = plan["frames"][k], plan["frames"][k + 1]
+    x_guess = np.asarray(plan["x_true"][k - 1], dtype=np.float64)    # constant velocity: the previous pair's motion
 c = api.Context(0, icp_skip=1)
 c.set_target(*tgt)
 acc = np.zeros(6); moves = []; nv = []
