@@ -417,7 +417,7 @@ def compact_line(full, detail_name=None):
     crf.update(_pick(rf, ("share", "launches", "avg_launch_us", "algorithmic_bytes_per_launch", "traffic_source")))
     crf["note"] = "dominant kernel by share of the timed region's kernel time; HIP events on the launching stream; traffic = fabric-side bytes per launch from the committed PMC pass, or null"
     line["roofline"] = crf
-    line["kernels"] = [dict(_pick(k, ("kernel", "share", "avg_launch_us", "frac")), traffic=k.get("traffic")) for k in (full.get("kernels") or [])[:3]]
+    line["kernels"] = [dict(_pick(k, ("kernel", "share", "avg_launch_us", "algorithmic_bytes_per_launch", "frac")), traffic=k.get("traffic")) for k in (full.get("kernels") or [])[:3]]
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict):
         c = _pick(cb, ("value", "unit", "cores", "kind", "sample", "single_thread_pairs_per_s", "pose_diff_vs_gpu"))
