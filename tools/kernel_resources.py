@@ -8,10 +8,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import velo_amd
 from velo_amd import build
-src = os.path.join(build.CSRC, "velo_hip.hip")
 flags = [f for f in build.HIPCC_FLAGS if f not in ("-shared", "-fPIC")]
-cmd = ["hipcc", *flags, "-I", os.path.join(ROOT, "include"), "--cuda-device-only", "-c", "-o", "/dev/null", src, "-Rpass-analysis=kernel-resource-usage"]
-out = subprocess.run(cmd, capture_output=True, text=True).stderr
+out = ""
+for unit in build.KERNEL_UNITS:                                  # every unit that holds device code, with the flags only it gets
+    src = os.path.join(build.CSRC, unit)
+    cmd = ["hipcc", *flags, *build.SOURCES[unit], "-I", os.path.join(ROOT, "include"), "--cuda-device-only", "-c", "-o", "/dev/null", src, "-Rpass-analysis=kernel-resource-usage"]
+    out += subprocess.run(cmd, capture_output=True, text=True).stderr
 filt = sys.argv[1] if len(sys.argv) > 1 else ""
 cur = None
 rows = []

@@ -18,9 +18,13 @@ ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libvelo_hip.so")
 LIB_DIAG = os.path.join(CSRC, "libvelo_hip_diag.so")     # the tools' build: -DVELO_DIAGNOSTICS (stamps, counters, VELO_DEBUG_SKIP)
-# translation units, each with the flags only it gets.  velo_lm_ag.hip: the one-launch Levenberg-Marquardt solve, built without machine-level
-# loop-invariant code motion (velo_lm_ag_kernels.h says why); the units are compiled side by side and linked into ONE shared library.
-SOURCES = {"velo_hip.hip": [], "velo_lm_ag.hip": ["-mllvm", "-disable-machine-licm"]}
+# Translation units, each with the flags only it gets, compiled side by side and linked into ONE shared library (round 6: ~10 s instead of
+# 27 s for the product build).  velo_hip.hip is the host side of the C-ABI and defines no kernel; every kernel family is defined -- its device
+# code generated -- in exactly one velo_unit_*.hip (velo_kernels.h, "translation units"); velo_lm_ag.hip is the one-launch Levenberg-Marquardt
+# solve, built without machine-level loop-invariant code motion (velo_lm_ag_kernels.h says why).
+SOURCES = {"velo_hip.hip": [], "velo_unit_load.hip": [], "velo_unit_assoc.hip": [], "velo_unit_lm_a.hip": [], "velo_unit_lm_b.hip": [],
+           "velo_lm_ag.hip": ["-mllvm", "-disable-machine-licm"]}
+KERNEL_UNITS = ["velo_unit_load.hip", "velo_unit_assoc.hip", "velo_unit_lm_a.hip", "velo_unit_lm_b.hip", "velo_lm_ag.hip"]   # the units that hold device code (tools/kernel_resources.py)
 HEADERS = ["velo_kernels.h", "velo_lm_ag_kernels.h", "velo_depth_kernels.h", "velo_tri_kernels.h", "velo_device_math.h", os.path.join(ROOT, "include", "velo_hip.h")]
 
 HIPCC_FLAGS = [
@@ -54,7 +58,7 @@ def build_hip(force: bool = False, verbose: bool = False, extra_flags=(), diagno
     """The product library; diagnostics=True builds the tools' variant next to it (same source, -DVELO_DIAGNOSTICS: the
     VELO_DEBUG_SKIP hooks exist only there, so a leaked environment variable cannot corrupt a product registration)."""
     hipcc = shutil.which("hipcc") or os.path.join(_rocm(), "bin", "hipcc")
-    srcs = [os.path.join(CSRC, s) for s in SOURCES]          # (the units share the kernel headers: any change rebuilds both)
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]          # (the units share the kernel headers: any change rebuilds all of them)
     deps = srcs + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     out = out or (LIB_DIAG if diagnostics else LIB)      # out: an A/B build of the same source somewhere else (tools/ab_env.py, VELO_LIB_PATH)
     os.makedirs(os.path.dirname(out), exist_ok=True)

@@ -22,7 +22,9 @@ struct CamWindow { float tx, ty, tz; double min_x, max_x, min_y, max_y; };
 constexpr int kProjChunk = 1024;
 __global__ void __launch_bounds__(256)
 project_ring_kernel(const float4* __restrict__ pts, const int* __restrict__ off, int n_rings, CamWindow W,
-                    float4* __restrict__ pstack, float4* __restrict__ vstack, int* __restrict__ cnt) {
+                    float4* __restrict__ pstack, float4* __restrict__ vstack, int* __restrict__ cnt)
+#if VELO_DEF_LOAD
+{
     __shared__ float4 s_e[kProjChunk];                               // {c.x, c.y, shifted z, bits(index inside the ring)}
     __shared__ float4 s_p[kProjChunk];                               // un-shifted point
     const int ring = blockIdx.x;
@@ -84,6 +86,9 @@ project_ring_kernel(const float4* __restrict__ pts, const int* __restrict__ off,
     }
     if (tid == 0) cnt[ring] = top;
 }
+#else
+;
+#endif
 
 // util::linterpolate (utility.h:7-29), float arithmetic, products and sum left unfused
 __device__ __forceinline__ float lerp_f(float p1, float p2, float start, float end, float mid) {
@@ -106,7 +111,9 @@ __device__ __forceinline__ void lerp_p(const float p1[3], const float p2[3], flo
 __global__ void __launch_bounds__(256)
 depth_assoc_kernel(const float2* __restrict__ kps, int n_kp, const float4* __restrict__ pstack, const float4* __restrict__ vstack,
                    const int* __restrict__ off, const int* __restrict__ cnt, int n_rings, double thresh,
-                   float4* __restrict__ kp_point, int* __restrict__ flag) {
+                   float4* __restrict__ kp_point, int* __restrict__ flag)
+#if VELO_DEF_LOAD
+{
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (k >= n_kp) return;
@@ -160,14 +167,22 @@ depth_assoc_kernel(const float2* __restrict__ kps, int n_kp, const float4* __res
     }
     if (lane == 0) flag[k] = hit;
 }
+#else
+;
+#endif
 
 // has_depth[k] = flag ? exclusive count : -1 ; the interpolated points are appended in keypoint order (velo.h:481-483)
 __global__ void depth_compact_kernel(const int* __restrict__ flag, const int* __restrict__ excl, const float4* __restrict__ kp_point, int n_kp,
-                                     int* __restrict__ has_depth, float4* __restrict__ out) {
+                                     int* __restrict__ has_depth, float4* __restrict__ out)
+#if VELO_DEF_LOAD
+{
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_kp) return;
     if (flag[k]) { has_depth[k] = excl[k]; out[excl[k]] = kp_point[k]; }
     else has_depth[k] = -1;
 }
+#else
+;
+#endif
 
 }  // namespace velo

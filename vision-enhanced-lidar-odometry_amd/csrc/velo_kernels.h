@@ -16,6 +16,29 @@
 
 #include "velo_device_math.h"
 
+// ---- translation units (round 6) ---------------------------------------------------------------------------------------------------------
+// The library is built from several units compiled side by side (build.py): velo_hip.hip holds the host side of the C-ABI and DEFINES NO
+// KERNEL; each kernel family is defined -- its device code generated -- in exactly one unit:
+//     VELO_DEF_LOAD   velo_unit_load.hip    scan ingestion, index build, the group loaders, the widened rows (projection, depth, triangulation)
+//     VELO_DEF_ASSOC  velo_unit_assoc.hip   the association family (tube / direct / asker / lane / box-walk kernels, seeds, merge)
+//     VELO_DEF_LMA    velo_unit_lm_a.hip    visual gate, residual statistics, the sweep and step kernels, one-launch iterations, peer exchange
+//     VELO_DEF_LMB    velo_unit_lm_b.hip    the fused sweep + step family of the lock-step groups, single-launch solves, chain finish, functors
+// Every other unit sees a kernel's DECLARATION (the `#else ;` branch behind its signature) and launches it through the host stub the
+// defining unit exports; template kernels are instantiated explicitly in their unit and declared `extern template` elsewhere (the list
+// at the end of this header).  Device functions and data layouts stay visible to every unit.
+#ifndef VELO_DEF_LOAD
+#define VELO_DEF_LOAD 0
+#endif
+#ifndef VELO_DEF_ASSOC
+#define VELO_DEF_ASSOC 0
+#endif
+#ifndef VELO_DEF_LMA
+#define VELO_DEF_LMA 0
+#endif
+#ifndef VELO_DEF_LMB
+#define VELO_DEF_LMB 0
+#endif
+
 namespace velo {
 
 constexpr int kWave = 64;
@@ -114,23 +137,35 @@ __device__ __forceinline__ int cell_coord(float p, float o, float inv_h, int n) 
 // ---- point packing: (stride-addressed xyz) -> float4 ---------------------------------------------------------
 // records from page-locked host memory into a device buffer, as a launch: the runtime's copy of a few tens of KB (its DMA path) was seen to
 // block the submitting thread for 6-14 ms once in a hundred steps with four busy queues; a launch never does
-__global__ void __launch_bounds__(256) upload_words_kernel(const int* __restrict__ src, int* __restrict__ dst, int n_words) {
+__global__ void __launch_bounds__(256) upload_words_kernel(const int* __restrict__ src, int* __restrict__ dst, int n_words)
+#if VELO_DEF_LOAD
+{
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n_words) dst[i] = __builtin_nontemporal_load(src + i);
 }
-__global__ void pack_points_kernel(const char* __restrict__ src, int64_t stride, int n, float4* __restrict__ dst) {
+#else
+;
+#endif
+__global__ void pack_points_kernel(const char* __restrict__ src, int64_t stride, int n, float4* __restrict__ dst)
+#if VELO_DEF_LOAD
+{
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* p = (const float*)(src + (int64_t)i * stride);
     dst[i] = make_float4(p[0], p[1], p[2], 0.0f);
 }
+#else
+;
+#endif
 
 // ring id per point (binary search in ring_offsets) -- the target's gidx -> ring map
 // (a context may hold only a block of whole rings of the target -- target-sharded mode -- so ring ids and point
 //  indices that leave the kernels are GLOBAL: local ring + first_ring, local index + first_point)
 // (bbox_init: the six keys bbox_kernel folds into -- min keys all ones, max keys zero -- are initialised here, one launch ahead of it,
 //  instead of by a copy operation of their own)
-__global__ void ring_of_kernel(const int* __restrict__ off, int n_rings, int n, int first_ring, int* __restrict__ ring_of, unsigned* __restrict__ bbox_init) {
+__global__ void ring_of_kernel(const int* __restrict__ off, int n_rings, int n, int first_ring, int* __restrict__ ring_of, unsigned* __restrict__ bbox_init)
+#if VELO_DEF_LOAD
+{
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (bbox_init && i < 6) bbox_init[i] = i < 3 ? 0xffffffffu : 0u;
     if (i >= n) return;
@@ -138,13 +173,18 @@ __global__ void ring_of_kernel(const int* __restrict__ off, int n_rings, int n, 
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= i) lo = mid; else hi = mid; }
     ring_of[i] = lo + first_ring;
 }
+#else
+;
+#endif
 
 // Ring-major copy of the target with one wrap-around sentinel on either side of every ring:
 //     ring r (n_r points at [off[r], off[r+1])) -> pad[off[r] + 2 r] = its LAST point, then its points, then its FIRST point,
 // so the cyclic ring neighbours (velo.h:852-854) of point i of local ring r are pad[i + 2 r] and pad[i + 2 r + 2], whatever i:
 // the finish of the association reads three adjacent records and needs neither the ring bounds nor a second trip for the wrap.
 __global__ void pad_rings_kernel(const float4* __restrict__ tgt, const int* __restrict__ off, const int* __restrict__ ring_of, int n, int first_ring,
-                                 float4* __restrict__ pad) {
+                                 float4* __restrict__ pad)
+#if VELO_DEF_LOAD
+{
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int r = ring_of[i] - first_ring, base = off[r], end = off[r + 1];
@@ -153,12 +193,20 @@ __global__ void pad_rings_kernel(const float4* __restrict__ tgt, const int* __re
     if (i == base) pad[end + 2 * r + 1] = p;          // trailing sentinel = first point
     if (i == end - 1) pad[base + 2 * r] = p;          // leading sentinel = last point
 }
+#else
+;
+#endif
 
 // compact query points: qpts[i] = src[q_src[i]] (icp_skip > 1; with icp_skip == 1 the source cloud itself is the list)
-__global__ void gather_queries_kernel(const float4* __restrict__ src, const int* __restrict__ q_src, int nq, float4* __restrict__ qpts) {
+__global__ void gather_queries_kernel(const float4* __restrict__ src, const int* __restrict__ q_src, int nq, float4* __restrict__ qpts)
+#if VELO_DEF_LOAD
+{
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nq) qpts[i] = src[q_src[i]];
 }
+#else
+;
+#endif
 
 // ---- patch order of the queries ---------------------------------------------------------------------------------------------------
 // The tube kernel gives 64 consecutive queries to a workgroup.  In ring order that is a 2 m long line of one ring (a tube of ~125
@@ -189,7 +237,9 @@ __host__ __device__ inline int patch_position(const int* q_off, int n_rings, int
 // query list: position -> global source index.  Ring r contributes ceil(n_r / skip) queries (velo.h:806-807); patch != 0: the list is
 // in patch order, else in the reference's order (ring by ring).
 __global__ void query_list_kernel(const int* __restrict__ src_off, const int* __restrict__ q_off, int n_rings,
-                                  int skip, int nq, int patch, int patch_rings, int patch_len, int* __restrict__ q_src) {
+                                  int skip, int nq, int patch, int patch_rings, int patch_len, int* __restrict__ q_src)
+#if VELO_DEF_LOAD
+{
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
     int lo = 0, hi = n_rings;
@@ -197,13 +247,18 @@ __global__ void query_list_kernel(const int* __restrict__ src_off, const int* __
     const int k = i - q_off[lo];
     q_src[patch ? patch_position(q_off, n_rings, lo, k, patch_rings, patch_len) : i] = src_off[lo] + k * skip;
 }
+#else
+;
+#endif
 
 // ---- scan ingestion on the device: KITTI records -> camera-0-frame rings (kitti.h:121-185), "next" row 1 of SURVEY 8(f) ----
 // 1. ring_break_kernel: flag[i] = i > 0 && x_i > 0 && (y_i > 0) != (y_{i-1} > 0)            (kitti.h:164-168, velodyne frame)
 // 2. exclusive scan of the flags (scan_tiles/sums/add above) -> ring id per point, ring count
 // 3. ring_offsets_kernel: off[ring] = first point of that ring (the flagged points), off[n_rings] = n
 // 4. ring_reorder_kernel: camera-frame copy  q = velo_to_cam * p  in float, stored at  new[i] = old[n-1-((i + n/2) % n)]  (kitti.h:178-183)
-__global__ void ring_break_kernel(const char* __restrict__ rec, int64_t stride, int n, int* __restrict__ flag) {
+__global__ void ring_break_kernel(const char* __restrict__ rec, int64_t stride, int n, int* __restrict__ flag)
+#if VELO_DEF_LOAD
+{
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* p = (const float*)(rec + (int64_t)i * stride);
@@ -214,9 +269,14 @@ __global__ void ring_break_kernel(const char* __restrict__ rec, int64_t stride, 
     }
     flag[i] = f;
 }
+#else
+;
+#endif
 // ring_id[i] = (exclusive scan of flag)[i] + flag[i]; the flagged points start rings 1.., point 0 starts ring 0
 __global__ void ring_offsets_kernel(const int* __restrict__ excl, const int* __restrict__ flag, int n, int* __restrict__ ring_id, int* __restrict__ off,
-                                    int* __restrict__ n_rings_out) {
+                                    int* __restrict__ n_rings_out)
+#if VELO_DEF_LOAD
+{
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int r = excl[i] + flag[i];
@@ -224,9 +284,14 @@ __global__ void ring_offsets_kernel(const int* __restrict__ excl, const int* __r
     if (i == 0 || flag[i]) off[r] = i;
     if (i == n - 1) { off[r + 1] = n; *n_rings_out = r + 1; }
 }
+#else
+;
+#endif
 struct Mat34f { float m[12]; };   // rows of velo_to_cam (kitti.h:100-107)
 __global__ void ring_reorder_kernel(const char* __restrict__ rec, int64_t stride, int n, const int* __restrict__ ring_id, const int* __restrict__ off,
-                                    Mat34f M, float4* __restrict__ dst) {
+                                    Mat34f M, float4* __restrict__ dst)
+#if VELO_DEF_LOAD
+{
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* p = (const float*)(rec + (int64_t)i * stride);
@@ -241,6 +306,9 @@ __global__ void ring_reorder_kernel(const char* __restrict__ rec, int64_t stride
     if (ip < 0) ip += m;
     dst[base + ip] = make_float4(cx, cy, cz, 0.f);
 }
+#else
+;
+#endif
 
 // ---- bounding box of the finite points: per-block min/max then atomics on order-preserving integer keys ----
 __device__ __forceinline__ unsigned f2key(float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
@@ -253,7 +321,9 @@ __host__ __device__ __forceinline__ float key2f(unsigned k) {
 #endif
 }
 __global__ void __launch_bounds__(256)
-bbox_kernel(const float4* __restrict__ pts, int n, unsigned* __restrict__ mnmx /* [6]: min xyz, max xyz keys */) {
+bbox_kernel(const float4* __restrict__ pts, int n, unsigned* __restrict__ mnmx /* [6]: min xyz, max xyz keys */)
+#if VELO_DEF_LOAD
+{
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const float4 p = pts[i];
@@ -281,6 +351,9 @@ bbox_kernel(const float4* __restrict__ pts, int n, unsigned* __restrict__ mnmx /
         if (k < 3) atomicMin(&mnmx[k], f2key(v)); else atomicMax(&mnmx[k], f2key(v));
     }
 }
+#else
+;
+#endif
 
 // ---- a scan enters a context in ONE launch per side -----------------------------------------------------------------------------------
 // With several registrations in flight a queue operation costs 5-10 us of hand-over whatever it does, and loading a pair used to take
@@ -296,7 +369,9 @@ constexpr int kIngestPerThread = 4;                                    // points
 __global__ void __launch_bounds__(256)
 target_ingest_kernel(const char* src, int64_t stride, int n, const int* __restrict__ off, int n_rings, int first_ring,
                      float4* tgt, int* __restrict__ ring_of, float4* __restrict__ pad, unsigned* __restrict__ mnmx,
-                     unsigned long long* __restrict__ lb_status, int lb_words) {
+                     unsigned long long* __restrict__ lb_status, int lb_words)
+#if VELO_DEF_LOAD
+{
     for (int j = blockIdx.x * 256 + threadIdx.x; j < lb_words; j += gridDim.x * 256) lb_status[j] = 0ull;
     float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
 #pragma unroll
@@ -338,10 +413,15 @@ target_ingest_kernel(const char* src, int64_t stride, int n, const int* __restri
         if (k < 3) { if (v < 3.0e38f && key < cur) atomicMin(&mnmx[k], key); } else { if (v > -3.0e38f && key > cur) atomicMax(&mnmx[k], key); }
     }
 }
+#else
+;
+#endif
 __global__ void __launch_bounds__(256)
 source_ingest_kernel(const char* __restrict__ raw, int64_t stride, int n, float4* __restrict__ src, int nb_pack,
                      const int* __restrict__ src_off, const int* __restrict__ q_off, int n_rings, int skip, int nq, int patch, int patch_rings, int patch_len,
-                     int* __restrict__ q_src, float4* __restrict__ qpts, unsigned* __restrict__ mnmx) {
+                     int* __restrict__ q_src, float4* __restrict__ qpts, unsigned* __restrict__ mnmx)
+#if VELO_DEF_LOAD
+{
     if ((int)blockIdx.x < nb_pack) {
         // (the pack blocks also take the cloud's bounding box -- the keys target_ingest_kernel would compute for the same points: a drive
         //  promotes this scan to target one frame later, and with the box already on the host the index build needs no host wait)
@@ -381,6 +461,9 @@ source_ingest_kernel(const char* __restrict__ raw, int64_t stride, int n, float4
     q_src[pos] = si;
     if (qpts) { const float* p = (const float*)(raw + (int64_t)si * stride); qpts[pos] = make_float4(p[0], p[1], p[2], 0.0f); }
 }
+#else
+;
+#endif
 
 // ---- grid build: count, exclusive scan (3 kernels), scatter ----------------------------------------------------
 __device__ __forceinline__ int cell_of_point(const GridDesc& g, const float4& p) {
@@ -408,7 +491,9 @@ __device__ __forceinline__ void run_of_lane(int c, int lane, bool* head, int* fi
     *head = c >= 0; *first = lane; *len = 1;
 #endif
 }
-__global__ void grid_count_kernel(GridDesc g, const float4* __restrict__ pts, int n, int* __restrict__ cell_of, int* __restrict__ table) {
+__global__ void grid_count_kernel(GridDesc g, const float4* __restrict__ pts, int n, int* __restrict__ cell_of, int* __restrict__ table)
+#if VELO_DEF_LOAD
+{
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int c = -1;
     if (i < n) {
@@ -420,13 +505,18 @@ __global__ void grid_count_kernel(GridDesc g, const float4* __restrict__ pts, in
     run_of_lane(c, threadIdx.x & 63, &head, &first, &len);
     if (head) atomicAdd(&table[c + 1], len);
 }
+#else
+;
+#endif
 
 // ---- compressed table (large grids) ----------------------------------------------------------------------------------------------------
 // mark: cell id per point (cell_of) + one bit per occupied cell (a run of equal cells sends one atomicOr); word_popc: occupied cells per
 // word, ready for the one-pass scan; ccount: every point's COMPACT cell number (its rank among the occupied cells, overwriting cell_of)
 // counted into table[k + 1] like grid_count_kernel does for the dense table.  Scan and scatter are the dense path's kernels on the
 // compact table: ~8 B per point of table traffic instead of 4 B per CELL read and written twice.
-__global__ void grid_mark_kernel(GridDesc g, const float4* __restrict__ pts, int n, int* __restrict__ cell_of, unsigned long long* __restrict__ wmask, int wpr) {
+__global__ void grid_mark_kernel(GridDesc g, const float4* __restrict__ pts, int n, int* __restrict__ cell_of, unsigned long long* __restrict__ wmask, int wpr)
+#if VELO_DEF_LOAD
+{
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int c = -1;
     if (i < n) {
@@ -443,13 +533,23 @@ __global__ void grid_mark_kernel(GridDesc g, const float4* __restrict__ pts, int
         if (!(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(w, bit);   // (a set bit stays set: most runs find theirs set already)
     }
 }
-__global__ void word_popc_kernel(const unsigned long long* __restrict__ wmask, int n_words, int* __restrict__ wprefix) {
+#else
+;
+#endif
+__global__ void word_popc_kernel(const unsigned long long* __restrict__ wmask, int n_words, int* __restrict__ wprefix)
+#if VELO_DEF_LOAD
+{
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_words) wprefix[i] = __popcll(wmask[i]);
     else if (i == n_words) wprefix[i] = 0;                              // the sentinel word behind the last row
 }
+#else
+;
+#endif
 __global__ void grid_ccount_kernel(GridDesc g, int* __restrict__ cell_of, int n, const unsigned long long* __restrict__ wmask, const int* __restrict__ wprefix, int wpr,
-                                   int* __restrict__ table) {
+                                   int* __restrict__ table)
+#if VELO_DEF_LOAD
+{
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     int k = -1;
     if (i < n) {
@@ -465,6 +565,9 @@ __global__ void grid_ccount_kernel(GridDesc g, int* __restrict__ cell_of, int n,
     run_of_lane(k, threadIdx.x & 63, &head, &first, &len);
     if (head) atomicAdd(&table[k + 1], len);
 }
+#else
+;
+#endif
 
 constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;                      // per thread
@@ -583,7 +686,9 @@ scan_lookback_kernel(int* __restrict__ data, int n, unsigned long long* __restri
 }
 // (three-kernel scan, kept for the device ring segmenter's small arrays)
 // pass 1: tile-local exclusive scan in place (counts -> local offsets), tile totals out
-__global__ void scan_tiles_kernel(int* __restrict__ data, int n, int* __restrict__ tile_sums) {
+__global__ void scan_tiles_kernel(int* __restrict__ data, int n, int* __restrict__ tile_sums)
+#if VELO_DEF_LOAD
+{
     const int base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
     int v[kScanItems], s = 0;
 #pragma unroll
@@ -594,8 +699,13 @@ __global__ void scan_tiles_kernel(int* __restrict__ data, int n, int* __restrict
     for (int k = 0; k < kScanItems; k++) { if (base + k < n) data[base + k] = ex; ex += v[k]; }
     if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
 }
+#else
+;
+#endif
 // pass 2: one workgroup scans the tile totals in place (exclusive) and writes the grand total to data_total
-__global__ void scan_sums_kernel(int* __restrict__ tile_sums, int n_tiles, int* __restrict__ grand_total) {
+__global__ void scan_sums_kernel(int* __restrict__ tile_sums, int n_tiles, int* __restrict__ grand_total)
+#if VELO_DEF_LOAD
+{
     __shared__ int carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
@@ -612,13 +722,21 @@ __global__ void scan_sums_kernel(int* __restrict__ tile_sums, int n_tiles, int* 
     }
     if (threadIdx.x == 0) *grand_total = carry_s;
 }
+#else
+;
+#endif
 // pass 3: add tile offsets; also seed the scatter cursor; element n receives the grand total
 __global__ void scan_add_kernel(int* __restrict__ data, int n, const int* __restrict__ tile_sums, const int* __restrict__ grand_total,
-                                int* __restrict__ cursor) {
+                                int* __restrict__ cursor)
+#if VELO_DEF_LOAD
+{
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { const int v = data[i] + tile_sums[i / kScanTile]; data[i] = v; cursor[i] = v; }
     else if (i == n) data[n] = *grand_total;
 }
+#else
+;
+#endif
 __device__ __forceinline__ void grid_scatter_body(const float4* __restrict__ pts, const int* __restrict__ cell_of, const int* __restrict__ ring_of, int n,
                                                   int* __restrict__ cursor, const int* __restrict__ n_finite, int first_point,
                                                   float4* __restrict__ sorted, int* __restrict__ sring, const int bx) {
@@ -641,9 +759,14 @@ __device__ __forceinline__ void grid_scatter_body(const float4* __restrict__ pts
 }
 __global__ void __launch_bounds__(256)
 grid_scatter_kernel(const float4* __restrict__ pts, const int* __restrict__ cell_of, const int* __restrict__ ring_of, int n,
-                    int* __restrict__ cursor, const int* __restrict__ n_finite, int first_point, float4* __restrict__ sorted, int* __restrict__ sring) {
+                    int* __restrict__ cursor, const int* __restrict__ n_finite, int first_point, float4* __restrict__ sorted, int* __restrict__ sring)
+#if VELO_DEF_LOAD
+{
     grid_scatter_body(pts, cell_of, ring_of, n, cursor, n_finite, first_point, sorted, sring, (int)blockIdx.x);
 }
+#else
+;
+#endif
 
 // ---- the next frame of a drive in three launches for a whole lock-step group (velo_hint_next_frame) -------------------------------------
 // A drive's step loads a frame on both sides: the scan the context holds as source becomes the target (ring ids, padded rings, index), the
@@ -676,14 +799,21 @@ struct AdvBatch { AdvJob job[kAdvJobs]; };
 
 // every context's index table zeroed in one launch (the runtime's fill is a queue operation per table)
 __global__ void __launch_bounds__(256)
-advance_clear_kernel(AdvBatch B) {
+advance_clear_kernel(AdvBatch B)
+#if VELO_DEF_LOAD
+{
     const AdvJob& J = B.job[blockIdx.y];
     int4* p = reinterpret_cast<int4*>(J.clear);                        // (hipMalloc'd: 256-byte aligned; n_clear rounded up to whole int4s by the host, inside the allocation)
     const int n4 = J.n_clear >> 2;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) p[i] = make_int4(0, 0, 0, 0);
 }
+#else
+;
+#endif
 __global__ void __launch_bounds__(256)
-advance_ingest_kernel(AdvBatch B) {
+advance_ingest_kernel(AdvBatch B)
+#if VELO_DEF_LOAD
+{
     const AdvJob& J = B.job[blockIdx.y];
     __shared__ int s_off[kAdvRings + 2], s_qoff[kAdvRings + 2];
     __shared__ float red[4][6];
@@ -795,6 +925,9 @@ advance_ingest_kernel(AdvBatch B) {
         if (k < 3) { if (vv < 3.0e38f && key < cur) atomicMin(&J.keys[k], key); } else { if (vv > -3.0e38f && key > cur) atomicMax(&J.keys[k], key); }
     }
 }
+#else
+;
+#endif
 template <int kLbItems>
 __global__ void __launch_bounds__(kScanThreads)
 advance_scan_kernel(AdvBatch B) {
@@ -803,7 +936,9 @@ advance_scan_kernel(AdvBatch B) {
     scan_lookback_body<kLbItems>(J.table + 1, J.nc, J.lb_status, J.lb_ticket, J.scan_total);
 }
 __global__ void __launch_bounds__(256)
-advance_scatter_kernel(AdvBatch B) {
+advance_scatter_kernel(AdvBatch B)
+#if VELO_DEF_LOAD
+{
     const AdvJob& J = B.job[blockIdx.y];
     if ((int)blockIdx.x >= J.nb_sc) return;
     // (the source's bounding box, complete since the ingest launch ended, written where the host reads it before the scan's promotion one
@@ -811,6 +946,9 @@ advance_scatter_kernel(AdvBatch B) {
     if (blockIdx.x == 0 && threadIdx.x < 6 && J.h_keys) J.h_keys[threadIdx.x] = J.keys[threadIdx.x];
     grid_scatter_body(J.tgt, J.cell_of, J.ring_of, J.n_t, J.table + 1, J.scan_total, J.first_point, J.sorted, J.sring, (int)blockIdx.x);
 }
+#else
+;
+#endif
 
 // ---- association ------------------------------------------------------------------------------------------------
 // Candidate order inside the scan is irrelevant: candidates are compared through the total order
@@ -1030,7 +1168,9 @@ __device__ __forceinline__ void finish_correspondence_pad(
 // best1 = min key1; best2 = min( key1 of the other ranks, key2 of the winning rank ).
 __global__ void merge_partials_kernel(const PartialRec* __restrict__ tables, int world, int table_stride, int q_begin, int q_end,
                                       const float4* __restrict__ src, const int* __restrict__ q_src, unsigned long long key_inf,
-                                      double norm_cond, AssocOut out, int want_aux) {
+                                      double norm_cond, AssocOut out, int want_aux)
+#if VELO_DEF_ASSOC
+{
     const int qi = q_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= q_end) return;
     const int li = qi - q_begin;
@@ -1061,13 +1201,18 @@ __global__ void merge_partials_kernel(const PartialRec* __restrict__ tables, int
     if (ring_i >= 0 && ring_j >= 0) valid = plane_from_points(v0, v1, v2, norm_cond, n);
     write_correspondence(qi, src[q_src[qi]], valid, n, v0, ring_i, idx_i, ring_j, idx_j, idx_k, di, dj, out, want_aux != 0);
 }
+#else
+;
+#endif
 
 // Reference association search (VELO_ASSOC_VARIANT=0, kept for A/B checks): one lane per query, each lane walks the
 // x-runs of its own (2 reach + 1)^3 cell neighbourhood, reach = ceil(gate radius / cell).
 __global__ void __launch_bounds__(kAssocThreads)
 assoc_search_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
                     const float4* __restrict__ tgt, const int* __restrict__ tgt_off, const int* __restrict__ ring_of,
-                    unsigned gate_bits, double norm_cond, int reach, AssocOut out, int want_aux) {
+                    unsigned gate_bits, double norm_cond, int reach, AssocOut out, int want_aux)
+#if VELO_DEF_ASSOC
+{
     const int qi = q_begin + blockIdx.x * blockDim.x + threadIdx.x;
     const bool active = qi < q_end;
     const unsigned long long key_inf = ((unsigned long long)gate_bits + 1ull) << 32;
@@ -1108,6 +1253,9 @@ assoc_search_kernel(PoseScalars P, GridView G, const float4* __restrict__ src, c
     }
     if (active) finish_correspondence(qi, psrc, qx, qy, qz, b1, b2, key_inf, tgt, tgt_off, ring_of, norm_cond, out, want_aux != 0);
 }
+#else
+;
+#endif
 
 // ---- running (best1, best2) over distinct rings ---------------------------------------------------------------------
 struct Top2 {
@@ -2137,16 +2285,26 @@ assoc_asker_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_dev, 
 }
 __global__ void __launch_bounds__(64)
 assoc_asker_kernel(PoseScalars P, const PoseRecord* __restrict__ P_dev, const int* __restrict__ chain_fail, GridView G, const float4* __restrict__ qpts,
-                   const float4* __restrict__ tgt_pad, const int* __restrict__ tgt_off, unsigned gate_bits, double norm_cond, float h_safe, AssocOut out, int want_aux) {
+                   const float4* __restrict__ tgt_pad, const int* __restrict__ tgt_off, unsigned gate_bits, double norm_cond, float h_safe, AssocOut out, int want_aux)
+#if VELO_DEF_ASSOC
+{
     assoc_asker_body(P, P_dev, chain_fail, G, qpts, tgt_pad, tgt_off, gate_bits, norm_cond, h_safe, out, want_aux, (int)blockIdx.x, (int)gridDim.x);
 }
+#else
+;
+#endif
 __global__ void __launch_bounds__(64)
-assoc_asker_batch_kernel(AssocBatch B) {
+assoc_asker_batch_kernel(AssocBatch B)
+#if VELO_DEF_ASSOC
+{
     const AssocArgs& a = B.item[blockIdx.y];
     const int n_waves = (a.q_end - a.q_begin + kAskChunk - 1) / kAskChunk;
     if (!a.out.ask_list || (int)blockIdx.x >= n_waves + 8) return;      // (+ 8: the XCD-chunked map rounds the list up to eight equal parts)
     assoc_asker_body(a.P, a.P_dev, a.chain_fail, a.G, a.qpts, a.tgt_pad, a.tgt_off, a.gate_bits, a.norm_cond, a.h_safe, a.out, a.want_aux, (int)blockIdx.x, n_waves);
 }
+#else
+;
+#endif
 
 // ---- seeds from the target's direction image -----------------------------------------------------------------------------------
 // A round's search starts from two candidates per query ("seeds", AssocOut::prev_*): any real target points will do -- the tube kernel
@@ -2172,7 +2330,9 @@ __device__ __forceinline__ void dimg_bucket(float x, float y, float z, int* a, i
     *e = min(max(ie, 0), kDimgH - 1);
 }
 __global__ void __launch_bounds__(256)
-dimg_build_kernel(const float4* __restrict__ tgt, int n, unsigned long long* __restrict__ dimg) {
+dimg_build_kernel(const float4* __restrict__ tgt, int n, unsigned long long* __restrict__ dimg)
+#if VELO_DEF_ASSOC
+{
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 p = tgt[i];
@@ -2182,6 +2342,9 @@ dimg_build_kernel(const float4* __restrict__ tgt, int n, unsigned long long* __r
     const float r2 = p.x * p.x + p.y * p.y + p.z * p.z;
     atomicMin(&dimg[e * kDimgW + a], ((unsigned long long)__float_as_uint(r2) << 32) | (unsigned)i);
 }
+#else
+;
+#endif
 struct SeedArgs {
     PoseScalars P; const PoseRecord* P_dev; const int* chain_fail;
     const float4* qpts; int q_begin, q_end;
@@ -2238,9 +2401,19 @@ __device__ __forceinline__ void seed_body(const SeedArgs& A, const int i) {
     A.prev_r[i] = make_int2(t.r1, t.r2);
 }
 __global__ void __launch_bounds__(256)
-seed_kernel(SeedArgs A) { seed_body(A, A.q_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x)); }
+seed_kernel(SeedArgs A)
+#if VELO_DEF_ASSOC
+{ seed_body(A, A.q_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x)); }
+#else
+;
+#endif
 __global__ void __launch_bounds__(256)
-seed_batch_kernel(SeedBatch B) { const SeedArgs& A = B.item[blockIdx.y]; seed_body(A, A.q_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x)); }
+seed_batch_kernel(SeedBatch B)
+#if VELO_DEF_ASSOC
+{ const SeedArgs& A = B.item[blockIdx.y]; seed_body(A, A.q_begin + (int)(blockIdx.x * blockDim.x + threadIdx.x)); }
+#else
+;
+#endif
 
 // ---- sparse queries: one wave per query -------------------------------------------------------------------------------------
 // With the reference's own constants (icp_skip = 200, kitti.h:8) a round has 640 queries, 6 m apart along their rings: the 64
@@ -2290,15 +2463,25 @@ assoc_direct_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_dev,
 }
 __global__ void __launch_bounds__(64)
 assoc_direct_kernel(PoseScalars P, const PoseRecord* __restrict__ P_dev, int* __restrict__ chain_fail, GridView G, const float4* __restrict__ qpts, int q_begin, int q_end,
-                    const float4* __restrict__ tgt_pad, const int* __restrict__ tgt_off, unsigned gate_bits, double norm_cond, float h_safe, AssocOut out, int want_aux) {
+                    const float4* __restrict__ tgt_pad, const int* __restrict__ tgt_off, unsigned gate_bits, double norm_cond, float h_safe, AssocOut out, int want_aux)
+#if VELO_DEF_ASSOC
+{
     assoc_direct_body(P, P_dev, chain_fail, G, qpts, q_begin, q_end, tgt_pad, tgt_off, gate_bits, norm_cond, h_safe, out, want_aux, (int)blockIdx.x);
 }
+#else
+;
+#endif
 __global__ void __launch_bounds__(64)
-assoc_direct_batch_kernel(AssocBatch B) {
+assoc_direct_batch_kernel(AssocBatch B)
+#if VELO_DEF_ASSOC
+{
     const AssocArgs& a = B.item[blockIdx.y];
     if ((int)blockIdx.x >= a.q_end - a.q_begin) return;
     assoc_direct_body(a.P, a.P_dev, a.chain_fail, a.G, a.qpts, a.q_begin, a.q_end, a.tgt_pad, a.tgt_off, a.gate_bits, a.norm_cond, a.h_safe, a.out, a.want_aux, (int)blockIdx.x);
 }
+#else
+;
+#endif
 
 // ---- association search, lane variant: the rounds that start from seeds ------------------------------------------------------
 // The tube kernel shares every staged candidate among the 64 queries of a group: 350 candidates x 64 lanes per warm round, of
@@ -2463,16 +2646,26 @@ assoc_lane_body(const PoseScalars& P_in, const PoseRecord* __restrict__ P_dev, i
 
 __global__ void __launch_bounds__(256)
 assoc_lane_kernel(PoseScalars P, const PoseRecord* __restrict__ P_dev, int* __restrict__ chain_fail, GridView G, const float4* __restrict__ qpts, int q_begin, int q_end,
-                  const float4* __restrict__ tgt_pad, const int* __restrict__ tgt_off, unsigned gate_bits, double norm_cond, AssocOut out, int want_aux) {
+                  const float4* __restrict__ tgt_pad, const int* __restrict__ tgt_off, unsigned gate_bits, double norm_cond, AssocOut out, int want_aux)
+#if VELO_DEF_ASSOC
+{
     assoc_lane_body<false>(P, P_dev, chain_fail, G, qpts, q_begin, q_end, tgt_pad, tgt_off, gate_bits, norm_cond, out, want_aux, (int)blockIdx.x);
 }
+#else
+;
+#endif
 // the same round of several contexts in one launch (blockIdx.y = context)
 __global__ void __launch_bounds__(256)
-assoc_lane_batch_kernel(AssocBatch B) {
+assoc_lane_batch_kernel(AssocBatch B)
+#if VELO_DEF_ASSOC
+{
     const AssocArgs& a = B.item[blockIdx.y];
     if ((int)blockIdx.x * 256 >= a.q_end - a.q_begin) return;
     assoc_lane_body<false>(a.P, a.P_dev, a.chain_fail, a.G, a.qpts, a.q_begin, a.q_end, a.tgt_pad, a.tgt_off, a.gate_bits, a.norm_cond, a.out, a.want_aux, (int)blockIdx.x);
 }
+#else
+;
+#endif
 
 // ---- association as a balanced pipeline: prepare (clusters -> work items) + persistent per-cluster search -----------------
 // The monolithic kernel above walks a group's clusters one after the other, so a 64-query group with several clusters and
@@ -2500,7 +2693,9 @@ struct AssocQueue {
 
 __global__ void __launch_bounds__(64)
 assoc_prepare_kernel(PoseScalars P, GridDesc g, const float4* __restrict__ src, const int* __restrict__ q_src, int q_begin, int q_end,
-                     int cluster_w, AssocQueue Q) {
+                     int cluster_w, AssocQueue Q)
+#if VELO_DEF_ASSOC
+{
     const int lane = threadIdx.x;
     const int group = blockIdx.x;
     const int qi = q_begin + group * 64 + lane;
@@ -2557,6 +2752,9 @@ assoc_prepare_kernel(PoseScalars P, GridDesc g, const float4* __restrict__ src, 
         pending = pending && !member;
     }
 }
+#else
+;
+#endif
 
 template <int NW, int MINW>
 __global__ void __launch_bounds__(NW * 64, MINW)
@@ -2854,19 +3052,29 @@ __device__ __forceinline__ void visual_gate_body(const double* __restrict__ xdev
     }
 }
 __global__ void visual_gate_kernel(const double* __restrict__ xdev, VisualParams V, const VisualMatch* __restrict__ matches, int n, int iter,
-                                   unsigned char* __restrict__ flags, int* __restrict__ counts) {
+                                   unsigned char* __restrict__ flags, int* __restrict__ counts)
+#if VELO_DEF_LMA
+{
     visual_gate_body(xdev, V, matches, n, iter, flags, counts, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
+#else
+;
+#endif
 // the gates of all contexts of a lock-step group in one launch (a queue operation per context and f2f iteration less)
 constexpr int kGateJobs = 8;
 struct GateBatch {
     const double* x[kGateJobs]; const VisualMatch* m[kGateJobs]; unsigned char* flags[kGateJobs]; int* counts[kGateJobs]; int n[kGateJobs];
     VisualParams V; int iter;
 };
-__global__ void __launch_bounds__(128) visual_gate_batch_kernel(GateBatch G) {
+__global__ void __launch_bounds__(128) visual_gate_batch_kernel(GateBatch G)
+#if VELO_DEF_LMA
+{
     const int j = blockIdx.y;
     visual_gate_body(G.x[j], G.V, G.m[j], G.n[j], G.iter, G.flags[j], G.counts[j], (int)(blockIdx.x * 128 + threadIdx.x));
 }
+#else
+;
+#endif
 
 // ---- LM state (row S1) ------------------------------------------------------------------------------------------------------
 enum { PHASE_INIT = 0, PHASE_CAND = 1 };
@@ -2987,7 +3195,9 @@ struct StatWork {                             // device scratch of one statistic
 };
 __global__ void __launch_bounds__(256)
 residual_norms_kernel(const double* __restrict__ xdev, EvalArgs A, double* __restrict__ vals, signed char* __restrict__ types,
-                      double* __restrict__ part /* [gridDim.x][kStatTypes + 1] */) {
+                      double* __restrict__ part /* [gridDim.x][kStatTypes + 1] */)
+#if VELO_DEF_LMA
+{
     __shared__ PoseEval s_P;
     __shared__ double s_red[256];
     if (threadIdx.x == 0) {
@@ -3032,9 +3242,14 @@ residual_norms_kernel(const double* __restrict__ xdev, EvalArgs A, double* __res
         __syncthreads();
     }
 }
+#else
+;
+#endif
 // pass p (0..3): histogram of digit p (16 bits, from the top) over the elements whose higher digits equal the prefix found so far
 __global__ void __launch_bounds__(256)
-stats_hist_kernel(const double* __restrict__ vals, const signed char* __restrict__ types, int n, int pass, const StatWork* __restrict__ W, int* __restrict__ hist) {
+stats_hist_kernel(const double* __restrict__ vals, const signed char* __restrict__ types, int n, int pass, const StatWork* __restrict__ W, int* __restrict__ hist)
+#if VELO_DEF_LMA
+{
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int t = types[i];
@@ -3043,9 +3258,14 @@ stats_hist_kernel(const double* __restrict__ vals, const signed char* __restrict
     if (pass > 0 && (b >> (64 - 16 * pass)) != W->prefix[t]) return;
     atomicAdd(&hist[(size_t)t * kStatBins + (int)((b >> (48 - 16 * pass)) & 0xffffull)], 1);
 }
+#else
+;
+#endif
 // one workgroup per type: the bin that holds rank k; pass 0 also derives count and k = count / 2.  Clears the bins behind itself.
 __global__ void __launch_bounds__(256)
-stats_pick_kernel(int pass, StatWork* __restrict__ W, int* __restrict__ hist) {
+stats_pick_kernel(int pass, StatWork* __restrict__ W, int* __restrict__ hist)
+#if VELO_DEF_LMA
+{
     __shared__ long long s_tot[256];
     const int t = blockIdx.x, tid = threadIdx.x;
     int* h = hist + (size_t)t * kStatBins;
@@ -3071,7 +3291,12 @@ stats_pick_kernel(int pass, StatWork* __restrict__ W, int* __restrict__ hist) {
     __syncthreads();
     for (int u = 0; u < per; u++) h[tid * per + u] = 0;
 }
-__global__ void stats_final_kernel(const double* __restrict__ part, int n_blocks, StatWork* __restrict__ W, velo_residual_stats* __restrict__ out) {
+#else
+;
+#endif
+__global__ void stats_final_kernel(const double* __restrict__ part, int n_blocks, StatWork* __restrict__ W, velo_residual_stats* __restrict__ out)
+#if VELO_DEF_LMA
+{
     const int t = threadIdx.x;
     if (t > kStatTypes) return;
     double s = 0.0;
@@ -3082,6 +3307,9 @@ __global__ void stats_final_kernel(const double* __restrict__ part, int n_blocks
     out->type[t].mean = n > 0 ? s / (double)n : 0.0;
     out->type[t].median = n > 0 ? __longlong_as_double((long long)W->prefix[t]) : 0.0;
 }
+#else
+;
+#endif
 
 // Time line of the LM chain (tools/lm_trace.py): every workgroup's thread 0 stamps the stages it passes with the 100 MHz real-time
 // counter; per evaluation and stage the buffer keeps the first and the last stamp.  Compiled only into the tools' build.
@@ -3297,7 +3525,12 @@ __device__ __forceinline__ void eval_icp_body(const EvalArgs& A, const int bx, c
 }
 
 __global__ void __launch_bounds__(kEvalThreads)
-eval_icp_kernel(EvalArgs A) { eval_icp_body(A, blockIdx.x, gridDim.x); }
+eval_icp_kernel(EvalArgs A)
+#if VELO_DEF_LMA
+{ eval_icp_body(A, blockIdx.x, gridDim.x); }
+#else
+;
+#endif
 
 // ---- several contexts in one launch (velo_frame_to_frame_batch): blockIdx.y = context -------------------------------------------
 // Each context keeps its own state, partial sums and correspondence table; the batch only shares LAUNCHES, so a sweep over 8
@@ -3314,11 +3547,16 @@ struct LMBatchItem {
     SolveLog* log;         //   "          and the summary of the solve
 };
 __global__ void __launch_bounds__(kEvalThreads)
-eval_icp_batch_kernel(const LMBatchItem* __restrict__ items) {
+eval_icp_batch_kernel(const LMBatchItem* __restrict__ items)
+#if VELO_DEF_LMA
+{
     const LMBatchItem& it = items[blockIdx.y];
     if ((int)blockIdx.x >= it.nb_icp) return;
     eval_icp_body(it.A, blockIdx.x, it.nb_icp);
 }
+#else
+;
+#endif
 // visual blocks (rows R2-R5; losses velo.h:688,714-717,748-751,781-784)
 // the visual blocks of workgroup bx of nbx at the eval point pt (in LDS), summed into acc[28]
 __device__ __forceinline__ void visual_sweep_acc(const EvalArgs& A, const LMEvalPoint& pt, const int bx, const int nbx, double acc[kNumAcc]) {
@@ -3437,13 +3675,23 @@ __device__ __forceinline__ void eval_visual_body(const EvalArgs& A, const int bx
 }
 
 __global__ void __launch_bounds__(kEvalThreads)
-eval_visual_kernel(EvalArgs A) { eval_visual_body(A, blockIdx.x, gridDim.x); }
+eval_visual_kernel(EvalArgs A)
+#if VELO_DEF_LMA
+{ eval_visual_body(A, blockIdx.x, gridDim.x); }
+#else
+;
+#endif
 __global__ void __launch_bounds__(kEvalThreads)
-eval_visual_batch_kernel(const LMBatchItem* __restrict__ items) {
+eval_visual_batch_kernel(const LMBatchItem* __restrict__ items)
+#if VELO_DEF_LMA
+{
     const LMBatchItem& it = items[blockIdx.y];
     if ((int)blockIdx.x >= it.nb_vis) return;
     eval_visual_body(it.A, blockIdx.x, it.nb_vis);
 }
+#else
+;
+#endif
 
 // ---- one-shot all-reduce of the 28-double block through peer-mapped slabs (SURVEY.md sections 5 and 8(e)) -------------------------
 // Query-sharded registration all-reduces 224 bytes per LM evaluation: pure latency.  Every rank owns a small slab in fine-grained
@@ -3510,7 +3758,9 @@ __device__ __forceinline__ void peer_allreduce28(const PeerComm& C, double* __re
 // every rank pushes its own prediction (from its own call history) into every peer's slab and takes the maximum over ranks --
 // uniform by construction, whatever the ranks' histories are.  One wave; `out` is host-pinned memory the host reads after a sync.
 struct AgreeCounts { int v[64]; };
-__global__ void __launch_bounds__(64) peer_agree_kernel(PeerComm C, AgreeCounts mine, int n, int* __restrict__ out) {
+__global__ void __launch_bounds__(64) peer_agree_kernel(PeerComm C, AgreeCounts mine, int n, int* __restrict__ out)
+#if VELO_DEF_LMA
+{
     const int t = threadIdx.x;
     const unsigned long long seq = *C.kseq + 1ull;
     const int par = (int)(seq & 1ull);
@@ -3533,6 +3783,9 @@ __global__ void __launch_bounds__(64) peer_agree_kernel(PeerComm C, AgreeCounts 
     }
     if (t == 0) *C.kseq = seq;
 }
+#else
+;
+#endif
 
 #ifndef VELO_UNIT_LM_ONLY        // (the record exchange of the target-sharded mode takes the association unit's PartialRec)
 // ---- target-sharded mode over the same peers (BASELINE config 5): the per-round exchange of the per-query top-2 records -------------
@@ -3547,7 +3800,9 @@ struct PeerRecs {
     size_t parity_stride;                      // records per parity half (= world * max_share, rounded up by the host)
 };
 __global__ void __launch_bounds__(256)
-peer_scatter_records_kernel(const PartialRec* __restrict__ mine, int n_q, PeerRecs R, int parity) {
+peer_scatter_records_kernel(const PartialRec* __restrict__ mine, int n_q, PeerRecs R, int parity)
+#if VELO_DEF_LMA
+{
     const int qi = blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= n_q) return;
     int owner = 0, qb = 0;
@@ -3562,8 +3817,13 @@ peer_scatter_records_kernel(const PartialRec* __restrict__ mine, int n_q, PeerRe
     for (int k = 0; k < 5; k++) dst[k] = src[k];
     __threadfence_system();
 }
+#else
+;
+#endif
 __global__ void __launch_bounds__(64)
-peer_exchange_sync_kernel(PeerComm C, unsigned long long seq) {
+peer_exchange_sync_kernel(PeerComm C, unsigned long long seq)
+#if VELO_DEF_LMA
+{
     const int t = threadIdx.x, par = (int)(seq & 1ull);
     if (t < C.world) {
         // the scatter kernel ahead of this one on the stream has completed: its stores are out
@@ -3576,10 +3836,15 @@ peer_exchange_sync_kernel(PeerComm C, unsigned long long seq) {
     }
     __threadfence_system();
 }
+#else
+;
+#endif
 
 // velo_evaluate behind a peer communicator: fixed-order sum of my partial rows, all-reduce, out[28]
 __global__ void __launch_bounds__(256)
-peer_reduce_kernel(const double* __restrict__ partials, int n_blocks, PeerComm C, double* __restrict__ out) {
+peer_reduce_kernel(const double* __restrict__ partials, int n_blocks, PeerComm C, double* __restrict__ out)
+#if VELO_DEF_LMA
+{
     __shared__ double E[32];
     if (threadIdx.x < kNumAcc) {
         double v = 0.0;
@@ -3590,10 +3855,15 @@ peer_reduce_kernel(const double* __restrict__ partials, int n_blocks, PeerComm C
     peer_allreduce28(C, E);
     if (threadIdx.x < kNumAcc) out[threadIdx.x] = E[threadIdx.x];
 }
+#else
+;
+#endif
 
 #endif  // VELO_UNIT_LM_ONLY
 // sums the per-workgroup partials in a fixed order into out[28] (used before the RCCL all-reduce and by velo_evaluate)
-__global__ void reduce_partials_kernel(const LMState* __restrict__ state, const double* __restrict__ partials, int n_blocks, double* __restrict__ out) {
+__global__ void reduce_partials_kernel(const LMState* __restrict__ state, const double* __restrict__ partials, int n_blocks, double* __restrict__ out)
+#if VELO_DEF_LMA
+{
     if (state && state->done) return;
     if (threadIdx.x < kNumAcc) {
         double v = 0.0;
@@ -3601,6 +3871,9 @@ __global__ void reduce_partials_kernel(const LMState* __restrict__ state, const 
         out[threadIdx.x] = v;
     }
 }
+#else
+;
+#endif
 
 // ---- one trust-region LM state transition --------------------------------------------------------------------------
 // 6x6 SPD solve by Cholesky; one reciprocal per pivot, everything else multiplies (the serial critical path of the
@@ -3703,10 +3976,15 @@ __device__ __forceinline__ void lm_begin_body(LMState* S, LMEvalPoint* pt, const
     }
     if (t < 4) eval_point_column(x, 0, t, pt);
 }
-__global__ void lm_begin_kernel(LMState* S, LMEvalPoint* pt, const double* __restrict__ x_in, const int* __restrict__ n_valid, PoseRecord* __restrict__ pose_out) {
+__global__ void lm_begin_kernel(LMState* S, LMEvalPoint* pt, const double* __restrict__ x_in, const int* __restrict__ n_valid, PoseRecord* __restrict__ pose_out)
+#if VELO_DEF_LMA
+{
     lm_begin_body(S, pt, x_in, n_valid);
     if (threadIdx.x == 0 && pose_out) pose_out->ready = 0;              // chain mode: the next round's association waits for this solve
 }
+#else
+;
+#endif
 
 // The LM step of one solve, by one 256-thread workgroup: fixed-order sum of the per-workgroup partial rows [n_blocks][28] (or of
 // the already reduced [1][28] block behind an all-reduce), ONE trust-region state transition, and the eval point of the next
@@ -3890,25 +4168,40 @@ __device__ __forceinline__ void lm_iter_body(const EvalArgs& A, const LMParams& 
 __global__ void __launch_bounds__(kEvalThreads)
 lm_iter_kernel(EvalArgs A, LMParams Q, const LMState* __restrict__ Sin, LMState* __restrict__ Sout, const double* __restrict__ pin, int n_in,
                double* __restrict__ pout, int first, const double* __restrict__ x_in, const int* __restrict__ n_valid,
-               PoseRecord* pose_out, SolveLog* log) {
+               PoseRecord* pose_out, SolveLog* log)
+#if VELO_DEF_LMA
+{
     lm_iter_body<false>(A, Q, Sin, Sout, pin, n_in, pout, first, x_in, n_valid, blockIdx.x, gridDim.x, pose_out, log);
 }
+#else
+;
+#endif
 // grid = nb_icp + nb_vis workgroups
 __global__ void __launch_bounds__(kEvalThreads)
 lm_iter_vis_kernel(EvalArgs A, LMParams Q, const LMState* __restrict__ Sin, LMState* __restrict__ Sout, const double* __restrict__ pin, int n_in,
                    double* __restrict__ pout, int first, const double* __restrict__ x_in, const int* __restrict__ n_valid,
-                   PoseRecord* pose_out, SolveLog* log, int nb_icp, int nb_vis) {
+                   PoseRecord* pose_out, SolveLog* log, int nb_icp, int nb_vis)
+#if VELO_DEF_LMA
+{
     lm_iter_body<true>(A, Q, Sin, Sout, pin, n_in, pout, first, x_in, n_valid, blockIdx.x, nb_icp, pose_out, log, nb_vis);
 }
+#else
+;
+#endif
 // the same for the contexts of a lock-step group: blockIdx.y = context, k = index of the launch within the solve (its parity
 // selects the halves of every context's state / partial-row double buffer; `half` = doubles per half)
 __global__ void __launch_bounds__(kEvalThreads)
-lm_iter_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int k, size_t half) {
+lm_iter_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int k, size_t half)
+#if VELO_DEF_LMA
+{
     const LMBatchItem& it = items[blockIdx.y];
     if ((int)blockIdx.x >= it.nb_icp) return;
     lm_iter_body<false>(it.A, Q, it.S + (k & 1), it.S + ((k + 1) & 1), it.A.partials + (size_t)(k & 1) * half, it.nb_icp,
                  it.A.partials + (size_t)((k + 1) & 1) * half, k == 0 ? 1 : 0, it.xd, it.n_valid, blockIdx.x, it.nb_icp, it.pose_out, it.log);
 }
+#else
+;
+#endif
 
 // need_step != null: the trust-region step is left to the caller (lm_compute_step_wave), *need_step says whether one is due
 __device__ __forceinline__ void lm_transition_local(const LMParams& Q, LMState* S, const double* E, bool* need_step) {
@@ -4080,25 +4373,45 @@ __device__ __forceinline__ void lm_transition_wave(const LMParams& Q, LMState* s
 
 __global__ void __launch_bounds__(256)
 lm_step_kernel(LMParams Q, LMState* S, LMEvalPoint* pt, const double* __restrict__ partials, int n_blocks, unsigned long long* trace, int trace_eval,
-               PoseRecord* __restrict__ pose_out, SolveLog* __restrict__ log) {
+               PoseRecord* __restrict__ pose_out, SolveLog* __restrict__ log)
+#if VELO_DEF_LMA
+{
     lm_transition(Q, S, pt, partials, n_blocks, trace, trace_eval, nullptr, pose_out, log);
 }
+#else
+;
+#endif
 // the LM step of a query-sharded solve: my partial rows, the peer all-reduce, the transition -- one launch
 __global__ void __launch_bounds__(256)
 lm_step_peer_kernel(LMParams Q, LMState* S, LMEvalPoint* pt, const double* __restrict__ partials, int n_blocks, PeerComm C,
-                    PoseRecord* __restrict__ pose_out, SolveLog* __restrict__ log) {
+                    PoseRecord* __restrict__ pose_out, SolveLog* __restrict__ log)
+#if VELO_DEF_LMA
+{
     lm_transition(Q, S, pt, partials, n_blocks, nullptr, 0, &C, pose_out, log);
 }
-__global__ void lm_begin_batch_kernel(const LMBatchItem* __restrict__ items) {
+#else
+;
+#endif
+__global__ void lm_begin_batch_kernel(const LMBatchItem* __restrict__ items)
+#if VELO_DEF_LMA
+{
     const LMBatchItem& it = items[blockIdx.x];
     lm_begin_body(it.S, const_cast<LMEvalPoint*>(it.A.pt), it.xd, it.n_valid);
     if (threadIdx.x == 0 && it.pose_out) it.pose_out->ready = 0;       // chain mode: the next round's association waits for this solve
 }
+#else
+;
+#endif
 __global__ void __launch_bounds__(256)
-lm_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items) {
+lm_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items)
+#if VELO_DEF_LMA
+{
     const LMBatchItem& it = items[blockIdx.x];
     lm_transition(Q, it.S, const_cast<LMEvalPoint*>(it.A.pt), it.A.partials, it.n_rows, nullptr, 0, nullptr, it.pose_out, it.log);
 }
+#else
+;
+#endif
 // Sweep AND step of a lock-step group in ONE launch per LM iteration (point-to-plane rows only): every workgroup sweeps its rows
 // and publishes its partial row with agent-scope stores; the workgroup of a context that draws the last ticket then does what
 // lm_step_batch_kernel does -- the same fixed-order sum over the same rows, the same transition, so the results are bit-identical
@@ -4160,9 +4473,14 @@ __device__ __forceinline__ void eval_step_batch_body(const LMParams& Q, const LM
 }
 // alone on the chip: matrices in registers, four prefetched rows (240 VGPRs, 33 KB of LDS: two waves per SIMD)
 __global__ void __launch_bounds__(kEvalThreads)
-eval_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets, int first) {
+eval_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets, int first)
+#if VELO_DEF_LMB
+{
     eval_step_batch_body<false, kPre, kStepChunk>(Q, items[blockIdx.y], tickets, first);
 }
+#else
+;
+#endif
 // The LEAN instantiation, for launches that share the chip with other lock-step groups' association kernels: matrices read from LDS,
 // VELO_LEAN_PRE prefetched rows, the step's partial rows 64 at a time -- few enough registers and LDS (<= 152 VGPRs, < 25 KB) that a
 // workgroup fits on a CU beside FIVE association workgroups (5 x 72 VGPRs of 512 per SIMD, 5 x 27 KB of 160 KB with the pad the batch
@@ -4171,32 +4489,62 @@ eval_step_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* _
 #define VELO_LEAN_PRE 1
 #endif
 __global__ void __launch_bounds__(kEvalThreads) __attribute__((amdgpu_num_vgpr(152)))
-eval_step_batch_lean_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets, int first) {
+eval_step_batch_lean_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets, int first)
+#if VELO_DEF_LMB
+{
     eval_step_batch_body<true, VELO_LEAN_PRE, 64>(Q, items[blockIdx.y], tickets, first);
 }
+#else
+;
+#endif
 __global__ void __launch_bounds__(kEvalThreads) __attribute__((amdgpu_num_vgpr(152)))
-eval_step_batch_lean_vis_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets, int first) {
+eval_step_batch_lean_vis_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets, int first)
+#if VELO_DEF_LMB
+{
     eval_step_batch_body<true, VELO_LEAN_PRE, 64, true>(Q, items[blockIdx.y], tickets, first);
 }
+#else
+;
+#endif
 __global__ void __launch_bounds__(kEvalThreads)
-eval_step_batch_vis_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets, int first) {
+eval_step_batch_vis_kernel(LMParams Q, const LMBatchItem* __restrict__ items, int* __restrict__ tickets, int first)
+#if VELO_DEF_LMB
+{
     eval_step_batch_body<false, kPre, kStepChunk, true>(Q, items[blockIdx.y], tickets, first);
 }
+#else
+;
+#endif
 // The same two with the group's items BY VALUE in the kernel arguments (groups of up to four contexts): no copy of the items into
 // device memory ahead of every round of a chained call -- six copy operations, and the queue hand-overs around them, per call.
 struct LMBatchPackV { LMBatchItem item[4]; };
 __global__ void __launch_bounds__(kEvalThreads)
-eval_step_batch_v_kernel(LMParams Q, LMBatchPackV P, int* __restrict__ tickets, int first) {
+eval_step_batch_v_kernel(LMParams Q, LMBatchPackV P, int* __restrict__ tickets, int first)
+#if VELO_DEF_LMB
+{
     eval_step_batch_body<false, kPre, kStepChunk>(Q, P.item[blockIdx.y], tickets, first);
 }
+#else
+;
+#endif
 __global__ void __launch_bounds__(kEvalThreads) __attribute__((amdgpu_num_vgpr(152)))
-eval_step_batch_lean_v_kernel(LMParams Q, LMBatchPackV P, int* __restrict__ tickets, int first) {
+eval_step_batch_lean_v_kernel(LMParams Q, LMBatchPackV P, int* __restrict__ tickets, int first)
+#if VELO_DEF_LMB
+{
     eval_step_batch_body<true, VELO_LEAN_PRE, 64>(Q, P.item[blockIdx.y], tickets, first);
 }
+#else
+;
+#endif
 __global__ void __launch_bounds__(kEvalThreads) __attribute__((amdgpu_num_vgpr(152)))
-eval_step_batch_lean_vis_v_kernel(LMParams Q, LMBatchPackV P, int* __restrict__ tickets, int first) {
+eval_step_batch_lean_vis_v_kernel(LMParams Q, LMBatchPackV P, int* __restrict__ tickets, int first)
+#if VELO_DEF_LMB
+{
     eval_step_batch_body<true, VELO_LEAN_PRE, 64, true>(Q, P.item[blockIdx.y], tickets, first);
 }
+#else
+;
+#endif
 // The one-launch iteration of the single-pair path (every workgroup runs the transition itself, then sweeps: no last-workgroup hand-over
 // inside the launch) for the contexts of a lock-step group, in the LEAN shape of eval_step_batch_lean_kernel (matrices from LDS, one
 // prefetched row, 64-row chunks), items by value.  parity selects the halves of every context's state / partial-row double buffer (a
@@ -4221,12 +4569,17 @@ __device__ __forceinline__ void lm_iter_lean_body(const EvalArgs& A, const LMPar
     block_reduce_store(acc, pout + (size_t)bx * kNumAcc, s_scratch);
 }
 __global__ void __launch_bounds__(kEvalThreads) __attribute__((amdgpu_num_vgpr(152)))
-lm_iter_batch_lean_kernel(LMParams Q, LMBatchPackV P, int parity, int first, size_t half) {
+lm_iter_batch_lean_kernel(LMParams Q, LMBatchPackV P, int parity, int first, size_t half)
+#if VELO_DEF_LMB
+{
     const LMBatchItem& it = P.item[blockIdx.y];
     if ((int)blockIdx.x >= it.nb_icp) return;
     lm_iter_lean_body<true, VELO_LEAN_PRE, 64>(it.A, Q, it.S + parity, it.S + (parity ^ 1), it.A.partials + (size_t)parity * half, it.nb_icp,
                                                it.A.partials + (size_t)(parity ^ 1) * half, first, it.xd, it.n_valid, blockIdx.x, it.nb_icp, it.pose_out, it.log);
 }
+#else
+;
+#endif
 // (the all-gather solve, lm_solve_ag_batch_kernel, lives in velo_lm_ag_kernels.h / velo_lm_ag.hip: a translation unit of its own)
 __device__ __forceinline__ int ctl_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void ctl_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -4348,16 +4701,26 @@ __device__ __forceinline__ void lm_solve_persist_body(const LMParams& Q, const L
     }
 }
 __global__ void __launch_bounds__(kEvalThreads, 3)                    // <= 168 VGPRs: the workgroups stay for a whole solve, beside other groups' association workgroups
-lm_solve_persist_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, SolveCtl* __restrict__ ctl, int kmax) {
+lm_solve_persist_batch_kernel(LMParams Q, const LMBatchItem* __restrict__ items, SolveCtl* __restrict__ ctl, int kmax)
+#if VELO_DEF_LMB
+{
     lm_solve_persist_body<VELO_LEAN_PRE>(Q, items + blockIdx.y, ctl + blockIdx.y, kmax, (int)gridDim.x);
 }
+#else
+;
+#endif
 
 // all states of the batch into one contiguous block (one D2H copy per chunk instead of one per context)
-__global__ void lm_gather_states_kernel(const LMBatchItem* __restrict__ items, LMState* __restrict__ out, int which) {
+__global__ void lm_gather_states_kernel(const LMBatchItem* __restrict__ items, LMState* __restrict__ out, int which)
+#if VELO_DEF_LMB
+{
     const unsigned* src = reinterpret_cast<const unsigned*>(items[blockIdx.x].S + which);
     unsigned* dst = reinterpret_cast<unsigned*>(out + blockIdx.x);
     for (int k = threadIdx.x; k < (int)(sizeof(LMState) / 4); k += blockDim.x) dst[k] = src[k];
 }
+#else
+;
+#endif
 
 // The end of a chained call of a lock-step group in ONE launch instead of a gather launch + three to seven copies: every context's final
 // state, the solve logs, the chain's failure flags (and, with visual blocks, the match flags and block counts) written straight into the
@@ -4372,7 +4735,9 @@ struct ChainFinish {
     LMState* h_states; SolveLog* h_logs; int* h_fail;
     int n, n_logs, n_counts;
 };
-__global__ void __launch_bounds__(256) chain_finish_kernel(ChainFinish F) {
+__global__ void __launch_bounds__(256) chain_finish_kernel(ChainFinish F)
+#if VELO_DEF_LMB
+{
     const int i = blockIdx.x, t = threadIdx.x;
     {
         const unsigned* src = reinterpret_cast<const unsigned*>(F.S[i]);
@@ -4390,6 +4755,9 @@ __global__ void __launch_bounds__(256) chain_finish_kernel(ChainFinish F) {
         for (int k = t; k < F.n_counts; k += 256) F.h_vis_counts[i][k] = F.vis_counts[i][k];
     }
 }
+#else
+;
+#endif
 
 // A whole ceres::Solve in ONE single-workgroup launch, for problems whose sweep is at most kSmallRows workgroups anyway (the
 // reference's own configuration: icp_skip = 200 -> 640 queries = one workgroup).  There a solve is ~8 LM iterations x two
@@ -4473,9 +4841,14 @@ lm_solve_small_body(const EvalArgs& A, const LMParams& Q, LMState* Sg, const dou
 }
 __global__ void __launch_bounds__(kEvalThreads)
 lm_solve_small_kernel(EvalArgs A, LMParams Q, LMState* Sg, const double* __restrict__ x_in, const int* __restrict__ n_valid,
-                      int nb_icp, int nb_vis, int max_sweeps, PoseRecord* __restrict__ pose_out, SolveLog* __restrict__ log) {
+                      int nb_icp, int nb_vis, int max_sweeps, PoseRecord* __restrict__ pose_out, SolveLog* __restrict__ log)
+#if VELO_DEF_LMB
+{
     lm_solve_small_body(A, Q, Sg, x_in, n_valid, nb_icp, nb_vis, max_sweeps, pose_out, log);
 }
+#else
+;
+#endif
 // the solves of a lock-step group, one workgroup per context (the reference's constants in batches: 640 queries per pair).  The items
 // come BY VALUE, up to kItemsByValue per launch: read through a pointer their fields stay live across the body's stores (424 bytes of
 // scratch, ~11 us per launch); in the argument segment they are constants the compiler reloads where it needs them.
@@ -4483,20 +4856,35 @@ constexpr int kItemsByValue = 4;
 struct LMBatchPack { LMBatchItem item[kItemsByValue]; };
 static_assert(sizeof(LMBatchPack) + 256 <= 4096, "the pack must fit the kernel argument segment");
 __global__ void __launch_bounds__(kEvalThreads)
-lm_solve_small_batch_kernel(LMParams Q, LMBatchPack P, int max_sweeps) {
+lm_solve_small_batch_kernel(LMParams Q, LMBatchPack P, int max_sweeps)
+#if VELO_DEF_LMB
+{
     const LMBatchItem& it = P.item[blockIdx.x];
     lm_solve_small_body(it.A, Q, it.S, it.xd, it.n_valid, it.nb_icp, it.nb_vis, max_sweeps, it.pose_out, it.log);
 }
+#else
+;
+#endif
 __global__ void __launch_bounds__(kEvalThreads)
-lm_solve_small_icp_batch_kernel(LMParams Q, LMBatchPack P, int max_sweeps) {
+lm_solve_small_icp_batch_kernel(LMParams Q, LMBatchPack P, int max_sweeps)
+#if VELO_DEF_LMB
+{
     const LMBatchItem& it = P.item[blockIdx.x];
     lm_solve_small_body<false>(it.A, Q, it.S, it.xd, it.n_valid, it.nb_icp, 0, max_sweeps, it.pose_out, it.log);
 }
+#else
+;
+#endif
 __global__ void __launch_bounds__(kEvalThreads)
 lm_solve_small_icp_kernel(EvalArgs A, LMParams Q, LMState* Sg, const double* __restrict__ x_in, const int* __restrict__ n_valid,
-                          int nb_icp, int max_sweeps, PoseRecord* __restrict__ pose_out, SolveLog* __restrict__ log) {
+                          int nb_icp, int max_sweeps, PoseRecord* __restrict__ pose_out, SolveLog* __restrict__ log)
+#if VELO_DEF_LMB
+{
     lm_solve_small_body<false>(A, Q, Sg, x_in, n_valid, nb_icp, 0, max_sweeps, pose_out, log);
 }
+#else
+;
+#endif
 
 // ---- seam 2 by value: a batch of residual functors (costfunctions.h:17-220) at one pose -----------------------------------
 // One record per functor: kind (ResidualType order 0..3, 4 = cost3DPD) and the constructor arguments widened to double in the
@@ -4506,7 +4894,9 @@ struct FunctorRec { int kind; int reserved; double c[9]; };
 static_assert(sizeof(FunctorRec) == 80, "velo_functor layout");
 
 __global__ void __launch_bounds__(256)
-functor_batch_kernel(const FunctorRec* __restrict__ f, int n, const double* __restrict__ xd, double* __restrict__ res, double* __restrict__ jac) {
+functor_batch_kernel(const FunctorRec* __restrict__ f, int n, const double* __restrict__ xd, double* __restrict__ res, double* __restrict__ jac)
+#if VELO_DEF_LMB
+{
     __shared__ PoseRot s_R, s_Rinv;
     __shared__ double s_t[3];
     if (threadIdx.x == 0) {
@@ -4538,5 +4928,62 @@ functor_batch_kernel(const FunctorRec* __restrict__ f, int n, const double* __re
         for (int k = 0; k < 18; k++) jac[(size_t)18 * i + k] = J[k];
     }
 }
+#else
+;
+#endif
+
+// ---- template kernels: instantiated by the unit that owns the family, `extern template` for everybody else --------------------------------
+#ifndef VELO_UNIT_LM_ONLY
+#if VELO_DEF_LOAD
+#define VELO_INST_LOAD template
+#else
+#define VELO_INST_LOAD extern template
+#endif
+#if VELO_DEF_ASSOC
+#define VELO_INST_ASSOC template
+#else
+#define VELO_INST_ASSOC extern template
+#endif
+VELO_INST_LOAD __global__ void scan_lookback_kernel<kLbItemsSmall>(int*, int, unsigned long long*, int*, int*);
+VELO_INST_LOAD __global__ void scan_lookback_kernel<kLbItemsLarge>(int*, int, unsigned long long*, int*, int*);
+VELO_INST_LOAD __global__ void advance_scan_kernel<kLbItemsSmall>(AdvBatch);
+VELO_INST_LOAD __global__ void advance_scan_kernel<kLbItemsLarge>(AdvBatch);
+#define VELO_V5_ARGS (PoseScalars, const PoseRecord*, int*, GridView, const float4*, int, int, const float4*, const int*, unsigned, double, int, float, AssocOut, int, const int*, int, int)
+#define VELO_V3_ARGS (PoseScalars, GridView, const float4*, const int*, int, int, const float4*, const int*, const int*, unsigned, double, int, float, AssocOut, int, int, int)
+#define VELO_CLUSTER_ARGS (GridView, AssocQueue, const float4*, const int*, int, int, const float4*, const int*, const int*, unsigned, double, float, AssocOut, int)
+VELO_INST_ASSOC __global__ void assoc_search_v5_kernel<4, 5, false, 2, 0> VELO_V5_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v5_kernel<4, 5, false, 2, 1> VELO_V5_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v5_batch_kernel<4, 5, false, 2, 0>(AssocBatch);
+VELO_INST_ASSOC __global__ void assoc_search_v5_batch_kernel<4, 5, false, 2, 1>(AssocBatch);
+VELO_INST_ASSOC __global__ void assoc_search_v5_batch_kernel<4, 5, false, 2, 2>(AssocBatch);
+#ifdef VELO_DIAGNOSTICS   // the A/B instantiations of the tools' build
+VELO_INST_ASSOC __global__ void assoc_search_v5_kernel<4, 5, true, 2, 1> VELO_V5_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v5_kernel<4, 5, false, 4, 1> VELO_V5_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v5_kernel<4, 6, false, 2, 1> VELO_V5_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v5_kernel<4, 6, false, 2, 0> VELO_V5_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v5_kernel<4, 7, false, 2, 0> VELO_V5_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v5_kernel<4, 8, false, 2, 0> VELO_V5_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v3_kernel<1, 1, false> VELO_V3_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v3_kernel<1, 1, true> VELO_V3_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v3_kernel<2, 1, false> VELO_V3_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v3_kernel<2, 1, true> VELO_V3_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v3_kernel<4, 5, false> VELO_V3_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v3_kernel<4, 5, true> VELO_V3_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v3_kernel<4, 6, false> VELO_V3_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v3_kernel<4, 6, true> VELO_V3_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v3_kernel<4, 7, false> VELO_V3_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v3_kernel<4, 7, true> VELO_V3_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v3_kernel<4, 8, false> VELO_V3_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v3_kernel<4, 8, true> VELO_V3_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v3_kernel<8, 8, false> VELO_V3_ARGS;
+VELO_INST_ASSOC __global__ void assoc_search_v3_kernel<8, 8, true> VELO_V3_ARGS;
+VELO_INST_ASSOC __global__ void assoc_cluster_kernel<2, 1> VELO_CLUSTER_ARGS;
+VELO_INST_ASSOC __global__ void assoc_cluster_kernel<4, 6> VELO_CLUSTER_ARGS;
+VELO_INST_ASSOC __global__ void assoc_cluster_kernel<8, 6> VELO_CLUSTER_ARGS;
+#endif
+#undef VELO_V5_ARGS
+#undef VELO_V3_ARGS
+#undef VELO_CLUSTER_ARGS
+#endif  // VELO_UNIT_LM_ONLY
 
 }  // namespace velo

@@ -218,7 +218,9 @@ __device__ __forceinline__ void tri_solve(Eval&& eval, const TriParams& P, doubl
 __global__ void __launch_bounds__(64)
 triangulate_kernel(const TriFrame* __restrict__ frames, const double* __restrict__ cam_t, const velo_tri_obs* __restrict__ obs,
                    const int* __restrict__ off, int n, TriParams P, float* __restrict__ pts, const unsigned char* __restrict__ init,
-                   velo_tri_result* __restrict__ results) {
+                   velo_tri_result* __restrict__ results)
+#if VELO_DEF_LOAD
+{
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (l >= n) return;
     const int b = off[l], n_obs = off[l + 1] - b;
@@ -236,6 +238,9 @@ triangulate_kernel(const TriFrame* __restrict__ frames, const double* __restrict
     pts[3 * l] = (float)x[0]; pts[3 * l + 1] = (float)x[1]; pts[3 * l + 2] = (float)x[2];   // velo.h:1124-1126
     if (results) results[l] = S;
 }
+#else
+;
+#endif
 
 // ---- one WAVE per landmark (default) ----------------------------------------------------------------------------------------
 // The thread-per-landmark kernel above is a single dependent chain per landmark: every evaluation walks the observations one
@@ -349,7 +354,9 @@ __device__ __forceinline__ void tri_evaluate_wave(TriShared& sh, const TriFrame*
 __global__ void __launch_bounds__(64)
 triangulate_wave_kernel(const TriFrame* __restrict__ frames, const double* __restrict__ cam_t, const velo_tri_obs* __restrict__ obs,
                         const int* __restrict__ off, int n, TriParams P, float* __restrict__ pts, const unsigned char* __restrict__ init,
-                        velo_tri_result* __restrict__ results) {
+                        velo_tri_result* __restrict__ results)
+#if VELO_DEF_LOAD
+{
     __shared__ TriShared sh;
     const int l = blockIdx.x;
     if (l >= n) return;
@@ -377,5 +384,8 @@ triangulate_wave_kernel(const TriFrame* __restrict__ frames, const double* __res
         if (results) results[l] = S;
     }
 }
+#else
+;
+#endif
 
 }  // namespace velo
