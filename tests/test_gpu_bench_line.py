@@ -54,7 +54,7 @@ def test_single_gpu_bench_line_meets_the_contract(hip_lib, tmp_path):
     rf = line["roofline"]
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us"):
         assert key in rf, key
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-6 * rf["frac"] + 1e-9      # (six significant digits in the line)
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-5 * rf["frac"]      # (six significant digits in the line)
     assert rf["kernel"].endswith("_kernel") and 0 < rf["frac"] < 1
     # traffic: the PMC figure of THIS kernel instantiation from the committed passes, or null -- never another instantiation's
     import glob
