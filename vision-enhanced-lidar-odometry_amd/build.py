@@ -25,7 +25,10 @@ LIB_DIAG = os.path.join(CSRC, "libvelo_hip_diag.so")     # the tools' build: -DV
 SOURCES = {"velo_hip.hip": [], "velo_unit_load.hip": [], "velo_unit_assoc.hip": [], "velo_unit_lm_a.hip": [], "velo_unit_lm_b.hip": [],
            "velo_lm_ag.hip": ["-mllvm", "-disable-machine-licm"]}
 KERNEL_UNITS = ["velo_unit_load.hip", "velo_unit_assoc.hip", "velo_unit_lm_a.hip", "velo_unit_lm_b.hip", "velo_lm_ag.hip"]   # the units that hold device code (tools/kernel_resources.py)
-HEADERS = ["velo_kernels.h", "velo_lm_ag_kernels.h", "velo_depth_kernels.h", "velo_tri_kernels.h", "velo_device_math.h", os.path.join(ROOT, "include", "velo_hip.h")]
+HEADERS = ["velo_kernels.h", "velo_lm_ag_kernels.h", "velo_depth_kernels.h", "velo_tri_kernels.h", "velo_device_math.h", os.path.join(ROOT, "include", "velo_hip.h"),
+           # the parts of the host side (velo_hip.hip includes them in this order: one translation unit)
+           "velo_host_types.inl", "velo_host_index.inl", "velo_host_assoc.inl", "velo_host_lm.inl", "velo_host_loaders.inl", "velo_host_pool.inl",
+           "velo_api_context.inl", "velo_api_solve.inl", "velo_host_chain.inl", "velo_host_batch.inl", "velo_api_pose_comm.inl", "velo_api_next_rows.inl"]
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
