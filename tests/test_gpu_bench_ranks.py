@@ -64,3 +64,26 @@ def test_bench_starts_its_own_ranks_when_no_launcher_wraps_it(hip_lib):
     assert line["n_gpus"] == 2 and line["value"] > 0
     for mode in ("sharded", "target_sharded"):
         assert line["modes"][mode]["communicator"]["ranks"] == 2, line["modes"][mode]
+
+
+@pytest.mark.timeout(900)
+def test_eight_rank_bench_line_is_one_small_line(hip_lib):
+    """The driver's 8-GPU command shape -- `python bench.py --gpus 8 --steps K --warmup W`, the script starting its own ranks -- with all eight
+    ranks forced onto the one GPU of the box: the line adds `modes` for N > 1 and must still be ONE line of at most 8 KB that parses
+    (BENCH_r05.json: parsed null was a line that had outgrown the driver), with both modes' communicators reporting eight ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--force-device", "0", "--dist-backend", "gloo",
+           "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-oracle-check"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=850, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(rows) == 1 and out.stdout.strip().splitlines()[-1] == rows[0]
+    assert len(rows[0]) <= 8192, len(rows[0])
+    line = json.loads(rows[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["value"] > 0 and line["config"]["pairs_in_flight_per_gpu"] == 8
+    for key in ("metric", "unit", "steps", "warmup", "ms_per_step", "roofline", "dtype", "data"):
+        assert key in line, key
+    for mode in ("sharded", "target_sharded"):
+        m = line["modes"][mode]
+        assert not m.get("error"), m
+        assert m["communicator"]["ranks"] == 8 and m["pairs_per_s"] > 0
