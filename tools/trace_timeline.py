@@ -19,7 +19,13 @@ k0 = int(n * 3 / 13)
 gaps = [(ab[i + 1][0] - ab[i][1], i + 1) for i in range(n // 2)]
 if gaps and max(gaps)[0] > 5_000_000:
     k0 = max(k0, max(gaps)[1])
-t0, t1 = ab[k0][0], ab[-1][1]
+# (round 6: behind the timed region bench.py replays two timed pairs through the CPU oracle -- seconds without a launch -- and then registers one
+#  more frame off the clock: the stretch ends ahead of the longest pause of the second half of the run)
+k1 = n - 1
+gaps2 = [(ab[i + 1][0] - ab[i][1], i) for i in range(max(k0, n // 2), n - 1)]
+if gaps2 and max(gaps2)[0] > 5_000_000:
+    k1 = max(gaps2)[1]
+t0, t1 = ab[k0][0], ab[k1][1]
 sel = [r for r in rows if r[0] >= t0 and r[1] <= t1]
 
 
