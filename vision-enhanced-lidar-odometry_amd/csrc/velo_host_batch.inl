@@ -632,8 +632,13 @@ static int f2f_batch_lockstep(velo_ctx** ctxs, int n, double* x, double* T, velo
         if (ahead_trace && hinted) { if (!tr0) { HIP_TRY(hipEventCreate(&tr0)); HIP_TRY(hipEventCreate(&tr1)); } HIP_TRY(hipEventRecord(tr0, bs)); }
         if (hinted) VELO_TRY(preload_group(ctxs, n, bs, &preloaded));    // velo_hint_next_frame: the next frame's promotion, ingest and index build behind this chain
         if (ahead_trace && hinted) HIP_TRY(hipEventRecord(tr1, bs));
+        static const bool enq_trace = dev_env("VELO_ENQ_TRACE") != nullptr;         // dev aid: how long the host needs to ENQUEUE a group's chain, and how long it then waits
+        const auto t_enq_done = std::chrono::steady_clock::now();
         if (preloaded) HIP_TRY(hipEventSynchronize(c0->nf.call_done));   // the results are in; the next frame's loads are still running
         else HIP_TRY(hipStreamSynchronize(bs));
+        if (enq_trace) fprintf(stderr, "[velo enq] %d contexts: entry -> chain enqueued %.0f us (of it before the first launch %.0f us); then waited %.0f us for the results\n", n,
+                               std::chrono::duration<double, std::micro>(t_enq_done - t_entry).count(), std::chrono::duration<double, std::micro>(t_chain1 - t_entry).count(),
+                               std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enq_done).count());
         c0->last_chain_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_chain1).count();   // (enqueue -> results in)
         if (turn_trace) { t_results = std::chrono::steady_clock::now(); t_results_valid = true; }
         if (ahead_trace && hinted) {
