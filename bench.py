@@ -731,6 +731,8 @@ def run_leg(rig, a, workload, mode, B, steps, warmup, single_leg=True, comm="pee
         rig.barrier(ctxs)
         dt = rig.max_over_ranks(time.perf_counter() - t0)
         kept_pick = {(i, f): kept[f][i] for f in range(len(kept)) for i in range(len(kept[f]))} if (walker is not None and not seq) else {}
+        if os.environ.get("VELO_BENCH_DUMP_EVALS"):              # dev aid: evaluations per step, context and solve (what the chain's launch prediction has to guess)
+            np.save(os.environ["VELO_BENCH_DUMP_EVALS"], np.array([[[s.solves[k].evaluations for k in range(s.n_solves)] for s in ss] for ss in kept], dtype=np.int32))
         for step_summaries in kept:
             for s in step_summaries:
                 assoc_ms += s.assoc_kernel_ms
